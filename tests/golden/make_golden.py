@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE implementation (aosokin/os2d) in the dev container.
+
+Run only where ``/root/reference`` exists:   python tests/golden/make_golden.py
+It writes ``tests/golden/head_*.npz`` + ``decode_*.npz`` (inputs, seeds for the weights, expected outputs).
+Nothing from the reference travels: the fixtures are data (inputs and expected outputs).
+
+torchvision is not installed in this image and cannot be installed (no network), while the reference
+imports it at module level (reference os2d/modeling/box_coder.py:7, os2d/structures/bounding_box.py:4-5,
+os2d/modeling/feature_extractor.py:5).  To import the reference we register a minimal stand-in for
+those module names.  Only these stand-in functions are numerically exercised by the paths we record:
+  * ``encode_boxes``            (box_coder.py:316, inside Os2dHead.forward)
+  * ``BoxCoder.decode_single``  (box_coder.py:329, decode_pyramid)
+  * ``clip_boxes_to_image``, ``nms``, ``box_area``  (bounding_box.py:262,367, decode_pyramid)
+They are restated here from torchvision's published closed forms (torchvision 0.5 / 0.14,
+torchvision/models/detection/_utils.py and torchvision/ops/boxes.py).  Parity at the torchvision
+boundary is therefore pinned to the published formulas, not to a torchvision binary.
+"""
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
+REFERENCE = "/root/reference"
+sys.path.insert(0, REPO)
+
+from os2d_amd.utils import synthetic  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- torchvision stand-in
+def _tv_encode_boxes(reference_boxes, proposals, weights):
+    # published closed form: dx = wx*(gcx-ecx)/ew, dy likewise, dw = ww*log(gw/ew), dh likewise
+    wx, wy, ww, wh = [float(w) for w in weights]
+    px1, py1, px2, py2 = proposals.unbind(1)
+    gx1, gy1, gx2, gy2 = reference_boxes.unbind(1)
+    ew, eh = px2 - px1, py2 - py1
+    ecx, ecy = px1 + 0.5 * ew, py1 + 0.5 * eh
+    gw, gh = gx2 - gx1, gy2 - gy1
+    gcx, gcy = gx1 + 0.5 * gw, gy1 + 0.5 * gh
+    return torch.stack([wx * (gcx - ecx) / ew, wy * (gcy - ecy) / eh,
+                        ww * torch.log(gw / ew), wh * torch.log(gh / eh)], dim=1)
+
+
+class _TvBoxCoder(object):
+    def __init__(self, weights, bbox_xform_clip=math.log(1000.0 / 16)):
+        self.weights = weights
+        self.bbox_xform_clip = bbox_xform_clip
+
+    def decode_single(self, rel_codes, boxes):
+        boxes = boxes.to(rel_codes.dtype)
+        w = boxes[:, 2] - boxes[:, 0]
+        h = boxes[:, 3] - boxes[:, 1]
+        cx = boxes[:, 0] + 0.5 * w
+        cy = boxes[:, 1] + 0.5 * h
+        wx, wy, ww, wh = [float(v) for v in self.weights]
+        dx = rel_codes[:, 0::4] / wx
+        dy = rel_codes[:, 1::4] / wy
+        dw = torch.clamp(rel_codes[:, 2::4] / ww, max=self.bbox_xform_clip)
+        dh = torch.clamp(rel_codes[:, 3::4] / wh, max=self.bbox_xform_clip)
+        pcx = dx * w[:, None] + cx[:, None]
+        pcy = dy * h[:, None] + cy[:, None]
+        pw = torch.exp(dw) * w[:, None]
+        ph = torch.exp(dh) * h[:, None]
+        return torch.cat([pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph], dim=1)
+
+
+def _tv_box_area(b):
+    return (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+
+
+def _tv_box_iou(a, b):
+    lt = torch.max(a[:, None, :2], b[None, :, :2])
+    rb = torch.min(a[:, None, 2:], b[None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    return inter / (_tv_box_area(a)[:, None] + _tv_box_area(b)[None, :] - inter)
+
+
+def _tv_clip_boxes_to_image(boxes, size):
+    h, w = size
+    x = boxes[:, 0::2].clamp(min=0, max=w)
+    y = boxes[:, 1::2].clamp(min=0, max=h)
+    return torch.stack([x[:, 0], y[:, 0], x[:, 1], y[:, 1]], dim=1)
+
+
+def _tv_nms(boxes, scores, thr):
+    # greedy NMS: visit by decreasing score, suppress IoU > thr; returns kept indices sorted by score
+    order = torch.argsort(scores, descending=True, stable=True)
+    keep = []
+    suppressed = torch.zeros(boxes.shape[0], dtype=torch.bool)
+    iou = _tv_box_iou(boxes, boxes) if boxes.shape[0] else None
+    for i in order.tolist():
+        if suppressed[i]:
+            continue
+        keep.append(i)
+        suppressed |= iou[i] > thr
+    return torch.tensor(keep, dtype=torch.long)
+
+
+def install_torchvision_standin():
+    def mod(name):
+        m = types.ModuleType(name)
+        sys.modules[name] = m
+        return m
+
+    tv = mod("torchvision")
+    models = mod("torchvision.models")
+    resnet = mod("torchvision.models.resnet")
+    det = mod("torchvision.models.detection")
+    utils = mod("torchvision.models.detection._utils")
+    ops = mod("torchvision.ops")
+    boxes = mod("torchvision.ops.boxes")
+    transforms = mod("torchvision.transforms")
+    tv.models, tv.ops, tv.transforms = models, ops, transforms
+    models.resnet, models.detection = resnet, det
+    det._utils = utils
+    ops.boxes = boxes
+
+    class ResNet(torch.nn.Module):  # placeholder: the backbone is not part of the recorded path
+        pass
+
+    resnet.ResNet = ResNet
+    resnet.resnet50 = resnet.resnet101 = lambda **kw: None
+    utils.encode_boxes = _tv_encode_boxes
+    utils.BoxCoder = _TvBoxCoder
+
+    class Matcher(object):  # training only, never reached
+        def __init__(self, *a, **k):
+            pass
+
+    utils.Matcher = Matcher
+    boxes.nms = ops.nms = _tv_nms
+    boxes.box_iou = ops.box_iou = _tv_box_iou
+    boxes.box_area = ops.box_area = _tv_box_area
+    boxes.clip_boxes_to_image = ops.clip_boxes_to_image = _tv_clip_boxes_to_image
+
+
+# ----------------------------------------------------------------------------- head fixtures
+HEAD_CASES = [
+    # name,            P, inverse, C,  H,  W,  class map sizes (h, w),                seeds (fm, cls, net)
+    ("v2_affine_inv",  6, True,    64, 11, 13, [(15, 15), (12, 18), (17, 13)],        (11, 1100, 21)),
+    ("v1_simple",      4, False,   64, 12, 14, [(15, 15), (18, 12), (13, 17)],        (12, 1200, 22)),
+    ("affine_noinv",   6, False,   48,  9, 16, [(14, 16), (15, 15)],                  (13, 1300, 23)),
+    ("simple_inv",     4, True,    32, 16,  9, [(15, 15), (16, 14), (15, 15), (11, 20)], (14, 1400, 24)),
+    ("v2_c256_wide",   6, True,   256, 10, 33, [(15, 15), (13, 17)],                  (15, 1500, 25)),
+]
+
+
+def run_reference_head(P, inverse, fm, class_fms, state):
+    from os2d.modeling.head import build_os2d_head_creator
+    from os2d.structures.feature_map import FeatureMapSize
+
+    creator = build_os2d_head_creator(P == 4, False, inverse,
+                                      FeatureMapSize(w=16, h=16), FeatureMapSize(w=16, h=16))
+    creator.aligner.parameter_regressor.load_state_dict(state)
+    creator.eval()
+    grabbed = {}
+    hook = creator.aligner.parameter_regressor.register_forward_hook(
+        lambda m, i, o: grabbed.update(corr=i[0].detach().clone(), params=o.detach().clone()))
+    with torch.no_grad():
+        head = creator.create_os2d_head(class_fms)
+        loc, cls, cls_det, corners = head(fm)
+    hook.remove()
+    return dict(loc=loc, cls=cls, cls_detached=cls_det, corners=corners.contiguous(),
+                q15=head.class_feature_maps, corr=grabbed["corr"], params=grabbed["params"])
+
+
+def make_head_fixtures():
+    for name, P, inverse, C, H, W, sizes, (s_fm, s_cls, s_net) in HEAD_CASES:
+        fm = synthetic.make_feature_map(C, H, W, seed=s_fm)
+        class_fms = synthetic.make_class_feature_maps(len(sizes), C, sizes=sizes, seed=s_cls)
+        state = synthetic.make_transform_net_state(P, seed=s_net)
+        out = run_reference_head(P, inverse, fm, class_fms, state)
+        theta = out["params"]
+        print("{:16s} cls[{:+.4f},{:+.4f}] |p - id| max {:.3f}  loc absmax {:.3f}".format(
+            name, float(out["cls"].min()), float(out["cls"].max()),
+            float((theta - theta.mean(dim=(2, 3), keepdim=True)).abs().max()), float(out["loc"].abs().max())))
+        arrays = dict(P=np.int64(P), inverse=np.int64(inverse), seed_net=np.int64(s_net),
+                      net_checksum=np.float64(synthetic.state_checksum(state)),
+                      fm=fm.numpy(), n_classes=np.int64(len(class_fms)))
+        for b, c in enumerate(class_fms):
+            arrays["class_fm_{}".format(b)] = c.numpy()
+        for k, v in out.items():
+            arrays["ref_" + k] = v.numpy()
+        np.savez_compressed(os.path.join(HERE, "head_{}.npz".format(name)), **arrays)
+
+
+# ----------------------------------------------------------------------------- decode fixtures
+def make_decode_fixture():
+    """decode_pyramid (reference box_coder.py:448-536) on a 2-level pyramid, 3 classes."""
+    from os2d.modeling.box_coder import Os2dBoxCoder, BoxGridGenerator
+    from os2d.structures.feature_map import FeatureMapSize
+
+    gen = BoxGridGenerator(box_size=FeatureMapSize(w=240, h=240), box_stride=FeatureMapSize(w=16, h=16))
+
+    def fm_size(img_size):
+        f = lambda s: -(-(-(-(-(-(-(-s // 2)) // 2)) // 2)) // 2)  # ceil-halving four times
+        return FeatureMapSize(w=f(img_size.w), h=f(img_size.h))
+
+    coder = Os2dBoxCoder(0.5, 0.1, 0.5, 0.1, gen, fm_size, do_nms_across_classes=False)
+    rs = np.random.RandomState(77)
+    img_sizes = [FeatureMapSize(w=208, h=176), FeatureMapSize(w=320, h=272)]
+    n_cls = 3
+    locs, clss = [], []
+    for s in img_sizes:
+        f = fm_size(s)
+        n = f.w * f.h
+        locs.append(torch.from_numpy((rs.standard_normal((n_cls, 4, n)) * np.array([2.0, 2.0, 1.5, 1.5])[None, :, None]).astype(np.float32)))
+        clss.append(torch.from_numpy(rs.uniform(-1, 1, size=(n_cls, n)).astype(np.float32)))
+    arrays = dict(n_levels=np.int64(len(img_sizes)), n_classes=np.int64(n_cls),
+                  img_sizes=np.array([[s.w, s.h] for s in img_sizes], dtype=np.int64))
+    for i, (l, c) in enumerate(zip(locs, clss)):
+        arrays["loc_{}".format(i)] = l.numpy()
+        arrays["cls_{}".format(i)] = c.numpy()
+        # per-level decode (box_coder.py:319-330) + clip, before masking / NMS
+        default_boxes = coder._get_default_boxes(img_sizes[i])
+        per_class = []
+        for k in range(n_cls):
+            bl = coder.build_boxes_from_loc_scores(l[k].transpose(0, 1), default_boxes)
+            bl.clip_to_image(remove_empty=False)
+            per_class.append(bl.bbox_xyxy.clone())
+        arrays["ref_boxes_{}".format(i)] = torch.stack(per_class, 0).numpy()
+    # the eval path maps every level back to the original image with a resize (reference
+    # os2d/data/dataloader.py:326-336, os2d/structures/transforms.py:12-27,70-96)
+    from os2d.structures.transforms import TransformList
+    orig_size = FeatureMapSize(w=416, h=352)
+    arrays["orig_size"] = np.array([orig_size.w, orig_size.h], dtype=np.int64)
+    inverse = []
+    for s in img_sizes:
+        t = TransformList()
+        t.append(lambda boxes: boxes.resize(orig_size))
+        inverse.append(t)
+    for thr_name, score_thr in (("t0", 0.0), ("tinf", float("-inf")), ("t06", 0.6)):
+        res = coder.decode_pyramid([l.clone() for l in locs], [c.clone() for c in clss], img_sizes,
+                                   class_ids=list(range(n_cls)), nms_score_threshold=score_thr,
+                                   nms_iou_threshold=0.3, inverse_box_transforms=inverse)
+        order = torch.argsort(res.get_field("labels") * 10 - res.get_field("scores"), stable=True)
+        arrays["ref_{}_boxes".format(thr_name)] = res.bbox_xyxy[order].numpy()
+        arrays["ref_{}_scores".format(thr_name)] = res.get_field("scores")[order].numpy()
+        arrays["ref_{}_labels".format(thr_name)] = res.get_field("labels")[order].numpy()
+        print("decode {}: {} detections".format(thr_name, len(order)))
+    np.savez_compressed(os.path.join(HERE, "decode_pyramid.npz"), **arrays)
+
+
+def main():
+    if not os.path.isdir(REFERENCE):
+        raise SystemExit("the reference checkout {} is not present; fixtures can only be regenerated "
+                         "in the development container".format(REFERENCE))
+    install_torchvision_standin()
+    sys.path.insert(0, REFERENCE)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    make_head_fixtures()
+    make_decode_fixture()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,93 @@
+/* os2d_hip.h -- C ABI of libos2d_hip.so: the MI355X (gfx950) OS2D correlation + alignment head.
+ *
+ * The reference (aosokin/os2d) is pure Python/PyTorch and has no FFI; the interface it exposes for this path is
+ * the Python class API (Os2dHeadCreator.create_os2d_head / Os2dHead.forward / Os2dBoxCoder decode).  This header is
+ * the boundary our Python mirror of that API (os2d_amd/modeling) binds with ctypes; each entry point cites the
+ * reference code it replaces (paths relative to the reference checkout).  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. the torch caching allocator); fp32, row-major,
+ *     dense; nothing is allocated or freed inside the library;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the null stream) and
+ *     re-entrant: no global mutable state except the thread-local error string;
+ *   - return value: 0 on success, negative on error (-1 bad argument, -2 workspace too small, -3 unsupported
+ *     shape, -4 HIP runtime error); os2d_last_error() then describes it.  Nothing throws.
+ */
+#ifndef OS2D_HIP_H
+#define OS2D_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OS2D_ABI_VERSION 1
+
+/* ABI version of the loaded library (compare with OS2D_ABI_VERSION). */
+int os2d_abi_version(void);
+
+/* Thread-local description of the last error returned on this thread ("" if none). */
+const char* os2d_last_error(void);
+
+/* ---- TransformNet weight packing: reference os2d/modeling/head.py:604-646 (TransformationNet.__init__) holds
+ * conv.0/conv.1(BN)/conv.3/conv.4(BN)/linear; eval-mode BatchNorm (head.py:623) is folded here and the filters are
+ * re-laid-out for the MFMA implicit-GEMM kernels.  Sizes of the packed buffers (in floats): */
+size_t os2d_packed_conv_floats(int layer /*1|2|3*/);       /* weights */
+size_t os2d_packed_bias_floats(int layer /*1|2|3*/);       /* bias    */
+/* layer 1: w[128,225,7,7]; layer 2: w[64,128,5,5]; layer 3: w[P,64,5,5] (bn_* = NULL, P = 6 or 4).
+ * bn_eps is BatchNorm2d.eps (1e-5 in the reference). */
+int os2d_pack_conv(int layer, int P, const float* w, const float* b, const float* bn_weight, const float* bn_bias,
+                   const float* bn_running_mean, const float* bn_running_var, float bn_eps, float* packed_w,
+                   float* packed_b, void* stream);
+
+/* ---- class feature map preparation: reference head.py:241-259 (resize_feature_maps_to_reference_size) and
+ * head.py:293 (normalize_feature_map_L2, eps 1e-5; skipped when normalize == 0) for ONE class map src[C,h,w]:
+ *   q15 [C,15,15]  resized + L2-normalised map (what Os2dHead.class_feature_maps holds)
+ *   qp  [C,256]    the same values as the correlation GEMM operand: row m = x_T*15 + y_T, rows 225..255 zero. */
+int os2d_class_prepare(const float* src, int C, int h, int w, int normalize, float* q15, float* qp, void* stream);
+
+/* ---- the head: reference head.py:308-435 (Os2dHead.forward, eval mode) for B classes on A image feature maps.
+ *   fm [A,C,H,W] raw backbone features; qp [B,C,256] from os2d_class_prepare; packed TransformNet from os2d_pack_conv
+ *   P = 6 (affine, head.py:98-100) or 4 (simplified affine, head.py:101-107); inverse = use_inverse_geom_model
+ *   stride / rec_field: backbone stride and receptive field (16 / 16 for ResNet-C4, feature_extractor.py:115-117)
+ *   outputs loc [A,B,4,H,W], cls [A,B,1,H,W], corners [A,B,8,H,W]  (cls_detached aliases cls in eval, head.py:400-402)
+ * The workspace may be smaller than os2d_head_workspace_bytes(A,B,...) reports: classes are then processed in
+ * chunks; it must hold at least os2d_head_workspace_bytes(A,1,...) bytes.  C must be a multiple of 4. */
+int os2d_head_workspace_bytes(int A, int B, int C, int H, int W, int P, size_t* bytes);
+int os2d_head_forward(const float* fm, const float* qp, const float* w1, const float* b1, const float* w2,
+                      const float* b2, const float* w3, const float* b3, int A, int B, int C, int H, int W, int P,
+                      int inverse, int stride, int rec_field, float* loc, float* cls, float* corners,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- per-stage entry points (same kernels, exposed for unit parity tests and profiling) ---- */
+/* sumsq [A,H*W] = sum_c fm^2 (head.py:339 norm).                                                              */
+int os2d_fm_sumsq(const float* fm, float* sumsq, int A, int C, int H, int W, void* stream);
+/* correlation head.py:339-350 + TransformNet input normalisation head.py:650:
+ *   corr [A*B,225,H*W] raw;  rnorm [A*B,226,PLANE] relu+L2 (eps 1e-6) in the zero-bordered plane layout,
+ *   PLANE = os2d_plane_floats(H,W).                                                                            */
+size_t os2d_plane_floats(int H, int W);
+int os2d_corr(const float* fm, const float* qp, const float* sumsq, float* corr, float* rnorm, int A, int B, int C,
+              int H, int W, void* stream);
+/* standalone TransformNet input normalisation head.py:650 (relu, L2 over 225 channels, eps 1e-6) of an arbitrary
+ * correlation tensor corr [NB,225,H*W] -> rnorm [NB,226,PLANE]; used by TransformationNet.forward.               */
+int os2d_corr_normalize(const float* corr, float* rnorm, int NB, int H, int W, void* stream);
+/* TransformNet layer head.py:619-629 (layer 1,2: conv+BN+ReLU, padded-plane in/out; layer 3: conv, compact
+ * [NB,P,H*W] out).  NB = A*B.                                                                                  */
+int os2d_transform_conv(int layer, const float* in, const float* packed_w, const float* packed_b, float* out,
+                        int NB, int P, int H, int W, void* stream);
+/* alignment epilogue head.py:81-153,184,371-435: params [NB,P,H*W] + corr [NB,225,H*W] -> loc/cls/corners
+ * laid out [NB,4|1|8,H*W].                                                                                      */
+int os2d_sample_decode(const float* corr, const float* params, int NB, int H, int W, int P, int inverse, int stride,
+                       int rec_field, float* loc, float* cls, float* corners, void* stream);
+
+/* ---- per-location box decode: reference os2d/modeling/box_coder.py:319-330 (torchvision BoxCoder.decode_single,
+ * weights (10,10,5,5), dw/dh clamp log(1000/16)) + clip to the level image (os2d/structures/bounding_box.py:261-265).
+ *   loc [NB,4,H*W] -> boxes [NB,H*W,4] xyxy; img_w <= 0 or img_h <= 0 skips the clip.                                                                  */
+int os2d_decode_boxes(const float* loc, int NB, int H, int W, int stride, int rec_field, float img_w, float img_h,
+                      float* boxes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OS2D_HIP_H */

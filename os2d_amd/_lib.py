@@ -1,0 +1,101 @@
+"""ctypes binding of libos2d_hip.so (C ABI declared in include/os2d_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or does not export the declared ABI the
+import of the compute path fails loudly (``Os2dLibraryError``).  Build it with ``python -m os2d_amd.build``
+(or ``__graft_entry__.build()``).
+"""
+import ctypes
+import os
+
+from .build import LIB_PATH
+
+ABI_VERSION = 1
+
+_c_float_p = ctypes.c_void_p   # device pointers travel as raw addresses (tensor.data_ptr())
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes): must list EVERY symbol of include/os2d_hip.h (tests/test_abi.py checks the header)
+SIGNATURES = {
+    "os2d_abi_version": (_i, []),
+    "os2d_last_error": (ctypes.c_char_p, []),
+    "os2d_packed_conv_floats": (_sz, [_i]),
+    "os2d_packed_bias_floats": (_sz, [_i]),
+    "os2d_pack_conv": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
+    "os2d_class_prepare": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "os2d_head_workspace_bytes": (_i, [_i, _i, _i, _i, _i, _i, ctypes.POINTER(_sz)]),
+    "os2d_head_forward": (_i, [_vp] * 8 + [_i] * 9 + [_vp, _vp, _vp, _vp, _sz, _vp]),
+    "os2d_fm_sumsq": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "os2d_plane_floats": (_sz, [_i, _i]),
+    "os2d_corr": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "os2d_corr_normalize": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "os2d_transform_conv": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "os2d_sample_decode": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "os2d_decode_boxes": (_i, [_vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp]),
+}
+
+
+class Os2dLibraryError(RuntimeError):
+    pass
+
+
+_LIB = None
+
+
+def lib_path():
+    return os.environ.get("OS2D_HIP_LIB", LIB_PATH)
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises Os2dLibraryError if it is not there."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise Os2dLibraryError(
+            "libos2d_hip.so not found at {} - the OS2D head has no CPU or PyTorch fallback; build the HIP "
+            "extension first: python -m os2d_amd.build".format(path))
+    # torch must be imported first so that the HIP runtime already mapped in the process (same soname,
+    # libamdhip64.so.7) is the one our library binds to: one runtime, shared streams and allocations.
+    import torch  # noqa: F401
+    try:
+        handle = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
+    except OSError as e:
+        raise Os2dLibraryError("cannot load {}: {}".format(path, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError:
+            raise Os2dLibraryError("{} does not export {} (stale build? run python -m os2d_amd.build --force)".format(path, name))
+        fn.restype = res
+        fn.argtypes = args
+    if handle.os2d_abi_version() != ABI_VERSION:
+        raise Os2dLibraryError("ABI version mismatch: library {} vs binding {}".format(handle.os2d_abi_version(), ABI_VERSION))
+    _LIB = handle
+    return _LIB
+
+
+def check(rc, what):
+    """Raise RuntimeError with the library's message if a call returned an error code."""
+    if rc != 0:
+        msg = load().os2d_last_error()
+        raise RuntimeError("{} failed (code {}): {}".format(what, rc, msg.decode("utf-8", "replace") if msg else "?"))
+
+
+def ptr(t):
+    """Device address of a contiguous float32 CUDA/HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    import torch
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype in (torch.float32, torch.uint8, torch.int32, torch.int64) and t.is_contiguous()):
+        raise ValueError("expected a contiguous device tensor, got {}".format(
+            (type(t).__name__, getattr(t, "device", None), getattr(t, "dtype", None))))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

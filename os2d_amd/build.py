@@ -1,0 +1,61 @@
+"""In-tree build of libos2d_hip.so for gfx950 with hipcc (no JIT cache: the .so travels with the tree).
+
+    python -m os2d_amd.build          # build if stale
+    python -m os2d_amd.build --force
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libos2d_hip.so")
+BUILD_DIR = os.path.join(HERE, "csrc", "build")
+SOURCES = ["abi.hip", "prep.hip", "corr_mfma.hip", "conv_mfma.hip", "sample_decode.hip", "nms.hip"]
+HEADERS = [os.path.join(CSRC, "os2d_common.h"), os.path.join(HERE, "..", "include", "os2d_hip.h")]
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=True):
+    """Compile every HIP translation unit for gfx950 and link libos2d_hip.so. Returns the library path."""
+    hipcc = _hipcc()
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    objs = []
+    for s in srcs:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(BUILD_DIR, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + HEADERS):
+            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print("[os2d_amd.build]", " ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    if force or _stale(LIB_PATH, objs):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        if verbose:
+            print("[os2d_amd.build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,238 @@
+// C ABI of libos2d_hip.so (include/os2d_hip.h): argument checking, workspace carving, stage sequencing.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/os2d_hip.h"
+#include "os2d_common.h"
+
+namespace {
+thread_local char g_err[512] = {0};
+
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+struct ConvShape {
+  int cout, cin, ks, mt;
+};
+bool conv_shape(int layer, int P, ConvShape* s) {
+  switch (layer) {
+    case 1: *s = {128, OS2D_K, 7, 128}; return true;
+    case 2: *s = {64, 128, 5, 64}; return true;
+    case 3: *s = {P, 64, 5, 32}; return true;
+    default: return false;
+  }
+}
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// workspace carve for a chunk of Bc classes
+struct Carve {
+  size_t sumsq, corr, rpad, h1, h2, params, total;
+};
+Carve carve(int A, int Bc, int H, int W, int P) {
+  const size_t HW = (size_t)H * W, PL = os2d_plane(H, W), NB = (size_t)A * Bc;
+  Carve c;
+  size_t off = 0;
+  auto take = [&](size_t floats) {
+    size_t o = off;
+    off = align_up(off + floats * sizeof(float), 256);
+    return o;
+  };
+  c.sumsq = take((size_t)A * HW);
+  c.corr = take(NB * OS2D_K * HW);
+  c.rpad = take(NB * OS2D_KP * PL);
+  c.h1 = take(NB * 128 * PL);
+  c.h2 = take(NB * 64 * PL);
+  c.params = take(NB * P * HW);
+  c.total = off;
+  return c;
+}
+
+bool head_args_ok(int A, int B, int C, int H, int W, int P) {
+  if (A < 1 || B < 1 || C < 4 || (C & 3) || H < 1 || W < 1 || (P != 6 && P != 4)) {
+    os2d_set_error("bad head shape A=%d B=%d C=%d H=%d W=%d P=%d (need A,B,H,W>=1, C%%4==0, P in {6,4})", A, B, C, H,
+                   W, P);
+    return false;
+  }
+  return true;
+}
+}  // namespace
+
+void os2d_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" {
+
+int os2d_abi_version(void) { return OS2D_ABI_VERSION; }
+const char* os2d_last_error(void) { return g_err; }
+
+size_t os2d_packed_conv_floats(int layer) {
+  ConvShape s;
+  if (!conv_shape(layer, 6, &s)) return 0;
+  return (size_t)((s.cin + 1) / 2) * s.ks * s.ks * 2 * s.mt;
+}
+size_t os2d_packed_bias_floats(int layer) {
+  ConvShape s;
+  if (!conv_shape(layer, 6, &s)) return 0;
+  return (size_t)s.mt;
+}
+
+int os2d_pack_conv(int layer, int P, const float* w, const float* b, const float* bn_weight, const float* bn_bias,
+                   const float* bn_running_mean, const float* bn_running_var, float bn_eps, float* packed_w,
+                   float* packed_b, void* stream) {
+  ConvShape s;
+  if (!conv_shape(layer, P, &s) || (layer == 3 && P != 6 && P != 4)) {
+    os2d_set_error("os2d_pack_conv: bad layer %d / P %d", layer, P);
+    return -1;
+  }
+  if (!w || !b || !packed_w || !packed_b) {
+    os2d_set_error("os2d_pack_conv: null pointer");
+    return -1;
+  }
+  const bool has_bn = bn_weight || bn_bias || bn_running_mean || bn_running_var;
+  if (has_bn && !(bn_weight && bn_bias && bn_running_mean && bn_running_var)) {
+    os2d_set_error("os2d_pack_conv: BatchNorm needs all four of weight/bias/running_mean/running_var");
+    return -1;
+  }
+  return os2d_launch_pack_conv(w, b, bn_weight, bn_bias, bn_running_mean, bn_running_var, bn_eps, s.cout, s.cin, s.ks,
+                               s.mt, packed_w, packed_b, S(stream));
+}
+
+int os2d_class_prepare(const float* src, int C, int h, int w, int normalize, float* q15, float* qp, void* stream) {
+  if (!src || !q15 || !qp || C < 1 || h < 1 || w < 1) {
+    os2d_set_error("os2d_class_prepare: bad arguments (C=%d h=%d w=%d)", C, h, w);
+    return -1;
+  }
+  return os2d_launch_class_prepare(src, C, h, w, normalize, q15, qp, S(stream));
+}
+
+size_t os2d_plane_floats(int H, int W) { return (size_t)os2d_plane(H, W); }
+
+int os2d_head_workspace_bytes(int A, int B, int C, int H, int W, int P, size_t* bytes) {
+  if (!bytes) {
+    os2d_set_error("os2d_head_workspace_bytes: null output");
+    return -1;
+  }
+  if (!head_args_ok(A, B, C, H, W, P)) return -1;
+  *bytes = carve(A, B, H, W, P).total;
+  return 0;
+}
+
+int os2d_fm_sumsq(const float* fm, float* sumsq, int A, int C, int H, int W, void* stream) {
+  if (!fm || !sumsq || A < 1 || C < 1 || H < 1 || W < 1) {
+    os2d_set_error("os2d_fm_sumsq: bad arguments");
+    return -1;
+  }
+  return os2d_launch_fm_sumsq(fm, sumsq, A, C, H * W, S(stream));
+}
+
+int os2d_corr(const float* fm, const float* qp, const float* sumsq, float* corr, float* rnorm, int A, int B, int C,
+              int H, int W, void* stream) {
+  if (!fm || !qp || !sumsq || !corr || !rnorm) {
+    os2d_set_error("os2d_corr: null pointer");
+    return -1;
+  }
+  if (!head_args_ok(A, B, C, H, W, 6)) return -1;
+  int rc = os2d_launch_border_zero(rnorm, A * B * OS2D_KP, H, W, S(stream));
+  if (rc) return rc;
+  return os2d_launch_corr(fm, qp, sumsq, corr, rnorm, A, B, C, H, W, S(stream));
+}
+
+int os2d_corr_normalize(const float* corr, float* rnorm, int NB, int H, int W, void* stream) {
+  if (!corr || !rnorm || NB < 1 || H < 1 || W < 1) {
+    os2d_set_error("os2d_corr_normalize: bad arguments");
+    return -1;
+  }
+  return os2d_launch_corr_normalize(corr, rnorm, NB, H, W, S(stream));
+}
+
+int os2d_transform_conv(int layer, const float* in, const float* packed_w, const float* packed_b, float* out, int NB,
+                        int P, int H, int W, void* stream) {
+  if (!in || !packed_w || !packed_b || !out || NB < 1 || H < 1 || W < 1 || (layer == 3 && P != 6 && P != 4)) {
+    os2d_set_error("os2d_transform_conv: bad arguments (layer=%d NB=%d P=%d)", layer, NB, P);
+    return -1;
+  }
+  return os2d_launch_conv(layer, in, packed_w, packed_b, out, NB, P, H, W, S(stream));
+}
+
+int os2d_sample_decode(const float* corr, const float* params, int NB, int H, int W, int P, int inverse, int stride,
+                       int rec_field, float* loc, float* cls, float* corners, void* stream) {
+  if (!corr || !params || !loc || !cls || !corners || NB < 1 || H < 1 || W < 1 || (P != 6 && P != 4)) {
+    os2d_set_error("os2d_sample_decode: bad arguments");
+    return -1;
+  }
+  return os2d_launch_sample_decode(corr, params, NB, H, W, P, inverse, stride, rec_field, NB, NB, 0, loc, cls,
+                                   corners, S(stream));
+}
+
+int os2d_decode_boxes(const float* loc, int NB, int H, int W, int stride, int rec_field, float img_w, float img_h,
+                      float* boxes, void* stream) {
+  if (!loc || !boxes || NB < 1 || H < 1 || W < 1) {
+    os2d_set_error("os2d_decode_boxes: bad arguments");
+    return -1;
+  }
+  return os2d_launch_decode_boxes(loc, NB, H, W, stride, rec_field, img_w, img_h, boxes, S(stream));
+}
+
+int os2d_head_forward(const float* fm, const float* qp, const float* w1, const float* b1, const float* w2,
+                      const float* b2, const float* w3, const float* b3, int A, int B, int C, int H, int W, int P,
+                      int inverse, int stride, int rec_field, float* loc, float* cls, float* corners, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  if (!fm || !qp || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !loc || !cls || !corners || !workspace) {
+    os2d_set_error("os2d_head_forward: null pointer");
+    return -1;
+  }
+  if (!head_args_ok(A, B, C, H, W, P)) return -1;
+  if (stride < 1 || rec_field < 1) {
+    os2d_set_error("os2d_head_forward: bad stride/rec_field %d/%d", stride, rec_field);
+    return -1;
+  }
+  if (reinterpret_cast<uintptr_t>(workspace) & 255) {
+    os2d_set_error("os2d_head_forward: workspace must be 256-byte aligned");
+    return -1;
+  }
+  // largest class chunk that fits the workspace (footprint is affine in Bc)
+  const size_t one = carve(A, 1, H, W, P).total;
+  if (workspace_bytes < one) {
+    os2d_set_error("os2d_head_forward: workspace too small (%zu B, need >= %zu B for one class)", workspace_bytes, one);
+    return -2;
+  }
+  int Bc = B;
+  while (Bc > 1 && carve(A, Bc, H, W, P).total > workspace_bytes) {
+    const size_t two = carve(A, 2, H, W, P).total;
+    const size_t per = two - one;
+    int guess = per ? (int)((workspace_bytes - one) / per) + 1 : 1;
+    if (guess >= Bc) guess = Bc - 1;
+    if (guess < 1) guess = 1;
+    Bc = guess;
+  }
+  hipStream_t st = S(stream);
+  char* ws = static_cast<char*>(workspace);
+  const Carve c = carve(A, Bc, H, W, P);
+  float* sumsq = reinterpret_cast<float*>(ws + c.sumsq);
+  float* corr = reinterpret_cast<float*>(ws + c.corr);
+  float* rpad = reinterpret_cast<float*>(ws + c.rpad);
+  float* h1 = reinterpret_cast<float*>(ws + c.h1);
+  float* h2 = reinterpret_cast<float*>(ws + c.h2);
+  float* params = reinterpret_cast<float*>(ws + c.params);
+
+  int rc = os2d_launch_fm_sumsq(fm, sumsq, A, C, H * W, st);
+  if (rc) return rc;
+  for (int b0 = 0; b0 < B; b0 += Bc) {
+    const int bc = (B - b0 < Bc) ? (B - b0) : Bc;
+    const int NB = A * bc;
+    if ((rc = os2d_launch_border_zero(rpad, NB * OS2D_KP, H, W, st))) return rc;
+    if ((rc = os2d_launch_corr(fm, qp + (size_t)b0 * C * OS2D_QROWS, sumsq, corr, rpad, A, bc, C, H, W, st))) return rc;
+    if ((rc = os2d_launch_conv(1, rpad, w1, b1, h1, NB, P, H, W, st))) return rc;
+    if ((rc = os2d_launch_conv(2, h1, w2, b2, h2, NB, P, H, W, st))) return rc;
+    if ((rc = os2d_launch_conv(3, h2, w3, b3, params, NB, P, H, W, st))) return rc;
+    if ((rc = os2d_launch_sample_decode(corr, params, NB, H, W, P, inverse, stride, rec_field, bc, B, b0, loc, cls,
+                                        corners, st)))
+      return rc;
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,200 @@
+// Small HBM-bound helper kernels around the MFMA kernels (gfx950):
+//   fm_sumsq       per-position sum of squares over channels of the image feature map (head.py:339)
+//   border_zero    zero the border cells (and the 226th pad channel) of the normalised-correlation planes
+//   class_prepare  class feature map -> 15x15 bilinear resize + L2 normalisation + GEMM packing
+//                  (head.py:241-259, :293; the per-class constants an Os2dHead holds)
+//   pack_conv      fold eval-mode BatchNorm into a convolution and repack it for conv_mfma.hip
+#include "os2d_common.h"
+
+namespace {
+
+// ---- fm_sumsq: grid (ceil(HW/64), CSPLIT); block 256 = 64 positions x 4 channel lanes; atomicAdd partials
+constexpr int CSPLIT = 16;
+
+__global__ __launch_bounds__(256) void fm_sumsq_kernel(const float* __restrict__ fm, float* __restrict__ sumsq, int A,
+                                                       int C, int HW) {
+  __shared__ float red[4][64];
+  const int col = threadIdx.x & 63, cl = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + col;
+  const int cper = (C + CSPLIT - 1) / CSPLIT;
+  const int c0 = blockIdx.y * cper, c1 = min(C, c0 + cper);
+  for (int a = 0; a < A; ++a) {
+    float s = 0.f;
+    if (n < HW)
+      for (int c = c0 + cl; c < c1; c += 4) {
+        const float v = fm[((size_t)a * C + c) * HW + n];
+        s += v * v;
+      }
+    red[cl][col] = s;
+    __syncthreads();
+    if (cl == 0 && n < HW) atomicAdd(&sumsq[(size_t)a * HW + n], red[0][col] + red[1][col] + red[2][col] + red[3][col]);
+    __syncthreads();
+  }
+}
+
+// ---- border_zero: one block per plane
+__global__ __launch_bounds__(256) void border_zero_kernel(float* __restrict__ rpad, int H, int W, int PLANE) {
+  const int Ws = W + 2 * OS2D_PAD, Hp = H + 2 * OS2D_PAD;
+  const int ch = blockIdx.x % OS2D_KP;
+  float* p = rpad + (size_t)blockIdx.x * PLANE;
+  const bool whole = ch >= OS2D_K;
+  for (int i = threadIdx.x; i < Hp * Ws; i += 256) {
+    const int hr = i / Ws, wc = i - hr * Ws;
+    const bool interior = hr >= OS2D_PAD && hr < H + OS2D_PAD && wc >= OS2D_PAD && wc < W + OS2D_PAD;
+    if (whole || !interior) p[i] = 0.f;
+  }
+}
+
+// ---- corr_normalize: standalone relu -> L2 over the 225 channels (head.py:650) of an arbitrary correlation
+// tensor [NB][225][HW] into the padded-plane layout (the fused path does this in the GEMM epilogue)
+__global__ __launch_bounds__(256) void corr_normalize_kernel(const float* __restrict__ corr, float* __restrict__ rpad,
+                                                             int H, int W, int PLANE) {
+  const int HW = H * W, Ws = W + 2 * OS2D_PAD;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int nb = blockIdx.y;
+  if (n >= HW) return;
+  const float* c = corr + (size_t)nb * OS2D_K * HW + n;
+  float s = 0.f;
+  for (int k = 0; k < OS2D_K; ++k) {
+    const float v = fmaxf(c[(size_t)k * HW], 0.f);
+    s += v * v;
+  }
+  const float inv = 1.0f / (sqrtf(s) + 1e-6f);
+  const int h = n / W, w = n - h * W;
+  float* o = rpad + (size_t)nb * OS2D_KP * PLANE + (size_t)(h + OS2D_PAD) * Ws + (w + OS2D_PAD);
+  for (int k = 0; k < OS2D_K; ++k) o[(size_t)k * PLANE] = fmaxf(c[(size_t)k * HW], 0.f) * inv;
+}
+
+// ---- class_prepare: grid 225 (one block per template cell), block 256 loops over channels
+__global__ __launch_bounds__(256) void class_prepare_kernel(const float* __restrict__ src, int C, int h, int w, int normalize,
+                                                            float* __restrict__ q15, float* __restrict__ qp) {
+  __shared__ float red[4];
+  const int cell = blockIdx.x;  // i*15 + j  (row i, col j)
+  const int i = cell / OS2D_T, j = cell - i * OS2D_T;
+  // sampling position of the identity grid, as F.affine_grid(align_corners=True) + F.grid_sample build it
+  const float step = 2.0f / (OS2D_T - 1);
+  const float xu = (j < (OS2D_T + 1) / 2) ? (-1.0f + step * j) : (1.0f - step * (OS2D_T - 1 - j));
+  const float yu = (i < (OS2D_T + 1) / 2) ? (-1.0f + step * i) : (1.0f - step * (OS2D_T - 1 - i));
+  const float ix = ((xu + 1.0f) * 0.5f) * (float)(w - 1);
+  const float iy = ((yu + 1.0f) * 0.5f) * (float)(h - 1);
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  const float ax = ix - fx0, ay = iy - fy0;
+  // zero padding: corners outside the map contribute 0 (their weight is 0 anyway on the identity grid)
+  const bool x0in = x0 >= 0 && x0 < w, x1in = x0 + 1 >= 0 && x0 + 1 < w;
+  const bool y0in = y0 >= 0 && y0 < h, y1in = y0 + 1 >= 0 && y0 + 1 < h;
+  auto sample = [&](int c) -> float {
+    const float* p = src + (size_t)c * h * w;
+    const float v00 = (x0in && y0in) ? p[y0 * w + x0] : 0.f;
+    const float v01 = (x1in && y0in) ? p[y0 * w + x0 + 1] : 0.f;
+    const float v10 = (x0in && y1in) ? p[(y0 + 1) * w + x0] : 0.f;
+    const float v11 = (x1in && y1in) ? p[(y0 + 1) * w + x0 + 1] : 0.f;
+    return v00 * (1.f - ax) * (1.f - ay) + v01 * ax * (1.f - ay) + v10 * (1.f - ax) * ay + v11 * ax * ay;
+  };
+  float s = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float v = sample(c);
+    s += v * v;
+  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float inv = normalize ? 1.0f / (sqrtf(red[0] + red[1] + red[2] + red[3]) + 1e-5f) : 1.0f;  // head.py:293
+  const int m = j * OS2D_T + i;  // x-major correlation channel (head.py:342-344)
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float v = sample(c) * inv;
+    q15[(size_t)c * OS2D_K + cell] = v;
+    qp[(size_t)c * OS2D_QROWS + m] = v;
+  }
+  // zero the 31 pad rows of the GEMM operand (done by the block of cell 0)
+  if (cell == 0)
+    for (int t = threadIdx.x; t < C * (OS2D_QROWS - OS2D_K); t += 256) {
+      const int c = t / (OS2D_QROWS - OS2D_K), r = t - c * (OS2D_QROWS - OS2D_K);
+      qp[(size_t)c * OS2D_QROWS + OS2D_K + r] = 0.f;
+    }
+}
+
+// ---- pack_conv: wp[cp][tap][half][o] = w[o][2cp+half][tap] * bn_scale[o]; bp[o] = folded bias
+__global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict__ w, const float* __restrict__ b,
+                                                        const float* __restrict__ bn_w, const float* __restrict__ bn_b,
+                                                        const float* __restrict__ bn_mean,
+                                                        const float* __restrict__ bn_var, float bn_eps, int Cout,
+                                                        int Cin, int KS, int MT, float* __restrict__ wp,
+                                                        float* __restrict__ bp) {
+  const int taps = KS * KS;
+  const int CinP = (Cin + 1) & ~1;
+  const size_t total = (size_t)(CinP / 2) * taps * 2 * MT;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int o = idx % MT;
+    const int half = (idx / MT) % 2;
+    const int tap = (idx / (2 * MT)) % taps;
+    const int cp = idx / ((size_t)2 * MT * taps);
+    const int c = 2 * cp + half;
+    float v = 0.f;
+    if (o < Cout && c < Cin) {
+      const float s = bn_w ? bn_w[o] / sqrtf(bn_var[o] + bn_eps) : 1.0f;
+      v = w[((size_t)o * Cin + c) * taps + tap] * s;
+    }
+    wp[idx] = v;
+  }
+  if (blockIdx.x == 0)
+    for (int o = threadIdx.x; o < MT; o += 256) {
+      float v = 0.f;
+      if (o < Cout) {
+        if (bn_w) {
+          const float s = bn_w[o] / sqrtf(bn_var[o] + bn_eps);
+          v = (b[o] - bn_mean[o]) * s + bn_b[o];
+        } else {
+          v = b[o];
+        }
+      }
+      bp[o] = v;
+    }
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    os2d_set_error("%s launch: %s", what, hipGetErrorString(e));
+    return -4;
+  }
+  return 0;
+}
+
+}  // namespace
+
+int os2d_launch_fm_sumsq(const float* fm, float* sumsq, int A, int C, int HW, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(sumsq, 0, (size_t)A * HW * sizeof(float), stream);
+  if (e != hipSuccess) {
+    os2d_set_error("memset(sumsq): %s", hipGetErrorString(e));
+    return -4;
+  }
+  hipLaunchKernelGGL(fm_sumsq_kernel, dim3((HW + 63) / 64, CSPLIT), dim3(256), 0, stream, fm, sumsq, A, C, HW);
+  return check_launch("fm_sumsq");
+}
+
+int os2d_launch_border_zero(float* rpad, int planes_total, int H, int W, hipStream_t stream) {
+  hipLaunchKernelGGL(border_zero_kernel, dim3(planes_total), dim3(256), 0, stream, rpad, H, W, os2d_plane(H, W));
+  return check_launch("border_zero");
+}
+
+int os2d_launch_corr_normalize(const float* corr, float* rpad, int NB, int H, int W, hipStream_t stream) {
+  int rc = os2d_launch_border_zero(rpad, NB * OS2D_KP, H, W, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(corr_normalize_kernel, dim3((H * W + 255) / 256, NB), dim3(256), 0, stream, corr, rpad, H, W,
+                     os2d_plane(H, W));
+  return check_launch("corr_normalize");
+}
+
+int os2d_launch_class_prepare(const float* src, int C, int h, int w, int normalize, float* q15, float* qp, hipStream_t stream) {
+  hipLaunchKernelGGL(class_prepare_kernel, dim3(OS2D_K), dim3(256), 0, stream, src, C, h, w, normalize, q15, qp);
+  return check_launch("class_prepare");
+}
+
+int os2d_launch_pack_conv(const float* w, const float* b, const float* bn_w, const float* bn_b, const float* bn_mean,
+                          const float* bn_var, float bn_eps, int Cout, int Cin, int KS, int MT, float* wp, float* bp,
+                          hipStream_t stream) {
+  hipLaunchKernelGGL(pack_conv_kernel, dim3(512), dim3(256), 0, stream, w, b, bn_w, bn_b, bn_mean, bn_var, bn_eps,
+                     Cout, Cin, KS, MT, wp, bp);
+  return check_launch("pack_conv");
+}

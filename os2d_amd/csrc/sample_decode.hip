@@ -1,0 +1,196 @@
+// Fused alignment epilogue of the OS2D head (gfx950): per (class, location) it turns the TransformNet
+// parameters into the affine map, resamples + pools the correlation tensor along the transformed 15x15
+// template grid, and encodes the transformed template box.  Replaces, without materialising any
+// [H,W,15,15,2] grid tensor:
+//   reference os2d/modeling/head.py:81-153   (theta assembly, optional inverse)
+//                                  :184      (F.affine_grid, align_corners=True)
+//                                  :371-384  (local -> feature-map coordinates, clamp)
+//                                  :439-520  (resample_of_correlation_map_fast + mask pooling; fp64 there,
+//                                             fp32 here - agrees to ~1e-7, see tests)
+//                                  :405-435  (image-level points, min/max box, corners, build_loc_targets)
+//   reference os2d/modeling/box_coder.py:306-317, os2d/structures/bounding_box.py:267-277 (encode, min size)
+// plus the per-location decode that follows the head (box_coder.py:319-330 + clip, bounding_box.py:261-265).
+//
+// One thread per location, consecutive lanes = consecutive w: the 4 bilinear taps of neighbouring lanes
+// fall in the same or adjacent cache lines of one correlation channel (the transforms vary smoothly), so
+// each of the 121x4 gathers is a near-coalesced L2 read of the 4.3 MB per-class correlation block.
+#include "os2d_common.h"
+
+namespace {
+
+constexpr int POOL_LO = 2, POOL_HI = OS2D_T - 2;  // head.py:280,296-302: pool_border_width = 2
+
+__global__ __launch_bounds__(256) void sample_decode_kernel(const float* __restrict__ corr,    // [NB][225][HW]
+                                                            const float* __restrict__ params,  // [NB][P][HW]
+                                                            int H, int W, int P, int inverse, float stride,
+                                                            float half_box, int Bc, int Btot, int b0,
+                                                            float* __restrict__ loc, float* __restrict__ cls,
+                                                            float* __restrict__ corners) {
+  const int HW = H * W;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int nb = blockIdx.y;  // index inside the class chunk: a*Bc + b_local
+  if (n >= HW) return;
+  // output slot in the full [A,Btot,...] tensors
+  const int img = nb / Bc;
+  const size_t ob = (size_t)img * Btot + b0 + (nb - img * Bc);
+  const int h = n / W, w = n - h * W;
+
+  const float* pp = params + (size_t)nb * P * HW + n;
+  float t00, t01, t02, t10, t11, t12;
+  if (P == 6) {  // head.py:98-100
+    t00 = pp[0];
+    t01 = pp[HW];
+    t02 = pp[2 * (size_t)HW];
+    t10 = pp[3 * (size_t)HW];
+    t11 = pp[4 * (size_t)HW];
+    t12 = pp[5 * (size_t)HW];
+  } else {  // head.py:101-107: scale + translation only
+    t00 = pp[0];
+    t01 = 0.f;
+    t02 = pp[HW];
+    t10 = 0.f;
+    t11 = pp[2 * (size_t)HW];
+    t12 = pp[3 * (size_t)HW];
+  }
+  if (inverse) {  // head.py:111-151: inverse of [[A t],[0 0 1]] = [[A^-1, -A^-1 t],[0 0 1]]
+    float det = t00 * t11 - t01 * t10;
+    float hom = 1.0f;
+    if (det == 0.0f) {
+      // torch.inverse raises on an exactly singular matrix and the reference then retries the whole chunk with
+      // +1e-5 on the diagonal (head.py:125-134).  We regularise only the singular matrix itself.
+      t00 += 1e-5f;
+      t11 += 1e-5f;
+      hom = 1.0f + 1e-5f;
+      det = t00 * t11 - t01 * t10;
+    }
+    const float r = 1.0f / det;
+    const float i00 = t11 * r, i01 = -t01 * r, i10 = -t10 * r, i11 = t00 * r;
+    const float i02 = -(i00 * t02 + i01 * t12) / hom;
+    const float i12 = -(i10 * t02 + i11 * t12) / hom;
+    t00 = i00;
+    t01 = i01;
+    t02 = i02;
+    t10 = i10;
+    t11 = i11;
+    t12 = i12;
+  }
+
+  // ---- resample + pool: 11x11 inner template points, channel = j*15 + i (x-major)
+  const float step = 2.0f / (OS2D_T - 1);
+  const float half_t = 0.5f * OS2D_T;  // feature-map level anchor: box 15, stride 1, centre (w+.5, h+.5)
+  const float cx = (float)w + 0.5f, cy = (float)h + 0.5f;
+  const float wmax = (float)(W - 1), hmax = (float)(H - 1);
+  const float* cbase = corr + (size_t)nb * OS2D_K * HW;
+  float sum = 0.f;
+  for (int j = POOL_LO; j < POOL_HI; ++j) {
+    const float xj = -1.0f + step * (float)j;
+#pragma unroll
+    for (int i = POOL_LO; i < POOL_HI; ++i) {
+      const float yi = -1.0f + step * (float)i;
+      const float gx = t00 * xj + t01 * yi + t02;
+      const float gy = t10 * xj + t11 * yi + t12;
+      const float X = fminf(fmaxf(gx * half_t + cx, 0.f), wmax);
+      const float Y = fminf(fmaxf(gy * half_t + cy, 0.f), hmax);
+      const float fx0 = floorf(X), fy0 = floorf(Y);
+      const float ax = X - fx0, ay = Y - fy0;
+      const int x0 = (int)fx0, y0 = (int)fy0;
+      const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+      const float* c = cbase + (size_t)(j * OS2D_T + i) * HW;
+      const float v00 = c[y0 * W + x0], v01 = c[y0 * W + x1];
+      const float v10 = c[y1 * W + x0], v11 = c[y1 * W + x1];
+      sum += (v00 * (1.f - ax) + v01 * ax) * (1.f - ay) + (v10 * (1.f - ax) + v11 * ax) * ay;
+    }
+  }
+  cls[ob * HW + n] = sum * (1.0f / ((POOL_HI - POOL_LO) * (POOL_HI - POOL_LO)));
+
+  // ---- box of the transformed template in image coordinates (the 4 corners bound the affine image)
+  const float ecx = stride * cx, ecy = stride * cy;
+  float U[4], V[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float yi = (k & 2) ? 1.0f : -1.0f;  // template row 0 / 14
+    const float xj = (k & 1) ? 1.0f : -1.0f;  // template col 0 / 14
+    U[k] = (t00 * xj + t01 * yi + t02) * half_box + ecx;
+    V[k] = (t10 * xj + t11 * yi + t12) * half_box + ecy;
+    corners[(ob * 8 + 2 * k) * HW + n] = U[k];
+    corners[(ob * 8 + 2 * k + 1) * HW + n] = V[k];
+  }
+  float x1 = fminf(fminf(U[0], U[1]), fminf(U[2], U[3]));
+  float x2 = fmaxf(fmaxf(U[0], U[1]), fmaxf(U[2], U[3]));
+  float y1 = fminf(fminf(V[0], V[1]), fminf(V[2], V[3]));
+  float y2 = fmaxf(fmaxf(V[0], V[1]), fmaxf(V[2], V[3]));
+  if (x1 + 1.0f > x2) x2 = x1 + 1.0f;  // bounding_box.py:267-277
+  if (y1 + 1.0f > y2) y2 = y1 + 1.0f;
+  const float size = 2.0f * half_box;
+  const float bw = x2 - x1, bh = y2 - y1;
+  const float gcx = x1 + 0.5f * bw, gcy = y1 + 0.5f * bh;
+  // anchors as the reference builds them: xyxy = centre -+ size/2, then centre = x1 + 0.5*w
+  const float ax1 = ecx - half_box, ay1 = ecy - half_box;
+  const float aw = (ecx + half_box) - ax1, ah = (ecy + half_box) - ay1;
+  const float acx = ax1 + 0.5f * aw, acy = ay1 + 0.5f * ah;
+  (void)size;
+  loc[(ob * 4 + 0) * HW + n] = 10.0f * (gcx - acx) / aw;
+  loc[(ob * 4 + 1) * HW + n] = 10.0f * (gcy - acy) / ah;
+  loc[(ob * 4 + 2) * HW + n] = 5.0f * logf(bw / aw);
+  loc[(ob * 4 + 3) * HW + n] = 5.0f * logf(bh / ah);
+}
+
+// per-location decode: loc [NB][4][HW] -> boxes [NB][HW][4] xyxy clipped to the level image
+__global__ __launch_bounds__(256) void decode_boxes_kernel(const float* __restrict__ loc, int H, int W, float stride,
+                                                           float half_box, float img_w, float img_h,
+                                                           float* __restrict__ boxes) {
+  const int HW = H * W;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int nb = blockIdx.y;
+  if (n >= HW) return;
+  const int h = n / W, w = n - h * W;
+  const float ecx = stride * ((float)w + 0.5f), ecy = stride * ((float)h + 0.5f);
+  const float ax1 = ecx - half_box, ay1 = ecy - half_box;
+  const float aw = (ecx + half_box) - ax1, ah = (ecy + half_box) - ay1;
+  const float acx = ax1 + 0.5f * aw, acy = ay1 + 0.5f * ah;
+  const float* l = loc + (size_t)nb * 4 * HW + n;
+  const float clipv = 4.135166556742356f;  // log(1000/16): torchvision BoxCoder.bbox_xform_clip
+  const float dx = l[0] / 10.0f, dy = l[HW] / 10.0f;
+  const float dw = fminf(l[2 * (size_t)HW] / 5.0f, clipv), dh = fminf(l[3 * (size_t)HW] / 5.0f, clipv);
+  const float pcx = dx * aw + acx, pcy = dy * ah + acy;
+  const float pw = expf(dw) * aw, ph = expf(dh) * ah;
+  float4 o = make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph);
+  if (img_w > 0.f && img_h > 0.f) {  // clip_boxes_to_image; a non-positive size means "leave unclipped"
+    o.x = fminf(fmaxf(o.x, 0.f), img_w);
+    o.y = fminf(fmaxf(o.y, 0.f), img_h);
+    o.z = fminf(fmaxf(o.z, 0.f), img_w);
+    o.w = fminf(fmaxf(o.w, 0.f), img_h);
+  }
+  reinterpret_cast<float4*>(boxes)[(size_t)nb * HW + n] = o;
+}
+
+}  // namespace
+
+int os2d_launch_sample_decode(const float* corr, const float* params, int NB, int H, int W, int P, int inverse,
+                              int stride, int rec_field, int Bc, int Btot, int b0, float* loc, float* cls,
+                              float* corners, hipStream_t stream) {
+  const float half_box = 0.5f * (float)(stride * (OS2D_T - 1) + rec_field);  // head.py:236-237: 16*14+16 = 240
+  dim3 grid((H * W + 255) / 256, NB);
+  hipLaunchKernelGGL(sample_decode_kernel, grid, dim3(256), 0, stream, corr, params, H, W, P, inverse, (float)stride,
+                     half_box, Bc, Btot, b0, loc, cls, corners);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    os2d_set_error("sample_decode launch: %s", hipGetErrorString(e));
+    return -4;
+  }
+  return 0;
+}
+
+int os2d_launch_decode_boxes(const float* loc, int NB, int H, int W, int stride, int rec_field, float img_w,
+                             float img_h, float* boxes, hipStream_t stream) {
+  const float half_box = 0.5f * (float)(stride * (OS2D_T - 1) + rec_field);
+  dim3 grid((H * W + 255) / 256, NB);
+  hipLaunchKernelGGL(decode_boxes_kernel, grid, dim3(256), 0, stream, loc, H, W, (float)stride, half_box, img_w,
+                     img_h, boxes);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    os2d_set_error("decode_boxes launch: %s", hipGetErrorString(e));
+    return -4;
+  }
+  return 0;
+}

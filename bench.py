@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X OS2D head: query-image-pairs/s (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--classes B_per_gpu] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = the whole head (correlation -> TransformNet -> resample/pool -> box encode) for ONE 1280x960 image
+feature map [1,1024,60,80] against B classes per GPU (default 64 = BASELINE.json configs[1]); with N GPUs the classes
+are sharded (weak scaling: N*B classes in total) and every step ends with the RCCL all-gather of the per-class
+output maps, exactly as ``os2d_amd.parallel.ClassShardedHead`` does it.  Inputs are synthetic (post-ReLU Gaussian
+features, perturbed TransformNet) and resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0 with the driver's contract fields plus
+  roofline     - the dominant kernel (conv 7x7 225->128 MFMA implicit GEMM): algorithmic FLOPs per launch divided by its
+                 mean launch duration, measured with HIP events recorded on the launch stream inside the timed steps
+  stages_ms    - mean duration of every stage of the step (same events)
+  cpu_baseline - the oracle (torch-CPU restatement of the reference head, driven one class at a time like the
+                 reference's evaluation) timed on the host cores, rank 0 / N=1 only, on a bounded class sample.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+C_FEAT, H_FM, W_FM = 1024, 60, 80          # ResNet50-C4 features of a 1280x960 input
+FLOP_PER_LOC = {"corr": 2 * 225 * 1024, "conv1": 2 * 128 * 225 * 49, "conv2": 2 * 64 * 128 * 25}
+PEAK_F32_MFMA = 157.3e12                   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+STAGES = ("corr", "conv1", "conv2", "conv3", "sample")
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--classes", type=int, default=64, help="classes per GPU")
+    ap.add_argument("--variant", default="v2", choices=["v2", "v1"], help="v2: affine+inverse (P=6); v1: simplified (P=4)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(fm_cpu, class_fms_cpu, state, inverse, budget_s):
+    """Time the oracle the way the reference evaluates (one head per class, looped) on the host cores."""
+    from oracle import head_oracle as O
+    ncores = os.cpu_count() or 1
+    threads = max(1, min(ncores, 64))      # torch intra-op scaling saturates well below 256 hw threads
+    torch.set_num_threads(threads)
+    q = O.prepare_class_maps(class_fms_cpu)
+    with torch.no_grad():
+        O.head_forward(fm_cpu, q[:1], state, inverse)        # warm-up
+        done, t0 = 0, time.perf_counter()
+        while done < q.size(0) and (time.perf_counter() - t0) < budget_s:
+            O.head_forward(fm_cpu, q[done:done + 1], state, inverse)
+            done += 1
+        dt = time.perf_counter() - t0
+    return {"value": round(done / dt, 3), "unit": "query-image-pairs/s", "cores": threads, "kind": "port",
+            "sample": "{} classes looped one at a time (reference evaluate.py:323-331 call pattern) on one "
+                      "60x80x1024 feature map, {:.1f} s, torch CPU fp32, {} threads of {} hw threads".format(done, dt, threads, ncores)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus {} needs a torchrun launch with one process per GPU".format(args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the OS2D head has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from os2d_amd import _lib
+    from os2d_amd.modeling.head import build_os2d_head_creator
+    from os2d_amd.parallel import ClassShardedHead
+    from os2d_amd.structures.feature_map import FeatureMapSize
+    from os2d_amd.utils import synthetic
+    lib = _lib.load()
+
+    P, inverse = (6, True) if args.variant == "v2" else (4, False)
+    B = args.classes
+    state = synthetic.make_transform_net_state(P, seed=1)
+    fm_cpu = synthetic.make_feature_map(C_FEAT, H_FM, W_FM, seed=0)
+    # this rank's classes: global class ids rank*B .. rank*B+B-1 (seeds 1000+id)
+    class_fms_cpu = synthetic.make_class_feature_maps(B, C_FEAT, sizes=[(15, 15)], seed=1000 + rank * B)
+    creator = build_os2d_head_creator(P == 4, False, inverse, FeatureMapSize(w=16, h=16), FeatureMapSize(w=16, h=16))
+    creator.aligner.parameter_regressor.load_state_dict(state)
+    creator.to(dev).eval()
+    fm = fm_cpu.to(dev)
+    with torch.no_grad():
+        head = creator.create_os2d_head([c.to(dev) for c in class_fms_cpu])
+    sharded = ClassShardedHead(creator, group=None, num_classes=B * world, local_head=head) if world > 1 else None
+
+    # one set of 10 stage events per timed step, so nothing has to be read back inside the timed region
+    def new_event_set():
+        arr = (ctypes.c_void_p * 10)()
+        for i in range(10):
+            ev = ctypes.c_void_p()
+            _lib.check(lib.os2d_prof_event_create(ctypes.byref(ev)), "os2d_prof_event_create")
+            arr[i] = ev.value
+        return arr
+
+    event_sets = [new_event_set() for _ in range(args.steps)] if sharded is None else []
+
+    def step(events):
+        with torch.no_grad():
+            if sharded is not None:
+                return sharded(fm)
+            return head(fm, stage_events=events)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step(None)
+    sync_all()
+    # ---- timed region: exactly K steps; stage events are recorded on the launch stream inside these steps
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(event_sets[i] if event_sets else None)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    total_pairs = B * world * args.steps
+    result = {
+        "metric": "query-image-pairs/s (1280-px input, ResNet50, N-class)",
+        "value": round(total_pairs / dt, 2),
+        "unit": "query-image-pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "OS2D head, ResNet50-C4 features of one 1280x960 image (1x1024x60x80), {} classes per GPU "
+                               "({} total), single scale, {} (P={}, inverse={}), head only, features resident in HBM"
+                               .format(B, B * world, args.variant.upper(), P, int(inverse)),
+                   "classes_per_gpu": B, "classes_total": B * world, "feature_map": [C_FEAT, H_FM, W_FM],
+                   "parallelism": "class-sharded x{} + all-gather".format(world) if world > 1 else "single GPU"},
+    }
+    per_step_stage = []
+    ms = ctypes.c_float()
+    for evs in event_sets:
+        row = []
+        for st in range(5):
+            _lib.check(lib.os2d_prof_event_elapsed_ms(evs[2 * st], evs[2 * st + 1], ctypes.byref(ms)), "elapsed")
+            row.append(ms.value)
+        per_step_stage.append(row)
+    if per_step_stage:
+        n = len(per_step_stage)
+        stage_ms = [sum(r[st] for r in per_step_stage) / n for st in range(5)]
+        result["stages_ms"] = {k: round(v, 4) for k, v in zip(STAGES, stage_ms)}
+        flops = FLOP_PER_LOC["conv1"] * H_FM * W_FM * B            # algorithmic FLOPs of ONE conv1 launch
+        achieved = flops / (stage_ms[1] * 1e-3)
+        result["roofline"] = {"kernel": "conv_mfma_kernel<7,128,...> (TransformNet conv 7x7 225->128)",
+                              "bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": PEAK_F32_MFMA / 1e12,
+                              "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": None,
+                              "flops_per_launch": flops, "avg_launch_ms": round(stage_ms[1], 4)}
+        whole = (FLOP_PER_LOC["corr"] + FLOP_PER_LOC["conv1"] + FLOP_PER_LOC["conv2"] + 2 * P * 64 * 25) * H_FM * W_FM
+        result["head_tflops"] = round(whole * result["value"] / 1e12, 3)
+        result["head_frac_of_f32_mfma_peak"] = round(whole * result["value"] / PEAK_F32_MFMA, 4)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(fm_cpu, class_fms_cpu, state, inverse, args.cpu_seconds)
+        result["speedup_vs_cpu_baseline"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

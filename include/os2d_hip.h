@@ -60,6 +60,20 @@ int os2d_head_forward(const float* fm, const float* qp, const float* w1, const f
                       int inverse, int stride, int rec_field, float* loc, float* cls, float* corners,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- profiling variant used by bench.py: identical to os2d_head_forward, plus
+ *   stage_events  NULL, or an array of 10 hipEvent_t (from os2d_prof_event_create); events [2s] / [2s+1] are recorded
+ *                 on `stream` right before / after stage s of the FIRST class chunk
+ *                 (s = 0 correlation, 1 conv 7x7, 2 conv 5x5 128->64, 3 conv 5x5 64->P, 4 resample+encode);
+ *   chunk_classes NULL, or receives the number of classes per chunk chosen for the given workspace.              */
+int os2d_head_forward_profiled(const float* fm, const float* qp, const float* w1, const float* b1, const float* w2,
+                               const float* b2, const float* w3, const float* b3, int A, int B, int C, int H, int W,
+                               int P, int inverse, int stride, int rec_field, float* loc, float* cls, float* corners,
+                               void* workspace, size_t workspace_bytes, void* stream, void** stage_events,
+                               int* chunk_classes);
+int os2d_prof_event_create(void** ev);
+int os2d_prof_event_destroy(void* ev);
+int os2d_prof_event_elapsed_ms(void* begin, void* end, float* ms);   /* both events must have completed */
+
 /* ---- per-stage entry points (same kernels, exposed for unit parity tests and profiling) ---- */
 /* sumsq [A,H*W] = sum_c fm^2 (head.py:339 norm).                                                              */
 int os2d_fm_sumsq(const float* fm, float* sumsq, int A, int C, int H, int W, void* stream);

@@ -27,6 +27,10 @@ SIGNATURES = {
     "os2d_class_prepare": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "os2d_head_workspace_bytes": (_i, [_i, _i, _i, _i, _i, _i, ctypes.POINTER(_sz)]),
     "os2d_head_forward": (_i, [_vp] * 8 + [_i] * 9 + [_vp, _vp, _vp, _vp, _sz, _vp]),
+    "os2d_head_forward_profiled": (_i, [_vp] * 8 + [_i] * 9 + [_vp, _vp, _vp, _vp, _sz, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_i)]),
+    "os2d_prof_event_create": (_i, [ctypes.POINTER(_vp)]),
+    "os2d_prof_event_destroy": (_i, [_vp]),
+    "os2d_prof_event_elapsed_ms": (_i, [_vp, _vp, ctypes.POINTER(_f)]),
     "os2d_fm_sumsq": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "os2d_plane_floats": (_sz, [_i, _i]),
     "os2d_corr": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -176,10 +176,11 @@ int os2d_decode_boxes(const float* loc, int NB, int H, int W, int stride, int re
   return os2d_launch_decode_boxes(loc, NB, H, W, stride, rec_field, img_w, img_h, boxes, S(stream));
 }
 
-int os2d_head_forward(const float* fm, const float* qp, const float* w1, const float* b1, const float* w2,
-                      const float* b2, const float* w3, const float* b3, int A, int B, int C, int H, int W, int P,
-                      int inverse, int stride, int rec_field, float* loc, float* cls, float* corners, void* workspace,
-                      size_t workspace_bytes, void* stream) {
+int os2d_head_forward_profiled(const float* fm, const float* qp, const float* w1, const float* b1, const float* w2,
+                               const float* b2, const float* w3, const float* b3, int A, int B, int C, int H, int W,
+                               int P, int inverse, int stride, int rec_field, float* loc, float* cls, float* corners,
+                               void* workspace, size_t workspace_bytes, void* stream, void** stage_events,
+                               int* chunk_classes) {
   if (!fm || !qp || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !loc || !cls || !corners || !workspace) {
     os2d_set_error("os2d_head_forward: null pointer");
     return -1;
@@ -218,19 +219,62 @@ int os2d_head_forward(const float* fm, const float* qp, const float* w1, const f
   float* h2 = reinterpret_cast<float*>(ws + c.h2);
   float* params = reinterpret_cast<float*>(ws + c.params);
 
+  if (chunk_classes) *chunk_classes = Bc;
+  // optional per-stage events (first class chunk only): stage_events[2*s] / [2*s+1] bracket stage s
+  auto mark = [&](int b0, int idx) {
+    if (stage_events && b0 == 0 && stage_events[idx]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(stage_events[idx]), st);
+  };
   int rc = os2d_launch_fm_sumsq(fm, sumsq, A, C, H * W, st);
   if (rc) return rc;
   for (int b0 = 0; b0 < B; b0 += Bc) {
     const int bc = (B - b0 < Bc) ? (B - b0) : Bc;
     const int NB = A * bc;
+    mark(b0, 0);
     if ((rc = os2d_launch_border_zero(rpad, NB * OS2D_KP, H, W, st))) return rc;
     if ((rc = os2d_launch_corr(fm, qp + (size_t)b0 * C * OS2D_QROWS, sumsq, corr, rpad, A, bc, C, H, W, st))) return rc;
+    mark(b0, 1);
+    mark(b0, 2);
     if ((rc = os2d_launch_conv(1, rpad, w1, b1, h1, NB, P, H, W, st))) return rc;
+    mark(b0, 3);
+    mark(b0, 4);
     if ((rc = os2d_launch_conv(2, h1, w2, b2, h2, NB, P, H, W, st))) return rc;
+    mark(b0, 5);
+    mark(b0, 6);
     if ((rc = os2d_launch_conv(3, h2, w3, b3, params, NB, P, H, W, st))) return rc;
+    mark(b0, 7);
+    mark(b0, 8);
     if ((rc = os2d_launch_sample_decode(corr, params, NB, H, W, P, inverse, stride, rec_field, bc, B, b0, loc, cls,
                                         corners, st)))
       return rc;
+    mark(b0, 9);
+  }
+  return 0;
+}
+
+int os2d_head_forward(const float* fm, const float* qp, const float* w1, const float* b1, const float* w2,
+                      const float* b2, const float* w3, const float* b3, int A, int B, int C, int H, int W, int P,
+                      int inverse, int stride, int rec_field, float* loc, float* cls, float* corners, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  return os2d_head_forward_profiled(fm, qp, w1, b1, w2, b2, w3, b3, A, B, C, H, W, P, inverse, stride, rec_field, loc,
+                                    cls, corners, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+int os2d_prof_event_create(void** ev) {
+  hipEvent_t e;
+  hipError_t rc = hipEventCreate(&e);
+  if (rc != hipSuccess || !ev) {
+    os2d_set_error("hipEventCreate: %s", hipGetErrorString(rc));
+    return -4;
+  }
+  *ev = e;
+  return 0;
+}
+int os2d_prof_event_destroy(void* ev) { return hipEventDestroy(reinterpret_cast<hipEvent_t>(ev)) == hipSuccess ? 0 : -4; }
+int os2d_prof_event_elapsed_ms(void* a, void* b, float* ms) {
+  hipError_t rc = hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(a), reinterpret_cast<hipEvent_t>(b));
+  if (rc != hipSuccess) {
+    os2d_set_error("hipEventElapsedTime: %s", hipGetErrorString(rc));
+    return -4;
   }
   return 0;
 }

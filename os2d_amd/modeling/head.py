@@ -330,8 +330,12 @@ class Os2dHead(nn.Module):
         return cls(q15, h0.aligner, h0.box_grid_generator_image_level, h0.box_grid_generator_feature_map_level,
                    _prepared=qp)
 
-    def forward(self, feature_maps):
-        """feature_maps [A,C,H,W] -> (loc [A,B,4,H,W], cls [A,B,1,H,W], cls_detached (same), corners [A,B,8,H,W])."""
+    def forward(self, feature_maps, out=None, stage_events=None):
+        """feature_maps [A,C,H,W] -> (loc [A,B,4,H,W], cls [A,B,1,H,W], cls_detached (same), corners [A,B,8,H,W]).
+
+        ``out``: optional preallocated (loc, cls, corners) device tensors of exactly those shapes (contiguous) - used
+        by the class-sharded wrapper to let the kernels write straight into the all-gather buffer.
+        ``stage_events``: optional ctypes array of 10 event handles for os2d_head_forward_profiled (bench.py)."""
         feature_maps = _require_device_f32(feature_maps, "feature_maps")
         if feature_maps.dim() != 4:
             raise RuntimeError("feature_maps must be [A,C,H,W], got {}".format(tuple(feature_maps.shape)))
@@ -350,19 +354,25 @@ class Os2dHead(nn.Module):
         regressor = self.aligner.parameter_regressor
         P = regressor.output_dim
         w1, b1, w2, b2, w3, b3 = regressor.packed()
-        loc = torch.empty(A, B, 4, H, W, dtype=torch.float32, device=dev)
-        cls = torch.empty(A, B, 1, H, W, dtype=torch.float32, device=dev)
-        corners = torch.empty(A, B, 8, H, W, dtype=torch.float32, device=dev)
+        if out is None:
+            loc = torch.empty(A, B, 4, H, W, dtype=torch.float32, device=dev)
+            cls = torch.empty(A, B, 1, H, W, dtype=torch.float32, device=dev)
+            corners = torch.empty(A, B, 8, H, W, dtype=torch.float32, device=dev)
+        else:
+            loc, cls, corners = out
+            for t, k in ((loc, 4), (cls, 1), (corners, 8)):
+                if tuple(t.shape) != (A, B, k, H, W) or not t.is_contiguous() or t.device != dev or t.dtype != torch.float32:
+                    raise RuntimeError("out tensors must be contiguous float32 [A,B,{},H,W] on {}".format(k, dev))
         full = ctypes.c_size_t()
         one = ctypes.c_size_t()
         _lib.check(lib.os2d_head_workspace_bytes(A, B, C, H, W, P, ctypes.byref(full)), "os2d_head_workspace_bytes")
         _lib.check(lib.os2d_head_workspace_bytes(A, 1, C, H, W, P, ctypes.byref(one)), "os2d_head_workspace_bytes")
         ws = get_workspace(dev, full.value, one.value)
-        _lib.check(lib.os2d_head_forward(
+        _lib.check(lib.os2d_head_forward_profiled(
             _lib.ptr(feature_maps), _lib.ptr(self._qp), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2),
             _lib.ptr(w3), _lib.ptr(b3), A, B, C, H, W, P, 1 if self.aligner.use_inverse_geom_model else 0,
             self._stride, self._rec_field, _lib.ptr(loc), _lib.ptr(cls), _lib.ptr(corners),
-            _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)), "os2d_head_forward")
+            _lib.ptr(ws), ws.numel(), _lib.current_stream(dev), stage_events, None), "os2d_head_forward")
         return loc, cls, cls, corners
 
 

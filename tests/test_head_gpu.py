@@ -29,3 +29,79 @@ def test_head_matches_reference_golden(name, device):
     assert util.maxdiff(cls, fx["ref_cls"]) < TOL_CLS
     assert util.maxdiff(loc, fx["ref_loc"]) < TOL_LOC
     assert util.maxdiff(corners, fx["ref_corners"]) < TOL_CORNERS
+
+
+def _oracle(fm, class_fms, state, inverse):
+    from oracle import head_oracle as O
+    with torch.no_grad():
+        return O.head_forward(fm, O.prepare_class_maps(class_fms), state, inverse)
+
+
+@pytest.mark.parametrize("P,inverse", [(6, True), (4, False)])
+def test_full_size_matches_oracle(P, inverse, device):
+    """BASELINE.json sizes: C=1024, 60x80 feature map (1280x960 input); 2 classes so the oracle takes seconds."""
+    from os2d_amd.utils import synthetic
+    state = synthetic.make_transform_net_state(P, seed=1)
+    fm = synthetic.make_feature_map(1024, 60, 80, seed=0)
+    class_fms = synthetic.make_class_feature_maps(2, 1024, sizes=[(15, 15), (13, 17)], seed=1000)
+    creator = util.make_head_creator(P, inverse, state, device)
+    with torch.no_grad():
+        head = creator.create_os2d_head([c.to(device) for c in class_fms])
+        loc, cls, _, corners = head(fm.to(device))
+    ref = _oracle(fm, class_fms, state, inverse)
+    assert util.maxdiff(cls, ref[1]) < TOL_CLS
+    assert util.maxdiff(loc, ref[0]) < TOL_LOC
+    assert util.maxdiff(corners, ref[3]) < 5e-3   # coordinates up to ~1400 px at this size
+
+
+def test_image_batch_chunking_and_cat(device, monkeypatch):
+    """A=2 images, 5 classes, workspace capped so that classes go through in several chunks; per-class heads
+    concatenated with Os2dHead.cat give the same result as one batched head."""
+    from os2d_amd.modeling import head as head_mod
+    from os2d_amd.utils import synthetic
+    P, inverse = 6, True
+    state = synthetic.make_transform_net_state(P, seed=7)
+    fm = synthetic.make_feature_map(32, 9, 14, seed=5, A=2)
+    class_fms = synthetic.make_class_feature_maps(5, 32, sizes=[(15, 15), (14, 16), (16, 14)], seed=500)
+    creator = util.make_head_creator(P, inverse, state, device)
+    ref = _oracle(fm, class_fms, state, inverse)
+    with torch.no_grad():
+        head = creator.create_os2d_head([c.to(device) for c in class_fms])
+        out_full = head(fm.to(device))
+        # cap the workspace at ~2 classes per chunk
+        import ctypes
+        from os2d_amd import _lib
+        two = ctypes.c_size_t()
+        _lib.check(_lib.load().os2d_head_workspace_bytes(2, 2, 32, 9, 14, P, ctypes.byref(two)), "ws")
+        head_mod.release_workspaces()
+        monkeypatch.setattr(head_mod, "workspace_cap_bytes", lambda: two.value)
+        out_chunked = head(fm.to(device))
+        head_mod.release_workspaces()
+        monkeypatch.undo()
+        singles = [creator.create_os2d_head([c.to(device)]) for c in class_fms]
+        out_cat = head_mod.Os2dHead.cat(singles)(fm.to(device))
+    for i, tol in ((0, TOL_LOC), (1, TOL_CLS), (3, TOL_CORNERS)):
+        assert util.maxdiff(out_full[i], ref[i]) < tol
+        assert util.maxdiff(out_chunked[i], out_full[i]) == 0.0
+        assert util.maxdiff(out_cat[i], out_full[i]) == 0.0
+
+
+def test_transformation_net_forward(device):
+    """TransformationNet.forward (standalone normalise + 3 convs) against the oracle's transform_net."""
+    from oracle import head_oracle as O
+    fx = util.load_head_fixture("v2_affine_inv")
+    creator = util.make_head_creator(fx["P"], fx["inverse"], fx["state"], device)
+    with torch.no_grad():
+        p = creator.aligner.parameter_regressor(fx["ref_corr"].to(device))
+    assert util.maxdiff(p, fx["ref_params"]) < 1e-5
+    assert util.maxdiff(p, O.transform_net(fx["ref_corr"], fx["state"])) < 1e-5
+
+
+def test_cpu_tensors_fail_loudly(device):
+    fx = util.load_head_fixture("v1_simple")
+    creator = util.make_head_creator(fx["P"], fx["inverse"], fx["state"], device)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        creator.create_os2d_head(fx["class_fms"])          # CPU class maps
+    head = creator.create_os2d_head([c.to(device) for c in fx["class_fms"]])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        head(fx["fm"])                                      # CPU feature map

@@ -8,27 +8,29 @@
 
 namespace {
 
-// ---- fm_sumsq: grid (ceil(HW/64), CSPLIT); block 256 = 64 positions x 4 channel lanes; atomicAdd partials
-constexpr int CSPLIT = 16;
+// ---- fm_sumsq: one block per 64 positions, 1024 threads = 64 positions x 16 channel lanes, fixed-order LDS tree
+// (deterministic: no atomics, so repeated calls and class chunking give bit-identical results)
+constexpr int SUMSQ_LANES = 16;
 
-__global__ __launch_bounds__(256) void fm_sumsq_kernel(const float* __restrict__ fm, float* __restrict__ sumsq, int A,
-                                                       int C, int HW) {
-  __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void fm_sumsq_kernel(const float* __restrict__ fm, float* __restrict__ sumsq, int C,
+                                                        int HW) {
+  __shared__ float red[SUMSQ_LANES][64];
   const int col = threadIdx.x & 63, cl = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + col;
-  const int cper = (C + CSPLIT - 1) / CSPLIT;
-  const int c0 = blockIdx.y * cper, c1 = min(C, c0 + cper);
-  for (int a = 0; a < A; ++a) {
-    float s = 0.f;
-    if (n < HW)
-      for (int c = c0 + cl; c < c1; c += 4) {
-        const float v = fm[((size_t)a * C + c) * HW + n];
-        s += v * v;
-      }
-    red[cl][col] = s;
-    __syncthreads();
-    if (cl == 0 && n < HW) atomicAdd(&sumsq[(size_t)a * HW + n], red[0][col] + red[1][col] + red[2][col] + red[3][col]);
-    __syncthreads();
+  const int a = blockIdx.y;
+  float s = 0.f;
+  if (n < HW)
+    for (int c = cl; c < C; c += SUMSQ_LANES) {
+      const float v = fm[((size_t)a * C + c) * HW + n];
+      s += v * v;
+    }
+  red[cl][col] = s;
+  __syncthreads();
+  if (cl == 0 && n < HW) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < SUMSQ_LANES; ++i) t += red[i][col];
+    sumsq[(size_t)a * HW + n] = t;
   }
 }
 
@@ -164,12 +166,7 @@ int check_launch(const char* what) {
 }  // namespace
 
 int os2d_launch_fm_sumsq(const float* fm, float* sumsq, int A, int C, int HW, hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(sumsq, 0, (size_t)A * HW * sizeof(float), stream);
-  if (e != hipSuccess) {
-    os2d_set_error("memset(sumsq): %s", hipGetErrorString(e));
-    return -4;
-  }
-  hipLaunchKernelGGL(fm_sumsq_kernel, dim3((HW + 63) / 64, CSPLIT), dim3(256), 0, stream, fm, sumsq, A, C, HW);
+  hipLaunchKernelGGL(fm_sumsq_kernel, dim3((HW + 63) / 64, A), dim3(1024), 0, stream, fm, sumsq, C, HW);
   return check_launch("fm_sumsq");
 }
 

@@ -101,6 +101,15 @@ int os2d_sample_decode(const float* corr, const float* params, int NB, int H, in
 int os2d_decode_boxes(const float* loc, int NB, int H, int W, int stride, int rec_field, float img_w, float img_h,
                       float* boxes, void* stream);
 
+/* ---- per-class greedy NMS: reference os2d/modeling/box_coder.py:425-437 + os2d/structures/bounding_box.py:344-387
+ * (torchvision.ops.nms semantics: suppress when IoU > threshold).  Batched over NC independent lists:
+ *   boxes    [NC,N,4] xyxy, each list sorted by DECREASING score, the first counts[c] entries valid
+ *   keep     [NC,N]   1 = survives (in the sorted order), 0 otherwise;  num_keep [NC]
+ *   workspace os2d_nms_workspace_bytes(NC,N) bytes (kept-box lists), 16-byte aligned.                           */
+int os2d_nms_workspace_bytes(int NC, int N, size_t* bytes);
+int os2d_nms(const float* boxes, const int* counts, int NC, int N, float iou_threshold, unsigned char* keep,
+             int* num_keep, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

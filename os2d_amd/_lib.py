@@ -38,6 +38,8 @@ SIGNATURES = {
     "os2d_transform_conv": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "os2d_sample_decode": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "os2d_decode_boxes": (_i, [_vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp]),
+    "os2d_nms_workspace_bytes": (_i, [_i, _i, ctypes.POINTER(_sz)]),
+    "os2d_nms": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
 }
 
 

@@ -176,6 +176,32 @@ int os2d_decode_boxes(const float* loc, int NB, int H, int W, int stride, int re
   return os2d_launch_decode_boxes(loc, NB, H, W, stride, rec_field, img_w, img_h, boxes, S(stream));
 }
 
+int os2d_nms_workspace_bytes(int NC, int N, size_t* bytes) {
+  if (!bytes || NC < 1 || N < 1) {
+    os2d_set_error("os2d_nms_workspace_bytes: bad arguments");
+    return -1;
+  }
+  *bytes = (size_t)NC * N * 4 * sizeof(float);
+  return 0;
+}
+
+int os2d_nms(const float* boxes, const int* counts, int NC, int N, float iou_threshold, unsigned char* keep,
+             int* num_keep, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!boxes || !counts || !keep || !num_keep || !workspace || NC < 1 || N < 1) {
+    os2d_set_error("os2d_nms: bad arguments");
+    return -1;
+  }
+  if ((reinterpret_cast<uintptr_t>(boxes) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15)) {
+    os2d_set_error("os2d_nms: boxes and workspace must be 16-byte aligned");
+    return -1;
+  }
+  if (workspace_bytes < (size_t)NC * N * 4 * sizeof(float)) {
+    os2d_set_error("os2d_nms: workspace too small");
+    return -2;
+  }
+  return os2d_launch_nms(boxes, counts, NC, N, iou_threshold, keep, num_keep, workspace, S(stream));
+}
+
 int os2d_head_forward_profiled(const float* fm, const float* qp, const float* w1, const float* b1, const float* w2,
                                const float* b2, const float* w3, const float* b3, int A, int B, int C, int H, int W,
                                int P, int inverse, int stride, int rec_field, float* loc, float* cls, float* corners,

@@ -53,3 +53,6 @@ int os2d_launch_sample_decode(const float* corr, const float* params, int NB, in
                               float* corners, hipStream_t stream);
 int os2d_launch_decode_boxes(const float* loc, int NB, int H, int W, int stride, int rec_field, float img_w,
                              float img_h, float* boxes, hipStream_t stream);
+// nms.hip
+int os2d_launch_nms(const float* boxes, const int* counts, int NC, int N, float thr, unsigned char* keep, int* num_keep,
+                    void* workspace, hipStream_t stream);

@@ -101,3 +101,143 @@ class Os2dBoxCoder(object):
         img_size = default_boxes.image_size
         boxes = self.decode_level(loc_scores.t().contiguous().unsqueeze(0), img_size)[0]
         return BoxList(boxes, image_size=img_size, mode="xyxy")
+
+    # ------------------------------------------------------------------ NMS (os2d_nms)
+    @staticmethod
+    def nms_sorted(boxes_sorted, counts, iou_threshold):
+        """boxes_sorted [NC,N,4] (each list by decreasing score, counts[c] valid) -> keep mask [NC,N] bool."""
+        lib = _lib.load()
+        if not boxes_sorted.is_cuda:
+            raise RuntimeError("NMS runs on the HIP device only (no CPU fallback)")
+        boxes_sorted = boxes_sorted.contiguous().float()
+        NC, N, _ = boxes_sorted.shape
+        dev = boxes_sorted.device
+        counts = counts.to(device=dev, dtype=torch.int32).contiguous()
+        keep = torch.empty(NC, N, dtype=torch.uint8, device=dev)
+        num_keep = torch.empty(NC, dtype=torch.int32, device=dev)
+        nbytes = ctypes.c_size_t()
+        _lib.check(lib.os2d_nms_workspace_bytes(NC, N, ctypes.byref(nbytes)), "os2d_nms_workspace_bytes")
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        _lib.check(lib.os2d_nms(_lib.ptr(boxes_sorted), _lib.ptr(counts), NC, N, ctypes.c_float(iou_threshold),
+                                _lib.ptr(keep), _lib.ptr(num_keep), _lib.ptr(ws), ws.numel(),
+                                _lib.current_stream(dev)), "os2d_nms")
+        return keep.bool()
+
+    def _nms_lists(self, boxes, scores, valid, iou_threshold, nms_max_batch=10000):
+        """Batched equivalent of reference bounding_box.py:344-374 for NC independent lists padded to a common
+        length: boxes [NC,N,4], scores [NC,N], valid [NC,N] bool.  Lists longer than ``nms_max_batch`` go through
+        the reference's chunk-and-repeat scheme (chunks of 10000 in list order until one chunk is left or
+        nothing changes), so results match it exactly.  Returns a bool keep mask [NC,N]."""
+        NC, N = scores.shape
+        alive = valid.clone()
+        while True:
+            n_alive = alive.sum(1)
+            n_max = int(n_alive.max())
+            if n_max == 0:
+                return alive
+            # position of every alive entry among the alive ones (list order) -> chunk id
+            rank = torch.cumsum(alive.int(), 1) - 1
+            chunk = torch.div(rank, nms_max_batch, rounding_mode="floor")
+            num_chunks = (n_max + nms_max_batch - 1) // nms_max_batch
+            new_alive = torch.zeros_like(alive)
+            for ch in range(num_chunks):
+                sel = alive & (chunk == ch)
+                key = torch.where(sel, scores, torch.full_like(scores, float("-inf")))
+                # selected entries first, by decreasing score (stable: ties keep list order)
+                # (a selected entry always has a finite key: it passed ``score > threshold``)
+                order = torch.argsort(key, dim=1, descending=True, stable=True)
+                cnt = sel.sum(1)
+                width = int(cnt.max())
+                if width == 0:
+                    continue
+                order = order[:, :width]
+                b_sorted = torch.gather(boxes, 1, order.unsqueeze(-1).expand(-1, -1, 4))
+                keep_sorted = self.nms_sorted(b_sorted, cnt, iou_threshold)
+                new_alive.scatter_(1, order, keep_sorted)
+            changed = bool((new_alive != alive).any())
+            alive = new_alive
+            if num_chunks <= 1 or not changed:
+                return alive
+
+    def decode_pyramid(self, loc_scores_pyramid, cls_scores_pyramid, img_size_pyramid, class_ids,
+                       nms_score_threshold=0.0, nms_iou_threshold=0.3, inverse_box_transforms=None,
+                       transform_corners_pyramid=None):
+        """reference box_coder.py:448-536 on the device, batched over classes:
+        per level decode + clip (os2d_decode_boxes), score / empty-box mask, map to the original image
+        (``inverse_box_transforms[l]`` is applied ONCE to a BoxList holding the level's boxes of all classes),
+        concatenate levels, per-label NMS (os2d_nms), sort by score.  Entries of ``class_ids`` with the same id
+        are merged before NMS, labels appear in ascending order like the reference's ``set(class_ids)``.
+        Returns a BoxList with fields scores, labels, default_boxes (and transform_corners if given)."""
+        num_classes = len(class_ids)
+        dev = cls_scores_pyramid[0].device
+        boxes_l, scores_l, valid_l, dflt_l, corners_l = [], [], [], [], []
+        for lvl, (loc, cls, img_size) in enumerate(zip(loc_scores_pyramid, cls_scores_pyramid, img_size_pyramid)):
+            assert loc.device == dev and cls.device == dev, "scores and boxes should be on the same device"
+            boxes = self.decode_level(loc, img_size)                                    # [B,HW,4]
+            cls = cls.float()
+            empty = (boxes[..., 3] <= boxes[..., 1]) | (boxes[..., 2] <= boxes[..., 0])
+            valid = (cls > nms_score_threshold) & ~empty
+            HW = boxes.size(1)
+            dflt = self._get_default_boxes(img_size).bbox_xyxy.to(dev)                   # [HW,4]
+            corners = None
+            if transform_corners_pyramid is not None:
+                corners = transform_corners_pyramid[lvl].transpose(1, 2).reshape(num_classes * HW * 2, 4)
+            if inverse_box_transforms is not None:
+                t = inverse_box_transforms[lvl]
+                boxes = t(BoxList(boxes.reshape(-1, 4), img_size)).bbox_xyxy.reshape(num_classes, HW, 4)
+                dflt = t(BoxList(dflt, img_size)).bbox_xyxy
+                if corners is not None:
+                    corners = t(BoxList(corners, img_size)).bbox_xyxy
+            boxes_l.append(boxes)
+            scores_l.append(cls)
+            valid_l.append(valid)
+            dflt_l.append(dflt.unsqueeze(0).expand(num_classes, HW, 4))
+            if corners is not None:
+                corners_l.append(corners.reshape(num_classes, HW, 8))
+        boxes = torch.cat(boxes_l, 1)
+        scores = torch.cat(scores_l, 1)
+        valid = torch.cat(valid_l, 1)
+        dflt = torch.cat(dflt_l, 1)
+        corners = torch.cat(corners_l, 1) if corners_l else None
+        # merge rows that share a real label
+        labels_sorted = sorted(set(int(c) for c in class_ids))
+        groups = [[i for i, c in enumerate(class_ids) if int(c) == l] for l in labels_sorted]
+        if any(len(g) != 1 for g in groups) or labels_sorted != [int(c) for c in class_ids]:
+            width = max(len(g) for g in groups) * boxes.size(1)
+
+            def merge(t, fill):
+                out = []
+                for g in groups:
+                    m = torch.cat([t[i] for i in g], 0)
+                    pad = width - m.size(0)
+                    if pad:
+                        m = torch.cat([m, torch.full((pad,) + tuple(m.shape[1:]), fill, dtype=m.dtype, device=dev)], 0)
+                    out.append(m)
+                return torch.stack(out, 0)
+            boxes, scores, valid, dflt = merge(boxes, 0.0), merge(scores, float("-inf")), merge(valid, False), merge(dflt, 0.0)
+            corners = merge(corners, 0.0) if corners is not None else None
+        keep = self._nms_lists(boxes, scores, valid, nms_iou_threshold)
+        # per label: survivors by decreasing score (box_coder.py:431-437)
+        key = torch.where(keep, scores, torch.full_like(scores, float("-inf")))
+        order = torch.argsort(key, dim=1, descending=True, stable=True)
+        keep_sorted = torch.gather(keep, 1, order)
+        sel = keep_sorted.reshape(-1).nonzero().squeeze(1)
+        flat = (order + torch.arange(order.size(0), device=dev).unsqueeze(1) * order.size(1)).reshape(-1)[sel]
+        out_size = img_size_pyramid[0]
+        if inverse_box_transforms is not None:
+            out_size = inverse_box_transforms[0](BoxList(torch.zeros(1, 4, device=dev), img_size_pyramid[0])).image_size
+        result = BoxList(boxes.reshape(-1, 4)[flat], out_size)
+        result.add_field("scores", scores.reshape(-1)[flat])
+        lab = torch.tensor(labels_sorted, dtype=torch.long, device=dev).unsqueeze(1).expand(-1, order.size(1)).reshape(-1)
+        result.add_field("labels", lab[sel])
+        result.add_field("default_boxes", BoxList(dflt.reshape(-1, 4)[flat], out_size))
+        if corners is not None:
+            result.add_field("transform_corners", corners.reshape(-1, 8)[flat])
+        if self.do_nms_across_classes:
+            b = result.bbox_xyxy.unsqueeze(0)
+            s = result.get_field("scores").unsqueeze(0)
+            k = self._nms_lists(b, s, torch.ones_like(s, dtype=torch.bool), nms_iou_threshold)[0]
+            idx = k.nonzero().squeeze(1)
+            idx = idx[torch.argsort(s[0][idx], descending=True, stable=True)]
+            result = result[idx]
+        return result

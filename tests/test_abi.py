@@ -1,0 +1,62 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/os2d_hip.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+HEADER = os.path.join(REPO, "include", "os2d_hip.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(os2d_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    from os2d_amd import build
+    return build.build(verbose=False)
+
+
+def test_header_and_binding_agree():
+    from os2d_amd import _lib
+    assert declared_functions() == sorted(_lib.SIGNATURES), "include/os2d_hip.h and os2d_amd/_lib.py list different entry points"
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib_path]).decode()
+    exported = set(re.findall(r" T (os2d_[a-z0-9_]+)", out))
+    missing = [f for f in declared_functions() if f not in exported]
+    assert not missing, "not exported: {}".format(missing)
+
+
+def test_library_loads_and_reports_abi(lib_path):
+    from os2d_amd import _lib
+    lib = _lib.load()
+    assert lib.os2d_abi_version() == _lib.ABI_VERSION
+    # pure host-side helpers (no device needed)
+    assert lib.os2d_packed_conv_floats(1) == 113 * 49 * 2 * 128
+    assert lib.os2d_packed_conv_floats(2) == 64 * 25 * 2 * 64
+    assert lib.os2d_packed_conv_floats(3) == 32 * 25 * 2 * 32
+    assert lib.os2d_packed_bias_floats(1) == 128
+    assert lib.os2d_plane_floats(60, 80) % 64 == 0 and lib.os2d_plane_floats(60, 80) >= 63 * 83
+    n = ctypes.c_size_t()
+    assert lib.os2d_head_workspace_bytes(1, 64, 1024, 60, 80, 6, ctypes.byref(n)) == 0 and n.value > 0
+    one = ctypes.c_size_t()
+    assert lib.os2d_head_workspace_bytes(1, 1, 1024, 60, 80, 6, ctypes.byref(one)) == 0 and one.value < n.value
+    # argument errors are reported through return codes + os2d_last_error, never exceptions
+    assert lib.os2d_head_workspace_bytes(1, 1, 1023, 60, 80, 6, ctypes.byref(n)) == -1
+    assert b"C%4" in lib.os2d_last_error() or b"C" in lib.os2d_last_error()
+    assert lib.os2d_head_workspace_bytes(1, 1, 1024, 60, 80, 5, ctypes.byref(n)) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from os2d_amd import _lib
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setenv("OS2D_HIP_LIB", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.Os2dLibraryError, match="no CPU or PyTorch fallback"):
+        _lib.load()

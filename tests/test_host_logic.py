@@ -1,0 +1,111 @@
+"""CPU: host-side mirror of the reference API (no device compute): value types, anchors, module layout, state-dict
+keys, loud failures."""
+import pytest
+import torch
+
+from oracle import head_oracle as O
+from os2d_amd.modeling.box_coder import BoxGridGenerator, feature_map_size_c4
+from os2d_amd.modeling.head import Os2dHeadCreator, build_os2d_head_creator
+from os2d_amd.structures.bounding_box import BoxList, cat_boxlist
+from os2d_amd.structures.feature_map import FeatureMapSize
+
+
+def test_feature_map_size_semantics():
+    a = FeatureMapSize(w=80, h=60)
+    assert (a.w, a.h) == (80, 60) and a == FeatureMapSize(img=torch.zeros(1, 3, 60, 80)) and hash(a) == hash(FeatureMapSize(w=80, h=60))
+    with pytest.raises(AttributeError):
+        a.w = 3
+    with pytest.raises(RuntimeError):
+        FeatureMapSize()
+    assert repr(a) == "FeatureMapSize(w=80, h=60)"
+
+
+def test_c4_feature_map_sizes_of_the_pyramid():
+    # the 7-scale pyramid of a 1280x960 image
+    inp = [(640, 480), (800, 600), (1024, 768), (1280, 960), (1536, 1152), (1792, 1344), (2048, 1536)]
+    fms = [(40, 30), (50, 38), (64, 48), (80, 60), (96, 72), (112, 84), (128, 96)]
+    for (w, h), (fw, fh) in zip(inp, fms):
+        assert feature_map_size_c4(FeatureMapSize(w=w, h=h)) == FeatureMapSize(w=fw, h=fh)
+
+
+def test_anchor_grid_matches_oracle_and_is_row_major():
+    gen = BoxGridGenerator(box_size=FeatureMapSize(w=240, h=240), box_stride=FeatureMapSize(w=16, h=16))
+    a = gen.create_strided_boxes_columnfirst(FeatureMapSize(w=5, h=3))
+    assert torch.equal(a, O.anchor_grid(3, 5, 240.0, 16.0))
+    # index h*W + w: second entry moves along x
+    assert a[1, 0] - a[0, 0] == 16 and a[1, 1] == a[0, 1] and a[5, 1] - a[0, 1] == 16
+
+
+def test_rec_field_and_stride_composition():
+    rf, st = Os2dHeadCreator.get_rec_field_and_stride_after_concat_nets(
+        FeatureMapSize(w=16, h=16), FeatureMapSize(w=16, h=16), FeatureMapSize(w=15, h=15), FeatureMapSize(w=1, h=1))
+    assert rf == FeatureMapSize(w=240, h=240) and st == FeatureMapSize(w=16, h=16)
+
+
+@pytest.mark.parametrize("simple,P", [(False, 6), (True, 4)])
+def test_head_creator_layout_and_identity_init(simple, P):
+    creator = build_os2d_head_creator(simple, False, True, FeatureMapSize(w=16, h=16), FeatureMapSize(w=16, h=16))
+    keys = set(creator.state_dict().keys())
+    for k in ("conv.0.weight", "conv.0.bias", "conv.1.weight", "conv.1.bias", "conv.1.running_mean", "conv.1.running_var",
+              "conv.3.weight", "conv.4.running_var", "linear.weight", "linear.bias"):
+        assert "aligner.parameter_regressor." + k in keys
+    net = creator.aligner.parameter_regressor
+    assert tuple(net.conv[0].weight.shape) == (128, 225, 7, 7) and tuple(net.conv[3].weight.shape) == (64, 128, 5, 5)
+    assert tuple(net.linear.weight.shape) == (P, 64, 5, 5)
+    assert float(net.linear.weight.abs().max()) == 0.0
+    expect = [1, 0, 0, 0, 1, 0] if P == 6 else [1, 0, 1, 0]
+    assert net.linear.bias.tolist() == expect          # identity transform (reference head.py:632-642)
+    assert sum(p.numel() for p in net.parameters()) == (1626182 if P == 6 else 1626182 - 2 * (64 * 25 + 1))
+    assert creator.box_grid_generator_image_level.box_size == FeatureMapSize(w=240, h=240)
+    assert creator.box_grid_generator_feature_map_level.box_size == FeatureMapSize(w=15, h=15)
+    assert creator.aligner.model_type == ("simple_affine" if simple else "affine")
+
+
+def test_model_state_dict_keys_and_param_count():
+    from os2d_amd.modeling.model import Os2dModel
+    net = Os2dModel(is_cuda=False, merge_branch_parameters=True, backbone_arch="resnet50")
+    sd = net.state_dict()
+    assert "net_feature_maps.conv1.weight" in sd and "net_feature_maps.layer3.5.bn3.running_var" in sd
+    assert "net_label_features.net_class_features.layer1.0.downsample.0.weight" in sd
+    assert "os2d_head_creator.aligner.parameter_regressor.linear.bias" in sd
+    assert not any(k.startswith("net_feature_maps.layer4") or ".fc." in k for k in sd)
+    # the reference demo logs 10,169,478 parameters (demo.ipynb cell 5) for this configuration
+    assert sum(p.numel() for p in net.parameters()) == 10169478
+    assert net.get_feature_map_size(FeatureMapSize(w=1280, h=960)) == FeatureMapSize(w=80, h=60)
+    assert not net.training
+
+
+def test_backbone_output_shape_cpu():
+    from os2d_amd.modeling.feature_extractor import build_feature_extractor
+    net = build_feature_extractor("resnet50").eval()
+    with torch.no_grad():
+        y = net(torch.zeros(1, 3, 96, 130))
+    assert tuple(y.shape) == (1, 1024, 6, 9) and float(y.min()) >= 0
+    with pytest.raises(RuntimeError, match="Unknown backbone arch"):
+        build_feature_extractor("vgg")
+    assert build_feature_extractor("ResNet101").get_num_blocks_in_feature_extractor() == 1 + 3 + 4 + 23
+
+
+def test_head_refuses_cpu_tensors_without_touching_a_device():
+    creator = build_os2d_head_creator(False, False, True, FeatureMapSize(w=16, h=16), FeatureMapSize(w=16, h=16))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        creator.create_os2d_head([torch.zeros(1, 8, 15, 15)])
+    with pytest.raises(RuntimeError, match="move the model to the HIP device"):
+        creator.aligner.parameter_regressor.packed()
+    with pytest.raises(RuntimeError):
+        from os2d_amd.modeling.head import TransformationNet
+        TransformationNet(kernel_sizes=[3, 3], use_cuda=False)
+
+
+def test_boxlist_basics():
+    b = BoxList(torch.tensor([[0., 0., 10., 10.], [5., 5., 5., 9.], [-4., 2., 30., 50.]]), FeatureMapSize(w=20, h=40))
+    b.add_field("scores", torch.tensor([0.1, 0.2, 0.3]))
+    assert b.get_mask_empty_boxes().tolist() == [False, True, False]
+    c = b.resize(FeatureMapSize(w=40, h=40))
+    assert c.bbox_xyxy[0].tolist() == [0, 0, 20, 10] and c.image_size == FeatureMapSize(w=40, h=40)
+    b.clip_to_image(remove_empty=False)
+    assert b.bbox_xyxy[2].tolist() == [0, 2, 20, 40]
+    sel = b[torch.tensor([True, False, True])]
+    assert len(sel) == 2 and sel.get_field("scores").tolist() == pytest.approx([0.1, 0.3])
+    both = cat_boxlist([sel, sel])
+    assert len(both) == 4 and BoxList(torch.tensor([[5., 5., 2., 2.]]), b.image_size, mode="cx_cy_w_h").bbox_xyxy.tolist() == [[4, 4, 6, 6]]

@@ -1,0 +1,108 @@
+"""CPU: the oracle (oracle/*.py) against the golden vectors recorded from the reference itself
+(tests/golden/make_golden.py).  This is what pins the oracle; the GPU tests then compare HIP <-> oracle/golden."""
+import numpy as np
+import pytest
+import torch
+
+import util
+from oracle import decode_oracle as D
+from oracle import head_oracle as O
+
+
+@pytest.mark.parametrize("name", util.head_fixture_names())
+def test_head_oracle_is_bit_exact_with_reference(name):
+    fx = util.load_head_fixture(name)
+    q = O.prepare_class_maps(fx["class_fms"])
+    assert torch.equal(q, fx["ref_q15"])
+    with torch.no_grad():
+        loc, cls, cls2, corners, mid = O.head_forward(fx["fm"], q, fx["state"], fx["inverse"], return_intermediate=True)
+    # same operator sequence as the reference -> identical bits
+    assert torch.equal(mid["corr"], fx["ref_corr"])
+    assert torch.equal(mid["params"], fx["ref_params"])
+    assert torch.equal(loc, fx["ref_loc"])
+    assert torch.equal(cls, fx["ref_cls"])
+    assert torch.equal(corners, fx["ref_corners"])
+    assert cls2 is cls
+
+
+@pytest.mark.parametrize("name", util.head_fixture_names()[:3])
+def test_looped_equals_batched(name):
+    """evaluate.py drives one class per head call; batching classes must not change any value."""
+    fx = util.load_head_fixture(name)
+    q = O.prepare_class_maps(fx["class_fms"])
+    with torch.no_grad():
+        out = O.head_forward_looped(fx["fm"], q, fx["state"], fx["inverse"])
+    assert util.maxdiff(out[0], fx["ref_loc"]) < 1e-6
+    assert util.maxdiff(out[1], fx["ref_cls"]) < 1e-6
+    assert util.maxdiff(out[3], fx["ref_corners"]) < 1e-4
+
+
+@pytest.mark.parametrize("name", util.head_fixture_names())
+def test_closed_form_fp64_agrees(name):
+    """The independent closed form in float64: the error budget of the fp32 reference itself."""
+    fx = util.load_head_fixture(name)
+    q = O.prepare_class_maps(fx["class_fms"])
+    with torch.no_grad():
+        loc, cls, _, corners = O.head_forward_closed_form(fx["fm"], q, fx["state"], fx["inverse"])
+    assert util.maxdiff(cls, fx["ref_cls"]) < 1e-6
+    assert util.maxdiff(loc, fx["ref_loc"]) < 1e-5
+    assert util.maxdiff(corners, fx["ref_corners"]) < 5e-4
+
+
+def test_resample_fast_vs_simple_statement():
+    """The reference documents two statements of the resampling (head.py:439-520 fast, :523-594 simple); with the
+    symmetric pooling mask they agree.  Re-derive the 'simple' one here from its description: per template point a
+    separate bilinear grid_sample of channel x*15+y."""
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    A, B, H, W, T = 1, 2, 7, 9, 15
+    corr = torch.randn(A, B, T * T, H, W)
+    grid = torch.rand(A, B, H, W, T, T, 2) * 2.4 - 1.2
+    mask = O.pool_mask()
+    fast = O.resample_and_pool(corr, grid.clamp(-1, 1), mask)
+    acc = torch.zeros(A * B, H, W)
+    for x in range(T):
+        for y in range(T):
+            ch = corr.view(A * B, T * T, H, W)[:, x * T + y:x * T + y + 1]
+            pts = grid.view(A * B, H, W, T, T, 2)[:, :, :, y, x, :].clamp(-1, 1)
+            acc += mask[y, x] * F.grid_sample(ch, pts, mode="bilinear", padding_mode="border", align_corners=True)[:, 0]
+    assert util.maxdiff(fast.view(A * B, H, W), acc) < 1e-6
+
+
+def test_encode_decode_roundtrip():
+    """reference box_coder.py:323-325: build_loc_targets(build_boxes_from_loc_scores(loc)) == loc."""
+    rs = np.random.RandomState(3)
+    H, W = 6, 7
+    loc = torch.from_numpy((rs.standard_normal((2, 4, H * W)) * 1.5).astype(np.float32))
+    boxes = D.decode_level(loc, H, W, 1e9, 1e9)           # huge image: no clipping
+    boxes_noclip = boxes.clone()
+    anchors = O.anchor_grid(H, W, 240.0, 16.0)
+    for b in range(2):
+        bx = boxes_noclip[b]
+        if (bx[:, :2] <= 0).any():
+            continue
+        back = O.encode_boxes(bx, anchors)
+        assert util.maxdiff(back.t(), loc[b]) < 1e-4
+
+
+def test_decode_pyramid_matches_reference():
+    d = np.load(util.GOLDEN + "/decode_pyramid.npz")
+    L = int(d["n_levels"])
+    img = [tuple(int(v) for v in x) for x in d["img_sizes"]]
+
+    def c4(s):
+        for _ in range(4):
+            s = (s + 1) // 2
+        return s
+    fm_sizes = [(c4(h), c4(w)) for w, h in img]
+    locs = [torch.from_numpy(d["loc_%d" % i]) for i in range(L)]
+    clss = [torch.from_numpy(d["cls_%d" % i]) for i in range(L)]
+    for i in range(L):
+        bx = D.decode_level(locs[i], fm_sizes[i][0], fm_sizes[i][1], img[i][0], img[i][1])
+        assert torch.equal(bx, torch.from_numpy(d["ref_boxes_%d" % i]))
+    orig = tuple(int(v) for v in d["orig_size"])
+    for name, thr in (("t0", 0.0), ("tinf", float("-inf")), ("t06", 0.6)):
+        b, s, l = D.decode_pyramid(locs, clss, fm_sizes, img, orig, thr, 0.3)
+        assert torch.equal(b, torch.from_numpy(d["ref_%s_boxes" % name]))
+        assert torch.equal(s, torch.from_numpy(d["ref_%s_scores" % name]))
+        assert torch.equal(l, torch.from_numpy(d["ref_%s_labels" % name]))

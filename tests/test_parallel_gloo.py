@@ -1,0 +1,92 @@
+"""CPU, world_size 2 over gloo: the class-sharded path (shard plan, gather buffer layout, all-gather reassembly,
+ClassShardedHead.forward incl. the ragged last rank and the scores-only mode).  The per-rank compute is supplied by
+the ORACLE here (test infrastructure standing in for the HIP head, which needs a GPU); what is under test is the
+distributed logic of os2d_amd/parallel.py."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from os2d_amd.parallel import shard_bounds
+
+
+def test_shard_bounds():
+    assert shard_bounds(1024, 8) == [(i * 128, (i + 1) * 128) for i in range(8)]
+    assert shard_bounds(5, 2) == [(0, 3), (3, 5)]
+    assert shard_bounds(3, 4) == [(0, 1), (1, 2), (2, 3), (3, 3)]
+    b = shard_bounds(1000, 7)
+    assert b[0][0] == 0 and b[-1][1] == 1000 and all(b[i][1] == b[i + 1][0] for i in range(6))
+    assert max(e - s for s, e in b) - min(e - s for s, e in b) <= 1
+
+
+class _OracleHead(object):
+    """Stand-in with the Os2dHead calling convention, computing with the CPU oracle (test only)."""
+
+    def __init__(self, q_hat, state, inverse):
+        self.q, self.state, self.inverse = q_hat, state, inverse
+        self.class_batch_size = q_hat.size(0)
+
+    def __call__(self, fm, out=None, stage_events=None):
+        from oracle import head_oracle as O
+        with torch.no_grad():
+            loc, cls, _, corners = O.head_forward(fm, self.q, self.state, self.inverse)
+        if out is not None:
+            out[0].copy_(loc), out[1].copy_(cls), out[2].copy_(corners)
+            return out[0], out[1], out[1], out[2]
+        return loc, cls, cls, corners
+
+
+def _worker(rank, world, port, n_classes, gather, result_queue):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from oracle import head_oracle as O
+        from os2d_amd.parallel import ClassShardedHead
+        from os2d_amd.utils import synthetic
+        P, inverse = 6, True
+        state = synthetic.make_transform_net_state(P, seed=9)
+        fm = synthetic.make_feature_map(16, 7, 9, seed=2, A=2)
+        class_fms = synthetic.make_class_feature_maps(n_classes, 16, sizes=[(15, 15), (13, 16)], seed=40)
+        q = O.prepare_class_maps(class_fms)
+        s, e = shard_bounds(n_classes, world)[rank]
+        sharded = ClassShardedHead(None, gather=gather, num_classes=n_classes, local_head=_OracleHead(q[s:e], state, inverse))
+        loc, cls, cls_det, corners = sharded(fm)
+        with torch.no_grad():
+            ref = O.head_forward(fm, q, state, inverse)
+        ok = torch.equal(cls, ref[1]) and cls_det is cls
+        if gather == "all":
+            ok = ok and torch.equal(loc, ref[0]) and torch.equal(corners, ref[3])
+        else:
+            ok = ok and loc is None and corners is None
+        result_queue.put((rank, bool(ok), tuple(cls.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("n_classes,gather", [(4, "all"), (5, "all"), (5, "scores")])
+def test_class_sharded_head_world2(n_classes, gather):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_classes, gather, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, shape in sorted(results):
+        assert ok, "rank {} assembled a wrong result".format(rank)
+        assert shape == (2, n_classes, 1, 7, 9)

@@ -67,8 +67,9 @@ __global__ __launch_bounds__(256) void nms_kernel(const float4* __restrict__ box
       unsigned long long kbits = 0ull;
       const unsigned int lo = (unsigned int)sup_by, hi = (unsigned int)(sup_by >> 32);
       for (int i = 0; i < 64; ++i) {
-        const unsigned long long s = ((unsigned long long)__builtin_amdgcn_readlane(hi, i) << 32) |
-                                     (unsigned long long)__builtin_amdgcn_readlane(lo, i);
+        // readlane returns a signed int: go through unsigned int or bit 31 would sign-extend into the high word
+        const unsigned long long s = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)hi, i) << 32) |
+                                     (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)lo, i);
         if (((alive0 >> i) & 1ull) && (s & kbits) == 0ull) kbits |= (1ull << i);
       }
       const bool k = (kbits >> lane) & 1ull;

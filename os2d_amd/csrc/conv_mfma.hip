@@ -8,41 +8,52 @@
 // that both half-waves use the same tap shift: the per-lane LDS addresses are fixed for a whole channel
 // pair and every tap / 32-column block is a compile-time immediate (plus one add per kernel row dy).
 //
-// Work-group = 256 threads (4 waves), tile = MT output channels x NT=256 plane positions.
-// Per channel pair the group stages in LDS:  A slab  [KS*KS][2][MT]  (packed weights, contiguous in HBM/L2)
-//                                            B slab  [2][NT + 2*HALO] (input rows with halo)
-// then issues KS*KS taps x (MI x NI) MFMAs per wave.  conv1: 49 taps x 8 MFMA x 64 cycles = 25k cycles of
-// matrix work per 56 KB staged, i.e. the kernel is MFMA-bound; two groups per CU overlap each other's
-// staging.  Arithmetic is exact fp32 (the MFMA is a k-ordered fmaf chain).
+// Work-group = 256 threads (4 waves), tile = MT output channels x NT=256 plane positions starting at the first
+// data cell (tiles cover exactly the H*WS data rows; the first / last tile also zero the pad rows above / below).
+//
+// Software pipeline (one barrier per stage, global latency hidden behind the MFMAs of the previous stage):
+//   stage        = one channel pair x RS kernel rows  (conv1: RS=1 -> 7 taps x 8 MFMA = 3.6k matrix cycles per wave)
+//   LDS (x2 buf) = A slab [RS*KS][2][MT] packed weights (contiguous in HBM/L2)  +  B slab [2][NT+2*HALO] input rows
+//   iteration s  : issue the global loads of stage s+1 into registers -> MFMAs of stage s from buffer s&1 ->
+//                  write the registers into buffer (s+1)&1 -> barrier.
+// The B slab only changes with the channel pair, so it is prefetched with the last row-stage of the previous pair.
+// conv1 needs 2*(7 KB + 6 KB) = 27 KB of LDS per group, so occupancy is set by registers (2 waves / SIMD).
+// Arithmetic is exact fp32 (the MFMA is a k-ordered fmaf chain).
 #include "os2d_common.h"
 
 namespace {
 
-template <int KS, int MT, int WM, int WN, int NT, bool RELU, bool COMPACT>
+constexpr int NBPF = 3;  // max float4 per thread for the B-slab prefetch (SLAB <= 1536 floats)
+
+template <int KS, int RS, int MT, int WM, int WN, int NT, bool RELU, bool COMPACT>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const float* __restrict__ in,   // [NB][CinP][PLANE]
                                                            const float* __restrict__ wp,   // [CinP/2][KS*KS][2][MT]
                                                            const float* __restrict__ bp,   // [MT]
                                                            float* __restrict__ out, int CinP, int CoutStore,
                                                            int H, int W, int PLANE, int HALO) {
   constexpr int R = KS / 2;
-  constexpr int TAPS = KS * KS;
+  constexpr int SP = KS / RS;  // stages per channel pair
+  static_assert(SP * RS == KS, "RS must divide KS");
   constexpr int MW = MT / WM, NW = NT / WN;
   constexpr int MI = MW / 32, NI = NW / 32;
   static_assert(WM * WN == 4, "4 waves per work-group");
   static_assert(MW % 32 == 0 && NW % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA block");
-  constexpr int ASLAB = TAPS * 2 * MT;
+  constexpr int ASTAGE = RS * KS * 2 * MT;          // floats of one A stage slab
+  constexpr int NAPF = (ASTAGE / 4 + 255) / 256;    // float4 per thread for the A prefetch
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* ldsA = smem;
-  float* ldsB = smem + ASLAB;
-
-  const int Ws = W + 2 * OS2D_PAD, Hp = H + 2 * OS2D_PAD;
+  const int Ws = W + OS2D_PAD;
+  const int BASE = os2d_base(W);
+  const int DATA = H * Ws;  // flat extent of the data rows
   const int SLAB = NT + 2 * HALO;
+  float* ldsA = smem;                 // [2][ASTAGE]
+  float* ldsB = smem + 2 * ASTAGE;    // [2][2*SLAB]
+
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
   const int wm = wid / WN, wn = wid % WN;
   const int nb = blockIdx.y;
-  const int n0 = blockIdx.x * NT;
+  const int n0 = BASE + blockIdx.x * NT;
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -52,100 +63,144 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const float* __restri
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  // tiles that only cover border rows have nothing to accumulate (block-uniform)
-  const bool has_work = (n0 < (H + OS2D_PAD) * Ws) && (n0 + NT > OS2D_PAD * Ws);
-  if (has_work) {
-    const float* aBase = ldsA + hi * MT + wm * MW + l31;
-    const float* bBase = ldsB + hi * SLAB + wn * NW + l31 + HALO - R * Ws - R;
-    const int npairs = CinP >> 1;
-    for (int cp = 0; cp < npairs; ++cp) {
-      // ---- stage A: contiguous packed weights of this channel pair
-      {
-        const float4* src = reinterpret_cast<const float4*>(wp + (size_t)cp * ASLAB);
-        float4* dst = reinterpret_cast<float4*>(ldsA);
-        for (int i = tid; i < ASLAB / 4; i += 256) dst[i] = src[i];
-      }
-      // ---- stage B: two input channels, plane range [n0-HALO, n0+NT+HALO)
-      {
-        const int q4 = SLAB >> 2;
-        for (int i = tid; i < 2 * q4; i += 256) {
-          const int h2 = i >= q4 ? 1 : 0;
-          const int j = (i - h2 * q4) << 2;
-          const int g = n0 - HALO + j;  // plane-relative, multiple of 4
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (g >= 0 && g + 3 < PLANE)
-            v = *reinterpret_cast<const float4*>(in + ((size_t)nb * CinP + 2 * cp + h2) * PLANE + g);
-          *reinterpret_cast<float4*>(ldsB + h2 * SLAB + j) = v;
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int dy = 0; dy < KS; ++dy) {
-        const float* bRow = bBase + dy * Ws;
-#pragma unroll
-        for (int dx = 0; dx < KS; ++dx) {
-          const int tap = dy * KS + dx;
-          float a[MI], b[NI];
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) a[mi] = aBase[tap * 2 * MT + mi * 32];
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) b[ni] = bRow[dx + ni * 32];
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-        }
-      }
-      __syncthreads();
-    }
+  const int aOff = hi * MT + wm * MW + l31;
+  const int bOff = hi * SLAB + wn * NW + l31 + HALO - R * Ws - R;
+  const int npairs = CinP >> 1;
+  const int nstages = npairs * SP;
+  const int q4 = SLAB >> 2;  // float4 per channel of the B slab
+
+  f32x4 pfA[NAPF], pfB[NBPF];
+  const float* inb = in + (size_t)nb * CinP * PLANE;
+
+  // NOTE: the prefetch loads are UNCONDITIONAL (indices clamped, out-of-plane reads redirected to offset 0 and
+  // zeroed at store time).  A load under a divergent branch makes hipcc wait for it at the end of the branch
+  // (s_waitcnt vmcnt(0) before the MFMAs), which would serialise the very latency this pipeline hides.
+  // (Written as macros, not lambdas: by-reference capture of the register arrays sent them to scratch memory.)
+#define OS2D_LOAD_STAGE(S)                                                                                         \
+  {                                                                                                                \
+    const f32x4* src_ = reinterpret_cast<const f32x4*>(wp + (size_t)(S)*ASTAGE);                                  \
+    _Pragma("unroll") for (int k = 0; k < NAPF; ++k) pfA[k] = src_[min(tid + k * 256, ASTAGE / 4 - 1)];           \
+    if ((S) % SP == 0) {                                                                                           \
+      const int cp_ = (S) / SP;                                                                                    \
+      _Pragma("unroll") for (int k = 0; k < NBPF; ++k) {                                                          \
+        const int i_ = min(tid + k * 256, 2 * q4 - 1);                                                             \
+        const int h2_ = i_ >= q4 ? 1 : 0;                                                                          \
+        int g_ = n0 - HALO + ((i_ - h2_ * q4) << 2);                                                               \
+        g_ = (g_ >= 0 && g_ < PLANE) ? g_ : 0;                                                                     \
+        pfB[k] = *reinterpret_cast<const f32x4*>(inb + (size_t)(2 * cp_ + h2_) * PLANE + g_);                      \
+      }                                                                                                            \
+    }                                                                                                              \
+  }
+#define OS2D_STORE_STAGE(S)                                                                                        \
+  {                                                                                                                \
+    f32x4* dstA_ = reinterpret_cast<f32x4*>(ldsA + ((S)&1) * ASTAGE);                                              \
+    _Pragma("unroll") for (int k = 0; k < NAPF; ++k) {                                                            \
+      const int i_ = tid + k * 256;                                                                                \
+      if (i_ < ASTAGE / 4) dstA_[i_] = pfA[k];                                                                     \
+    }                                                                                                              \
+    if ((S) % SP == 0) {                                                                                           \
+      f32x4* dstB_ = reinterpret_cast<f32x4*>(ldsB + (((S) / SP) & 1) * 2 * SLAB);                                 \
+      _Pragma("unroll") for (int k = 0; k < NBPF; ++k) {                                                          \
+        const int i_ = tid + k * 256;                                                                              \
+        if (i_ < 2 * q4) {                                                                                         \
+          const int h2_ = i_ >= q4 ? 1 : 0;                                                                        \
+          const int g_ = n0 - HALO + ((i_ - h2_ * q4) << 2);                                                       \
+          const f32x4 z_ = {0.f, 0.f, 0.f, 0.f};                                                                   \
+          dstB_[i_] = (g_ >= 0 && g_ < PLANE) ? pfB[k] : z_;                                                       \
+        }                                                                                                          \
+      }                                                                                                            \
+    }                                                                                                              \
   }
 
-  // ---- epilogue: bias (+ReLU); border cells of a padded output are written as exact zeros
+  OS2D_LOAD_STAGE(0)
+  OS2D_STORE_STAGE(0)
+  __syncthreads();
+  for (int s = 0; s < nstages; ++s) {
+    const int s1 = min(s + 1, nstages - 1);  // the last iteration re-loads its own stage (harmless, never stored)
+    OS2D_LOAD_STAGE(s1)
+    const int cp = s / SP, rg = s - cp * SP;  // row group of this stage
+    const float* aBase = ldsA + (s & 1) * ASTAGE + aOff;
+    const float* bBase = ldsB + (cp & 1) * 2 * SLAB + bOff + rg * RS * Ws;
+#pragma unroll
+    for (int ry = 0; ry < RS; ++ry) {
+      const float* bRow = bBase + ry * Ws;
+#pragma unroll
+      for (int dx = 0; dx < KS; ++dx) {
+        float a[MI], b[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a[mi] = aBase[(ry * KS + dx) * 2 * MT + mi * 32];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b[ni] = bRow[dx + ni * 32];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+      }
+    }
+    if (s + 1 < nstages) OS2D_STORE_STAGE(s + 1)
+    __syncthreads();
+  }
+#undef OS2D_LOAD_STAGE
+#undef OS2D_STORE_STAGE
+
+  // ---- epilogue: bias (+ReLU); pad cells of a plane-layout output are written as exact zeros
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int n = n0 + wn * NW + ni * 32 + l31;
-    if (n >= Hp * Ws) continue;
-    const int hr = n / Ws, wc = n - hr * Ws;
-    const bool valid = hr >= OS2D_PAD && hr < H + OS2D_PAD && wc >= OS2D_PAD && wc < W + OS2D_PAD;
+    const int r = n - BASE;
+    const int hr = r / Ws, wc = r - hr * Ws;
+    const bool valid = r < DATA && wc < W;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = wm * MW + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      for (int k = 0; k < 16; ++k) {
+        const int m = wm * MW + mi * 32 + (k & 3) + 8 * (k >> 2) + 4 * hi;
         if (m >= CoutStore) continue;
-        float v = acc[mi][ni][r] + bp[m];
+        float v = acc[mi][ni][k] + bp[m];
         if (RELU) v = fmaxf(v, 0.f);
         if (COMPACT) {
-          if (valid) out[((size_t)nb * CoutStore + m) * (H * W) + (hr - OS2D_PAD) * W + (wc - OS2D_PAD)] = v;
-        } else {
+          if (valid) out[((size_t)nb * CoutStore + m) * (H * W) + hr * W + wc] = v;
+        } else if (n < PLANE) {
           out[((size_t)nb * CoutStore + m) * PLANE + n] = valid ? v : 0.f;
         }
       }
     }
   }
+  if (!COMPACT) {
+    // pad rows above the data (first tile) and whatever lies beyond the last tile
+    if (blockIdx.x == 0)
+      for (int i = tid; i < CoutStore * BASE; i += 256) out[((size_t)nb * CoutStore + i / BASE) * PLANE + i % BASE] = 0.f;
+    if (blockIdx.x == gridDim.x - 1) {
+      const int tail0 = BASE + gridDim.x * NT, tail = PLANE - tail0;
+      if (tail > 0)
+        for (int i = tid; i < CoutStore * tail; i += 256)
+          out[((size_t)nb * CoutStore + i / tail) * PLANE + tail0 + i % tail] = 0.f;
+    }
+  }
 }
 
-template <int KS, int MT, int WM, int WN, bool RELU, bool COMPACT>
+template <int KS, int RS, int MT, int WM, int WN, bool RELU, bool COMPACT>
 int launch(const float* in, const float* wp, const float* bp, float* out, int NB, int CinP, int CoutStore, int H,
            int W, hipStream_t stream) {
   constexpr int NT = 256;
   constexpr int R = KS / 2;
-  const int Ws = os2d_ws(W), Hp = os2d_hp(H), PLANE = os2d_plane(H, W);
+  const int Ws = os2d_ws(W), PLANE = os2d_plane(H, W);
   const int HALO = os2d_round_up(R * Ws + R, 4);
-  const size_t lds = (size_t)(KS * KS * 2 * MT + 2 * (NT + 2 * HALO)) * sizeof(float);
-  if (lds > 160 * 1024) {
-    os2d_set_error("conv%dx%d: feature map too wide for the LDS halo (W=%d needs %zu B)", KS, KS, W, lds);
+  const int SLAB = NT + 2 * HALO;
+  if (2 * (SLAB / 4) > NBPF * 256) {
+    os2d_set_error("conv%dx%d: feature map too wide for the B-slab prefetch (W=%d)", KS, KS, W);
     return -3;
   }
-  auto kern = conv_mfma_kernel<KS, MT, WM, WN, NT, RELU, COMPACT>;
+  const size_t lds = (size_t)(2 * RS * KS * 2 * MT + 4 * SLAB) * sizeof(float);
+  auto kern = conv_mfma_kernel<KS, RS, MT, WM, WN, NT, RELU, COMPACT>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) {
     os2d_set_error("hipFuncSetAttribute(conv): %s", hipGetErrorString(e));
     return -4;
   }
-  dim3 grid((Hp * Ws + NT - 1) / NT, NB);
+  dim3 grid((H * Ws + NT - 1) / NT, NB);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, in, wp, bp, out, CinP, CoutStore, H, W, PLANE, HALO);
   e = hipGetLastError();
   if (e != hipSuccess) {
@@ -157,14 +212,14 @@ int launch(const float* in, const float* wp, const float* bp, float* out, int NB
 
 }  // namespace
 
-// layer 1: 7x7 225(226)->128 +ReLU, padded out; layer 2: 5x5 128->64 +ReLU, padded out;
+// layer 1: 7x7 225(226)->128 +ReLU, plane out; layer 2: 5x5 128->64 +ReLU, plane out;
 // layer 3: 5x5 64->P (rows padded to 32 in the packed weights), compact [NB][P][H*W] out.
 int os2d_launch_conv(int layer, const float* in, const float* wp, const float* bp, float* out, int NB, int P, int H,
                      int W, hipStream_t stream) {
   switch (layer) {
-    case 1: return launch<7, 128, 2, 2, true, false>(in, wp, bp, out, NB, OS2D_KP, 128, H, W, stream);
-    case 2: return launch<5, 64, 1, 4, true, false>(in, wp, bp, out, NB, 128, 64, H, W, stream);
-    case 3: return launch<5, 32, 1, 4, false, true>(in, wp, bp, out, NB, 64, P, H, W, stream);
+    case 1: return launch<7, 1, 128, 2, 2, true, false>(in, wp, bp, out, NB, OS2D_KP, 128, H, W, stream);
+    case 2: return launch<5, 5, 64, 1, 4, true, false>(in, wp, bp, out, NB, 128, 64, H, W, stream);
+    case 3: return launch<5, 5, 32, 1, 4, false, true>(in, wp, bp, out, NB, 64, P, H, W, stream);
     default: os2d_set_error("os2d_launch_conv: bad layer %d", layer); return -1;
   }
 }

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_kernel(const float* __restri
   }
 
   // ---- epilogue
-  const int Ws = W + 2 * OS2D_PAD;
+  const int Ws = os2d_ws(W), BASE = os2d_base(W);
   float part[2];
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_kernel(const float* __restri
     if (n >= HW) continue;
     const float inv_r = 1.0f / (sqrtf(red[0][col] + red[1][col]) + 1e-6f);  // head.py:650,597 (eps 1e-6)
     const int h = n / W, w = n - h * W;
-    const size_t cell = (size_t)(h + OS2D_PAD) * Ws + (w + OS2D_PAD);
+    const size_t cell = (size_t)BASE + (size_t)h * Ws + w;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll

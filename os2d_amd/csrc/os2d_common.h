@@ -1,14 +1,16 @@
 // Shared definitions for the gfx950 (CDNA4) OS2D head kernels.
 //
-// Padded-plane geometry used by every TransformNet activation buffer:
-//   a feature map H x W is stored as (H+2*PAD) rows of WS = W+2*PAD floats with zero borders, PAD = 3
-//   (the largest conv radius, 7x7).  A plane is PLANE = round_up((H+2*PAD)*WS, 64) floats, so that every
-//   plane and every tile origin is 16-byte aligned.  With zero borders baked into the layout a KSxKS
-//   convolution is a pure shift-and-accumulate over the FLAT plane index n = h'*WS + w':
+// Zero-bordered plane layout used by every TransformNet activation buffer.  A feature map H x W is stored as
+// rows of WS = W + PAD floats (PAD = 3 = the largest conv radius): W data cells followed by PAD zero cells.  The
+// pad cells of row h double as the LEFT border of row h+1, so one gap of 3 zeros between rows serves both sides.
+// The map starts at flat offset BASE = round_up(PAD*WS + PAD, 4) (3 zero rows + 3 cells above it) and is followed
+// by the same amount of zeros;  PLANE = round_up(BASE + (H+PAD)*WS + PAD, 64) floats per channel, so every plane
+// and every tile origin is 16-byte aligned.  cell(h, w) = BASE + h*WS + w.
+// With the zeros baked in, a KSxKS convolution is a pure shift-and-accumulate over the FLAT index n:
 //       out[o][n] = sum_{c,dy,dx} w[o][c][dy][dx] * in[c][n + (dy-R)*WS + (dx-R)],   R = KS/2
-//   which is what lets the implicit-GEMM kernel read its B operand from LDS with one runtime row offset
-//   and compile-time immediates for dx and the 32-column blocks.  Outputs at border cells are computed
-//   as garbage by the MFMAs and replaced by 0 in the epilogue (7.5 % extra columns at 60x80).
+// which lets the implicit-GEMM kernel read its B operand from LDS with one runtime row offset per kernel row and
+// compile-time immediates for dx and the 32-column blocks.  Outputs at pad cells are computed as garbage by the
+// MFMAs and replaced by exact zeros in the epilogue (3/80 = 3.75 % extra columns at 60x80).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -22,12 +24,17 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-static inline __host__ __device__ int os2d_ws(int W) { return W + 2 * OS2D_PAD; }
-static inline __host__ __device__ int os2d_hp(int H) { return H + 2 * OS2D_PAD; }
-static inline __host__ __device__ int os2d_plane(int H, int W) {
-  return ((os2d_hp(H) * os2d_ws(W) + 63) / 64) * 64;
-}
 static inline __host__ __device__ int os2d_round_up(int x, int m) { return ((x + m - 1) / m) * m; }
+static inline __host__ __device__ int os2d_ws(int W) { return W + OS2D_PAD; }
+static inline __host__ __device__ int os2d_base(int W) { return os2d_round_up(OS2D_PAD * os2d_ws(W) + OS2D_PAD, 4); }
+static inline __host__ __device__ int os2d_plane(int H, int W) {
+  return os2d_round_up(os2d_base(W) + (H + OS2D_PAD) * os2d_ws(W) + OS2D_PAD, 64);
+}
+// is flat plane index n an interior (data) cell?
+static inline __host__ __device__ bool os2d_interior(int n, int H, int W) {
+  const int r = n - os2d_base(W);
+  return r >= 0 && r < H * os2d_ws(W) && (r % os2d_ws(W)) < W;
+}
 
 // error plumbing (abi.hip)
 void os2d_set_error(const char* fmt, ...);

@@ -36,22 +36,18 @@ __global__ __launch_bounds__(1024) void fm_sumsq_kernel(const float* __restrict_
 
 // ---- border_zero: one block per plane
 __global__ __launch_bounds__(256) void border_zero_kernel(float* __restrict__ rpad, int H, int W, int PLANE) {
-  const int Ws = W + 2 * OS2D_PAD, Hp = H + 2 * OS2D_PAD;
   const int ch = blockIdx.x % OS2D_KP;
   float* p = rpad + (size_t)blockIdx.x * PLANE;
   const bool whole = ch >= OS2D_K;
-  for (int i = threadIdx.x; i < Hp * Ws; i += 256) {
-    const int hr = i / Ws, wc = i - hr * Ws;
-    const bool interior = hr >= OS2D_PAD && hr < H + OS2D_PAD && wc >= OS2D_PAD && wc < W + OS2D_PAD;
-    if (whole || !interior) p[i] = 0.f;
-  }
+  for (int i = threadIdx.x; i < PLANE; i += 256)
+    if (whole || !os2d_interior(i, H, W)) p[i] = 0.f;
 }
 
 // ---- corr_normalize: standalone relu -> L2 over the 225 channels (head.py:650) of an arbitrary correlation
 // tensor [NB][225][HW] into the padded-plane layout (the fused path does this in the GEMM epilogue)
 __global__ __launch_bounds__(256) void corr_normalize_kernel(const float* __restrict__ corr, float* __restrict__ rpad,
                                                              int H, int W, int PLANE) {
-  const int HW = H * W, Ws = W + 2 * OS2D_PAD;
+  const int HW = H * W, Ws = os2d_ws(W);
   const int n = blockIdx.x * 256 + threadIdx.x;
   const int nb = blockIdx.y;
   if (n >= HW) return;
@@ -63,7 +59,7 @@ __global__ __launch_bounds__(256) void corr_normalize_kernel(const float* __rest
   }
   const float inv = 1.0f / (sqrtf(s) + 1e-6f);
   const int h = n / W, w = n - h * W;
-  float* o = rpad + (size_t)nb * OS2D_KP * PLANE + (size_t)(h + OS2D_PAD) * Ws + (w + OS2D_PAD);
+  float* o = rpad + (size_t)nb * OS2D_KP * PLANE + (size_t)os2d_base(W) + (size_t)h * Ws + w;
   for (int k = 0; k < OS2D_K; ++k) o[(size_t)k * PLANE] = fmaxf(c[(size_t)k * HW], 0.f) * inv;
 }
 

@@ -18,11 +18,15 @@ from os2d_amd import _lib  # noqa: E402
 
 
 def unpad(x, NB, Cst, H, W, plane):
-    Ws, Hp = W + 6, H + 6
-    x = x.view(NB, Cst, plane)[:, :, :Hp * Ws].view(NB, Cst, Hp, Ws)
+    """plane layout (os2d_common.h): cell(h,w) = BASE + h*(W+3) + w, BASE = round_up(3*(W+3)+3, 4)."""
+    Ws = W + 3
+    base = (3 * Ws + 3 + 3) // 4 * 4
+    x = x.view(NB, Cst, plane)
+    data = x[:, :, base:base + H * Ws].reshape(NB, Cst, H, Ws)
+    inner = data[:, :, :, :W].contiguous()
     border = x.clone()
-    border[:, :, 3:H + 3, 3:W + 3] = 0
-    return x[:, :, 3:H + 3, 3:W + 3].contiguous(), float(border.abs().max())
+    border[:, :, base:base + H * Ws].view(NB, Cst, H, Ws)[:, :, :, :W] = 0
+    return inner, float(border.abs().max())
 
 
 def main(name):

@@ -115,34 +115,37 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const float* __restri
   OS2D_LOAD_STAGE(0)
   OS2D_STORE_STAGE(0)
   __syncthreads();
-  for (int s = 0; s < nstages; ++s) {
-    const int s1 = min(s + 1, nstages - 1);  // the last iteration re-loads its own stage (harmless, never stored)
-    OS2D_LOAD_STAGE(s1)
-    const int cp = s / SP, rg = s - cp * SP;  // row group of this stage
-    const float* aBase = ldsA + (s & 1) * ASTAGE + aOff;
-    const float* bBase = ldsB + (cp & 1) * 2 * SLAB + bOff + rg * RS * Ws;
-#pragma unroll
-    for (int ry = 0; ry < RS; ++ry) {
-      const float* bRow = bBase + ry * Ws;
-#pragma unroll
-      for (int dx = 0; dx < KS; ++dx) {
-        float a[MI], b[NI];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) a[mi] = aBase[(ry * KS + dx) * 2 * MT + mi * 32];
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) b[ni] = bRow[dx + ni * 32];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-      }
-    }
-    if (s + 1 < nstages) OS2D_STORE_STAGE(s + 1)
+#define OS2D_COMPUTE_STAGE(S)                                                                                      \
+  {                                                                                                                \
+    const int cp_ = (S) / SP, rg_ = (S)-cp_ * SP; /* row group of this stage */                                    \
+    const float* aBase_ = ldsA + ((S)&1) * ASTAGE + aOff;                                                          \
+    const float* bBase_ = ldsB + (cp_ & 1) * 2 * SLAB + bOff + rg_ * RS * Ws;                                      \
+    _Pragma("unroll") for (int ry = 0; ry < RS; ++ry) {                                                           \
+      const float* bRow_ = bBase_ + ry * Ws;                                                                       \
+      _Pragma("unroll") for (int dx = 0; dx < KS; ++dx) {                                                         \
+        float a_[MI], b_[NI];                                                                                      \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) a_[mi] = aBase_[(ry * KS + dx) * 2 * MT + mi * 32];     \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) b_[ni] = bRow_[dx + ni * 32];                           \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                         \
+          _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                       \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[mi], b_[ni], acc[mi][ni], 0, 0, 0);              \
+      }                                                                                                            \
+    }                                                                                                              \
+  }
+  // The last stage is peeled so that load -> MFMA -> store is branch-free inside the loop: with the store under
+  // "if (s+1 < nstages)" hipcc may sink the (speculatable) prefetch loads into that branch, behind the MFMAs.
+  for (int s = 0; s + 1 < nstages; ++s) {
+    OS2D_LOAD_STAGE(s + 1)
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch loads ahead of the MFMAs
+    OS2D_COMPUTE_STAGE(s)
+    __builtin_amdgcn_sched_barrier(0);
+    OS2D_STORE_STAGE(s + 1)
     __syncthreads();
   }
+  OS2D_COMPUTE_STAGE(nstages - 1)
 #undef OS2D_LOAD_STAGE
 #undef OS2D_STORE_STAGE
+#undef OS2D_COMPUTE_STAGE
 
   // ---- epilogue: bias (+ReLU); pad cells of a plane-layout output are written as exact zeros
 #pragma unroll

@@ -10,7 +10,9 @@
 //
 // Work-group = 256 threads (4 waves as 2x2), tile = 256 (all rows of one class) x NT=128 positions, so the
 // whole 225-channel column of every position lives in one group and the channel L2-norm is a cross-wave LDS
-// reduction in the epilogue.  Outputs:
+// reduction in the epilogue.  K is consumed in chunks of KC=16 channels through double-buffered LDS with a
+// register prefetch (same pipeline as conv_mfma.hip: loads of chunk t+1 are issued before the MFMAs of chunk t,
+// written to the other buffer after them, one barrier per chunk).  Outputs:
 //   corr  [A*B][225][H*W]      raw correlation (input of the resampling kernel)
 //   rpad  [A*B][226][PLANE]    relu+L2-normalised, in the zero-bordered plane layout the conv kernels read
 #include "os2d_common.h"
@@ -18,15 +20,19 @@
 namespace {
 
 constexpr int NT = 128;
-constexpr int KC = 16;  // k-chunk staged per barrier
+constexpr int KC = 16;                        // k-chunk per pipeline stage
+constexpr int A4 = KC * OS2D_QROWS / 4 / 256;  // float4 per thread of an A chunk (4)
+constexpr int B4 = KC * NT / 4 / 256;          // float4 per thread of a B chunk (2)
+constexpr int B1 = KC * NT / 256;              // dwords per thread of a B chunk (8)
 
+template <bool VEC4>
 __global__ __launch_bounds__(256, 2) void corr_mfma_kernel(const float* __restrict__ fm,     // [A][C][HW]
                                                            const float* __restrict__ qp,     // [B][C][256]
                                                            const float* __restrict__ sumsq,  // [A][HW]
                                                            float* __restrict__ corr, float* __restrict__ rpad,
                                                            int B, int C, int H, int W, int PLANE) {
-  __shared__ __attribute__((aligned(16))) float ldsA[KC * OS2D_QROWS];
-  __shared__ __attribute__((aligned(16))) float ldsB[KC * NT];
+  __shared__ __attribute__((aligned(16))) float ldsA[2][KC * OS2D_QROWS];
+  __shared__ __attribute__((aligned(16))) float ldsB[2][KC * NT];
   __shared__ float red[2][NT];
 
   const int HW = H * W;
@@ -45,42 +51,96 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_kernel(const float* __restri
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  const float* aBase = ldsA + hi * OS2D_QROWS + wm * 128 + l31;
-  const float* bBase = ldsB + hi * NT + wn * 64 + l31;
+  const int aOff = hi * OS2D_QROWS + wm * 128 + l31;
+  const int bOff = hi * NT + wn * 64 + l31;
+  const float* qb = qp + (size_t)b * C * OS2D_QROWS;
+  const float* fa = fm + (size_t)a * C * HW;
+  const int nchunks = (C + KC - 1) / KC;
 
-  for (int k0 = 0; k0 < C; k0 += KC) {
-    {  // A: KC consecutive channels of the packed class map = KC*256 contiguous floats
-      const float4* src = reinterpret_cast<const float4*>(qp + ((size_t)b * C + k0) * OS2D_QROWS);
-      float4* dst = reinterpret_cast<float4*>(ldsA);
-      const int nvalid = (min(KC, C - k0) * OS2D_QROWS) >> 2;
-      for (int i = tid; i < (KC * OS2D_QROWS) / 4; i += 256)
-        dst[i] = i < nvalid ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    {  // B: KC rows of NT positions (dword loads: H*W need not be a multiple of 4)
-      for (int i = tid; i < KC * NT; i += 256) {
-        const int kk = i / NT, j = i - kk * NT;
-        const int n = n0 + j;
-        float v = 0.f;
-        if (k0 + kk < C && n < HW) v = fm[((size_t)a * C + k0 + kk) * HW + n];
-        ldsB[i] = v;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < KC / 2; ++p) {
-      float av[4], bv[2];
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) av[mi] = aBase[2 * p * OS2D_QROWS + mi * 32];
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) bv[ni] = bBase[2 * p * NT + ni * 32];
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
-    }
+  f32x4 pfA[A4];
+  f32x4 pfB4[B4];
+  float pfB1[B1];
+
+  // Unconditional, clamped prefetch loads (a load under a divergent branch would be waited for at the branch end);
+  // rows past C and columns past H*W are zeroed when the registers are written to LDS.
+#define CORR_LOAD(T)                                                                                              \
+  {                                                                                                               \
+    const int k0_ = (T)*KC;                                                                                       \
+    _Pragma("unroll") for (int k = 0; k < A4; ++k) {                                                              \
+      const int i_ = tid + k * 256; /* float4 index: row = i_/64 */                                               \
+      const int row_ = min(k0_ + (i_ >> 6), C - 1);                                                               \
+      pfA[k] = *reinterpret_cast<const f32x4*>(qb + (size_t)row_ * OS2D_QROWS + ((i_ & 63) << 2));                \
+    }                                                                                                             \
+    if (VEC4) {                                                                                                   \
+      _Pragma("unroll") for (int k = 0; k < B4; ++k) {                                                            \
+        const int i_ = tid + k * 256; /* float4 index: row = i_/32 */                                             \
+        const int row_ = min(k0_ + (i_ >> 5), C - 1);                                                             \
+        const int n_ = min(n0 + ((i_ & 31) << 2), HW - 4);                                                        \
+        pfB4[k] = *reinterpret_cast<const f32x4*>(fa + (size_t)row_ * HW + n_);                                   \
+      }                                                                                                           \
+    } else {                                                                                                      \
+      _Pragma("unroll") for (int k = 0; k < B1; ++k) {                                                            \
+        const int i_ = tid + k * 256; /* dword index: row = i_/128 */                                             \
+        const int row_ = min(k0_ + (i_ >> 7), C - 1);                                                             \
+        const int n_ = min(n0 + (i_ & 127), HW - 1);                                                              \
+        pfB1[k] = fa[(size_t)row_ * HW + n_];                                                                     \
+      }                                                                                                           \
+    }                                                                                                             \
+  }
+#define CORR_STORE(T)                                                                                             \
+  {                                                                                                               \
+    const int k0_ = (T)*KC;                                                                                       \
+    const f32x4 z_ = {0.f, 0.f, 0.f, 0.f};                                                                        \
+    _Pragma("unroll") for (int k = 0; k < A4; ++k) {                                                              \
+      const int i_ = tid + k * 256;                                                                               \
+      reinterpret_cast<f32x4*>(ldsA[(T)&1])[i_] = (k0_ + (i_ >> 6) < C) ? pfA[k] : z_;                            \
+    }                                                                                                             \
+    if (VEC4) {                                                                                                   \
+      _Pragma("unroll") for (int k = 0; k < B4; ++k) {                                                            \
+        const int i_ = tid + k * 256;                                                                             \
+        const bool ok_ = (k0_ + (i_ >> 5) < C) && (n0 + ((i_ & 31) << 2) < HW); /* HW % 4 == 0 here */            \
+        reinterpret_cast<f32x4*>(ldsB[(T)&1])[i_] = ok_ ? pfB4[k] : z_;                                           \
+      }                                                                                                           \
+    } else {                                                                                                      \
+      _Pragma("unroll") for (int k = 0; k < B1; ++k) {                                                            \
+        const int i_ = tid + k * 256;                                                                             \
+        const bool ok_ = (k0_ + (i_ >> 7) < C) && (n0 + (i_ & 127) < HW);                                         \
+        ldsB[(T)&1][i_] = ok_ ? pfB1[k] : 0.f;                                                                    \
+      }                                                                                                           \
+    }                                                                                                             \
+  }
+
+  CORR_LOAD(0)
+  CORR_STORE(0)
+  __syncthreads();
+#define CORR_COMPUTE(T)                                                                                           \
+  {                                                                                                               \
+    const float* aBase_ = ldsA[(T)&1] + aOff;                                                                     \
+    const float* bBase_ = ldsB[(T)&1] + bOff;                                                                     \
+    _Pragma("unroll") for (int p = 0; p < KC / 2; ++p) {                                                          \
+      float av_[4], bv_[2];                                                                                       \
+      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) av_[mi] = aBase_[2 * p * OS2D_QROWS + mi * 32];            \
+      _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) bv_[ni] = bBase_[2 * p * NT + ni * 32];                    \
+      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                            \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                          \
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[mi], bv_[ni], acc[mi][ni], 0, 0, 0);             \
+    }                                                                                                             \
+  }
+  // The last chunk is peeled so that load -> MFMA -> store is branch-free inside the loop: with the store under
+  // "if (t+1 < nchunks)" hipcc sinks the (speculatable) prefetch loads into that branch, i.e. behind the MFMAs.
+  for (int t = 0; t + 1 < nchunks; ++t) {
+    CORR_LOAD(t + 1)
+    __builtin_amdgcn_sched_barrier(0);  // and keep the scheduler from moving them below the MFMAs
+    CORR_COMPUTE(t)
+    __builtin_amdgcn_sched_barrier(0);
+    CORR_STORE(t + 1)
     __syncthreads();
   }
+  CORR_COMPUTE(nchunks - 1)
+  __syncthreads();  // red[] / LDS reuse below
+#undef CORR_COMPUTE
+#undef CORR_LOAD
+#undef CORR_STORE
 
   // ---- epilogue
   const int Ws = os2d_ws(W), BASE = os2d_base(W);
@@ -135,8 +195,14 @@ int os2d_launch_corr(const float* fm, const float* qp, const float* sumsq, float
                      int C, int H, int W, hipStream_t stream) {
   const int HW = H * W;
   dim3 grid((HW + NT - 1) / NT, B, A);
-  hipLaunchKernelGGL(corr_mfma_kernel, grid, dim3(256), 0, stream, fm, qp, sumsq, corr, rpad, B, C, H, W,
-                     os2d_plane(H, W));
+  // float4 loads of the image map need 16-byte aligned rows: H*W % 4 == 0 (and a 16-byte aligned base)
+  const bool vec4 = (HW % 4 == 0) && HW >= 4 && ((reinterpret_cast<uintptr_t>(fm) & 15) == 0);
+  if (vec4)
+    hipLaunchKernelGGL(corr_mfma_kernel<true>, grid, dim3(256), 0, stream, fm, qp, sumsq, corr, rpad, B, C, H, W,
+                       os2d_plane(H, W));
+  else
+    hipLaunchKernelGGL(corr_mfma_kernel<false>, grid, dim3(256), 0, stream, fm, qp, sumsq, corr, rpad, B, C, H, W,
+                       os2d_plane(H, W));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     os2d_set_error("corr launch: %s", hipGetErrorString(e));

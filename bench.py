@@ -58,13 +58,26 @@ def cpu_baseline(fm_cpu, class_fms_cpu, state, inverse, budget_s):
     with torch.no_grad():
         O.head_forward(fm_cpu, q[:1], state, inverse)        # warm-up
         done, t0 = 0, time.perf_counter()
-        while done < q.size(0) and (time.perf_counter() - t0) < budget_s:
-            O.head_forward(fm_cpu, q[done:done + 1], state, inverse)
+        while (time.perf_counter() - t0) < budget_s:      # cycles over the class sample until the budget is spent
+            b = done % q.size(0)
+            O.head_forward(fm_cpu, q[b:b + 1], state, inverse)
             done += 1
         dt = time.perf_counter() - t0
     return {"value": round(done / dt, 3), "unit": "query-image-pairs/s", "cores": threads, "kind": "port",
-            "sample": "{} classes looped one at a time (reference evaluate.py:323-331 call pattern) on one "
+            "sample": "{} class calls looped one at a time (reference evaluate.py:323-331 call pattern) on one "
                       "60x80x1024 feature map, {:.1f} s, torch CPU fp32, {} threads of {} hw threads".format(done, dt, threads, ncores)}
+
+
+def measured_traffic(B):
+    """HBM bytes per conv1 launch from the committed rocprofv3 PMC passes (profiles/conv1_traffic.json, written by
+    tools/summarize_prof.py --traffic: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate passes),
+    scaled to the class count of this run; None if no profile has been recorded."""
+    path = os.path.join(REPO, "profiles", "conv1_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        t = json.load(f)
+    return int(t["bytes_per_class"] * B)
 
 
 def main():
@@ -174,7 +187,8 @@ def main():
         achieved = flops / (stage_ms[1] * 1e-3)
         result["roofline"] = {"kernel": "conv_mfma_kernel<7,128,...> (TransformNet conv 7x7 225->128)",
                               "bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": PEAK_F32_MFMA / 1e12,
-                              "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": None,
+                              "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA, 4),
+                              "traffic": measured_traffic(B),
                               "flops_per_launch": flops, "avg_launch_ms": round(stage_ms[1], 4)}
         whole = (FLOP_PER_LOC["corr"] + FLOP_PER_LOC["conv1"] + FLOP_PER_LOC["conv2"] + 2 * P * 64 * 25) * H_FM * W_FM
         result["head_tflops"] = round(whole * result["value"] / 1e12, 3)

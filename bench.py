@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--classes", type=int, default=64, help="classes per GPU")
     ap.add_argument("--variant", default="v2", choices=["v2", "v1"], help="v2: affine+inverse (P=6); v1: simplified (P=4)")
+    ap.add_argument("--pyramid", action="store_true",
+                    help="BASELINE configs[4]: 7-scale pyramid (0.5-1.6) of the 1280x960 image, one HIP stream per level; "
+                         "a pair then means one (image, class) over all 7 levels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -128,10 +131,19 @@ def main():
             arr[i] = ev.value
         return arr
 
-    event_sets = [new_event_set() for _ in range(args.steps)] if sharded is None else []
+    event_sets = [new_event_set() for _ in range(args.steps)] if (sharded is None and not args.pyramid) else []
+
+    runner, level_fms = None, None
+    if args.pyramid:
+        from os2d_amd.engine.pyramid import PyramidHeadRunner
+        level_hw = [(30, 40), (38, 50), (48, 64), (60, 80), (72, 96), (84, 112), (96, 128)]
+        level_fms = [synthetic.make_feature_map(C_FEAT, h, w, seed=100 + i).to(dev) for i, (h, w) in enumerate(level_hw)]
+        runner = PyramidHeadRunner(sharded if sharded is not None else head, device=dev)
 
     def step(events):
         with torch.no_grad():
+            if runner is not None:
+                return runner.run(level_fms, inputs_are_features=True)
             if sharded is not None:
                 return sharded(fm)
             return head(fm, stage_events=events)
@@ -165,9 +177,11 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "OS2D head, ResNet50-C4 features of one 1280x960 image (1x1024x60x80), {} classes per GPU "
-                               "({} total), single scale, {} (P={}, inverse={}), head only, features resident in HBM"
-                               .format(B, B * world, args.variant.upper(), P, int(inverse)),
+        "config": {"workload": "OS2D head, ResNet50-C4 features of one 1280x960 image ({}), {} classes per GPU "
+                               "({} total), {}, {} (P={}, inverse={}), head only, features resident in HBM"
+                               .format("7-level pyramid 30x40..96x128, 39580 locations" if args.pyramid else "1x1024x60x80",
+                                       B, B * world, "7 scales 0.5-1.6, one HIP stream per level" if args.pyramid else "single scale",
+                                       args.variant.upper(), P, int(inverse)),
                    "classes_per_gpu": B, "classes_total": B * world, "feature_map": [C_FEAT, H_FM, W_FM],
                    "parallelism": "class-sharded x{} + all-gather".format(world) if world > 1 else "single GPU"},
     }
@@ -193,7 +207,7 @@ def main():
         whole = (FLOP_PER_LOC["corr"] + FLOP_PER_LOC["conv1"] + FLOP_PER_LOC["conv2"] + 2 * P * 64 * 25) * H_FM * W_FM
         result["head_tflops"] = round(whole * result["value"] / 1e12, 3)
         result["head_frac_of_f32_mfma_peak"] = round(whole * result["value"] / PEAK_F32_MFMA, 4)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.pyramid:
         result["cpu_baseline"] = cpu_baseline(fm_cpu, class_fms_cpu, state, inverse, args.cpu_seconds)
         result["speedup_vs_cpu_baseline"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
     if rank == 0:

@@ -1,0 +1,79 @@
+"""Image-pyramid driver of the head: the build's counterpart of the hot loop of the reference's evaluation iterator
+(reference os2d/engine/evaluate.py:278-371: for each pyramid level one backbone pass, then the heads of ALL
+classes; os2d/data/dataloader.py:326 for the level sizes; os2d/config.py:194 for the default 7 scales).
+
+MI355X-first differences from the reference loop:
+  * all classes go through ONE class-batched head call per level (the reference loops B=1 heads);
+  * every level runs on its own HIP stream with its own workspace, so the small levels (30x40 at scale 0.5) fill
+    the CUs left idle by the tail of the large ones, and the per-level all-gather of the class-sharded variant
+    overlaps the next level's compute;
+  * nothing synchronises with the host until the caller asks for the results (the reference calls
+    ``torch.cuda.synchronize()`` twice per level, evaluate.py:312,332).
+"""
+import torch
+
+from ..structures.feature_map import FeatureMapSize
+
+DEFAULT_SCALES = (0.5, 0.625, 0.8, 1.0, 1.2, 1.4, 1.6)   # reference os2d/config.py:194
+
+
+def pyramid_sizes(img_size, scales=DEFAULT_SCALES):
+    """reference dataloader.py:326: level size = (int(w*s), int(h*s))."""
+    return [FeatureMapSize(w=int(img_size.w * s), h=int(img_size.h * s)) for s in scales]
+
+
+class PyramidHeadRunner(object):
+    """Runs ``head`` (an ``Os2dHead`` / ``ClassShardedHead``) on the feature maps of every pyramid level, one HIP
+    stream per level.  ``features`` may be the backbone (a module mapping [1,3,h,w] -> [1,C,H,W]) or None when the
+    caller passes feature maps directly."""
+
+    def __init__(self, head, features=None, num_streams=None, device=None):
+        self.head = head
+        self.features = features
+        self.device = device or (head.class_feature_maps.device if hasattr(head, "class_feature_maps") else torch.device("cuda"))
+        self._streams = []
+        self._num_streams = num_streams
+
+    def _stream(self, i):
+        n = self._num_streams
+        if n is not None and n <= 1:
+            return torch.cuda.current_stream(self.device)
+        slot = i if n is None else i % n
+        while len(self._streams) <= slot:
+            self._streams.append(torch.cuda.Stream(device=self.device))
+        return self._streams[slot]
+
+    def run(self, level_inputs, inputs_are_features=False):
+        """level_inputs: list of image tensors [A,3,h_l,w_l] (or feature maps [A,C,H_l,W_l] if
+        ``inputs_are_features``).  Returns per level lists (loc [A,B,4,HW], cls [A,B,HW], corners [A,B,8,HW],
+        FeatureMapSize), laid out like ``Os2dModel.forward``.  The calling stream waits for all levels on return
+        (stream-ordered, no host synchronisation)."""
+        main = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        locs, clss, corners_l, sizes = [], [], [], []
+        done = []
+        with torch.no_grad():
+            for i, x in enumerate(level_inputs):
+                st = self._stream(i)
+                st.wait_event(ready)
+                with torch.cuda.stream(st):
+                    fm = x if inputs_are_features else self.features(x)
+                    loc, cls, _, corners = self.head(fm)
+                    A, B = cls.size(0), cls.size(1)
+                    locs.append(loc.reshape(A, B, 4, -1))
+                    clss.append(cls.reshape(A, B, -1))
+                    corners_l.append(corners.reshape(A, B, 8, -1) if corners is not None else None)
+                    sizes.append(FeatureMapSize(img=fm))
+                    # caching-allocator bookkeeping: the input was allocated on the caller's stream and is read on
+                    # `st`; the outputs are allocated on `st` and will be read on the caller's stream
+                    x.record_stream(st)
+                    for t in (loc, cls, corners):
+                        if t is not None:
+                            t.record_stream(main)
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    done.append(ev)
+        for ev in done:
+            main.wait_event(ev)
+        return locs, clss, corners_l, sizes

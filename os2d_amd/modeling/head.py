@@ -45,8 +45,11 @@ def workspace_cap_bytes():
 
 
 def get_workspace(device, wanted, minimum):
+    """Grow-only scratch buffer, one per (device, stream): concurrent heads on different HIP streams (the pyramid
+    runner) must not share intermediates."""
     size = max(min(wanted, workspace_cap_bytes()), minimum)
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (device.type, index, torch.cuda.current_stream(device).cuda_stream)
     buf = _WORKSPACES.get(key)
     if buf is None or buf.numel() < size:
         _WORKSPACES[key] = None

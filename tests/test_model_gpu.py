@@ -1,0 +1,77 @@
+"""GPU: the model-level API (Os2dModel.forward both signatures, random-init ResNet50-C4 in PyTorch-ROCm feeding the HIP
+head) and the pyramid runner with per-level HIP streams."""
+import pytest
+import torch
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(device, P=6, inverse=True, seed=3):
+    from os2d_amd.modeling.model import Os2dModel
+    from os2d_amd.utils import synthetic
+    torch.manual_seed(seed)
+    net = Os2dModel(is_cuda=False, merge_branch_parameters=True, backbone_arch="resnet50",
+                    use_inverse_geom_model=inverse, simplify_affine=(P == 4))
+    state = synthetic.make_transform_net_state(P, seed=seed)
+    net.os2d_head_creator.aligner.parameter_regressor.load_state_dict(state)
+    net.to(device).eval()
+    return net, state
+
+
+def test_model_forward_images_and_class_images(device):
+    """app.py / demo signature: net(images=..., class_images=[...]) (reference model.py:259-269)."""
+    from oracle import head_oracle as O
+    net, state = _model(device)
+    g = torch.Generator().manual_seed(0)
+    images = torch.randn(1, 3, 128, 176, generator=g).to(device)
+    class_images = [torch.randn(3, 96, 96, generator=g).to(device), torch.randn(3, 80, 112, generator=g).to(device)]
+    with torch.no_grad():
+        loc, cls, cls_det, fm_size, corners = net(images=images, class_images=class_images)
+        fm = net.net_feature_maps(images)
+        class_fms = net.net_label_features(class_images)
+    assert (fm_size.w, fm_size.h) == (11, 8) and tuple(cls.shape) == (1, 2, 88) and tuple(loc.shape) == (1, 2, 4, 88)
+    assert tuple(corners.shape) == (1, 2, 8, 88) and cls_det is cls
+    with torch.no_grad():
+        ref = O.head_forward(fm.cpu(), O.prepare_class_maps([c.cpu() for c in class_fms]), state, True)
+    assert util.maxdiff(cls.view(1, 2, 1, 8, 11), ref[1]) < 1e-5
+    assert util.maxdiff(loc.view(1, 2, 4, 8, 11), ref[0]) < 1e-4
+    assert util.maxdiff(corners.view(1, 2, 8, 8, 11), ref[3]) < 2e-3
+    # evaluation signature: pre-extracted features + prebuilt head
+    head = net.os2d_head_creator.create_os2d_head(class_fms)
+    out2 = net(feature_maps=fm, class_head=head)
+    # (the first call re-ran the MIOpen backbone, which is not bit-reproducible call to call: compare to 1e-5)
+    assert util.maxdiff(out2[1], cls) < 1e-5 and util.maxdiff(out2[0], loc) < 1e-4
+    out3 = net(feature_maps=fm, class_head=head)
+    assert torch.equal(out3[1], out2[1]) and torch.equal(out3[0], out2[0]) and torch.equal(out3[4], out2[4])
+    with pytest.raises(RuntimeError, match="out of scope"):
+        net(images=images, class_images=class_images, train_mode=True)
+
+
+def test_pyramid_runner_streams_match_single_stream(device):
+    """Every level on its own HIP stream (per-stream workspaces) gives bit-identical results to sequential calls."""
+    from os2d_amd.engine.pyramid import PyramidHeadRunner, pyramid_sizes
+    from os2d_amd.structures.feature_map import FeatureMapSize
+    from os2d_amd.utils import synthetic
+    sizes = pyramid_sizes(FeatureMapSize(w=1280, h=960))
+    assert [(s.w, s.h) for s in sizes] == [(640, 480), (800, 600), (1024, 768), (1280, 960), (1536, 1152), (1792, 1344), (2048, 1536)]
+    P, inverse = 6, True
+    state = synthetic.make_transform_net_state(P, seed=11)
+    creator = util.make_head_creator(P, inverse, state, device)
+    class_fms = synthetic.make_class_feature_maps(6, 64, sizes=[(15, 15), (12, 18)], seed=70)
+    levels = [synthetic.make_feature_map(64, h, w, seed=20 + i).to(device) for i, (h, w) in enumerate([(8, 10), (12, 16), (19, 25), (30, 40)])]
+    with torch.no_grad():
+        head = creator.create_os2d_head([c.to(device) for c in class_fms])
+        seq = [head(fm) for fm in levels]
+        torch.cuda.synchronize()
+        runner = PyramidHeadRunner(head)
+        for _ in range(3):          # repeat: workspaces are re-used per stream
+            locs, clss, corners, fms = runner.run(levels, inputs_are_features=True)
+        torch.cuda.synchronize()
+    for lvl, (l, c, k, f) in enumerate(zip(locs, clss, corners, fms)):
+        H, W = levels[lvl].shape[-2:]
+        assert (f.h, f.w) == (H, W)
+        assert torch.equal(l.view_as(seq[lvl][0]), seq[lvl][0])
+        assert torch.equal(c.view_as(seq[lvl][1]), seq[lvl][1])
+        assert torch.equal(k.view_as(seq[lvl][3]), seq[lvl][3])

@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--pyramid", action="store_true",
                     help="BASELINE configs[4]: 7-scale pyramid (0.5-1.6) of the 1280x960 image, one HIP stream per level; "
                          "a pair then means one (image, class) over all 7 levels")
+    ap.add_argument("--precision", default=os.environ.get("OS2D_PRECISION", "f32"), choices=["f32", "f16x3"],
+                    help="arithmetic of the two large TransformNet convolutions (DESIGN.md section 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -120,6 +122,7 @@ def main():
     fm = fm_cpu.to(dev)
     with torch.no_grad():
         head = creator.create_os2d_head([c.to(dev) for c in class_fms_cpu])
+    head.precision = args.precision
     sharded = ClassShardedHead(creator, group=None, num_classes=B * world, local_head=head) if world > 1 else None
 
     # one set of 10 stage events per timed step, so nothing has to be read back inside the timed region
@@ -176,7 +179,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.precision == "f32" else "f32 operands as fp16 hi+lo (3 half MFMAs per product, fp32 accumulate)",
+        "data": "synthetic",
         "config": {"workload": "OS2D head, ResNet50-C4 features of one 1280x960 image ({}), {} classes per GPU "
                                "({} total), {}, {} (P={}, inverse={}), head only, features resident in HBM"
                                .format("7-level pyramid 30x40..96x128, 39580 locations" if args.pyramid else "1x1024x60x80",

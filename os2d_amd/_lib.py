@@ -9,7 +9,7 @@ import os
 
 from .build import LIB_PATH
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c_float_p = ctypes.c_void_p   # device pointers travel as raw addresses (tensor.data_ptr())
 _vp = ctypes.c_void_p
@@ -27,7 +27,10 @@ SIGNATURES = {
     "os2d_class_prepare": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "os2d_head_workspace_bytes": (_i, [_i, _i, _i, _i, _i, _i, ctypes.POINTER(_sz)]),
     "os2d_head_forward": (_i, [_vp] * 8 + [_i] * 9 + [_vp, _vp, _vp, _vp, _sz, _vp]),
-    "os2d_head_forward_profiled": (_i, [_vp] * 8 + [_i] * 9 + [_vp, _vp, _vp, _vp, _sz, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_i)]),
+    "os2d_packed_conv_bytes": (_sz, [_i, _i]),
+    "os2d_pack_conv_f16x3": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),
+    "os2d_head_forward_ex": (_i, [_vp] * 8 + [_i] * 9 + [_vp, _vp, _vp, _vp, _sz, _vp, _i, _i, _i,
+                                  ctypes.POINTER(_vp), ctypes.POINTER(_i)]),
     "os2d_prof_event_create": (_i, [ctypes.POINTER(_vp)]),
     "os2d_prof_event_destroy": (_i, [_vp]),
     "os2d_prof_event_elapsed_ms": (_i, [_vp, _vp, ctypes.POINTER(_f)]),

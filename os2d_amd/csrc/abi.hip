@@ -38,7 +38,7 @@ Carve carve(int A, int Bc, int H, int W, int P) {
   };
   c.sumsq = take((size_t)A * HW);
   c.corr = take(NB * OS2D_K * HW);
-  c.rpad = take(NB * OS2D_KP * PL);
+  c.rpad = take(NB * (OS2D_G * 2 * 4) * PL);  // fp32: 226 planes; f16x3: 29 groups x (hi|lo) x 16 B = 232 floats
   c.h1 = take(NB * 128 * PL);
   c.h2 = take(NB * 64 * PL);
   c.params = take(NB * P * HW);
@@ -137,7 +137,7 @@ int os2d_corr(const float* fm, const float* qp, const float* sumsq, float* corr,
   if (!head_args_ok(A, B, C, H, W, 6)) return -1;
   int rc = os2d_launch_border_zero(rnorm, A * B * OS2D_KP, H, W, S(stream));
   if (rc) return rc;
-  return os2d_launch_corr(fm, qp, sumsq, corr, rnorm, A, B, C, H, W, S(stream));
+  return os2d_launch_corr(fm, qp, sumsq, corr, rnorm, A, B, C, H, W, 0, S(stream));
 }
 
 int os2d_corr_normalize(const float* corr, float* rnorm, int NB, int H, int W, void* stream) {
@@ -202,13 +202,17 @@ int os2d_nms(const float* boxes, const int* counts, int NC, int N, float iou_thr
   return os2d_launch_nms(boxes, counts, NC, N, iou_threshold, keep, num_keep, workspace, S(stream));
 }
 
-int os2d_head_forward_profiled(const float* fm, const float* qp, const float* w1, const float* b1, const float* w2,
-                               const float* b2, const float* w3, const float* b3, int A, int B, int C, int H, int W,
-                               int P, int inverse, int stride, int rec_field, float* loc, float* cls, float* corners,
-                               void* workspace, size_t workspace_bytes, void* stream, void** stage_events,
-                               int* chunk_classes) {
+int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const float* b1, const void* w2,
+                         const float* b2, const float* w3, const float* b3, int A, int B, int C, int H, int W, int P,
+                         int inverse, int stride, int rec_field, float* loc, float* cls, float* corners,
+                         void* workspace, size_t workspace_bytes, void* stream, int precision, int scale1_log2,
+                         int scale2_log2, void** stage_events, int* chunk_classes) {
   if (!fm || !qp || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !loc || !cls || !corners || !workspace) {
     os2d_set_error("os2d_head_forward: null pointer");
+    return -1;
+  }
+  if (precision != OS2D_PRECISION_F32 && precision != OS2D_PRECISION_F16X3) {
+    os2d_set_error("os2d_head_forward: unknown precision %d", precision);
     return -1;
   }
   if (!head_args_ok(A, B, C, H, W, P)) return -1;
@@ -255,15 +259,29 @@ int os2d_head_forward_profiled(const float* fm, const float* qp, const float* w1
   for (int b0 = 0; b0 < B; b0 += Bc) {
     const int bc = (B - b0 < Bc) ? (B - b0) : Bc;
     const int NB = A * bc;
+    const bool f16 = precision == OS2D_PRECISION_F16X3;
     mark(b0, 0);
-    if ((rc = os2d_launch_border_zero(rpad, NB * OS2D_KP, H, W, st))) return rc;
-    if ((rc = os2d_launch_corr(fm, qp + (size_t)b0 * C * OS2D_QROWS, sumsq, corr, rpad, A, bc, C, H, W, st))) return rc;
+    if (f16) {
+      if ((rc = os2d_launch_border_zero_shb(rpad, NB, H, W, st))) return rc;
+    } else {
+      if ((rc = os2d_launch_border_zero(rpad, NB * OS2D_KP, H, W, st))) return rc;
+    }
+    if ((rc = os2d_launch_corr(fm, qp + (size_t)b0 * C * OS2D_QROWS, sumsq, corr, rpad, A, bc, C, H, W, f16 ? 1 : 0, st)))
+      return rc;
     mark(b0, 1);
     mark(b0, 2);
-    if ((rc = os2d_launch_conv(1, rpad, w1, b1, h1, NB, P, H, W, st))) return rc;
+    if (f16) {
+      if ((rc = os2d_launch_conv_f16x3(1, rpad, w1, b1, ldexpf(1.0f, -scale1_log2), h1, NB, H, W, st))) return rc;
+    } else {
+      if ((rc = os2d_launch_conv(1, rpad, static_cast<const float*>(w1), b1, h1, NB, P, H, W, st))) return rc;
+    }
     mark(b0, 3);
     mark(b0, 4);
-    if ((rc = os2d_launch_conv(2, h1, w2, b2, h2, NB, P, H, W, st))) return rc;
+    if (f16) {
+      if ((rc = os2d_launch_conv_f16x3(2, h1, w2, b2, ldexpf(1.0f, -scale2_log2), h2, NB, H, W, st))) return rc;
+    } else {
+      if ((rc = os2d_launch_conv(2, h1, static_cast<const float*>(w2), b2, h2, NB, P, H, W, st))) return rc;
+    }
     mark(b0, 5);
     mark(b0, 6);
     if ((rc = os2d_launch_conv(3, h2, w3, b3, params, NB, P, H, W, st))) return rc;
@@ -281,8 +299,36 @@ int os2d_head_forward(const float* fm, const float* qp, const float* w1, const f
                       const float* b2, const float* w3, const float* b3, int A, int B, int C, int H, int W, int P,
                       int inverse, int stride, int rec_field, float* loc, float* cls, float* corners, void* workspace,
                       size_t workspace_bytes, void* stream) {
-  return os2d_head_forward_profiled(fm, qp, w1, b1, w2, b2, w3, b3, A, B, C, H, W, P, inverse, stride, rec_field, loc,
-                                    cls, corners, workspace, workspace_bytes, stream, nullptr, nullptr);
+  return os2d_head_forward_ex(fm, qp, w1, b1, w2, b2, w3, b3, A, B, C, H, W, P, inverse, stride, rec_field, loc, cls,
+                              corners, workspace, workspace_bytes, stream, OS2D_PRECISION_F32, 0, 0, nullptr, nullptr);
+}
+
+size_t os2d_packed_conv_bytes(int layer, int precision) {
+  if (precision == OS2D_PRECISION_F32 || layer == 3) return os2d_packed_conv_floats(layer) * sizeof(float);
+  if (precision != OS2D_PRECISION_F16X3) return 0;
+  // [G][steps padded to whole stages][2][2][MT] units of 16 B (conv_f16x3.hip: layer 1 SS=5, layer 2 SS=7)
+  if (layer == 1) return (size_t)OS2D_G * 25 * 4 * 128 * 16;
+  if (layer == 2) return (size_t)16 * 14 * 4 * 64 * 16;
+  return 0;
+}
+
+int os2d_pack_conv_f16x3(int layer, const float* w, const float* b, const float* bn_weight, const float* bn_bias,
+                         const float* bn_running_mean, const float* bn_running_var, float bn_eps, int scale_log2,
+                         void* packed_w, float* packed_b, void* stream) {
+  if ((layer != 1 && layer != 2) || !w || !b || !packed_w || !packed_b || !bn_weight || !bn_bias || !bn_running_mean ||
+      !bn_running_var) {
+    os2d_set_error("os2d_pack_conv_f16x3: bad arguments (layer must be 1 or 2, BatchNorm tensors required)");
+    return -1;
+  }
+  if (scale_log2 < -60 || scale_log2 > 60) {
+    os2d_set_error("os2d_pack_conv_f16x3: scale_log2 %d out of range", scale_log2);
+    return -1;
+  }
+  if (layer == 1)
+    return os2d_launch_pack_conv_f16(w, b, bn_weight, bn_bias, bn_running_mean, bn_running_var, bn_eps, 128, OS2D_K, 7,
+                                     128, 25, scale_log2, packed_w, packed_b, S(stream));
+  return os2d_launch_pack_conv_f16(w, b, bn_weight, bn_bias, bn_running_mean, bn_running_var, bn_eps, 64, 128, 5, 64, 14,
+                                   scale_log2, packed_w, packed_b, S(stream));
 }
 
 int os2d_prof_event_create(void** ev) {

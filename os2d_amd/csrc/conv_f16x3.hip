@@ -1,0 +1,295 @@
+// TransformNet convolutions on the half-precision matrix cores with fp32-equivalent accuracy ("f16x3"), gfx950.
+//
+// Why: v_mfma_f32_32x32x2_f32 runs at the fp32 vector rate (157 TFLOP/s); v_mfma_f32_32x32x16_f16 is 16x faster.
+// Every fp32 operand x is stored as TWO halves, hi = rn16(x), lo = rn16(x - hi) (22 mantissa bits together), and a
+// product a*b is evaluated as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with exact fp16 products accumulated in fp32 by the
+// MFMA - three instructions instead of sixteen-times-slower one.  Weights are pre-multiplied by a power of two so that
+// their lo parts stay normal fp16 numbers (undone exactly in the epilogue).  On the reference's golden vectors the
+// resulting TransformNet parameters differ from the fp32 path by <= 3e-7 (tests/test_head_gpu.py, precision=f16x3).
+//
+// Layouts ("split-half blocked", SHB): activations [NB][G = C/8][2 = hi|lo][PLANE] units of 16 B = 8 channels of one
+// plane cell (zero-bordered plane geometry of os2d_common.h).  One MFMA k-step = 16 k = 8 channels x 2 TAPS:
+// lanes 0-31 take tap 2p, lanes 32-63 tap 2p+1 of the same channel group, so a work-group only needs an 8-channel
+// input slab in LDS (the halo makes that slab 3x the tile).  Packed weights [G][STEPS][2 half-wave][2 hi|lo][MT] units.
+//
+// Work-group = 512 threads (8 waves, 2 per SIMD) on MT x NT = (WM*MI*32) x (WN*NI*32) outputs.  Pipeline per channel
+// group: the weight slab streams through double-buffered LDS stages of SS k-steps (global -> registers issued before the
+// MFMAs of the previous stage, registers -> LDS after them, one barrier per stage); the input slab of the next group is
+// fetched with the last stage of the current one.  All prefetch indices are clamped instead of predicated so the loop
+// is branch-free (hipcc otherwise sinks the loads behind the MFMAs).
+#include "os2d_common.h"
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // 16-byte unit (8 halves); ext vector: stays in VGPRs
+#define U32X4_ZERO (u32x4{0u, 0u, 0u, 0u})
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split_half(float x, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)x;
+  lo = (_Float16)(x - (float)hi);
+}
+
+constexpr int NTHR = 512;
+
+template <int KS, int MT, int WM, int WN, int NI, int SS, bool RELU, int OUT_MODE /*0 SHB, 1 fp32 plane*/>
+__global__ __launch_bounds__(NTHR, 2) void conv_f16x3_kernel(const u32x4* in,  // SHB [NB][G][2][PLANE] (no __restrict__: invariant loads get
+                                                             const u32x4* wp,  // rematerialised BEHIND the MFMAs by the register allocator)
+                                                             const float* __restrict__ bp,  // [MT] fp32 folded bias
+                                                             float unscale, void* __restrict__ outv, int G,
+                                                             int CoutStore, int H, int W, int PLANE, int HALO) {
+  constexpr int R = KS / 2;
+  constexpr int TAPS = KS * KS;
+  constexpr int STEPS = (TAPS + 1) / 2;
+  constexpr int NST = (STEPS + SS - 1) / SS;  // stages per channel group
+  constexpr int MW = MT / WM, MI = MW / 32;
+  constexpr int NW = NI * 32, NT = WN * NW;
+  static_assert(WM * WN == 8, "8 waves per work-group");
+  static_assert(MW % 32 == 0, "wave tile rows must be a multiple of 32");
+  constexpr int ASTAGE = SS * 4 * MT;  // 16-byte units per weight stage
+  constexpr int NAPF = (ASTAGE + NTHR - 1) / NTHR;
+  constexpr int NBPF = 4;  // 16-byte units per thread for the input slab (2*SLAB <= 2048 units)
+
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
+  const int Ws = W + OS2D_PAD;
+  const int BASE = os2d_base(W);
+  const int DATA = H * Ws;
+  const int SLAB = NT + 2 * HALO;
+  u32x4* ldsA = smem16;               // [2][ASTAGE]
+  u32x4* ldsB = smem16 + 2 * ASTAGE;  // [2 parts][SLAB]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, hw = lane >> 5;
+  const int wm = wid / WN, wn = wid % WN;
+  const int nb = blockIdx.y;
+  const int n0 = BASE + blockIdx.x * NT;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const u32x4* inb = in + (size_t)nb * G * 2 * PLANE;
+  const int aLane = wm * MW + l31;
+  // B lane bases (units): same-row tap pair -> upper half-wave reads the next cell; row-crossing pair -> next row start
+  const int bLane = wn * NW + l31 + HALO - R * Ws - R;
+  const int bSame = bLane + hw;
+  const int bCross = bLane + hw * (Ws - (KS - 1));
+
+  u32x4 pfA[NAPF], pfB[NBPF];
+
+#define F16_LOAD_A(S)                                                                                             \
+  {                                                                                                               \
+    const u32x4* src_ = wp + (size_t)(S)*ASTAGE;                                                                  \
+    _Pragma("unroll") for (int k = 0; k < NAPF; ++k) pfA[k] = src_[min(tid + k * NTHR, ASTAGE - 1)];              \
+  }
+#define F16_STORE_A(S)                                                                                            \
+  {                                                                                                               \
+    u32x4* dst_ = ldsA + ((S)&1) * ASTAGE;                                                                        \
+    _Pragma("unroll") for (int k = 0; k < NAPF; ++k) {                                                            \
+      const int i_ = tid + k * NTHR;                                                                              \
+      if (i_ < ASTAGE) dst_[i_] = pfA[k];                                                                         \
+    }                                                                                                             \
+  }
+#define F16_LOAD_B(GRP)                                                                                           \
+  {                                                                                                               \
+    _Pragma("unroll") for (int k = 0; k < NBPF; ++k) {                                                            \
+      const int i_ = min(tid + k * NTHR, 2 * SLAB - 1);                                                           \
+      const int part_ = i_ >= SLAB ? 1 : 0;                                                                       \
+      int g_ = n0 - HALO + (i_ - part_ * SLAB);                                                                   \
+      g_ = (g_ >= 0 && g_ < PLANE) ? g_ : 0;                                                                      \
+      pfB[k] = inb[((size_t)(GRP)*2 + part_) * PLANE + g_];                                                       \
+    }                                                                                                             \
+  }
+#define F16_STORE_B()                                                                                             \
+  {                                                                                                               \
+    _Pragma("unroll") for (int k = 0; k < NBPF; ++k) {                                                            \
+      const int i_ = tid + k * NTHR;                                                                              \
+      if (i_ < 2 * SLAB) {                                                                                        \
+        const int part_ = i_ >= SLAB ? 1 : 0;                                                                     \
+        const int g_ = n0 - HALO + (i_ - part_ * SLAB);                                                           \
+        ldsB[i_] = (g_ >= 0 && g_ < PLANE) ? pfB[k] : U32X4_ZERO;                                 \
+      }                                                                                                           \
+    }                                                                                                             \
+  }
+  // MFMAs of stage ST (compile-time) of the current group from weight buffer BUF (runtime 0/1)
+#define F16_COMPUTE(ST, BUF)                                                                                      \
+  {                                                                                                               \
+    const u32x4* aS_ = ldsA + (BUF)*ASTAGE + aLane;                                                               \
+    _Pragma("unroll") for (int p = 0; p < SS; ++p) {                                                              \
+      const int ps_ = (ST)*SS + p; /* k-step inside the group */                                                  \
+      if (ps_ < STEPS) {                                                                                          \
+        const int t0_ = 2 * ps_, t1_ = (2 * ps_ + 1 < TAPS) ? 2 * ps_ + 1 : 2 * ps_;                              \
+        const int dy0_ = t0_ / KS, dx0_ = t0_ % KS, dy1_ = t1_ / KS;                                              \
+        const int bsel_ = (t1_ == t0_) ? bLane : (dy1_ == dy0_ ? bSame : bCross);                                 \
+        const u32x4* bS_ = ldsB + bsel_ + dy0_ * Ws + dx0_;                                                       \
+        half8 ah_[MI], al_[MI];                                                                                   \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                       \
+          ah_[mi] = *reinterpret_cast<const half8*>(aS_ + ((p * 2 + hw) * 2 + 0) * MT + mi * 32);                 \
+          al_[mi] = *reinterpret_cast<const half8*>(aS_ + ((p * 2 + hw) * 2 + 1) * MT + mi * 32);                 \
+        }                                                                                                         \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                                       \
+          const half8 bh_ = *reinterpret_cast<const half8*>(bS_ + ni * 32);                                       \
+          const half8 bl_ = *reinterpret_cast<const half8*>(bS_ + SLAB + ni * 32);                                \
+          _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                     \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al_[mi], bh_, acc[mi][ni], 0, 0, 0);             \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_[mi], bl_, acc[mi][ni], 0, 0, 0);             \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_[mi], bh_, acc[mi][ni], 0, 0, 0);             \
+          }                                                                                                       \
+        }                                                                                                         \
+      }                                                                                                           \
+    }                                                                                                             \
+  }
+
+  // ---- prologue: group 0 slab + stage 0 weights
+  F16_LOAD_B(0)
+  F16_LOAD_A(0)
+  F16_STORE_B()
+  F16_STORE_A(0)
+  __syncthreads();
+  const int nstages = G * NST;
+  for (int g = 0; g < G; ++g) {
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      const int s = g * NST + st;
+      const int s1 = min(s + 1, nstages - 1);  // clamped: the very last iteration re-loads its own stage (harmless)
+      F16_LOAD_A(s1)
+      if (st == NST - 1) {
+        const int g1 = min(g + 1, G - 1);
+        F16_LOAD_B(g1)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      F16_COMPUTE(st, (s & 1))
+      __builtin_amdgcn_sched_barrier(0);
+      if (st == NST - 1) {
+        __syncthreads();  // every wave is done with this group's input slab
+        F16_STORE_B()
+      }
+      F16_STORE_A(s + 1)
+      __syncthreads();
+    }
+  }
+#undef F16_LOAD_A
+#undef F16_STORE_A
+#undef F16_LOAD_B
+#undef F16_STORE_B
+#undef F16_COMPUTE
+
+  // ---- epilogue: undo the weight scale, bias (+ReLU); pad cells are written as exact zeros
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n0 + wn * NW + ni * 32 + l31;
+    const int r = n - BASE;
+    const int hr = r / Ws, wc = r - hr * Ws;
+    const bool valid = r < DATA && wc < W;
+    if (n >= PLANE) continue;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m0 = wm * MW + mi * 32 + 8 * q + 4 * hw;  // this lane holds rows m0 .. m0+3 (regs 4q .. 4q+3)
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float t = acc[mi][ni][4 * q + k] * unscale + bp[m0 + k];
+          if (RELU) t = fmaxf(t, 0.f);
+          v[k] = (valid && m0 + k < CoutStore) ? t : 0.f;
+        }
+        if (OUT_MODE == 0) {
+          // SHB: 8-channel group = rows 8*(m0/8) .. +7; this lane writes channels 4*hw .. 4*hw+3 (8 bytes) of hi and lo
+          const int grp = m0 >> 3;
+          if (grp * 8 >= CoutStore) continue;
+          half4 hi4, lo4;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            _Float16 h_, l_;
+            split_half(v[k], h_, l_);
+            hi4[k] = h_;
+            lo4[k] = l_;
+          }
+          const int Gout = (CoutStore + 7) >> 3;
+          char* o = reinterpret_cast<char*>(outv) + (((size_t)nb * Gout + grp) * 2 * PLANE + n) * 16 + hw * 8;
+          *reinterpret_cast<half4*>(o) = hi4;
+          *reinterpret_cast<half4*>(o + (size_t)PLANE * 16) = lo4;
+        } else {
+          float* o = reinterpret_cast<float*>(outv);
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (m0 + k < CoutStore) o[((size_t)nb * CoutStore + m0 + k) * PLANE + n] = v[k];
+        }
+      }
+    }
+  }
+  // pad rows above the data (first tile) and whatever lies beyond the last tile
+  {
+    const int tail0 = BASE + gridDim.x * NT, tail = PLANE - tail0;
+    const bool first = blockIdx.x == 0, last = blockIdx.x == gridDim.x - 1;
+    if (OUT_MODE == 0) {
+      const int planes = ((CoutStore + 7) >> 3) * 2;
+      u32x4* o = reinterpret_cast<u32x4*>(outv) + (size_t)nb * planes * PLANE;
+      if (first)
+        for (int i = tid; i < planes * BASE; i += NTHR) o[(size_t)(i / BASE) * PLANE + i % BASE] = U32X4_ZERO;
+      if (last && tail > 0)
+        for (int i = tid; i < planes * tail; i += NTHR)
+          o[(size_t)(i / tail) * PLANE + tail0 + i % tail] = U32X4_ZERO;
+    } else {
+      float* o = reinterpret_cast<float*>(outv) + (size_t)nb * CoutStore * PLANE;
+      if (first)
+        for (int i = tid; i < CoutStore * BASE; i += NTHR) o[(size_t)(i / BASE) * PLANE + i % BASE] = 0.f;
+      if (last && tail > 0)
+        for (int i = tid; i < CoutStore * tail; i += NTHR) o[(size_t)(i / tail) * PLANE + tail0 + i % tail] = 0.f;
+    }
+  }
+}
+
+template <int KS, int MT, int WM, int WN, int NI, int SS, bool RELU, int OUT_MODE>
+int launch(const void* in, const void* wp, const float* bp, float unscale, void* out, int NB, int G, int CoutStore,
+           int H, int W, hipStream_t stream) {
+  constexpr int R = KS / 2;
+  constexpr int NT = WN * NI * 32;
+  const int Ws = os2d_ws(W), PLANE = os2d_plane(H, W);
+  const int HALO = R * Ws + R;
+  const int SLAB = NT + 2 * HALO;
+  if (2 * SLAB > 4 * NTHR) {
+    os2d_set_error("conv%dx%d (f16x3): feature map too wide for the input-slab prefetch (W=%d)", KS, KS, W);
+    return -3;
+  }
+  const size_t lds = (size_t)(2 * SS * 4 * MT + 2 * SLAB) * 16;
+  if (lds > 160 * 1024) {
+    os2d_set_error("conv%dx%d (f16x3): LDS budget exceeded (%zu B, W=%d)", KS, KS, lds, W);
+    return -3;
+  }
+  auto kern = conv_f16x3_kernel<KS, MT, WM, WN, NI, SS, RELU, OUT_MODE>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds);
+  if (e != hipSuccess) {
+    os2d_set_error("hipFuncSetAttribute(conv f16x3): %s", hipGetErrorString(e));
+    return -4;
+  }
+  dim3 grid((H * Ws + NT - 1) / NT, NB);
+  hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds, stream, reinterpret_cast<const u32x4*>(in),
+                     reinterpret_cast<const u32x4*>(wp), bp, unscale, out, G, CoutStore, H, W, PLANE, HALO);
+  e = hipGetLastError();
+  if (e != hipSuccess) {
+    os2d_set_error("conv f16x3 launch: %s", hipGetErrorString(e));
+    return -4;
+  }
+  return 0;
+}
+
+}  // namespace
+
+// layer 1: 7x7, 29 input groups (225 ch), 128 out, SHB out;  layer 2: 5x5, 16 groups, 64 out, fp32 plane out
+// (conv3 stays on the fp32 kernel: 0.5 % of the FLOPs).
+int os2d_launch_conv_f16x3(int layer, const void* in, const void* wp, const float* bp, float unscale, void* out, int NB,
+                           int H, int W, hipStream_t stream) {
+  switch (layer) {
+    case 1: return launch<7, 128, 2, 4, 2, 5, true, 0>(in, wp, bp, unscale, out, NB, 29, 128, H, W, stream);
+    case 2: return launch<5, 64, 2, 4, 2, 7, true, 1>(in, wp, bp, unscale, out, NB, 16, 64, H, W, stream);
+    default: os2d_set_error("os2d_launch_conv_f16x3: bad layer %d", layer); return -1;
+  }
+}

@@ -25,7 +25,7 @@ constexpr int A4 = KC * OS2D_QROWS / 4 / 256;  // float4 per thread of an A chun
 constexpr int B4 = KC * NT / 4 / 256;          // float4 per thread of a B chunk (2)
 constexpr int B1 = KC * NT / 256;              // dwords per thread of a B chunk (8)
 
-template <bool VEC4>
+template <bool VEC4, bool SHB>
 __global__ __launch_bounds__(256, 2) void corr_mfma_kernel(const float* __restrict__ fm,     // [A][C][HW]
                                                            const float* __restrict__ qp,     // [B][C][256]
                                                            const float* __restrict__ sumsq,  // [A][HW]
@@ -179,30 +179,59 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_kernel(const float* __restri
     const float inv_r = 1.0f / (sqrtf(red[0][col] + red[1][col]) + 1e-6f);  // head.py:650,597 (eps 1e-6)
     const int h = n / W, w = n - h * W;
     const size_t cell = (size_t)BASE + (size_t)h * Ws + w;
+    if (!SHB) {
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (m < OS2D_K) rpad[((size_t)nb * OS2D_KP + m) * PLANE + cell] = fmaxf(acc[mi][ni][r], 0.f) * inv_r;
-      }
+        for (int r = 0; r < 16; ++r) {
+          const int m = wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (m < OS2D_K) rpad[((size_t)nb * OS2D_KP + m) * PLANE + cell] = fmaxf(acc[mi][ni][r], 0.f) * inv_r;
+        }
+    } else {
+      // split-half blocked output for conv_f16x3.hip: [nb][29 groups][hi|lo][PLANE] units of 8 halves.  Registers
+      // 4q..4q+3 of a lane are rows m0..m0+3 = channels 4*hi..4*hi+3 of group m0/8: one 8-byte store each for hi, lo.
+      typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+      char* base = reinterpret_cast<char*>(rpad);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m0 = wm * 128 + mi * 32 + 8 * q + 4 * hi;
+          const int grp = m0 >> 3;
+          if (grp >= OS2D_G) continue;
+          half4 h4, l4;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float v = (m0 + k < OS2D_K) ? fmaxf(acc[mi][ni][4 * q + k], 0.f) * inv_r : 0.f;
+            const _Float16 hv = (_Float16)v;
+            h4[k] = hv;
+            l4[k] = (_Float16)(v - (float)hv);
+          }
+          char* o = base + (((size_t)nb * OS2D_G + grp) * 2 * PLANE + cell) * 16 + hi * 8;
+          *reinterpret_cast<half4*>(o) = h4;
+          *reinterpret_cast<half4*>(o + (size_t)PLANE * 16) = l4;
+        }
+    }
   }
 }
 
 }  // namespace
 
-int os2d_launch_corr(const float* fm, const float* qp, const float* sumsq, float* corr, float* rpad, int A, int B,
-                     int C, int H, int W, hipStream_t stream) {
+int os2d_launch_corr(const float* fm, const float* qp, const float* sumsq, float* corr, void* rnorm, int A, int B,
+                     int C, int H, int W, int shb, hipStream_t stream) {
   const int HW = H * W;
   dim3 grid((HW + NT - 1) / NT, B, A);
   // float4 loads of the image map need 16-byte aligned rows: H*W % 4 == 0 (and a 16-byte aligned base)
   const bool vec4 = (HW % 4 == 0) && HW >= 4 && ((reinterpret_cast<uintptr_t>(fm) & 15) == 0);
-  if (vec4)
-    hipLaunchKernelGGL(corr_mfma_kernel<true>, grid, dim3(256), 0, stream, fm, qp, sumsq, corr, rpad, B, C, H, W,
-                       os2d_plane(H, W));
-  else
-    hipLaunchKernelGGL(corr_mfma_kernel<false>, grid, dim3(256), 0, stream, fm, qp, sumsq, corr, rpad, B, C, H, W,
-                       os2d_plane(H, W));
+  float* rp = reinterpret_cast<float*>(rnorm);
+  const int PL = os2d_plane(H, W);
+#define CORR_GO(V, S) \
+  hipLaunchKernelGGL((corr_mfma_kernel<V, S>), grid, dim3(256), 0, stream, fm, qp, sumsq, corr, rp, B, C, H, W, PL)
+  if (vec4 && shb) CORR_GO(true, true);
+  else if (vec4) CORR_GO(true, false);
+  else if (shb) CORR_GO(false, true);
+  else CORR_GO(false, false);
+#undef CORR_GO
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     os2d_set_error("corr launch: %s", hipGetErrorString(e));

@@ -20,6 +20,7 @@
 #define OS2D_K 225           // T*T correlation channels
 #define OS2D_KP 226          // padded to an even channel count (MFMA 32x32x2 consumes channel pairs)
 #define OS2D_QROWS 256       // correlation GEMM M tile: 225 rows padded with zeros
+#define OS2D_G 29            // 8-channel groups of the 225 correlation channels (f16x3 path)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -48,9 +49,16 @@ int os2d_launch_class_prepare(const float* src, int C, int h, int w, int normali
 int os2d_launch_pack_conv(const float* w, const float* b, const float* bn_w, const float* bn_b,
                           const float* bn_mean, const float* bn_var, float bn_eps, int Cout, int Cin, int KS,
                           int MT, float* wp, float* bp, hipStream_t stream);
-// corr_mfma.hip
-int os2d_launch_corr(const float* fm, const float* qp, const float* sumsq, float* corr, float* rpad,
-                     int A, int B, int C, int H, int W, hipStream_t stream);
+int os2d_launch_border_zero_shb(void* rnorm, int NB, int H, int W, hipStream_t stream);
+int os2d_launch_pack_conv_f16(const float* w, const float* b, const float* bn_w, const float* bn_b, const float* bn_mean,
+                              const float* bn_var, float bn_eps, int Cout, int Cin, int KS, int MT, int steps_padded,
+                              int scale_log2, void* wp, float* bp, hipStream_t stream);
+// corr_mfma.hip (shb != 0: rnorm is written in the split-half blocked layout of conv_f16x3.hip)
+int os2d_launch_corr(const float* fm, const float* qp, const float* sumsq, float* corr, void* rnorm,
+                     int A, int B, int C, int H, int W, int shb, hipStream_t stream);
+// conv_f16x3.hip
+int os2d_launch_conv_f16x3(int layer, const void* in, const void* wp, const float* bp, float unscale, void* out, int NB,
+                           int H, int W, hipStream_t stream);
 // conv_mfma.hip
 int os2d_launch_conv(int layer, const float* in, const float* wp, const float* bp, float* out,
                      int NB, int P, int H, int W, hipStream_t stream);

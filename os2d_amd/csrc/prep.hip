@@ -150,6 +150,62 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict_
     }
 }
 
+// ---- f16x3 path (conv_f16x3.hip): packed weights [G][steps_padded][2 half-wave][2 hi|lo][MT] units of 8 halves.
+// Unit (g, ps, hw, part, o) holds channels 8g..8g+7 of output o at tap 2*ps+hw, scaled by 2^scale_log2 and BN-folded;
+// part 0 = rn16(x), part 1 = rn16(x - hi).  Taps / channels / outputs past the real sizes are zero.
+__global__ __launch_bounds__(256) void pack_conv_f16_kernel(const float* __restrict__ w, const float* __restrict__ b,
+                                                            const float* __restrict__ bn_w,
+                                                            const float* __restrict__ bn_b,
+                                                            const float* __restrict__ bn_mean,
+                                                            const float* __restrict__ bn_var, float bn_eps, int Cout,
+                                                            int Cin, int KS, int MT, int steps_padded, float scale,
+                                                            _Float16* __restrict__ wp, float* __restrict__ bp) {
+  const int taps = KS * KS;
+  const int G = (Cin + 7) / 8;
+  const size_t total = (size_t)G * steps_padded * 2 * 2 * MT * 8;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    size_t t = idx;
+    const int j = t % 8;
+    t /= 8;
+    const int o = t % MT;
+    t /= MT;
+    const int part = t % 2;
+    t /= 2;
+    const int hw = t % 2;
+    t /= 2;
+    const int ps = t % steps_padded;
+    const int g = t / steps_padded;
+    const int c = g * 8 + j, tap = 2 * ps + hw;
+    float v = 0.f;
+    if (o < Cout && c < Cin && tap < taps) {
+      const float s = bn_w ? bn_w[o] / sqrtf(bn_var[o] + bn_eps) : 1.0f;
+      v = w[((size_t)o * Cin + c) * taps + tap] * s * scale;
+    }
+    const _Float16 hi = (_Float16)v;
+    wp[idx] = part ? (_Float16)(v - (float)hi) : hi;
+  }
+  if (blockIdx.x == 0)
+    for (int o = threadIdx.x; o < MT; o += 256) {
+      float v = 0.f;
+      if (o < Cout) {
+        if (bn_w) {
+          const float s = bn_w[o] / sqrtf(bn_var[o] + bn_eps);
+          v = (b[o] - bn_mean[o]) * s + bn_b[o];
+        } else {
+          v = b[o];
+        }
+      }
+      bp[o] = v;
+    }
+}
+
+// border cells of the split-half blocked normalised-correlation buffer [NB][29][2][PLANE] x 16 B
+__global__ __launch_bounds__(256) void border_zero_shb_kernel(uint4* __restrict__ p, int H, int W, int PLANE) {
+  uint4* q = p + (size_t)blockIdx.x * PLANE;
+  for (int i = threadIdx.x; i < PLANE; i += 256)
+    if (!os2d_interior(i, H, W)) q[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -169,6 +225,20 @@ int os2d_launch_fm_sumsq(const float* fm, float* sumsq, int A, int C, int HW, hi
 int os2d_launch_border_zero(float* rpad, int planes_total, int H, int W, hipStream_t stream) {
   hipLaunchKernelGGL(border_zero_kernel, dim3(planes_total), dim3(256), 0, stream, rpad, H, W, os2d_plane(H, W));
   return check_launch("border_zero");
+}
+
+int os2d_launch_border_zero_shb(void* rnorm, int NB, int H, int W, hipStream_t stream) {
+  hipLaunchKernelGGL(border_zero_shb_kernel, dim3(NB * OS2D_G * 2), dim3(256), 0, stream,
+                     reinterpret_cast<uint4*>(rnorm), H, W, os2d_plane(H, W));
+  return check_launch("border_zero_shb");
+}
+
+int os2d_launch_pack_conv_f16(const float* w, const float* b, const float* bn_w, const float* bn_b, const float* bn_mean,
+                              const float* bn_var, float bn_eps, int Cout, int Cin, int KS, int MT, int steps_padded,
+                              int scale_log2, void* wp, float* bp, hipStream_t stream) {
+  hipLaunchKernelGGL(pack_conv_f16_kernel, dim3(1024), dim3(256), 0, stream, w, b, bn_w, bn_b, bn_mean, bn_var, bn_eps,
+                     Cout, Cin, KS, MT, steps_padded, ldexpf(1.0f, scale_log2), reinterpret_cast<_Float16*>(wp), bp);
+  return check_launch("pack_conv_f16");
 }
 
 int os2d_launch_corr_normalize(const float* corr, float* rpad, int NB, int H, int W, hipStream_t stream) {

@@ -14,6 +14,7 @@ memory, the stream and the parameter containers.  There is no CPU / eager fallba
 Training through the head (autograd) is out of scope and raises as well.
 """
 import ctypes
+import math
 import os
 
 import torch
@@ -25,6 +26,16 @@ from .box_coder import BoxGridGenerator
 
 TEMPLATE = 15
 QROWS = 256
+PRECISIONS = {"f32": 0, "f16x3": 1}     # OS2D_PRECISION_* of include/os2d_hip.h
+
+
+def resolve_precision(precision=None):
+    """Arithmetic of the two large TransformNet convolutions: "f32" (exact fp32 MFMA) or "f16x3" (fp16 hi/lo split on
+    the half-precision matrix cores, fp32-equivalent results).  Default from $OS2D_PRECISION, else "f32"."""
+    precision = precision or os.environ.get("OS2D_PRECISION", "f32")
+    if precision not in PRECISIONS:
+        raise ValueError("precision must be one of {}, got {!r}".format(sorted(PRECISIONS), precision))
+    return precision
 
 
 def build_os2d_head_creator(do_simple_affine, is_cuda, use_inverse_geom_model, feature_map_stride,
@@ -109,8 +120,7 @@ class TransformationNet(nn.Module):
                 self.linear.bias[0] = 1
                 self.linear.bias[2] = 1
         self.output_dim = output_dim
-        self._packed = None
-        self._packed_key = None
+        self._packed_cache = {}
         if use_cuda:
             self.conv.cuda()
             self.linear.cuda()
@@ -124,11 +134,15 @@ class TransformationNet(nn.Module):
         ts = list(self.parameters()) + list(self.buffers())
         return tuple((t.data_ptr(), t._version, str(t.device)) for t in ts)
 
-    def packed(self):
-        """(w1, b1, w2, b2, w3, b3) device tensors in the kernels' layout (os2d_pack_conv)."""
-        key = self._state_key()
-        if self._packed is not None and key == self._packed_key:
-            return self._packed
+    def packed(self, precision=None):
+        """Packed TransformNet for the kernels: (w1, b1, w2, b2, w3, b3, scale1_log2, scale2_log2).
+        precision "f32": os2d_pack_conv layouts (scales are 0); "f16x3": layers 1-2 in the split-half layout of
+        os2d_pack_conv_f16x3, pre-scaled by the largest power of two that keeps max|w| <= 16384."""
+        precision = resolve_precision(precision)
+        key = (precision,) + self._state_key()
+        cached = self._packed_cache.get(precision)
+        if cached is not None and cached[0] == key:
+            return cached[1]
         lib = _lib.load()
         dev = self.linear.weight.device
         if dev.type != "cuda":
@@ -138,24 +152,37 @@ class TransformationNet(nn.Module):
             raise RuntimeError("TransformationNet is in training mode: the HIP path implements eval-mode "
                                "BatchNorm (running statistics) only; call .eval()")
         stream = _lib.current_stream(dev)
-        out = []
+        out, scales = [], []
         P = self.output_dim
         layers = ((1, self.conv[0], self.conv[1]), (2, self.conv[3], self.conv[4]), (3, self.linear, None))
         for layer, conv, bn in layers:
             w = _require_device_f32(conv.weight.detach(), "conv weight")
             b = _require_device_f32(conv.bias.detach(), "conv bias")
-            pw = torch.empty(lib.os2d_packed_conv_floats(layer), dtype=torch.float32, device=dev)
             pb = torch.empty(lib.os2d_packed_bias_floats(layer), dtype=torch.float32, device=dev)
             if bn is not None:
                 bnp = [_require_device_f32(t.detach(), "bn") for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
                 eps = float(bn.eps)
             else:
                 bnp, eps = [None] * 4, 0.0
-            _lib.check(lib.os2d_pack_conv(layer, P, _lib.ptr(w), _lib.ptr(b), *[_lib.ptr(t) for t in bnp],
-                                          ctypes.c_float(eps), _lib.ptr(pw), _lib.ptr(pb), stream), "os2d_pack_conv")
+            if precision == "f16x3" and layer in (1, 2):
+                folded_max = float((w.abs().amax(dim=(1, 2, 3)) * (bnp[0] / torch.sqrt(bnp[3] + eps)).abs()).max())
+                scale_log2 = int(math.floor(math.log2(16384.0 / folded_max))) if folded_max > 0 else 0
+                scale_log2 = max(-60, min(60, scale_log2))
+                pw = torch.empty(lib.os2d_packed_conv_bytes(layer, PRECISIONS[precision]), dtype=torch.uint8, device=dev)
+                _lib.check(lib.os2d_pack_conv_f16x3(layer, _lib.ptr(w), _lib.ptr(b), *[_lib.ptr(t) for t in bnp],
+                                                    ctypes.c_float(eps), scale_log2, _lib.ptr(pw), _lib.ptr(pb), stream),
+                           "os2d_pack_conv_f16x3")
+                scales.append(scale_log2)
+            else:
+                pw = torch.empty(lib.os2d_packed_conv_floats(layer), dtype=torch.float32, device=dev)
+                _lib.check(lib.os2d_pack_conv(layer, P, _lib.ptr(w), _lib.ptr(b), *[_lib.ptr(t) for t in bnp],
+                                              ctypes.c_float(eps), _lib.ptr(pw), _lib.ptr(pb), stream), "os2d_pack_conv")
+                if layer in (1, 2):
+                    scales.append(0)
             out += [pw, pb]
-        self._packed, self._packed_key = tuple(out), key
-        return self._packed
+        result = tuple(out) + tuple(scales)
+        self._packed_cache[precision] = (key, result)
+        return result
 
     def forward(self, corr_maps):
         """corr_maps [N,225,H,W] -> transform parameters [N,P,H,W] (reference head.py:648-655), via
@@ -168,7 +195,7 @@ class TransformationNet(nn.Module):
         lib = _lib.load()
         N, _, H, W = corr_maps.shape
         dev = corr_maps.device
-        w1, b1, w2, b2, w3, b3 = self.packed()
+        w1, b1, w2, b2, w3, b3 = self.packed("f32")[:6]
         plane = lib.os2d_plane_floats(H, W)
         stream = _lib.current_stream(dev)
         r = torch.empty(N * 226 * plane, dtype=torch.float32, device=dev)
@@ -317,6 +344,7 @@ class Os2dHead(nn.Module):
         mask[:, :, pool_border_width:TEMPLATE - pool_border_width, pool_border_width:TEMPLATE - pool_border_width] = 1
         self.class_pool_mask = mask / mask.sum(dim=(2, 3), keepdim=True)
         self.aligner = aligner
+        self.precision = None      # None: follow $OS2D_PRECISION (default "f32"); or "f32" / "f16x3"
         box = box_grid_generator_image_level
         self._stride = int(box.box_stride.w)
         # image-level box = stride*(15-1) + receptive field (head.py:223-238)
@@ -333,7 +361,7 @@ class Os2dHead(nn.Module):
         return cls(q15, h0.aligner, h0.box_grid_generator_image_level, h0.box_grid_generator_feature_map_level,
                    _prepared=qp)
 
-    def forward(self, feature_maps, out=None, stage_events=None):
+    def forward(self, feature_maps, out=None, stage_events=None, precision=None):
         """feature_maps [A,C,H,W] -> (loc [A,B,4,H,W], cls [A,B,1,H,W], cls_detached (same), corners [A,B,8,H,W]).
 
         ``out``: optional preallocated (loc, cls, corners) device tensors of exactly those shapes (contiguous) - used
@@ -356,7 +384,8 @@ class Os2dHead(nn.Module):
         dev = feature_maps.device
         regressor = self.aligner.parameter_regressor
         P = regressor.output_dim
-        w1, b1, w2, b2, w3, b3 = regressor.packed()
+        precision = resolve_precision(precision or self.precision)
+        w1, b1, w2, b2, w3, b3, s1, s2 = regressor.packed(precision)
         if out is None:
             loc = torch.empty(A, B, 4, H, W, dtype=torch.float32, device=dev)
             cls = torch.empty(A, B, 1, H, W, dtype=torch.float32, device=dev)
@@ -371,11 +400,12 @@ class Os2dHead(nn.Module):
         _lib.check(lib.os2d_head_workspace_bytes(A, B, C, H, W, P, ctypes.byref(full)), "os2d_head_workspace_bytes")
         _lib.check(lib.os2d_head_workspace_bytes(A, 1, C, H, W, P, ctypes.byref(one)), "os2d_head_workspace_bytes")
         ws = get_workspace(dev, full.value, one.value)
-        _lib.check(lib.os2d_head_forward_profiled(
+        _lib.check(lib.os2d_head_forward_ex(
             _lib.ptr(feature_maps), _lib.ptr(self._qp), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2),
             _lib.ptr(w3), _lib.ptr(b3), A, B, C, H, W, P, 1 if self.aligner.use_inverse_geom_model else 0,
             self._stride, self._rec_field, _lib.ptr(loc), _lib.ptr(cls), _lib.ptr(corners),
-            _lib.ptr(ws), ws.numel(), _lib.current_stream(dev), stage_events, None), "os2d_head_forward")
+            _lib.ptr(ws), ws.numel(), _lib.current_stream(dev), PRECISIONS[precision], s1, s2, stage_events, None),
+            "os2d_head_forward_ex")
         return loc, cls, cls, corners
 
 

@@ -73,9 +73,14 @@ int os2d_pack_conv_f16x3(int layer /*1|2*/, const float* w, const float* b, cons
                          const float* bn_bias, const float* bn_running_mean, const float* bn_running_var, float bn_eps,
                          int scale_log2, void* packed_w, float* packed_b, void* stream);
 
+/* split class operand for the f16x3 correlation: qp [B,C,256] fp32 (os2d_class_prepare) -> qs [B, C/8, hi|lo, 256] units
+ * of 8 halves (B * ceil(C/8) * 2 * 256 * 16 bytes), scaled by 2^12.                                                 */
+int os2d_class_split(const float* qp, void* qs, int B, int C, void* stream);
+
 /* ---- extended head entry point: identical to os2d_head_forward, plus
- *   precision     OS2D_PRECISION_F32 (w1/w2 from os2d_pack_conv) or OS2D_PRECISION_F16X3 (w1/w2 from
- *                 os2d_pack_conv_f16x3 with scale1_log2 / scale2_log2); w3/b3 always from os2d_pack_conv;
+ *   precision     OS2D_PRECISION_F32 (w1/w2 from os2d_pack_conv; qs ignored) or OS2D_PRECISION_F16X3 (w1/w2 from
+ *                 os2d_pack_conv_f16x3 with scale1_log2 / scale2_log2, qs [B, C/8, 2, 256, 8] halves from
+ *                 os2d_class_split); w3/b3 always from os2d_pack_conv;
  *   stage_events  NULL, or an array of 10 hipEvent_t (from os2d_prof_event_create); events [2s] / [2s+1] are recorded
  *                 on `stream` right before / after stage s of the FIRST class chunk
  *                 (s = 0 correlation, 1 conv 7x7, 2 conv 5x5 128->64, 3 conv 5x5 64->P, 4 resample+encode);
@@ -83,8 +88,8 @@ int os2d_pack_conv_f16x3(int layer /*1|2*/, const float* w, const float* b, cons
 int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const float* b1, const void* w2,
                          const float* b2, const float* w3, const float* b3, int A, int B, int C, int H, int W, int P,
                          int inverse, int stride, int rec_field, float* loc, float* cls, float* corners,
-                         void* workspace, size_t workspace_bytes, void* stream, int precision, int scale1_log2,
-                         int scale2_log2, void** stage_events, int* chunk_classes);
+                         void* workspace, size_t workspace_bytes, void* stream, int precision, const void* qs,
+                         int scale1_log2, int scale2_log2, void** stage_events, int* chunk_classes);
 int os2d_prof_event_create(void** ev);
 int os2d_prof_event_destroy(void* ev);
 int os2d_prof_event_elapsed_ms(void* begin, void* end, float* ms);   /* both events must have completed */

@@ -25,9 +25,9 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // workspace carve for a chunk of Bc classes
 struct Carve {
-  size_t sumsq, corr, rpad, h1, h2, params, total;
+  size_t sumsq, fs, corr, rpad, h1, h2, params, total;
 };
-Carve carve(int A, int Bc, int H, int W, int P) {
+Carve carve(int A, int Bc, int C, int H, int W, int P) {
   const size_t HW = (size_t)H * W, PL = os2d_plane(H, W), NB = (size_t)A * Bc;
   Carve c;
   size_t off = 0;
@@ -37,6 +37,7 @@ Carve carve(int A, int Bc, int H, int W, int P) {
     return o;
   };
   c.sumsq = take((size_t)A * HW);
+  c.fs = take((size_t)A * ((C + 7) / 8) * 2 * HW * 4);  // f16x3: split image features, 16 B per (group, part, cell)
   c.corr = take(NB * OS2D_K * HW);
   c.rpad = take(NB * (OS2D_G * 2 * 4) * PL);  // fp32: 226 planes; f16x3: 29 groups x (hi|lo) x 16 B = 232 floats
   c.h1 = take(NB * 128 * PL);
@@ -116,7 +117,7 @@ int os2d_head_workspace_bytes(int A, int B, int C, int H, int W, int P, size_t* 
     return -1;
   }
   if (!head_args_ok(A, B, C, H, W, P)) return -1;
-  *bytes = carve(A, B, H, W, P).total;
+  *bytes = carve(A, B, C, H, W, P).total;
   return 0;
 }
 
@@ -205,14 +206,18 @@ int os2d_nms(const float* boxes, const int* counts, int NC, int N, float iou_thr
 int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const float* b1, const void* w2,
                          const float* b2, const float* w3, const float* b3, int A, int B, int C, int H, int W, int P,
                          int inverse, int stride, int rec_field, float* loc, float* cls, float* corners,
-                         void* workspace, size_t workspace_bytes, void* stream, int precision, int scale1_log2,
-                         int scale2_log2, void** stage_events, int* chunk_classes) {
+                         void* workspace, size_t workspace_bytes, void* stream, int precision, const void* qs,
+                         int scale1_log2, int scale2_log2, void** stage_events, int* chunk_classes) {
   if (!fm || !qp || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !loc || !cls || !corners || !workspace) {
     os2d_set_error("os2d_head_forward: null pointer");
     return -1;
   }
   if (precision != OS2D_PRECISION_F32 && precision != OS2D_PRECISION_F16X3) {
     os2d_set_error("os2d_head_forward: unknown precision %d", precision);
+    return -1;
+  }
+  if (precision == OS2D_PRECISION_F16X3 && !qs) {
+    os2d_set_error("os2d_head_forward: precision f16x3 needs the split class operand (os2d_class_split)");
     return -1;
   }
   if (!head_args_ok(A, B, C, H, W, P)) return -1;
@@ -225,14 +230,14 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     return -1;
   }
   // largest class chunk that fits the workspace (footprint is affine in Bc)
-  const size_t one = carve(A, 1, H, W, P).total;
+  const size_t one = carve(A, 1, C, H, W, P).total;
   if (workspace_bytes < one) {
     os2d_set_error("os2d_head_forward: workspace too small (%zu B, need >= %zu B for one class)", workspace_bytes, one);
     return -2;
   }
   int Bc = B;
-  while (Bc > 1 && carve(A, Bc, H, W, P).total > workspace_bytes) {
-    const size_t two = carve(A, 2, H, W, P).total;
+  while (Bc > 1 && carve(A, Bc, C, H, W, P).total > workspace_bytes) {
+    const size_t two = carve(A, 2, C, H, W, P).total;
     const size_t per = two - one;
     int guess = per ? (int)((workspace_bytes - one) / per) + 1 : 1;
     if (guess >= Bc) guess = Bc - 1;
@@ -241,8 +246,9 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
   }
   hipStream_t st = S(stream);
   char* ws = static_cast<char*>(workspace);
-  const Carve c = carve(A, Bc, H, W, P);
+  const Carve c = carve(A, Bc, C, H, W, P);
   float* sumsq = reinterpret_cast<float*>(ws + c.sumsq);
+  void* fsplit = ws + c.fs;
   float* corr = reinterpret_cast<float*>(ws + c.corr);
   float* rpad = reinterpret_cast<float*>(ws + c.rpad);
   float* h1 = reinterpret_cast<float*>(ws + c.h1);
@@ -256,6 +262,7 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
   };
   int rc = os2d_launch_fm_sumsq(fm, sumsq, A, C, H * W, st);
   if (rc) return rc;
+  if (precision == OS2D_PRECISION_F16X3 && (rc = os2d_launch_split_fm(fm, sumsq, fsplit, A, C, H * W, st))) return rc;
   for (int b0 = 0; b0 < B; b0 += Bc) {
     const int bc = (B - b0 < Bc) ? (B - b0) : Bc;
     const int NB = A * bc;
@@ -266,8 +273,13 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     } else {
       if ((rc = os2d_launch_border_zero(rpad, NB * OS2D_KP, H, W, st))) return rc;
     }
-    if ((rc = os2d_launch_corr(fm, qp + (size_t)b0 * C * OS2D_QROWS, sumsq, corr, rpad, A, bc, C, H, W, f16 ? 1 : 0, st)))
-      return rc;
+    if (f16) {
+      const char* qsb = static_cast<const char*>(qs) + (size_t)b0 * ((C + 7) / 8) * 2 * 256 * 16;
+      if ((rc = os2d_launch_corr_f16x3(fsplit, qsb, corr, rpad, A, bc, C, H, W, st))) return rc;
+    } else {
+      if ((rc = os2d_launch_corr(fm, qp + (size_t)b0 * C * OS2D_QROWS, sumsq, corr, rpad, A, bc, C, H, W, 0, st)))
+        return rc;
+    }
     mark(b0, 1);
     mark(b0, 2);
     if (f16) {
@@ -300,7 +312,16 @@ int os2d_head_forward(const float* fm, const float* qp, const float* w1, const f
                       int inverse, int stride, int rec_field, float* loc, float* cls, float* corners, void* workspace,
                       size_t workspace_bytes, void* stream) {
   return os2d_head_forward_ex(fm, qp, w1, b1, w2, b2, w3, b3, A, B, C, H, W, P, inverse, stride, rec_field, loc, cls,
-                              corners, workspace, workspace_bytes, stream, OS2D_PRECISION_F32, 0, 0, nullptr, nullptr);
+                              corners, workspace, workspace_bytes, stream, OS2D_PRECISION_F32, nullptr, 0, 0, nullptr,
+                              nullptr);
+}
+
+int os2d_class_split(const float* qp, void* qs, int B, int C, void* stream) {
+  if (!qp || !qs || B < 1 || C < 1) {
+    os2d_set_error("os2d_class_split: bad arguments");
+    return -1;
+  }
+  return os2d_launch_split_qp(qp, qs, B, C, S(stream));
 }
 
 size_t os2d_packed_conv_bytes(int layer, int precision) {

@@ -1,0 +1,261 @@
+// All-pairs feature correlation (reference os2d/modeling/head.py:339-350) + TransformNet input normalisation
+// (head.py:650) on the half-precision matrix cores with fp32-equivalent accuracy ("f16x3", see conv_f16x3.hip).
+//
+// Operands are pre-split once per image / per class into the split-half blocked layout, both scaled by 2^12
+// (values are L2-normalised, |x| <= 1, so hi <= 4096 and lo stays a normal fp16 number):
+//   fs [A][C/8][hi|lo][H*W]  units of 8 halves   image features, ALREADY L2-normalised over channels (split_fm_kernel)
+//   qs [B][C/8][hi|lo][256]  units of 8 halves   class features in the x-major channel order, rows 225..255 zero
+// One v_mfma_f32_32x32x16_f16 k-step = 16 channels = two 8-channel groups (lanes 0-31 / 32-63).
+//
+// Work-group = 512 threads (8 waves as 2 x 4), tile = 256 rows (one class) x 256 positions, wave tile 128 x 64.
+// K runs in chunks of 32 channels through double-buffered LDS with the register prefetch pipeline of the other
+// kernels.  With 256-wide tiles a group moves 2 MB per 134 MFLOP (3 x that in executed half-precision FLOPs), i.e. the
+// kernel needs ~5 TB/s of L2->LDS traffic at full matrix rate: it is the most bandwidth-hungry kernel of the head.
+// Outputs: corr [A*B][225][H*W] fp32 (for the resampler) and the relu+L2-normalised tensor in SHB layout.
+#include "os2d_common.h"
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define U32X4_ZERO (u32x4{0u, 0u, 0u, 0u})
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+constexpr int NTHR = 512;
+constexpr int NT = 256;
+constexpr int GC = 4;                    // 8-channel groups per K chunk (32 channels)
+constexpr int CH_UNITS = GC * 2 * 256;   // 16-byte units of one operand chunk (A and B alike): 2048 = 32 KB
+constexpr int NPF = CH_UNITS / NTHR;     // 4 units per thread per operand
+
+__global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  // [A][CG][2][HW]   (no __restrict__, see
+                                                             const u32x4* qs,  // [B][CG][2][256]    conv_f16x3.hip)
+                                                             float* __restrict__ corr, char* __restrict__ rshb, int B,
+                                                             int CG, int H, int W, int PLANE, float unscale) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
+  u32x4* ldsA = smem16;                 // [2][CH_UNITS]
+  u32x4* ldsB = smem16 + 2 * CH_UNITS;  // [2][CH_UNITS]
+  __shared__ float red[2][NT];
+
+  const int HW = H * W;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, hw = lane >> 5;
+  const int wm = wid >> 2, wn = wid & 3;  // wave tile: rows [wm*128,+128), cols [wn*64,+64)
+  const int n0 = blockIdx.x * NT;
+  const int b = blockIdx.y, a = blockIdx.z;
+  const int nb = a * B + b;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const u32x4* qb = qs + (size_t)b * CG * 2 * 256;
+  const u32x4* fa = fs + (size_t)a * CG * 2 * HW;
+  const int nchunks = (CG + GC - 1) / GC;
+  u32x4 pfA[NPF], pfB[NPF];
+
+  // unit i of a chunk: row = i / 256 = (group_local * 2 + part), col = i % 256
+#define CF_LOAD(T)                                                                                                \
+  {                                                                                                               \
+    const int g0_ = (T)*GC;                                                                                       \
+    _Pragma("unroll") for (int k = 0; k < NPF; ++k) {                                                             \
+      const int i_ = tid + k * NTHR;                                                                              \
+      const int row_ = i_ >> 8, col_ = i_ & 255;                                                                  \
+      const int grow_ = min(g0_ * 2 + row_, CG * 2 - 1); /* global (group, part) row, clamped */                  \
+      pfA[k] = qb[(size_t)grow_ * 256 + col_];                                                                    \
+      pfB[k] = fa[(size_t)grow_ * HW + min(n0 + col_, HW - 1)];                                                   \
+    }                                                                                                             \
+  }
+#define CF_STORE(T)                                                                                               \
+  {                                                                                                               \
+    const int g0_ = (T)*GC;                                                                                       \
+    _Pragma("unroll") for (int k = 0; k < NPF; ++k) {                                                             \
+      const int i_ = tid + k * NTHR;                                                                              \
+      const int row_ = i_ >> 8, col_ = i_ & 255;                                                                  \
+      const bool rok_ = g0_ * 2 + row_ < CG * 2;                                                                  \
+      ldsA[((T)&1) * CH_UNITS + i_] = rok_ ? pfA[k] : U32X4_ZERO;                                                 \
+      ldsB[((T)&1) * CH_UNITS + i_] = (rok_ && n0 + col_ < HW) ? pfB[k] : U32X4_ZERO;                             \
+    }                                                                                                             \
+  }
+#define CF_COMPUTE(T)                                                                                             \
+  {                                                                                                               \
+    const u32x4* aB_ = ldsA + ((T)&1) * CH_UNITS + wm * 128 + l31;                                                \
+    const u32x4* bB_ = ldsB + ((T)&1) * CH_UNITS + wn * 64 + l31;                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < GC / 2; ++ks) {                                                       \
+      const int rowh_ = ((2 * ks + hw) * 2 + 0) * 256, rowl_ = ((2 * ks + hw) * 2 + 1) * 256;                     \
+      half8 bh_[2], bl_[2];                                                                                       \
+      _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                                          \
+        bh_[ni] = *reinterpret_cast<const half8*>(bB_ + rowh_ + ni * 32);                                         \
+        bl_[ni] = *reinterpret_cast<const half8*>(bB_ + rowl_ + ni * 32);                                         \
+      }                                                                                                           \
+      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                                          \
+        const half8 ah_ = *reinterpret_cast<const half8*>(aB_ + rowh_ + mi * 32);                                 \
+        const half8 al_ = *reinterpret_cast<const half8*>(aB_ + rowl_ + mi * 32);                                 \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                                        \
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al_, bh_[ni], acc[mi][ni], 0, 0, 0);               \
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bl_[ni], acc[mi][ni], 0, 0, 0);               \
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bh_[ni], acc[mi][ni], 0, 0, 0);               \
+        }                                                                                                         \
+      }                                                                                                           \
+    }                                                                                                             \
+  }
+
+  CF_LOAD(0)
+  CF_STORE(0)
+  __syncthreads();
+  for (int t = 0; t + 1 < nchunks; ++t) {
+    CF_LOAD(t + 1)
+    __builtin_amdgcn_sched_barrier(0);
+    CF_COMPUTE(t)
+    __builtin_amdgcn_sched_barrier(0);
+    CF_STORE(t + 1)
+    __syncthreads();
+  }
+  CF_COMPUTE(nchunks - 1)
+#undef CF_LOAD
+#undef CF_STORE
+#undef CF_COMPUTE
+
+  // ---- epilogue (features were normalised before the split, so only the 2^-24 operand scale is undone)
+  const int Ws = os2d_ws(W), BASE = os2d_base(W);
+  float part[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int n = n0 + wn * 64 + ni * 32 + l31;
+    const bool nin = n < HW;
+    float s = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[mi][ni][r] * unscale;
+        acc[mi][ni][r] = v;
+        const int m = wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hw;
+        if (nin && m < OS2D_K) corr[((size_t)nb * OS2D_K + m) * HW + n] = v;
+        const float rl = fmaxf(v, 0.f);
+        s += rl * rl;
+      }
+    s += __shfl_xor(s, 32);
+    part[ni] = s;
+  }
+  if (hw == 0) {
+    red[wm][wn * 64 + l31] = part[0];
+    red[wm][wn * 64 + 32 + l31] = part[1];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int col = wn * 64 + ni * 32 + l31;
+    const int n = n0 + col;
+    if (n >= HW) continue;
+    const float inv_r = 1.0f / (sqrtf(red[0][col] + red[1][col]) + 1e-6f);  // head.py:650,597 (eps 1e-6)
+    const int h = n / W, w = n - h * W;
+    const size_t cell = (size_t)BASE + (size_t)h * Ws + w;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m0 = wm * 128 + mi * 32 + 8 * q + 4 * hw;
+        const int grp = m0 >> 3;
+        if (grp >= OS2D_G) continue;
+        half4 h4, l4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float v = (m0 + k < OS2D_K) ? fmaxf(acc[mi][ni][4 * q + k], 0.f) * inv_r : 0.f;
+          const _Float16 hv = (_Float16)v;
+          h4[k] = hv;
+          l4[k] = (_Float16)(v - (float)hv);
+        }
+        char* o = rshb + (((size_t)nb * OS2D_G + grp) * 2 * PLANE + cell) * 16 + hw * 8;
+        *reinterpret_cast<half4*>(o) = h4;
+        *reinterpret_cast<half4*>(o + (size_t)PLANE * 16) = l4;
+      }
+  }
+}
+
+// image features [A][C][HW] fp32 -> L2-normalised over channels (head.py:339, eps 1e-5), scaled, split, blocked
+__global__ __launch_bounds__(256) void split_fm_kernel(const float* __restrict__ fm, const float* __restrict__ sumsq,
+                                                       u32x4* __restrict__ fs, int C, int HW, float scale) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int g = blockIdx.y, a = blockIdx.z;
+  if (n >= HW) return;
+  const int CG = (C + 7) / 8;
+  const float inv = scale / (sqrtf(sumsq[(size_t)a * HW + n]) + 1e-5f);
+  half8 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = g * 8 + j;
+    const float v = c < C ? fm[((size_t)a * C + c) * HW + n] * inv : 0.f;
+    const _Float16 hv = (_Float16)v;
+    hi[j] = hv;
+    lo[j] = (_Float16)(v - (float)hv);
+  }
+  u32x4* o = fs + ((size_t)a * CG + g) * 2 * HW + n;
+  *reinterpret_cast<half8*>(o) = hi;
+  *reinterpret_cast<half8*>(o + HW) = lo;
+}
+
+// class operand [C][256] fp32 (os2d_class_prepare) -> [C/8][hi|lo][256] units, scaled
+__global__ __launch_bounds__(256) void split_qp_kernel(const float* __restrict__ qp, u32x4* __restrict__ qs, int C,
+                                                       float scale) {
+  const int m = threadIdx.x;  // 0..255
+  const int g = blockIdx.x, b = blockIdx.y;
+  const int CG = (C + 7) / 8;
+  half8 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = g * 8 + j;
+    const float v = c < C ? qp[((size_t)b * C + c) * OS2D_QROWS + m] * scale : 0.f;
+    const _Float16 hv = (_Float16)v;
+    hi[j] = hv;
+    lo[j] = (_Float16)(v - (float)hv);
+  }
+  u32x4* o = qs + ((size_t)b * CG + g) * 2 * 256 + m;
+  *reinterpret_cast<half8*>(o) = hi;
+  *reinterpret_cast<half8*>(o + 256) = lo;
+}
+
+constexpr int SCALE_LOG2 = 12;  // operands are L2-normalised (|x| <= 1): hi <= 4096, lo >= 2^-11 * 2^12 * x stays normal
+
+int check(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    os2d_set_error("%s launch: %s", what, hipGetErrorString(e));
+    return -4;
+  }
+  return 0;
+}
+
+}  // namespace
+
+int os2d_launch_split_fm(const float* fm, const float* sumsq, void* fs, int A, int C, int HW, hipStream_t stream) {
+  hipLaunchKernelGGL(split_fm_kernel, dim3((HW + 255) / 256, (C + 7) / 8, A), dim3(256), 0, stream, fm, sumsq,
+                     reinterpret_cast<u32x4*>(fs), C, HW, ldexpf(1.0f, SCALE_LOG2));
+  return check("split_fm");
+}
+
+int os2d_launch_split_qp(const float* qp, void* qs, int B, int C, hipStream_t stream) {
+  hipLaunchKernelGGL(split_qp_kernel, dim3((C + 7) / 8, B), dim3(256), 0, stream, qp, reinterpret_cast<u32x4*>(qs), C,
+                     ldexpf(1.0f, SCALE_LOG2));
+  return check("split_qp");
+}
+
+int os2d_launch_corr_f16x3(const void* fs, const void* qs, float* corr, void* rshb, int A, int B, int C, int H, int W,
+                           hipStream_t stream) {
+  const int HW = H * W;
+  const size_t lds = (size_t)4 * CH_UNITS * 16;  // 128 KB dynamic (+2 KB static)
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_f16x3_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) {
+    os2d_set_error("hipFuncSetAttribute(corr f16x3): %s", hipGetErrorString(e));
+    return -4;
+  }
+  dim3 grid((HW + NT - 1) / NT, B, A);
+  hipLaunchKernelGGL(corr_f16x3_kernel, grid, dim3(NTHR), lds, stream, reinterpret_cast<const u32x4*>(fs),
+                     reinterpret_cast<const u32x4*>(qs), corr, reinterpret_cast<char*>(rshb), B, (C + 7) / 8, H, W,
+                     os2d_plane(H, W), ldexpf(1.0f, -2 * SCALE_LOG2));
+  return check("corr_f16x3");
+}

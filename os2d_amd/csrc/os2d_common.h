@@ -71,3 +71,8 @@ int os2d_launch_decode_boxes(const float* loc, int NB, int H, int W, int stride,
 // nms.hip
 int os2d_launch_nms(const float* boxes, const int* counts, int NC, int N, float thr, unsigned char* keep, int* num_keep,
                     void* workspace, hipStream_t stream);
+// corr_f16x3.hip
+int os2d_launch_split_fm(const float* fm, const float* sumsq, void* fs, int A, int C, int HW, hipStream_t stream);
+int os2d_launch_split_qp(const float* qp, void* qs, int B, int C, hipStream_t stream);
+int os2d_launch_corr_f16x3(const void* fs, const void* qs, float* corr, void* rshb, int A, int B, int C, int H, int W,
+                           hipStream_t stream);

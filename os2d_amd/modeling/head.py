@@ -335,6 +335,7 @@ class Os2dHead(nn.Module):
             class_feature_maps, _prepared = _prepare_class_maps(class_feature_maps, normalise=True)
         self.class_feature_maps = class_feature_maps          # normalised, [B,C,15,15]
         self._qp = _prepared                                  # GEMM operand [B,C,256]
+        self._qs = None                                       # its fp16 hi/lo split (f16x3 mode), built on first use
         self.class_batch_size = self.class_feature_maps.size(0)
         self.box_grid_generator_image_level = box_grid_generator_image_level
         self.box_grid_generator_feature_map_level = box_grid_generator_feature_map_level
@@ -351,6 +352,17 @@ class Os2dHead(nn.Module):
         self._rec_field = int(box.box_size.w - self._stride * (TEMPLATE - 1))
         if box.box_stride.w != box.box_stride.h or box.box_size.w != box.box_size.h:
             raise RuntimeError("anisotropic strides / receptive fields are not supported by the HIP head")
+
+    def _split_class_operand(self):
+        """qs [B, C/8, hi|lo, 256] x 8 halves for the f16x3 correlation (os2d_class_split), built on first use."""
+        if self._qs is None:
+            lib = _lib.load()
+            B, C = self._qp.size(0), self._qp.size(1)
+            qs = torch.empty(B * ((C + 7) // 8) * 2 * 256 * 16, dtype=torch.uint8, device=self._qp.device)
+            _lib.check(lib.os2d_class_split(_lib.ptr(self._qp), _lib.ptr(qs), B, C, _lib.current_stream(self._qp.device)),
+                       "os2d_class_split")
+            self._qs = qs
+        return self._qs
 
     @classmethod
     def cat(cls, heads):
@@ -404,7 +416,8 @@ class Os2dHead(nn.Module):
             _lib.ptr(feature_maps), _lib.ptr(self._qp), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2),
             _lib.ptr(w3), _lib.ptr(b3), A, B, C, H, W, P, 1 if self.aligner.use_inverse_geom_model else 0,
             self._stride, self._rec_field, _lib.ptr(loc), _lib.ptr(cls), _lib.ptr(corners),
-            _lib.ptr(ws), ws.numel(), _lib.current_stream(dev), PRECISIONS[precision], s1, s2, stage_events, None),
+            _lib.ptr(ws), ws.numel(), _lib.current_stream(dev), PRECISIONS[precision],
+            _lib.ptr(self._split_class_operand()) if precision == "f16x3" else None, s1, s2, stage_events, None),
             "os2d_head_forward_ex")
         return loc, cls, cls, corners
 

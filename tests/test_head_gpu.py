@@ -15,13 +15,17 @@ pytestmark = pytest.mark.gpu
 TOL_CLS, TOL_LOC, TOL_CORNERS = 1e-5, 1e-4, 2e-3
 
 
+PRECISIONS = ["f32", "f16x3"]     # both arithmetic modes must meet the same tolerances
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", util.head_fixture_names())
-def test_head_matches_reference_golden(name, device):
+def test_head_matches_reference_golden(name, precision, device):
     fx = util.load_head_fixture(name)
     creator = util.make_head_creator(fx["P"], fx["inverse"], fx["state"], device)
     with torch.no_grad():
         head = creator.create_os2d_head([c.to(device) for c in fx["class_fms"]])
-        loc, cls, cls_det, corners = head(fx["fm"].to(device))
+        loc, cls, cls_det, corners = head(fx["fm"].to(device), precision=precision)
     torch.cuda.synchronize()
     assert cls_det is cls
     assert loc.shape == fx["ref_loc"].shape and cls.shape == fx["ref_cls"].shape and corners.shape == fx["ref_corners"].shape
@@ -37,8 +41,9 @@ def _oracle(fm, class_fms, state, inverse):
         return O.head_forward(fm, O.prepare_class_maps(class_fms), state, inverse)
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("P,inverse", [(6, True), (4, False)])
-def test_full_size_matches_oracle(P, inverse, device):
+def test_full_size_matches_oracle(P, inverse, precision, device):
     """BASELINE.json sizes: C=1024, 60x80 feature map (1280x960 input); 2 classes so the oracle takes seconds."""
     from os2d_amd.utils import synthetic
     state = synthetic.make_transform_net_state(P, seed=1)
@@ -47,14 +52,15 @@ def test_full_size_matches_oracle(P, inverse, device):
     creator = util.make_head_creator(P, inverse, state, device)
     with torch.no_grad():
         head = creator.create_os2d_head([c.to(device) for c in class_fms])
-        loc, cls, _, corners = head(fm.to(device))
+        loc, cls, _, corners = head(fm.to(device), precision=precision)
     ref = _oracle(fm, class_fms, state, inverse)
     assert util.maxdiff(cls, ref[1]) < TOL_CLS
     assert util.maxdiff(loc, ref[0]) < TOL_LOC
     assert util.maxdiff(corners, ref[3]) < 5e-3   # coordinates up to ~1400 px at this size
 
 
-def test_image_batch_chunking_and_cat(device, monkeypatch):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_image_batch_chunking_and_cat(precision, device, monkeypatch):
     """A=2 images, 5 classes, workspace capped so that classes go through in several chunks; per-class heads
     concatenated with Os2dHead.cat give the same result as one batched head."""
     from os2d_amd.modeling import head as head_mod
@@ -67,6 +73,7 @@ def test_image_batch_chunking_and_cat(device, monkeypatch):
     ref = _oracle(fm, class_fms, state, inverse)
     with torch.no_grad():
         head = creator.create_os2d_head([c.to(device) for c in class_fms])
+        head.precision = precision
         out_full = head(fm.to(device))
         # cap the workspace at ~2 classes per chunk
         import ctypes
@@ -79,7 +86,7 @@ def test_image_batch_chunking_and_cat(device, monkeypatch):
         head_mod.release_workspaces()
         monkeypatch.undo()
         singles = [creator.create_os2d_head([c.to(device)]) for c in class_fms]
-        out_cat = head_mod.Os2dHead.cat(singles)(fm.to(device))
+        out_cat = head_mod.Os2dHead.cat(singles)(fm.to(device), precision=precision)
     for i, tol in ((0, TOL_LOC), (1, TOL_CLS), (3, TOL_CORNERS)):
         assert util.maxdiff(out_full[i], ref[i]) < tol
         assert util.maxdiff(out_chunked[i], out_full[i]) == 0.0

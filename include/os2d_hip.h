@@ -65,11 +65,11 @@ int os2d_head_forward(const float* fm, const float* qp, const float* w1, const f
                       int inverse, int stride, int rec_field, float* loc, float* cls, float* corners,
                       void* workspace, size_t workspace_bytes, void* stream);
 
-/* ---- f16x3 weight packing for layers 1 and 2 (layer 3 always uses os2d_pack_conv).  The weights are multiplied by
+/* ---- f16x3 weight packing (bn_* = NULL for layer 3, as in os2d_pack_conv).  The weights are multiplied by
  * 2^scale_log2 before the fp16 hi/lo split so that the lo parts stay normal numbers; choose the largest scale with
  * max|w_folded| * 2^scale_log2 <= 16384 (the Python binding computes it).  Buffer sizes: os2d_packed_conv_bytes.      */
 size_t os2d_packed_conv_bytes(int layer, int precision);
-int os2d_pack_conv_f16x3(int layer /*1|2*/, const float* w, const float* b, const float* bn_weight,
+int os2d_pack_conv_f16x3(int layer /*1|2|3*/, int P, const float* w, const float* b, const float* bn_weight,
                          const float* bn_bias, const float* bn_running_mean, const float* bn_running_var, float bn_eps,
                          int scale_log2, void* packed_w, float* packed_b, void* stream);
 
@@ -78,18 +78,18 @@ int os2d_pack_conv_f16x3(int layer /*1|2*/, const float* w, const float* b, cons
 int os2d_class_split(const float* qp, void* qs, int B, int C, void* stream);
 
 /* ---- extended head entry point: identical to os2d_head_forward, plus
- *   precision     OS2D_PRECISION_F32 (w1/w2 from os2d_pack_conv; qs ignored) or OS2D_PRECISION_F16X3 (w1/w2 from
- *                 os2d_pack_conv_f16x3 with scale1_log2 / scale2_log2, qs [B, C/8, 2, 256, 8] halves from
- *                 os2d_class_split); w3/b3 always from os2d_pack_conv;
+ *   precision     OS2D_PRECISION_F32 (w1..w3 from os2d_pack_conv; qs / scale_log2 ignored) or OS2D_PRECISION_F16X3
+ *                 (w1..w3 from os2d_pack_conv_f16x3 with their three scale_log2 values, qs [B, C/8, 2, 256, 8] halves
+ *                 from os2d_class_split);
  *   stage_events  NULL, or an array of 10 hipEvent_t (from os2d_prof_event_create); events [2s] / [2s+1] are recorded
  *                 on `stream` right before / after stage s of the FIRST class chunk
  *                 (s = 0 correlation, 1 conv 7x7, 2 conv 5x5 128->64, 3 conv 5x5 64->P, 4 resample+encode);
  *   chunk_classes NULL, or receives the number of classes per chunk chosen for the given workspace.              */
 int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const float* b1, const void* w2,
-                         const float* b2, const float* w3, const float* b3, int A, int B, int C, int H, int W, int P,
+                         const float* b2, const void* w3, const float* b3, int A, int B, int C, int H, int W, int P,
                          int inverse, int stride, int rec_field, float* loc, float* cls, float* corners,
                          void* workspace, size_t workspace_bytes, void* stream, int precision, const void* qs,
-                         int scale1_log2, int scale2_log2, void** stage_events, int* chunk_classes);
+                         const int* scale_log2 /*[3], host memory*/, void** stage_events, int* chunk_classes);
 int os2d_prof_event_create(void** ev);
 int os2d_prof_event_destroy(void* ev);
 int os2d_prof_event_elapsed_ms(void* begin, void* end, float* ms);   /* both events must have completed */

@@ -204,10 +204,10 @@ int os2d_nms(const float* boxes, const int* counts, int NC, int N, float iou_thr
 }
 
 int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const float* b1, const void* w2,
-                         const float* b2, const float* w3, const float* b3, int A, int B, int C, int H, int W, int P,
+                         const float* b2, const void* w3, const float* b3, int A, int B, int C, int H, int W, int P,
                          int inverse, int stride, int rec_field, float* loc, float* cls, float* corners,
                          void* workspace, size_t workspace_bytes, void* stream, int precision, const void* qs,
-                         int scale1_log2, int scale2_log2, void** stage_events, int* chunk_classes) {
+                         const int* scale_log2, void** stage_events, int* chunk_classes) {
   if (!fm || !qp || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !loc || !cls || !corners || !workspace) {
     os2d_set_error("os2d_head_forward: null pointer");
     return -1;
@@ -216,8 +216,9 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     os2d_set_error("os2d_head_forward: unknown precision %d", precision);
     return -1;
   }
-  if (precision == OS2D_PRECISION_F16X3 && !qs) {
-    os2d_set_error("os2d_head_forward: precision f16x3 needs the split class operand (os2d_class_split)");
+  if (precision == OS2D_PRECISION_F16X3 && (!qs || !scale_log2)) {
+    os2d_set_error("os2d_head_forward: precision f16x3 needs the split class operand (os2d_class_split) and the "
+                   "three weight scales");
     return -1;
   }
   if (!head_args_ok(A, B, C, H, W, P)) return -1;
@@ -283,20 +284,24 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     mark(b0, 1);
     mark(b0, 2);
     if (f16) {
-      if ((rc = os2d_launch_conv_f16x3(1, rpad, w1, b1, ldexpf(1.0f, -scale1_log2), h1, NB, H, W, st))) return rc;
+      if ((rc = os2d_launch_conv_f16x3(1, rpad, w1, b1, ldexpf(1.0f, -scale_log2[0]), h1, NB, P, H, W, st))) return rc;
     } else {
       if ((rc = os2d_launch_conv(1, rpad, static_cast<const float*>(w1), b1, h1, NB, P, H, W, st))) return rc;
     }
     mark(b0, 3);
     mark(b0, 4);
     if (f16) {
-      if ((rc = os2d_launch_conv_f16x3(2, h1, w2, b2, ldexpf(1.0f, -scale2_log2), h2, NB, H, W, st))) return rc;
+      if ((rc = os2d_launch_conv_f16x3(2, h1, w2, b2, ldexpf(1.0f, -scale_log2[1]), h2, NB, P, H, W, st))) return rc;
     } else {
       if ((rc = os2d_launch_conv(2, h1, static_cast<const float*>(w2), b2, h2, NB, P, H, W, st))) return rc;
     }
     mark(b0, 5);
     mark(b0, 6);
-    if ((rc = os2d_launch_conv(3, h2, w3, b3, params, NB, P, H, W, st))) return rc;
+    if (f16) {
+      if ((rc = os2d_launch_conv_f16x3(3, h2, w3, b3, ldexpf(1.0f, -scale_log2[2]), params, NB, P, H, W, st))) return rc;
+    } else {
+      if ((rc = os2d_launch_conv(3, h2, static_cast<const float*>(w3), b3, params, NB, P, H, W, st))) return rc;
+    }
     mark(b0, 7);
     mark(b0, 8);
     if ((rc = os2d_launch_sample_decode(corr, params, NB, H, W, P, inverse, stride, rec_field, bc, B, b0, loc, cls,
@@ -312,7 +317,7 @@ int os2d_head_forward(const float* fm, const float* qp, const float* w1, const f
                       int inverse, int stride, int rec_field, float* loc, float* cls, float* corners, void* workspace,
                       size_t workspace_bytes, void* stream) {
   return os2d_head_forward_ex(fm, qp, w1, b1, w2, b2, w3, b3, A, B, C, H, W, P, inverse, stride, rec_field, loc, cls,
-                              corners, workspace, workspace_bytes, stream, OS2D_PRECISION_F32, nullptr, 0, 0, nullptr,
+                              corners, workspace, workspace_bytes, stream, OS2D_PRECISION_F32, nullptr, nullptr, nullptr,
                               nullptr);
 }
 
@@ -325,20 +330,22 @@ int os2d_class_split(const float* qp, void* qs, int B, int C, void* stream) {
 }
 
 size_t os2d_packed_conv_bytes(int layer, int precision) {
-  if (precision == OS2D_PRECISION_F32 || layer == 3) return os2d_packed_conv_floats(layer) * sizeof(float);
+  if (precision == OS2D_PRECISION_F32) return os2d_packed_conv_floats(layer) * sizeof(float);
   if (precision != OS2D_PRECISION_F16X3) return 0;
   // [G][steps padded to whole stages][2][2][MT] units of 16 B (conv_f16x3.hip: layer 1 SS=5, layer 2 SS=7)
   if (layer == 1) return (size_t)OS2D_G * 25 * 4 * 128 * 16;
   if (layer == 2) return (size_t)16 * 14 * 4 * 64 * 16;
+  if (layer == 3) return (size_t)8 * 14 * 4 * 32 * 16;
   return 0;
 }
 
-int os2d_pack_conv_f16x3(int layer, const float* w, const float* b, const float* bn_weight, const float* bn_bias,
+int os2d_pack_conv_f16x3(int layer, int P, const float* w, const float* b, const float* bn_weight, const float* bn_bias,
                          const float* bn_running_mean, const float* bn_running_var, float bn_eps, int scale_log2,
                          void* packed_w, float* packed_b, void* stream) {
-  if ((layer != 1 && layer != 2) || !w || !b || !packed_w || !packed_b || !bn_weight || !bn_bias || !bn_running_mean ||
-      !bn_running_var) {
-    os2d_set_error("os2d_pack_conv_f16x3: bad arguments (layer must be 1 or 2, BatchNorm tensors required)");
+  const bool has_bn = bn_weight || bn_bias || bn_running_mean || bn_running_var;
+  if (layer < 1 || layer > 3 || !w || !b || !packed_w || !packed_b ||
+      (has_bn && !(bn_weight && bn_bias && bn_running_mean && bn_running_var)) || (layer == 3 && P != 6 && P != 4)) {
+    os2d_set_error("os2d_pack_conv_f16x3: bad arguments (layer %d, P %d)", layer, P);
     return -1;
   }
   if (scale_log2 < -60 || scale_log2 > 60) {
@@ -348,7 +355,10 @@ int os2d_pack_conv_f16x3(int layer, const float* w, const float* b, const float*
   if (layer == 1)
     return os2d_launch_pack_conv_f16(w, b, bn_weight, bn_bias, bn_running_mean, bn_running_var, bn_eps, 128, OS2D_K, 7,
                                      128, 25, scale_log2, packed_w, packed_b, S(stream));
-  return os2d_launch_pack_conv_f16(w, b, bn_weight, bn_bias, bn_running_mean, bn_running_var, bn_eps, 64, 128, 5, 64, 14,
+  if (layer == 2)
+    return os2d_launch_pack_conv_f16(w, b, bn_weight, bn_bias, bn_running_mean, bn_running_var, bn_eps, 64, 128, 5, 64,
+                                     14, scale_log2, packed_w, packed_b, S(stream));
+  return os2d_launch_pack_conv_f16(w, b, bn_weight, bn_bias, bn_running_mean, bn_running_var, bn_eps, P, 64, 5, 32, 14,
                                    scale_log2, packed_w, packed_b, S(stream));
 }
 

@@ -31,10 +31,11 @@ __device__ __forceinline__ void split_half(float x, _Float16& hi, _Float16& lo) 
   lo = (_Float16)(x - (float)hi);
 }
 
-constexpr int NTHR = 512;
-
-template <int KS, int MT, int WM, int WN, int NI, int SS, bool RELU, int OUT_MODE /*0 SHB, 1 fp32 plane*/>
-__global__ __launch_bounds__(NTHR, 2) void conv_f16x3_kernel(const u32x4* in,  // SHB [NB][G][2][PLANE] (no __restrict__: invariant loads get
+// MTP = output rows of the packed weights (all output channels, padded), MT = rows handled by ONE work-group
+// (blockIdx.z selects the slice): splitting the output channels over two independent 4-wave groups per CU lets one
+// group's barrier / staging bubble be filled by the other's MFMAs.
+template <int KS, int MTP, int MT, int WM, int WN, int NI, int SS, bool RELU, int OUT_MODE /*0 SHB, 1 fp32 plane, 2 fp32 compact [NB][Cout][H*W]*/>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_f16x3_kernel(const u32x4* in,  // SHB [NB][G][2][PLANE] (no __restrict__: invariant loads get
                                                              const u32x4* wp,  // rematerialised BEHIND the MFMAs by the register allocator)
                                                              const float* __restrict__ bp,  // [MT] fp32 folded bias
                                                              float unscale, void* __restrict__ outv, int G,
@@ -45,11 +46,12 @@ __global__ __launch_bounds__(NTHR, 2) void conv_f16x3_kernel(const u32x4* in,  /
   constexpr int NST = (STEPS + SS - 1) / SS;  // stages per channel group
   constexpr int MW = MT / WM, MI = MW / 32;
   constexpr int NW = NI * 32, NT = WN * NW;
-  static_assert(WM * WN == 8, "8 waves per work-group");
-  static_assert(MW % 32 == 0, "wave tile rows must be a multiple of 32");
-  constexpr int ASTAGE = SS * 4 * MT;  // 16-byte units per weight stage
+  constexpr int NTHR = 64 * WM * WN;
+  static_assert(MW % 32 == 0 && MTP % MT == 0, "wave tile rows must be a multiple of 32");
+  constexpr int ASTAGE = SS * 4 * MT;    // 16-byte units per weight stage in LDS (this group's rows only)
+  constexpr int ASTAGE_G = SS * 4 * MTP;  // ... and in the packed global layout
   constexpr int NAPF = (ASTAGE + NTHR - 1) / NTHR;
-  constexpr int NBPF = 4;  // 16-byte units per thread for the input slab (2*SLAB <= 2048 units)
+  constexpr int NBPF = 2048 / NTHR;  // 16-byte units per thread for the input slab (2*SLAB <= 2048 units)
 
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
   const int Ws = W + OS2D_PAD;
@@ -64,6 +66,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_f16x3_kernel(const u32x4* in,  /
   const int wm = wid / WN, wn = wid % WN;
   const int nb = blockIdx.y;
   const int n0 = BASE + blockIdx.x * NT;
+  const int mOff = blockIdx.z * MT;  // first output row of this group
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -81,11 +84,15 @@ __global__ __launch_bounds__(NTHR, 2) void conv_f16x3_kernel(const u32x4* in,  /
   const int bCross = bLane + hw * (Ws - (KS - 1));
 
   u32x4 pfA[NAPF], pfB[NBPF];
+  half8 fah[2][MI], fal[2][MI], fbh[2][NI], fbl[2][NI];  // double-buffered MFMA fragments
 
 #define F16_LOAD_A(S)                                                                                             \
   {                                                                                                               \
-    const u32x4* src_ = wp + (size_t)(S)*ASTAGE;                                                                  \
-    _Pragma("unroll") for (int k = 0; k < NAPF; ++k) pfA[k] = src_[min(tid + k * NTHR, ASTAGE - 1)];              \
+    const u32x4* src_ = wp + (size_t)(S)*ASTAGE_G + mOff;                                                         \
+    _Pragma("unroll") for (int k = 0; k < NAPF; ++k) {                                                            \
+      const int i_ = min(tid + k * NTHR, ASTAGE - 1);                                                             \
+      pfA[k] = src_[(i_ / MT) * MTP + (i_ % MT)];                                                                 \
+    }                                                                                                             \
   }
 #define F16_STORE_A(S)                                                                                            \
   {                                                                                                               \
@@ -117,30 +124,52 @@ __global__ __launch_bounds__(NTHR, 2) void conv_f16x3_kernel(const u32x4* in,  /
     }                                                                                                             \
   }
   // MFMAs of stage ST (compile-time) of the current group from weight buffer BUF (runtime 0/1)
+  // Fragment reads of k-step P (compile-time, within stage ST) into register set SET
+#define F16_FRAGS(ST, BUF, P, SET)                                                                                \
+  {                                                                                                               \
+    const int ps_ = (ST)*SS + (P);                                                                                \
+    const int t0_ = 2 * ps_, t1_ = (2 * ps_ + 1 < TAPS) ? 2 * ps_ + 1 : 2 * ps_;                                  \
+    const int dy0_ = t0_ / KS, dx0_ = t0_ % KS, dy1_ = t1_ / KS;                                                  \
+    const int bsel_ = (t1_ == t0_) ? bLane : (dy1_ == dy0_ ? bSame : bCross);                                     \
+    const u32x4* bS_ = ldsB + bsel_ + dy0_ * Ws + dx0_;                                                           \
+    const u32x4* aS_ = ldsA + (BUF)*ASTAGE + aLane + (((P)*2 + hw) * 2) * MT;                                     \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                           \
+      fah[SET][mi] = *reinterpret_cast<const half8*>(aS_ + mi * 32);                                              \
+      fal[SET][mi] = *reinterpret_cast<const half8*>(aS_ + MT + mi * 32);                                         \
+    }                                                                                                             \
+    _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                                           \
+      fbh[SET][ni] = *reinterpret_cast<const half8*>(bS_ + ni * 32);                                              \
+      fbl[SET][ni] = *reinterpret_cast<const half8*>(bS_ + SLAB + ni * 32);                                       \
+    }                                                                                                             \
+  }
+  // three passes over the MI x NI blocks: consecutive MFMAs never touch the same accumulator
+#define F16_MFMAS(SET)                                                                                            \
+  {                                                                                                               \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                             \
+      _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                           \
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[SET][mi], fbh[SET][ni], acc[mi][ni], 0, 0, 0);   \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                             \
+      _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                           \
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[SET][mi], fbl[SET][ni], acc[mi][ni], 0, 0, 0);   \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                             \
+      _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                           \
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[SET][mi], fbh[SET][ni], acc[mi][ni], 0, 0, 0);   \
+  }
+  // MFMAs of stage ST (compile-time) of the current group from weight buffer BUF (runtime 0/1); the LDS fragment
+  // reads of k-step p+1 are issued BEFORE the 3*MI*NI MFMAs of k-step p (two register sets), and the scheduler is
+  // pinned to that order: a wave then waits for LDS only once per stage instead of once per k-step.
 #define F16_COMPUTE(ST, BUF)                                                                                      \
   {                                                                                                               \
-    const u32x4* aS_ = ldsA + (BUF)*ASTAGE + aLane;                                                               \
+    const int nsteps_ = (STEPS - (ST)*SS) < SS ? (STEPS - (ST)*SS) : SS; /* folds: ST is an unrolled index */     \
+    F16_FRAGS(ST, BUF, 0, 0)                                                                                      \
     _Pragma("unroll") for (int p = 0; p < SS; ++p) {                                                              \
-      const int ps_ = (ST)*SS + p; /* k-step inside the group */                                                  \
-      if (ps_ < STEPS) {                                                                                          \
-        const int t0_ = 2 * ps_, t1_ = (2 * ps_ + 1 < TAPS) ? 2 * ps_ + 1 : 2 * ps_;                              \
-        const int dy0_ = t0_ / KS, dx0_ = t0_ % KS, dy1_ = t1_ / KS;                                              \
-        const int bsel_ = (t1_ == t0_) ? bLane : (dy1_ == dy0_ ? bSame : bCross);                                 \
-        const u32x4* bS_ = ldsB + bsel_ + dy0_ * Ws + dx0_;                                                       \
-        half8 ah_[MI], al_[MI];                                                                                   \
-        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                       \
-          ah_[mi] = *reinterpret_cast<const half8*>(aS_ + ((p * 2 + hw) * 2 + 0) * MT + mi * 32);                 \
-          al_[mi] = *reinterpret_cast<const half8*>(aS_ + ((p * 2 + hw) * 2 + 1) * MT + mi * 32);                 \
+      if (p < nsteps_) {                                                                                          \
+        if (p + 1 < nsteps_) {                                                                                    \
+          F16_FRAGS(ST, BUF, p + 1, (p + 1) & 1)                                                                  \
+          __builtin_amdgcn_sched_barrier(0);                                                                      \
         }                                                                                                         \
-        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                                       \
-          const half8 bh_ = *reinterpret_cast<const half8*>(bS_ + ni * 32);                                       \
-          const half8 bl_ = *reinterpret_cast<const half8*>(bS_ + SLAB + ni * 32);                                \
-          _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                     \
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al_[mi], bh_, acc[mi][ni], 0, 0, 0);             \
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_[mi], bl_, acc[mi][ni], 0, 0, 0);             \
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_[mi], bh_, acc[mi][ni], 0, 0, 0);             \
-          }                                                                                                       \
-        }                                                                                                         \
+        F16_MFMAS(p & 1)                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
       }                                                                                                           \
     }                                                                                                             \
   }
@@ -178,6 +207,8 @@ __global__ __launch_bounds__(NTHR, 2) void conv_f16x3_kernel(const u32x4* in,  /
 #undef F16_LOAD_B
 #undef F16_STORE_B
 #undef F16_COMPUTE
+#undef F16_FRAGS
+#undef F16_MFMAS
 
   // ---- epilogue: undo the weight scale, bias (+ReLU); pad cells are written as exact zeros
 #pragma unroll
@@ -191,7 +222,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_f16x3_kernel(const u32x4* in,  /
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int m0 = wm * MW + mi * 32 + 8 * q + 4 * hw;  // this lane holds rows m0 .. m0+3 (regs 4q .. 4q+3)
+        const int m0 = mOff + wm * MW + mi * 32 + 8 * q + 4 * hw;  // this lane holds rows m0..m0+3 (regs 4q..4q+3)
         float v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -215,11 +246,16 @@ __global__ __launch_bounds__(NTHR, 2) void conv_f16x3_kernel(const u32x4* in,  /
           char* o = reinterpret_cast<char*>(outv) + (((size_t)nb * Gout + grp) * 2 * PLANE + n) * 16 + hw * 8;
           *reinterpret_cast<half4*>(o) = hi4;
           *reinterpret_cast<half4*>(o + (size_t)PLANE * 16) = lo4;
-        } else {
+        } else if (OUT_MODE == 1) {
           float* o = reinterpret_cast<float*>(outv);
 #pragma unroll
           for (int k = 0; k < 4; ++k)
             if (m0 + k < CoutStore) o[((size_t)nb * CoutStore + m0 + k) * PLANE + n] = v[k];
+        } else {
+          float* o = reinterpret_cast<float*>(outv);
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (valid && m0 + k < CoutStore) o[((size_t)nb * CoutStore + m0 + k) * (H * W) + hr * W + wc] = v[k];
         }
       }
     }
@@ -227,7 +263,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_f16x3_kernel(const u32x4* in,  /
   // pad rows above the data (first tile) and whatever lies beyond the last tile
   {
     const int tail0 = BASE + gridDim.x * NT, tail = PLANE - tail0;
-    const bool first = blockIdx.x == 0, last = blockIdx.x == gridDim.x - 1;
+    const bool first = blockIdx.x == 0 && blockIdx.z == 0, last = blockIdx.x == gridDim.x - 1 && blockIdx.z == 0;
     if (OUT_MODE == 0) {
       const int planes = ((CoutStore + 7) >> 3) * 2;
       u32x4* o = reinterpret_cast<u32x4*>(outv) + (size_t)nb * planes * PLANE;
@@ -236,7 +272,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_f16x3_kernel(const u32x4* in,  /
       if (last && tail > 0)
         for (int i = tid; i < planes * tail; i += NTHR)
           o[(size_t)(i / tail) * PLANE + tail0 + i % tail] = U32X4_ZERO;
-    } else {
+    } else if (OUT_MODE == 1) {
       float* o = reinterpret_cast<float*>(outv) + (size_t)nb * CoutStore * PLANE;
       if (first)
         for (int i = tid; i < CoutStore * BASE; i += NTHR) o[(size_t)(i / BASE) * PLANE + i % BASE] = 0.f;
@@ -246,7 +282,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_f16x3_kernel(const u32x4* in,  /
   }
 }
 
-template <int KS, int MT, int WM, int WN, int NI, int SS, bool RELU, int OUT_MODE>
+template <int KS, int MTP, int MT, int WM, int WN, int NI, int SS, bool RELU, int OUT_MODE>
 int launch(const void* in, const void* wp, const float* bp, float unscale, void* out, int NB, int G, int CoutStore,
            int H, int W, hipStream_t stream) {
   constexpr int R = KS / 2;
@@ -254,7 +290,8 @@ int launch(const void* in, const void* wp, const float* bp, float unscale, void*
   const int Ws = os2d_ws(W), PLANE = os2d_plane(H, W);
   const int HALO = R * Ws + R;
   const int SLAB = NT + 2 * HALO;
-  if (2 * SLAB > 4 * NTHR) {
+  constexpr int NTHR = 64 * WM * WN;
+  if (2 * SLAB > 2048) {
     os2d_set_error("conv%dx%d (f16x3): feature map too wide for the input-slab prefetch (W=%d)", KS, KS, W);
     return -3;
   }
@@ -263,14 +300,14 @@ int launch(const void* in, const void* wp, const float* bp, float unscale, void*
     os2d_set_error("conv%dx%d (f16x3): LDS budget exceeded (%zu B, W=%d)", KS, KS, lds, W);
     return -3;
   }
-  auto kern = conv_f16x3_kernel<KS, MT, WM, WN, NI, SS, RELU, OUT_MODE>;
+  auto kern = conv_f16x3_kernel<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) {
     os2d_set_error("hipFuncSetAttribute(conv f16x3): %s", hipGetErrorString(e));
     return -4;
   }
-  dim3 grid((H * Ws + NT - 1) / NT, NB);
+  dim3 grid((H * Ws + NT - 1) / NT, NB, MTP / MT);
   hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds, stream, reinterpret_cast<const u32x4*>(in),
                      reinterpret_cast<const u32x4*>(wp), bp, unscale, out, G, CoutStore, H, W, PLANE, HALO);
   e = hipGetLastError();
@@ -283,13 +320,14 @@ int launch(const void* in, const void* wp, const float* bp, float unscale, void*
 
 }  // namespace
 
-// layer 1: 7x7, 29 input groups (225 ch), 128 out, SHB out;  layer 2: 5x5, 16 groups, 64 out, fp32 plane out
-// (conv3 stays on the fp32 kernel: 0.5 % of the FLOPs).
+// layer 1: 7x7, 29 input groups (225 ch), 128 out, SHB out;  layer 2: 5x5, 16 groups, 64 out, SHB out;
+// layer 3: 5x5, 8 groups, P out (rows padded to 32), compact fp32 [NB][P][H*W] out.
 int os2d_launch_conv_f16x3(int layer, const void* in, const void* wp, const float* bp, float unscale, void* out, int NB,
-                           int H, int W, hipStream_t stream) {
+                           int P, int H, int W, hipStream_t stream) {
   switch (layer) {
-    case 1: return launch<7, 128, 2, 4, 2, 5, true, 0>(in, wp, bp, unscale, out, NB, 29, 128, H, W, stream);
-    case 2: return launch<5, 64, 2, 4, 2, 7, true, 1>(in, wp, bp, unscale, out, NB, 16, 64, H, W, stream);
+    case 1: return launch<7, 128, 64, 1, 4, 2, 5, true, 0>(in, wp, bp, unscale, out, NB, 29, 128, H, W, stream);
+    case 2: return launch<5, 64, 64, 1, 4, 2, 7, true, 0>(in, wp, bp, unscale, out, NB, 16, 64, H, W, stream);
+    case 3: return launch<5, 32, 32, 1, 4, 2, 7, false, 2>(in, wp, bp, unscale, out, NB, 8, P, H, W, stream);
     default: os2d_set_error("os2d_launch_conv_f16x3: bad layer %d", layer); return -1;
   }
 }

@@ -135,9 +135,9 @@ class TransformationNet(nn.Module):
         return tuple((t.data_ptr(), t._version, str(t.device)) for t in ts)
 
     def packed(self, precision=None):
-        """Packed TransformNet for the kernels: (w1, b1, w2, b2, w3, b3, scale1_log2, scale2_log2).
-        precision "f32": os2d_pack_conv layouts (scales are 0); "f16x3": layers 1-2 in the split-half layout of
-        os2d_pack_conv_f16x3, pre-scaled by the largest power of two that keeps max|w| <= 16384."""
+        """Packed TransformNet for the kernels: (w1, b1, w2, b2, w3, b3, scale_log2[3]).
+        precision "f32": os2d_pack_conv layouts (scales are 0); "f16x3": the split-half layout of
+        os2d_pack_conv_f16x3, each layer pre-scaled by the largest power of two that keeps max|w| <= 16384."""
         precision = resolve_precision(precision)
         key = (precision,) + self._state_key()
         cached = self._packed_cache.get(precision)
@@ -164,12 +164,15 @@ class TransformationNet(nn.Module):
                 eps = float(bn.eps)
             else:
                 bnp, eps = [None] * 4, 0.0
-            if precision == "f16x3" and layer in (1, 2):
-                folded_max = float((w.abs().amax(dim=(1, 2, 3)) * (bnp[0] / torch.sqrt(bnp[3] + eps)).abs()).max())
+            if precision == "f16x3":
+                wmax = w.abs().amax(dim=(1, 2, 3))
+                if bn is not None:
+                    wmax = wmax * (bnp[0] / torch.sqrt(bnp[3] + eps)).abs()
+                folded_max = float(wmax.max())
                 scale_log2 = int(math.floor(math.log2(16384.0 / folded_max))) if folded_max > 0 else 0
                 scale_log2 = max(-60, min(60, scale_log2))
                 pw = torch.empty(lib.os2d_packed_conv_bytes(layer, PRECISIONS[precision]), dtype=torch.uint8, device=dev)
-                _lib.check(lib.os2d_pack_conv_f16x3(layer, _lib.ptr(w), _lib.ptr(b), *[_lib.ptr(t) for t in bnp],
+                _lib.check(lib.os2d_pack_conv_f16x3(layer, P, _lib.ptr(w), _lib.ptr(b), *[_lib.ptr(t) for t in bnp],
                                                     ctypes.c_float(eps), scale_log2, _lib.ptr(pw), _lib.ptr(pb), stream),
                            "os2d_pack_conv_f16x3")
                 scales.append(scale_log2)
@@ -177,10 +180,9 @@ class TransformationNet(nn.Module):
                 pw = torch.empty(lib.os2d_packed_conv_floats(layer), dtype=torch.float32, device=dev)
                 _lib.check(lib.os2d_pack_conv(layer, P, _lib.ptr(w), _lib.ptr(b), *[_lib.ptr(t) for t in bnp],
                                               ctypes.c_float(eps), _lib.ptr(pw), _lib.ptr(pb), stream), "os2d_pack_conv")
-                if layer in (1, 2):
-                    scales.append(0)
+                scales.append(0)
             out += [pw, pb]
-        result = tuple(out) + tuple(scales)
+        result = tuple(out) + ((ctypes.c_int * 3)(*scales),)
         self._packed_cache[precision] = (key, result)
         return result
 
@@ -397,7 +399,7 @@ class Os2dHead(nn.Module):
         regressor = self.aligner.parameter_regressor
         P = regressor.output_dim
         precision = resolve_precision(precision or self.precision)
-        w1, b1, w2, b2, w3, b3, s1, s2 = regressor.packed(precision)
+        w1, b1, w2, b2, w3, b3, scales = regressor.packed(precision)
         if out is None:
             loc = torch.empty(A, B, 4, H, W, dtype=torch.float32, device=dev)
             cls = torch.empty(A, B, 1, H, W, dtype=torch.float32, device=dev)
@@ -417,7 +419,7 @@ class Os2dHead(nn.Module):
             _lib.ptr(w3), _lib.ptr(b3), A, B, C, H, W, P, 1 if self.aligner.use_inverse_geom_model else 0,
             self._stride, self._rec_field, _lib.ptr(loc), _lib.ptr(cls), _lib.ptr(corners),
             _lib.ptr(ws), ws.numel(), _lib.current_stream(dev), PRECISIONS[precision],
-            _lib.ptr(self._split_class_operand()) if precision == "f16x3" else None, s1, s2, stage_events, None),
+            _lib.ptr(self._split_class_operand()) if precision == "f16x3" else None, scales, stage_events, None),
             "os2d_head_forward_ex")
         return loc, cls, cls, corners
 

@@ -1,19 +1,29 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X OS2D head: query-image-pairs/s (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--classes B_per_gpu] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--classes B_per_gpu] [--precision f16x3|f32] [--pyramid]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 One "step" = the whole head (correlation -> TransformNet -> resample/pool -> box encode) for ONE 1280x960 image
 feature map [1,1024,60,80] against B classes per GPU (default 64 = BASELINE.json configs[1]); with N GPUs the classes
-are sharded (weak scaling: N*B classes in total) and every step ends with the RCCL all-gather of the per-class
-output maps, exactly as ``os2d_amd.parallel.ClassShardedHead`` does it.  Inputs are synthetic (post-ReLU Gaussian
-features, perturbed TransformNet) and resident in HBM before the timed region.
+are sharded (weak scaling: N*B classes in total) and every step ends with the RCCL all-gather of the per-class SCORE
+maps (north_star: "all-gather ... of per-class score maps before NMS"), as ``os2d_amd.parallel.ClassShardedHead``
+does it.  Inputs are synthetic (post-ReLU Gaussian features, perturbed TransformNet) and resident
+in HBM before the timed region.
+
+Arithmetic (``--precision``):
+  f16x3 (default)  every fp32 operand of the four GEMM-shaped stages is split into fp16 hi + lo and each product is
+                   evaluated with three v_mfma_f32_32x32x16_f16 (fp32 accumulation): outputs agree with the reference
+                   to the same 2.4e-7 as the fp32 mode (tests/test_head_gpu.py runs every parity case in both modes);
+  f32              v_mfma_f32_32x32x2_f32, exact fp32.
+The primary line is measured in the selected mode; the other mode is timed right after and reported under
+"other_precision" so both are always on record.
 
 Prints ONE JSON line on rank 0 with the driver's contract fields plus
-  roofline     - the dominant kernel (conv 7x7 225->128 MFMA implicit GEMM): algorithmic FLOPs per launch divided by its
-                 mean launch duration, measured with HIP events recorded on the launch stream inside the timed steps
+  roofline     - the dominant kernel (conv 7x7 225->128 MFMA implicit GEMM): ALGORITHMIC FLOPs per launch divided by its
+                 mean launch duration, measured with HIP events recorded on the launch stream inside the timed steps,
+                 against the dense MFMA peak of the instruction it runs on
   stages_ms    - mean duration of every stage of the step (same events)
   cpu_baseline - the oracle (torch-CPU restatement of the reference head, driven one class at a time like the
                  reference's evaluation) timed on the host cores, rank 0 / N=1 only, on a bounded class sample.
@@ -32,7 +42,7 @@ sys.path.insert(0, REPO)
 
 C_FEAT, H_FM, W_FM = 1024, 60, 80          # ResNet50-C4 features of a 1280x960 input
 FLOP_PER_LOC = {"corr": 2 * 225 * 1024, "conv1": 2 * 128 * 225 * 49, "conv2": 2 * 64 * 128 * 25}
-PEAK_F32_MFMA = 157.3e12                   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+PEAK = {"f32": 157.3e12, "f16x3": 2.5e15}  # dense MFMA peaks (MI355X_MICROARCH.md): fp32-input MFMA; fp16/bf16 MFMA
 STAGES = ("corr", "conv1", "conv2", "conv3", "sample")
 
 
@@ -43,12 +53,13 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--classes", type=int, default=64, help="classes per GPU")
     ap.add_argument("--variant", default="v2", choices=["v2", "v1"], help="v2: affine+inverse (P=6); v1: simplified (P=4)")
+    ap.add_argument("--precision", default=os.environ.get("OS2D_PRECISION", "f16x3"), choices=["f32", "f16x3"])
     ap.add_argument("--pyramid", action="store_true",
                     help="BASELINE configs[4]: 7-scale pyramid (0.5-1.6) of the 1280x960 image, one HIP stream per level; "
                          "a pair then means one (image, class) over all 7 levels")
-    ap.add_argument("--precision", default=os.environ.get("OS2D_PRECISION", "f32"), choices=["f32", "f16x3"],
-                    help="arithmetic of the two large TransformNet convolutions (DESIGN.md section 4)")
+    ap.add_argument("--gather", default="scores", choices=["scores", "all"], help="what the N>1 all-gather moves")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-precision", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -73,11 +84,11 @@ def cpu_baseline(fm_cpu, class_fms_cpu, state, inverse, budget_s):
                       "60x80x1024 feature map, {:.1f} s, torch CPU fp32, {} threads of {} hw threads".format(done, dt, threads, ncores)}
 
 
-def measured_traffic(B):
-    """HBM bytes per conv1 launch from the committed rocprofv3 PMC passes (profiles/conv1_traffic.json, written by
-    tools/summarize_prof.py --traffic: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate passes),
-    scaled to the class count of this run; None if no profile has been recorded."""
-    path = os.path.join(REPO, "profiles", "conv1_traffic.json")
+def measured_traffic(B, precision):
+    """HBM bytes per conv1 launch from the committed rocprofv3 PMC passes (profiles/conv1_traffic_<precision>.json,
+    written by tools/summarize_prof.py --traffic: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate
+    passes), scaled to the class count of this run; None if no profile has been recorded."""
+    path = os.path.join(REPO, "profiles", "conv1_traffic_{}.json".format(precision))
     if not os.path.exists(path):
         return None
     with open(path) as f:
@@ -122,10 +133,8 @@ def main():
     fm = fm_cpu.to(dev)
     with torch.no_grad():
         head = creator.create_os2d_head([c.to(dev) for c in class_fms_cpu])
-    head.precision = args.precision
-    sharded = ClassShardedHead(creator, group=None, num_classes=B * world, local_head=head) if world > 1 else None
+    sharded = ClassShardedHead(creator, group=None, gather=args.gather, num_classes=B * world, local_head=head) if world > 1 else None
 
-    # one set of 10 stage events per timed step, so nothing has to be read back inside the timed region
     def new_event_set():
         arr = (ctypes.c_void_p * 10)()
         for i in range(10):
@@ -134,8 +143,6 @@ def main():
             arr[i] = ev.value
         return arr
 
-    event_sets = [new_event_set() for _ in range(args.steps)] if (sharded is None and not args.pyramid) else []
-
     runner, level_fms = None, None
     if args.pyramid:
         from os2d_amd.engine.pyramid import PyramidHeadRunner
@@ -143,74 +150,109 @@ def main():
         level_fms = [synthetic.make_feature_map(C_FEAT, h, w, seed=100 + i).to(dev) for i, (h, w) in enumerate(level_hw)]
         runner = PyramidHeadRunner(sharded if sharded is not None else head, device=dev)
 
-    def step(events):
-        with torch.no_grad():
-            if runner is not None:
-                return runner.run(level_fms, inputs_are_features=True)
-            if sharded is not None:
-                return sharded(fm)
-            return head(fm, stage_events=events)
-
     def sync_all():
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step(None)
-    sync_all()
-    # ---- timed region: exactly K steps; stage events are recorded on the launch stream inside these steps
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(event_sets[i] if event_sets else None)
-    sync_all()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def run_mode(precision, steps, warmup):
+        """W warm-up + exactly K timed steps in one arithmetic mode; returns (seconds, per-stage mean ms or None)."""
+        head.precision = precision
+        # one set of 10 stage events per timed step, so nothing has to be read back inside the timed region
+        event_sets = [new_event_set() for _ in range(steps)] if (sharded is None and runner is None) else []
 
-    total_pairs = B * world * args.steps
+        def step(events):
+            with torch.no_grad():
+                if runner is not None:
+                    return runner.run(level_fms, inputs_are_features=True)
+                if sharded is not None:
+                    return sharded(fm)
+                return head(fm, stage_events=events)
+
+        for _ in range(warmup):
+            step(None)
+        sync_all()
+        # ---- timed region: exactly K steps; stage events are recorded on the launch stream inside these steps
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(event_sets[i] if event_sets else None)
+        sync_all()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        stage_ms = None
+        if event_sets:
+            ms = ctypes.c_float()
+            rows = []
+            for evs in event_sets:
+                row = []
+                for st in range(5):
+                    _lib.check(lib.os2d_prof_event_elapsed_ms(evs[2 * st], evs[2 * st + 1], ctypes.byref(ms)), "elapsed")
+                    row.append(ms.value)
+                rows.append(row)
+                for ev in evs:
+                    lib.os2d_prof_event_destroy(ev)
+            stage_ms = [sum(r[st] for r in rows) / len(rows) for st in range(5)]
+        return dt, stage_ms
+
+    def roofline(precision, stage_ms):
+        flops = FLOP_PER_LOC["conv1"] * H_FM * W_FM * B            # algorithmic FLOPs of ONE conv1 launch
+        achieved = flops / (stage_ms[1] * 1e-3)
+        peak = PEAK[precision]
+        r = {"kernel": "TransformNet conv 7x7 225->128 ({})".format(
+                 "conv_mfma_kernel<7,...>, v_mfma_f32_32x32x2_f32" if precision == "f32"
+                 else "conv_f16x3_kernel<7,...>, v_mfma_f32_32x32x16_f16 x3 per product"),
+             "bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": peak / 1e12, "unit": "TFLOP/s",
+             "frac": round(achieved / peak, 4), "traffic": measured_traffic(B, precision),
+             "flops_per_launch": flops, "avg_launch_ms": round(stage_ms[1], 4)}
+        if precision == "f16x3":
+            # every algorithmic product costs three half-precision MFMA products: the ceiling for algorithmic FLOP/s on
+            # this instruction is peak/3; the executed rate also includes the tile / channel-group padding (x1.118)
+            r["algorithmic_ceiling"] = round(peak / 3 / 1e12, 1)
+            r["frac_of_algorithmic_ceiling"] = round(achieved / (peak / 3), 4)
+            r["executed_mfma_tflops"] = round(3 * achieved * 1.118 / 1e12, 1)
+            r["executed_frac_of_peak"] = round(3 * achieved * 1.118 / peak, 4)
+        return r
+
+    whole = (FLOP_PER_LOC["corr"] + FLOP_PER_LOC["conv1"] + FLOP_PER_LOC["conv2"] + 2 * P * 64 * 25) * H_FM * W_FM
+    pairs_per_step = B * world
+    dt, stage_ms = run_mode(args.precision, args.steps, args.warmup)
+    value = pairs_per_step * args.steps / dt
+    dtype = {"f32": "f32", "f16x3": "f16x3 (fp32 operands split into fp16 hi+lo, 3 half MFMAs per product, fp32 accumulate)"}
     result = {
         "metric": "query-image-pairs/s (1280-px input, ResNet50, N-class)",
-        "value": round(total_pairs / dt, 2),
+        "value": round(value, 2),
         "unit": "query-image-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "f32" else "f32 operands as fp16 hi+lo (3 half MFMAs per product, fp32 accumulate)",
-        "data": "synthetic",
+        "dtype": dtype[args.precision], "data": "synthetic",
         "config": {"workload": "OS2D head, ResNet50-C4 features of one 1280x960 image ({}), {} classes per GPU "
                                "({} total), {}, {} (P={}, inverse={}), head only, features resident in HBM"
                                .format("7-level pyramid 30x40..96x128, 39580 locations" if args.pyramid else "1x1024x60x80",
                                        B, B * world, "7 scales 0.5-1.6, one HIP stream per level" if args.pyramid else "single scale",
                                        args.variant.upper(), P, int(inverse)),
                    "classes_per_gpu": B, "classes_total": B * world, "feature_map": [C_FEAT, H_FM, W_FM],
-                   "parallelism": "class-sharded x{} + all-gather".format(world) if world > 1 else "single GPU"},
+                   "precision": args.precision,
+                   "parallelism": "class-sharded x{} + all-gather of {}".format(world, "score maps" if args.gather == "scores" else "loc|cls|corners")
+                                  if world > 1 else "single GPU"},
     }
-    per_step_stage = []
-    ms = ctypes.c_float()
-    for evs in event_sets:
-        row = []
-        for st in range(5):
-            _lib.check(lib.os2d_prof_event_elapsed_ms(evs[2 * st], evs[2 * st + 1], ctypes.byref(ms)), "elapsed")
-            row.append(ms.value)
-        per_step_stage.append(row)
-    if per_step_stage:
-        n = len(per_step_stage)
-        stage_ms = [sum(r[st] for r in per_step_stage) / n for st in range(5)]
+    if stage_ms:
         result["stages_ms"] = {k: round(v, 4) for k, v in zip(STAGES, stage_ms)}
-        flops = FLOP_PER_LOC["conv1"] * H_FM * W_FM * B            # algorithmic FLOPs of ONE conv1 launch
-        achieved = flops / (stage_ms[1] * 1e-3)
-        result["roofline"] = {"kernel": "conv_mfma_kernel<7,128,...> (TransformNet conv 7x7 225->128)",
-                              "bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": PEAK_F32_MFMA / 1e12,
-                              "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA, 4),
-                              "traffic": measured_traffic(B),
-                              "flops_per_launch": flops, "avg_launch_ms": round(stage_ms[1], 4)}
-        whole = (FLOP_PER_LOC["corr"] + FLOP_PER_LOC["conv1"] + FLOP_PER_LOC["conv2"] + 2 * P * 64 * 25) * H_FM * W_FM
-        result["head_tflops"] = round(whole * result["value"] / 1e12, 3)
-        result["head_frac_of_f32_mfma_peak"] = round(whole * result["value"] / PEAK_F32_MFMA, 4)
+        result["roofline"] = roofline(args.precision, stage_ms)
+    if not args.pyramid:
+        result["head_tflops_algorithmic"] = round(whole * value / 1e12, 3)
+    if not args.no_other_precision:
+        other = "f32" if args.precision == "f16x3" else "f16x3"
+        dt2, stage2 = run_mode(other, args.steps, 1)
+        o = {"precision": other, "value": round(pairs_per_step * args.steps / dt2, 2), "ms_per_step": round(dt2 / args.steps * 1e3, 4)}
+        if stage2:
+            o["stages_ms"] = {k: round(v, 4) for k, v in zip(STAGES, stage2)}
+            o["roofline"] = roofline(other, stage2)
+        result["other_precision"] = o
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.pyramid:
         result["cpu_baseline"] = cpu_baseline(fm_cpu, class_fms_cpu, state, inverse, args.cpu_seconds)
         result["speedup_vs_cpu_baseline"] = round(result["value"] / result["cpu_baseline"]["value"], 1)

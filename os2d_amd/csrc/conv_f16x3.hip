@@ -228,6 +228,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_f16x3_kernel(const u32x4
         for (int k = 0; k < 4; ++k) {
           float t = acc[mi][ni][4 * q + k] * unscale + bp[m0 + k];
           if (RELU) t = fmaxf(t, 0.f);
+          if (OUT_MODE == 0) t = fminf(fmaxf(t, -65504.f), 65504.f);  // fp16 range of the split output (never hit in practice)
           v[k] = (valid && m0 + k < CoutStore) ? t : 0.f;
         }
         if (OUT_MODE == 0) {

@@ -34,7 +34,8 @@ __device__ __forceinline__ void split_half(float x, _Float16& hi, _Float16& lo) 
 // MTP = output rows of the packed weights (all output channels, padded), MT = rows handled by ONE work-group
 // (blockIdx.z selects the slice): splitting the output channels over two independent 4-wave groups per CU lets one
 // group's barrier / staging bubble be filled by the other's MFMAs.
-template <int KS, int MTP, int MT, int WM, int WN, int NI, int SS, bool RELU, int OUT_MODE /*0 SHB, 1 fp32 plane, 2 fp32 compact [NB][Cout][H*W]*/>
+template <int KS, int MTP, int MT, int WM, int WN, int NI, int SS, bool RELU, int OUT_MODE /*0 SHB, 1 fp32 plane, 2 fp32 compact [NB][Cout][H*W]*/,
+          int NBPF /*16-byte units per thread for the input-slab prefetch*/>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_f16x3_kernel(const u32x4* in,  // SHB [NB][G][2][PLANE] (no __restrict__: invariant loads get
                                                              const u32x4* wp,  // rematerialised BEHIND the MFMAs by the register allocator)
                                                              const float* __restrict__ bp,  // [MT] fp32 folded bias
@@ -51,7 +52,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_f16x3_kernel(const u32x4
   constexpr int ASTAGE = SS * 4 * MT;    // 16-byte units per weight stage in LDS (this group's rows only)
   constexpr int ASTAGE_G = SS * 4 * MTP;  // ... and in the packed global layout
   constexpr int NAPF = (ASTAGE + NTHR - 1) / NTHR;
-  constexpr int NBPF = 2048 / NTHR;  // 16-byte units per thread for the input slab (2*SLAB <= 2048 units)
 
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
   const int Ws = W + OS2D_PAD;
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_f16x3_kernel(const u32x4
   }
 }
 
-template <int KS, int MTP, int MT, int WM, int WN, int NI, int SS, bool RELU, int OUT_MODE>
+template <int KS, int MTP, int MT, int WM, int WN, int NI, int SS, bool RELU, int OUT_MODE, int NBPF = 0>
 int launch(const void* in, const void* wp, const float* bp, float unscale, void* out, int NB, int G, int CoutStore,
            int H, int W, hipStream_t stream) {
   constexpr int R = KS / 2;
@@ -292,7 +292,9 @@ int launch(const void* in, const void* wp, const float* bp, float unscale, void*
   const int HALO = R * Ws + R;
   const int SLAB = NT + 2 * HALO;
   constexpr int NTHR = 64 * WM * WN;
-  if (2 * SLAB > 2048) {
+  if (NBPF == 0) {  // pick the slab-prefetch depth: 8 units/thread up to W = 124 (fewer registers), 12 up to W = 209
+    if (2 * SLAB <= 8 * NTHR) return launch<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE, 8>(in, wp, bp, unscale, out, NB, G, CoutStore, H, W, stream);
+    if (2 * SLAB <= 12 * NTHR) return launch<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE, 12>(in, wp, bp, unscale, out, NB, G, CoutStore, H, W, stream);
     os2d_set_error("conv%dx%d (f16x3): feature map too wide for the input-slab prefetch (W=%d)", KS, KS, W);
     return -3;
   }
@@ -301,7 +303,7 @@ int launch(const void* in, const void* wp, const float* bp, float unscale, void*
     os2d_set_error("conv%dx%d (f16x3): LDS budget exceeded (%zu B, W=%d)", KS, KS, lds, W);
     return -3;
   }
-  auto kern = conv_f16x3_kernel<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE>;
+  auto kern = conv_f16x3_kernel<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE, (NBPF ? NBPF : 8)>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) {

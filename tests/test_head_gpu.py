@@ -112,3 +112,41 @@ def test_cpu_tensors_fail_loudly(device):
     head = creator.create_os2d_head([c.to(device) for c in fx["class_fms"]])
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         head(fx["fm"])                                      # CPU feature map
+
+
+def test_singular_transform_is_regularised_locally(device):
+    """use_inverse_geom_model with an exactly singular matrix at ONE location: torch.inverse raises and the reference
+    retries the whole 65535-matrix chunk with +1e-5 on the diagonal (head.py:125-134); we regularise only the singular
+    matrix.  All other locations must be untouched and the singular one finite and equal to the
+    regularised closed form."""
+    import ctypes
+    from os2d_amd import _lib
+    lib = _lib.load()
+    H, W, P = 5, 6, 6
+    HW = H * W
+    g = torch.Generator().manual_seed(1)
+    corr = torch.rand(1, 225, HW, generator=g)
+    params = torch.zeros(1, P, HW)
+    params[0, 0], params[0, 4] = 1.0, 1.0                      # identity everywhere
+    params[0, :, 7] = torch.tensor([2.0, 4.0, 0.3, 1.0, 2.0, -0.2])   # det = 2*2 - 4*1 = 0 at location 7
+    outs = []
+    for p in (params, params.clone()):
+        loc = torch.empty(1, 4, HW, device=device)
+        cls = torch.empty(1, 1, HW, device=device)
+        corners = torch.empty(1, 8, HW, device=device)
+        _lib.check(lib.os2d_sample_decode(_lib.ptr(corr.to(device)), _lib.ptr(p.to(device)), 1, H, W, P, 1, 16, 16,
+                                          _lib.ptr(loc), _lib.ptr(cls), _lib.ptr(corners), _lib.current_stream(device)), "sample")
+        outs.append((loc.cpu(), cls.cpu(), corners.cpu()))
+        p[0, :, 7] = torch.tensor([1.0, 0.0, 0.0, 0.0, 1.0, 0.0])   # second run: identity there too
+    (loc_s, cls_s, cor_s), (loc_i, cls_i, cor_i) = outs
+    assert torch.isfinite(loc_s).all() and torch.isfinite(cls_s).all() and torch.isfinite(cor_s).all()
+    others = [i for i in range(HW) if i != 7]
+    assert torch.equal(loc_s[..., others], loc_i[..., others]) and torch.equal(cls_s[..., others], cls_i[..., others])
+    # regularised closed form at the singular location: inverse of [[a+e, b, tx],[c, d+e, ty],[0,0,1+e]]
+    e = 1e-5
+    M = torch.tensor([[2.0 + e, 4.0, 0.3], [1.0, 2.0 + e, -0.2], [0.0, 0.0, 1.0 + e]], dtype=torch.float64)
+    Minv = torch.inverse(M)[:2]
+    h, w = 7 // W, 7 % W
+    expect = [120 * float(Minv[0] @ torch.tensor([x, y, 1.0], dtype=torch.float64)) + 16 * (w + 0.5) for y in (-1, 1) for x in (-1, 1)]
+    got = cor_s[0, 0::2, 7].double().tolist()
+    assert max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(got, expect)) < 1e-3

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""GPU timing of the decode + NMS step that follows the head (Os2dBoxCoder.decode_pyramid) on head outputs."""
+import os, sys, time
+import torch
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, REPO)
+from os2d_amd.modeling.head import build_os2d_head_creator
+from os2d_amd.modeling.box_coder import Os2dBoxCoder
+from os2d_amd.structures.feature_map import FeatureMapSize
+from os2d_amd.utils import synthetic
+
+dev = torch.device("cuda:0")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+thr = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
+P, inverse = 6, True
+state = synthetic.make_transform_net_state(P, seed=1)
+creator = build_os2d_head_creator(False, False, inverse, FeatureMapSize(w=16, h=16), FeatureMapSize(w=16, h=16))
+creator.aligner.parameter_regressor.load_state_dict(state)
+creator.to(dev).eval()
+fm = synthetic.make_feature_map(1024, 60, 80, seed=0).to(dev)
+with torch.no_grad():
+    head = creator.create_os2d_head([c.to(dev) for c in synthetic.make_class_feature_maps(B, 1024, seed=1000)])
+    loc, cls, _, corners = head(fm)
+coder = Os2dBoxCoder(output_box_grid_generator=creator.box_grid_generator_image_level)
+img = FeatureMapSize(w=1280, h=960)
+loc_l, cls_l, cor_l = loc[0].reshape(B, 4, -1), cls[0].reshape(B, -1), corners[0].reshape(B, 8, -1)
+for it in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    res = coder.decode_pyramid([loc_l], [cls_l], [img], class_ids=list(range(B)), nms_score_threshold=thr,
+                               nms_iou_threshold=0.3, transform_corners_pyramid=[cor_l])
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print("decode_pyramid B={} thr={}: {:.2f} ms, {} detections".format(B, thr, dt * 1e3, len(res)))

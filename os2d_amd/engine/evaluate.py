@@ -1,0 +1,61 @@
+"""The caller of the hot path, rebuilt for the class-batched HIP head: what the reference's
+``make_iterator_extract_scores_from_images_batched`` (os2d/engine/evaluate.py:177-371) and the decode step of
+``evaluate`` (:99-117) do for one image, minus datasets / dataloaders / mAP (out of scope).
+
+    build_class_head   reference evaluate.py:232-274  one backbone pass per class image -> one class-batched head
+                       (same-size class images go through the backbone as ONE batch instead of one call each)
+    extract_scores     reference evaluate.py:306-361  per pyramid level: backbone + heads of all classes
+    detect             reference evaluate.py:99-117   + Os2dBoxCoder.decode_pyramid (decode, clip, NMS, merge levels)
+"""
+from collections import OrderedDict
+
+import torch
+
+from ..structures.feature_map import FeatureMapSize
+from .pyramid import PyramidHeadRunner
+
+
+def build_class_head(net, class_images, batch_same_size=True):
+    """class_images: list of [3,h,w] device tensors (already normalised).  Returns the ``Os2dHead`` of all classes in
+    the given order.  The reference extracts class features one image at a time (model.py:80-88); images of equal size
+    are stacked here so the backbone sees a few large batches (identical arithmetic per image)."""
+    feats = [None] * len(class_images)
+    with torch.no_grad():
+        if batch_same_size:
+            groups = OrderedDict()
+            for i, img in enumerate(class_images):
+                groups.setdefault(tuple(img.shape), []).append(i)
+            for idx in groups.values():
+                out = net.net_label_features.net_class_features(torch.stack([class_images[i] for i in idx], 0))
+                for k, i in enumerate(idx):
+                    feats[i] = out[k:k + 1]
+        else:
+            feats = net.net_label_features(class_images)
+        return net.os2d_head_creator.create_os2d_head(feats)
+
+
+def extract_scores(net, image_levels, class_head, per_level_streams=True):
+    """image_levels: list of [A,3,h_l,w_l] tensors (the image pyramid, reference dataloader.py:326-347).
+    Returns dict(loc, cls, corners, fm_sizes, img_sizes) with one entry per level, shaped like ``Os2dModel.forward``:
+    loc [A,B,4,HW], cls [A,B,HW], corners [A,B,8,HW]."""
+    runner = PyramidHeadRunner(class_head, features=net.net_feature_maps,
+                               num_streams=None if per_level_streams else 1, device=image_levels[0].device)
+    loc, cls, corners, fm_sizes = runner.run(image_levels)
+    return dict(loc=loc, cls=cls, corners=corners, fm_sizes=fm_sizes,
+                img_sizes=[FeatureMapSize(img=x) for x in image_levels])
+
+
+def detect(net, box_coder, image_levels, class_head, class_ids, orig_size=None, nms_score_threshold=float("-inf"),
+           nms_iou_threshold=0.3, image_index=0, per_level_streams=True):
+    """Detections of ONE image (``image_index`` of the batch) over the whole pyramid as a ``BoxList`` in the
+    coordinates of ``orig_size`` (default: the first level's size), fields scores / labels / default_boxes /
+    transform_corners.  Thresholds default to the reference's eval config (config.py:198-200)."""
+    s = extract_scores(net, image_levels, class_head, per_level_streams)
+    a = image_index
+    inverse = None
+    if orig_size is not None:
+        inverse = [(lambda boxes, size=orig_size: boxes.resize(size)) for _ in image_levels]
+    return box_coder.decode_pyramid([l[a] for l in s["loc"]], [c[a] for c in s["cls"]], s["img_sizes"], class_ids,
+                                    nms_score_threshold=nms_score_threshold, nms_iou_threshold=nms_iou_threshold,
+                                    inverse_box_transforms=inverse,
+                                    transform_corners_pyramid=[k[a] for k in s["corners"]])

@@ -75,3 +75,32 @@ def test_pyramid_runner_streams_match_single_stream(device):
         assert torch.equal(l.view_as(seq[lvl][0]), seq[lvl][0])
         assert torch.equal(c.view_as(seq[lvl][1]), seq[lvl][1])
         assert torch.equal(k.view_as(seq[lvl][3]), seq[lvl][3])
+
+
+def test_detect_pipeline_end_to_end(device):
+    """backbone (torch) -> pyramid runner (HIP head, one stream per level) -> decode + NMS (HIP), against the same
+    composition done level by level on the default stream and the decode oracle."""
+    from oracle import decode_oracle as D
+    from os2d_amd.engine import evaluate as E
+    from os2d_amd.structures.feature_map import FeatureMapSize
+    net, state = _model(device, seed=5)
+    g = torch.Generator().manual_seed(2)
+    class_images = [torch.randn(3, 96, 96, generator=g).to(device), torch.randn(3, 96, 96, generator=g).to(device),
+                    torch.randn(3, 80, 112, generator=g).to(device)]
+    levels = [torch.randn(1, 3, 96, 128, generator=g).to(device), torch.randn(1, 3, 144, 192, generator=g).to(device)]
+    head = E.build_class_head(net, class_images)
+    head_seq = E.build_class_head(net, class_images, batch_same_size=False)
+    assert util.maxdiff(head.class_feature_maps, head_seq.class_feature_maps) < 1e-5      # batched backbone == one by one
+    coder = net.build_box_coder()
+    orig = FeatureMapSize(w=256, h=192)
+    det = E.detect(net, coder, levels, head, class_ids=[0, 1, 2], orig_size=orig, nms_score_threshold=0.0)
+    assert len(det) > 0 and det.image_size == orig and set(det.fields()) >= {"scores", "labels", "default_boxes", "transform_corners"}
+    # oracle decode of the scores the device produced
+    s = E.extract_scores(net, levels, head, per_level_streams=False)
+    fm = [(f.h, f.w) for f in s["fm_sizes"]]
+    img = [(x.w, x.h) for x in s["img_sizes"]]
+    b, sc, lab = D.decode_pyramid([l[0].cpu() for l in s["loc"]], [c[0].cpu() for c in s["cls"]], fm, img, (orig.w, orig.h), 0.0, 0.3)
+    assert len(sc) == len(det)
+    assert torch.equal(det.get_field("labels").cpu(), lab)
+    assert util.maxdiff(det.get_field("scores"), sc) < 1e-5
+    assert util.maxdiff(det.bbox_xyxy, b) < 1e-2

@@ -29,10 +29,23 @@ def unpad(x, NB, Cst, H, W, plane):
     return inner, float(border.abs().max())
 
 
+def synthetic_fixture(C, H, W, B, P=6, inverse=True):
+    """Fixture-like dict built from the oracle for an arbitrary shape: 'C,H,W,B' on the command line."""
+    from os2d_amd.utils import synthetic
+    state = synthetic.make_transform_net_state(P, seed=31)
+    fm = synthetic.make_feature_map(C, H, W, seed=41)
+    class_fms = synthetic.make_class_feature_maps(B, C, sizes=[(15, 15), (11, 19)], seed=900)
+    q = O.prepare_class_maps(class_fms)
+    with torch.no_grad():
+        loc, cls, _, corners, mid = O.head_forward(fm, q, state, inverse, return_intermediate=True)
+    return dict(P=P, inverse=inverse, state=state, fm=fm, class_fms=class_fms, ref_q15=q, ref_corr=mid["corr"],
+                ref_params=mid["params"], ref_loc=loc, ref_cls=cls, ref_corners=corners)
+
+
 def main(name):
     dev = torch.device("cuda:0")
     lib = _lib.load()
-    fx = util.load_head_fixture(name)
+    fx = synthetic_fixture(*[int(v) for v in name.split(",")]) if "," in name else util.load_head_fixture(name)
     P, inverse, state = fx["P"], fx["inverse"], fx["state"]
     fm = fx["fm"].to(dev)
     A, C, H, W = fm.shape
@@ -61,7 +74,7 @@ def main(name):
     rn, bmax = unpad(rpad, NB, 226, H, W, plane)
     print("rnorm     ", util.maxdiff(rn[:, :225], rn_ref), "pad-ch", float(rn[:, 225].abs().max()), "border", bmax)
 
-    w1, b1, w2, b2, w3, b3 = creator.aligner.parameter_regressor.packed()
+    w1, b1, w2, b2, w3, b3 = creator.aligner.parameter_regressor.packed("f32")[:6]
     fw = O.fold_batchnorm(state, torch.float32)
     h1 = torch.full((NB * 128 * plane,), float("nan"), device=dev)
     _lib.check(lib.os2d_transform_conv(1, _lib.ptr(rpad), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(h1), NB, P, H, W, st), "conv1")

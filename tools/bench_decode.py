@@ -30,3 +30,11 @@ for it in range(3):
                                nms_iou_threshold=0.3, transform_corners_pyramid=[cor_l])
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print("decode_pyramid B={} thr={}: {:.2f} ms, {} detections".format(B, thr, dt * 1e3, len(res)))
+
+# ---- breakdown with the torch profiler (kernel self times)
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    res = coder.decode_pyramid([loc_l], [cls_l], [img], class_ids=list(range(B)), nms_score_threshold=thr,
+                               nms_iou_threshold=0.3, transform_corners_pyramid=[cor_l])
+    torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=12, max_name_column_width=60))

@@ -1,0 +1,57 @@
+"""CPU: checkpoint compatibility of the model wrapper (reference os2d/modeling/model.py:290-426, os2d/utils/logger.py:137-160
+format: {"net": state_dict, "optimizer": ...}; backbone-only files; weakalign FeatureExtraction / FeatureRegression maps)."""
+import torch
+
+from os2d_amd.modeling.model import Os2dModel, init_from_weakalign_model
+
+
+def _perturbed(net, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(0.01 * torch.randn(p.shape, generator=g))
+    return net
+
+
+def test_full_checkpoint_roundtrip(tmp_path):
+    src = _perturbed(Os2dModel(is_cuda=False, merge_branch_parameters=True, backbone_arch="resnet50"), 1)
+    path = tmp_path / "checkpoint.pth"
+    torch.save({"net": src.state_dict(), "optimizer": {"state": {}, "param_groups": []}, "epoch": 3}, str(path))
+    dst = Os2dModel(is_cuda=False, merge_branch_parameters=True, backbone_arch="resnet50")
+    opt = dst.init_model_from_file(str(path))
+    assert opt == {"state": {}, "param_groups": []}
+    a, b = src.state_dict(), dst.state_dict()
+    assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_backbone_only_checkpoint(tmp_path):
+    """A plain torchvision-style ResNet state dict (incl. layer4 / fc, as downloaded) initialises both branches."""
+    src = _perturbed(Os2dModel(is_cuda=False, merge_branch_parameters=False, backbone_arch="resnet50"), 2)
+    sd = {k: v.clone() for k, v in src.net_feature_maps.state_dict().items()}
+    sd["fc.weight"] = torch.zeros(1000, 2048)            # extra keys of a full classification net are tolerated
+    sd["layer4.0.conv1.weight"] = torch.zeros(512, 1024, 1, 1)
+    path = tmp_path / "resnet50.pth"
+    torch.save(sd, str(path))
+    dst = Os2dModel(is_cuda=False, merge_branch_parameters=False, backbone_arch="resnet50")
+    dst.init_model_from_file(str(path))
+    for k, v in src.net_feature_maps.state_dict().items():
+        assert torch.equal(dst.net_label_features.net_class_features.state_dict()[k], v)
+        assert torch.equal(dst.net_feature_maps.state_dict()[k], v)
+
+
+def test_weakalign_transform_mapping():
+    """FeatureRegression.* -> TransformNet, with the FC weight [6, 64*5*5] reshaped to the 5x5 conv (model.py:415-426)."""
+    net = Os2dModel(is_cuda=False, merge_branch_parameters=True, backbone_arch="resnet101")
+    reg = net.os2d_head_creator.aligner.parameter_regressor
+    g = torch.Generator().manual_seed(4)
+    src = {}
+    for k, v in reg.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            continue
+        t = torch.randn(v.shape, generator=g)
+        src["FeatureRegression." + k] = t.reshape(6, -1) if k == "linear.weight" else t
+    init_from_weakalign_model(src, None, affine_regressor=reg)
+    got = reg.state_dict()
+    assert torch.equal(got["linear.weight"], src["FeatureRegression.linear.weight"].view(6, 64, 5, 5))
+    assert torch.equal(got["conv.0.weight"], src["FeatureRegression.conv.0.weight"])
+    assert torch.equal(got["conv.4.running_var"], src["FeatureRegression.conv.4.running_var"])

@@ -44,17 +44,12 @@ def alloc_gather_buffer(A, b_max, H, W, device, channels=OUT_CHANNELS):
     return flat, views
 
 
-def all_gather_class_outputs(flat_local, counts, A, H, W, group=None, channels=OUT_CHANNELS):
-    """All-gather the per-rank flat buffers (``alloc_gather_buffer`` layout, padded to b_max = max(counts) classes)
-    and return the full tensors [A, sum(counts), k, H, W] for each k in ``channels``, classes in global order."""
-    world = dist.get_world_size(group)
-    assert len(counts) == world
+def _assemble(gathered, counts, A, H, W, channels):
+    """[world, flat] gathered buffers -> full tensors [A, sum(counts), k, H, W] per k, classes in global order."""
+    world = len(counts)
     b_max = max(counts)
-    gathered = torch.empty(world * flat_local.numel(), dtype=flat_local.dtype, device=flat_local.device)
-    dist.all_gather_into_tensor(gathered, flat_local, group=group)
     gathered = gathered.view(world, -1)
-    outs = []
-    off = 0
+    outs, off = [], 0
     for k in channels:
         n = A * b_max * k * H * W
         block = gathered[:, off:off + n].view(world, A, b_max, k, H, W)
@@ -65,6 +60,37 @@ def all_gather_class_outputs(flat_local, counts, A, H, W, group=None, channels=O
             full = torch.cat([block[r, :, :counts[r]] for r in range(world)], dim=1)
         outs.append(full.contiguous())
     return outs
+
+
+class PendingGather(object):
+    """Handle of an all-gather in flight (``async_op=True``): ``wait()`` makes the current stream wait for the
+    collective and returns the assembled tensors.  Lets the caller launch the next image / pyramid level before the
+    previous gather has finished, so the xGMI transfer hides behind compute."""
+
+    def __init__(self, work, gathered, keep_alive, counts, A, H, W, channels):
+        self._work, self._gathered, self._keep = work, gathered, keep_alive
+        self._args = (counts, A, H, W, channels)
+        self._result = None
+
+    def wait(self):
+        if self._result is None:
+            self._work.wait()
+            self._result = _assemble(self._gathered, *self._args)
+            self._keep = None
+        return self._result
+
+
+def all_gather_class_outputs(flat_local, counts, A, H, W, group=None, channels=OUT_CHANNELS, async_op=False):
+    """All-gather the per-rank flat buffers (``alloc_gather_buffer`` layout, padded to b_max = max(counts) classes)
+    and return the full tensors [A, sum(counts), k, H, W] for each k in ``channels``, classes in global order
+    (or a ``PendingGather`` when ``async_op``)."""
+    world = dist.get_world_size(group)
+    assert len(counts) == world
+    gathered = torch.empty(world * flat_local.numel(), dtype=flat_local.dtype, device=flat_local.device)
+    work = dist.all_gather_into_tensor(gathered, flat_local, group=group, async_op=async_op)
+    if async_op:
+        return PendingGather(work, gathered, flat_local, list(counts), A, H, W, tuple(channels))
+    return _assemble(gathered, list(counts), A, H, W, tuple(channels))
 
 
 class ClassShardedHead(object):
@@ -99,7 +125,9 @@ class ClassShardedHead(object):
             assert local_head.class_batch_size == e - s, "local head holds {} classes, shard is {}".format(local_head.class_batch_size, e - s)
         self.counts = [e - s for s, e in self.bounds]
 
-    def forward(self, feature_maps):
+    def forward(self, feature_maps, async_gather=False):
+        """Full-size (loc, cls, cls, corners) on every rank; with ``async_gather`` a zero-argument callable is returned
+        instead that waits for the collective and yields that tuple (call it after queueing more work)."""
         A, _, H, W = feature_maps.shape
         b_loc = self.counts[self.rank]
         b_max = max(self.counts)
@@ -112,9 +140,15 @@ class ClassShardedHead(object):
             flat.zero_()
             loc[:, :b_loc], cls[:, :b_loc], corners[:, :b_loc] = l, c, k
         if self.gather == "scores":
-            (cls_full,) = all_gather_class_outputs(cls.reshape(-1), self.counts, A, H, W, self.group, channels=(1,))
-            return None, cls_full, cls_full, None
-        loc_f, cls_f, cor_f = all_gather_class_outputs(flat, self.counts, A, H, W, self.group)
-        return loc_f, cls_f, cls_f, cor_f
+            res = all_gather_class_outputs(cls.reshape(-1), self.counts, A, H, W, self.group, channels=(1,),
+                                           async_op=async_gather)
+            finish = lambda r: (None, r[0], r[0], None)
+        else:
+            res = all_gather_class_outputs(flat, self.counts, A, H, W, self.group, async_op=async_gather)
+            finish = lambda r: (r[0], r[1], r[1], r[2])
+        if async_gather:
+            # the closure keeps ``flat`` (the send buffer; for scores a view of it is sent) alive until the wait
+            return lambda _keep=flat: finish(res.wait())
+        return finish(res)
 
     __call__ = forward

@@ -56,6 +56,10 @@ def _worker(rank, world, port, n_classes, gather, result_queue):
         s, e = shard_bounds(n_classes, world)[rank]
         sharded = ClassShardedHead(None, gather=gather, num_classes=n_classes, local_head=_OracleHead(q[s:e], state, inverse))
         loc, cls, cls_det, corners = sharded(fm)
+        # asynchronous variant: two gathers in flight, waited for afterwards, same results
+        h1, h2 = sharded(fm, async_gather=True), sharded(fm, async_gather=True)
+        r2, r1 = h2(), h1()
+        assert torch.equal(r1[1], cls) and torch.equal(r2[1], cls)
         with torch.no_grad():
             ref = O.head_forward(fm, q, state, inverse)
         ok = torch.equal(cls, ref[1]) and cls_det is cls

@@ -81,3 +81,22 @@ def test_duplicate_class_ids_are_merged(device):
     assert lab.tolist() == [3] * len(s3) + [7] * len(s7)
     assert torch.equal(res.get_field("scores").cpu(), torch.cat([s3, s7]))
     assert util.maxdiff(res.bbox_xyxy, torch.cat([b3, b7])) < 1e-3
+
+
+def test_no_detections_and_single_box(device):
+    """Edge cases of the decode path: a threshold above every score (empty result), and lists with one survivor."""
+    from os2d_amd.structures.feature_map import FeatureMapSize
+    rs = np.random.RandomState(8)
+    size = FeatureMapSize(w=208, h=176)
+    H, W = 11, 13
+    loc = torch.from_numpy(rs.standard_normal((2, 4, H * W)).astype(np.float32)).to(device)
+    cls = torch.from_numpy(rs.uniform(-1, 1, size=(2, H * W)).astype(np.float32)).to(device)
+    coder = _coder()
+    res = coder.decode_pyramid([loc], [cls], [size], class_ids=[0, 1], nms_score_threshold=2.0)
+    assert len(res) == 0 and res.bbox_xyxy.shape == (0, 4) and res.get_field("scores").numel() == 0
+    cls2 = cls.clone()
+    cls2[1] = -1.0
+    cls2[1, 17] = 0.9        # class 1: exactly one candidate above the threshold
+    res = coder.decode_pyramid([loc], [cls2], [size], class_ids=[0, 1], nms_score_threshold=0.8)
+    lab = res.get_field("labels").cpu()
+    assert int((lab == 1).sum()) == 1 and abs(float(res.get_field("scores")[lab.tolist().index(1)]) - 0.9) < 1e-6

@@ -174,3 +174,22 @@ def test_odd_shapes_match_oracle(C, H, W, B, precision, device):
     assert util.maxdiff(cls, ref[1]) < TOL_CLS
     assert util.maxdiff(loc, ref[0]) < TOL_LOC
     assert util.maxdiff(corners, ref[3]) < TOL_CORNERS
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_full_size_class_batch_invariance(precision, device):
+    """Size-independent property at BASELINE.json's full size (C=1024, 60x80): a class's outputs do not depend on which
+    other classes share the batch, nor on the class order (the kernels shard work by class)."""
+    from os2d_amd.utils import synthetic
+    P, inverse = 6, True
+    state = synthetic.make_transform_net_state(P, seed=1)
+    fm = synthetic.make_feature_map(1024, 60, 80, seed=0).to(device)
+    class_fms = [c.to(device) for c in synthetic.make_class_feature_maps(6, 1024, seed=1000)]
+    creator = util.make_head_creator(P, inverse, state, device)
+    with torch.no_grad():
+        full = creator.create_os2d_head(class_fms)(fm, precision=precision)
+        part = creator.create_os2d_head(class_fms[4:] + class_fms[1:3])(fm, precision=precision)   # classes 4,5,1,2
+    for i in (0, 1, 3):
+        assert torch.equal(part[i][:, 0:2], full[i][:, 4:6]) and torch.equal(part[i][:, 2:4], full[i][:, 1:3])
+    assert torch.isfinite(full[0]).all() and torch.isfinite(full[1]).all() and torch.isfinite(full[3]).all()
+    assert float(full[1].min()) > 0.2 and float(full[1].max()) < 0.6      # post-ReLU features: scores 0.3-0.45

@@ -64,6 +64,15 @@ def load():
     if _LIB is not None:
         return _LIB
     path = lib_path()
+    if not os.path.exists(path) and "OS2D_HIP_LIB" not in os.environ:
+        # a fresh checkout (the .so is a build artefact, not tracked): compile it in-tree once.  This is the same
+        # HIP library, not a fallback implementation; if hipcc is missing the error below still fires.
+        try:
+            from . import build as _build
+            _build.build(verbose=False)
+        except Exception as e:  # noqa: BLE001
+            raise Os2dLibraryError("libos2d_hip.so is not built and building it failed ({}); the OS2D head has no "
+                                   "CPU or PyTorch fallback".format(e))
     if not os.path.exists(path):
         raise Os2dLibraryError(
             "libos2d_hip.so not found at {} - the OS2D head has no CPU or PyTorch fallback; build the HIP "

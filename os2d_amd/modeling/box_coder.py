@@ -200,9 +200,13 @@ class Os2dBoxCoder(object):
         dflt = torch.cat(dflt_l, 1)
         corners = torch.cat(corners_l, 1) if corners_l else None
         # merge rows that share a real label
-        labels_sorted = sorted(set(int(c) for c in class_ids))
-        groups = [[i for i, c in enumerate(class_ids) if int(c) == l] for l in labels_sorted]
-        if any(len(g) != 1 for g in groups) or labels_sorted != [int(c) for c in class_ids]:
+        ids = [int(c) for c in class_ids]
+        by_label = {}
+        for i, c in enumerate(ids):
+            by_label.setdefault(c, []).append(i)
+        labels_sorted = sorted(by_label)
+        groups = [by_label[l] for l in labels_sorted]
+        if len(labels_sorted) != len(ids) or labels_sorted != ids:
             width = max(len(g) for g in groups) * boxes.size(1)
 
             def merge(t, fill):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X OS2D head: query-image-pairs/s (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--classes B_per_gpu] [--precision f16x3|f32] [--pyramid]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--classes B_per_gpu] [--precision f16x3|f16x2|f32] [--pyramid]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -16,9 +16,12 @@ Arithmetic (``--precision``):
   f16x3 (default)  every fp32 operand of the four GEMM-shaped stages is split into fp16 hi + lo and each product is
                    evaluated with three v_mfma_f32_32x32x16_f16 (fp32 accumulation): outputs agree with the reference
                    to the same 2.4e-7 as the fp32 mode (tests/test_head_gpu.py runs every parity case in both modes);
+  f16x2            as f16x3, except that the dominant 7x7 layer takes its WEIGHTS as fp16 roundings only (two MFMAs per
+                   product, activations still split): scores within 1e-6 and box regression within 5e-5 of the fp32
+                   result - inside the 1e-4 parity bound of BASELINE.json, but no longer fp32-equivalent;
   f32              v_mfma_f32_32x32x2_f32, exact fp32.
-The primary line is measured in the selected mode; the other mode is timed right after and reported under
-"other_precision" so both are always on record.
+The primary line is measured in the selected mode; the other modes are timed right after and reported under
+"other_precisions" so all are always on record.
 
 Prints ONE JSON line on rank 0 with the driver's contract fields plus
   roofline     - the dominant kernel (conv 7x7 225->128 MFMA implicit GEMM): ALGORITHMIC FLOPs per launch divided by its
@@ -42,7 +45,7 @@ sys.path.insert(0, REPO)
 
 C_FEAT, H_FM, W_FM = 1024, 60, 80          # ResNet50-C4 features of a 1280x960 input
 FLOP_PER_LOC = {"corr": 2 * 225 * 1024, "conv1": 2 * 128 * 225 * 49, "conv2": 2 * 64 * 128 * 25}
-PEAK = {"f32": 157.3e12, "f16x3": 2.5e15}  # dense MFMA peaks (MI355X_MICROARCH.md): fp32-input MFMA; fp16/bf16 MFMA
+PEAK = {"f32": 157.3e12, "f16x3": 2.5e15, "f16x2": 2.5e15}  # dense MFMA peaks (MI355X_MICROARCH.md): fp32-input MFMA; fp16/bf16 MFMA
 STAGES = ("corr", "conv1", "conv2", "conv3", "sample")
 
 
@@ -53,7 +56,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--classes", type=int, default=64, help="classes per GPU")
     ap.add_argument("--variant", default="v2", choices=["v2", "v1"], help="v2: affine+inverse (P=6); v1: simplified (P=4)")
-    ap.add_argument("--precision", default=os.environ.get("OS2D_PRECISION", "f16x3"), choices=["f32", "f16x3"])
+    ap.add_argument("--precision", default=os.environ.get("OS2D_PRECISION", "f16x3"), choices=["f32", "f16x3", "f16x2"])
     ap.add_argument("--pyramid", action="store_true",
                     help="BASELINE configs[4]: 7-scale pyramid (0.5-1.6) of the 1280x960 image, one HIP stream per level; "
                          "a pair then means one (image, class) over all 7 levels")
@@ -220,24 +223,27 @@ def main():
         peak = PEAK[precision]
         r = {"kernel": "TransformNet conv 7x7 225->128 ({})".format(
                  "conv_mfma_kernel<7,...>, v_mfma_f32_32x32x2_f32" if precision == "f32"
-                 else "conv_f16x3_kernel<7,...>, v_mfma_f32_32x32x16_f16 x3 per product"),
+                 else "conv_f16x3_kernel<7,...>, v_mfma_f32_32x32x16_f16 x{} per product".format(precision[-1])),
              "bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": peak / 1e12, "unit": "TFLOP/s",
              "frac": round(achieved / peak, 4), "traffic": measured_traffic(B, precision),
              "flops_per_launch": flops, "avg_launch_ms": round(stage_ms[1], 4)}
-        if precision == "f16x3":
-            # every algorithmic product costs three half-precision MFMA products: the ceiling for algorithmic FLOP/s on
-            # this instruction is peak/3; the executed rate also includes the tile / channel-group padding (x1.118)
-            r["algorithmic_ceiling"] = round(peak / 3 / 1e12, 1)
-            r["frac_of_algorithmic_ceiling"] = round(achieved / (peak / 3), 4)
-            r["executed_mfma_tflops"] = round(3 * achieved * 1.118 / 1e12, 1)
-            r["executed_frac_of_peak"] = round(3 * achieved * 1.118 / peak, 4)
+        if precision != "f32":
+            # every algorithmic product costs three (f16x2: two) half-precision MFMA products: the ceiling for
+            # algorithmic FLOP/s on this instruction is peak/3 (peak/2); the executed rate also includes the tile /
+            # channel-group padding (x1.118)
+            terms = int(precision[-1])
+            r["algorithmic_ceiling"] = round(peak / terms / 1e12, 1)
+            r["frac_of_algorithmic_ceiling"] = round(achieved / (peak / terms), 4)
+            r["executed_mfma_tflops"] = round(terms * achieved * 1.118 / 1e12, 1)
+            r["executed_frac_of_peak"] = round(terms * achieved * 1.118 / peak, 4)
         return r
 
     whole = (FLOP_PER_LOC["corr"] + FLOP_PER_LOC["conv1"] + FLOP_PER_LOC["conv2"] + 2 * P * 64 * 25) * H_FM * W_FM
     pairs_per_step = B * world
     dt, stage_ms = run_mode(args.precision, args.steps, args.warmup)
     value = pairs_per_step * args.steps / dt
-    dtype = {"f32": "f32", "f16x3": "f16x3 (fp32 operands split into fp16 hi+lo, 3 half MFMAs per product, fp32 accumulate)"}
+    dtype = {"f32": "f32", "f16x3": "f16x3 (fp32 operands split into fp16 hi+lo, 3 half MFMAs per product, fp32 accumulate)",
+             "f16x2": "f16x2 (as f16x3; the 7x7 layer's weights enter as fp16 roundings only, 2 half MFMAs per product)"}
     result = {
         "metric": "query-image-pairs/s (1280-px input, ResNet50, N-class)",
         "value": round(value, 2),
@@ -262,13 +268,16 @@ def main():
     if not args.pyramid:
         result["head_tflops_algorithmic"] = round(whole * value / 1e12, 3)
     if not args.no_other_precision:
-        other = "f32" if args.precision == "f16x3" else "f16x3"
-        dt2, stage2 = run_mode(other, args.steps, 1)
-        o = {"precision": other, "value": round(pairs_per_step * args.steps / dt2, 2), "ms_per_step": round(dt2 / args.steps * 1e3, 4)}
-        if stage2:
-            o["stages_ms"] = {k: round(v, 4) for k, v in zip(STAGES, stage2)}
-            o["roofline"] = roofline(other, stage2)
-        result["other_precision"] = o
+        result["other_precisions"] = []
+        for other in ("f16x3", "f16x2", "f32"):
+            if other == args.precision:
+                continue
+            dt2, stage2 = run_mode(other, args.steps, 1)
+            o = {"precision": other, "value": round(pairs_per_step * args.steps / dt2, 2), "ms_per_step": round(dt2 / args.steps * 1e3, 4)}
+            if stage2:
+                o["stages_ms"] = {k: round(v, 4) for k, v in zip(STAGES, stage2)}
+                o["roofline"] = roofline(other, stage2)
+            result["other_precisions"].append(o)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.pyramid:
         result["cpu_baseline"] = cpu_baseline(fm_cpu, class_fms_cpu, state, inverse, args.cpu_seconds)
         result["speedup_vs_cpu_baseline"] = round(result["value"] / result["cpu_baseline"]["value"], 1)

@@ -28,6 +28,9 @@ extern "C" {
 #define OS2D_PRECISION_F32 0   /* v_mfma_f32_32x32x2_f32: exact fp32 (k-ordered fmaf chain)                            */
 #define OS2D_PRECISION_F16X3 1 /* operands split into fp16 hi+lo, three v_mfma_f32_32x32x16_f16 per product, fp32     */
                                /* accumulation: fp32-equivalent results at ~5x the matrix rate  */
+#define OS2D_PRECISION_F16X2 2 /* as F16X3 (same packed weights, same split operands), except that the 7x7 layer uses  */
+                               /* its weights as fp16 roundings only (two MFMAs per product): box regression within   */
+                               /* 5e-5, scores within 1e-6 of fp32 - inside the 1e-4 parity bound, 2/3 of the work     */
 
 /* ABI version of the loaded library (compare with OS2D_ABI_VERSION). */
 int os2d_abi_version(void);
@@ -78,7 +81,7 @@ int os2d_pack_conv_f16x3(int layer /*1|2|3*/, int P, const float* w, const float
 int os2d_class_split(const float* qp, void* qs, int B, int C, void* stream);
 
 /* ---- extended head entry point: identical to os2d_head_forward, plus
- *   precision     OS2D_PRECISION_F32 (w1..w3 from os2d_pack_conv; qs / scale_log2 ignored) or OS2D_PRECISION_F16X3
+ *   precision     OS2D_PRECISION_F32 (w1..w3 from os2d_pack_conv; qs / scale_log2 ignored) or OS2D_PRECISION_F16X3 / _F16X2
  *                 (w1..w3 from os2d_pack_conv_f16x3 with their three scale_log2 values, qs [B, C/8, 2, 256, 8] halves
  *                 from os2d_class_split);
  *   stage_events  NULL, or an array of 10 hipEvent_t (from os2d_prof_event_create); events [2s] / [2s+1] are recorded

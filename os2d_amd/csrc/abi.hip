@@ -212,12 +212,12 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     os2d_set_error("os2d_head_forward: null pointer");
     return -1;
   }
-  if (precision != OS2D_PRECISION_F32 && precision != OS2D_PRECISION_F16X3) {
+  if (precision != OS2D_PRECISION_F32 && precision != OS2D_PRECISION_F16X3 && precision != OS2D_PRECISION_F16X2) {
     os2d_set_error("os2d_head_forward: unknown precision %d", precision);
     return -1;
   }
-  if (precision == OS2D_PRECISION_F16X3 && (!qs || !scale_log2)) {
-    os2d_set_error("os2d_head_forward: precision f16x3 needs the split class operand (os2d_class_split) and the "
+  if (precision != OS2D_PRECISION_F32 && (!qs || !scale_log2)) {
+    os2d_set_error("os2d_head_forward: precision f16x3 / f16x2 needs the split class operand (os2d_class_split) and the "
                    "three weight scales");
     return -1;
   }
@@ -263,11 +263,12 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
   };
   int rc = os2d_launch_fm_sumsq(fm, sumsq, A, C, H * W, st);
   if (rc) return rc;
-  if (precision == OS2D_PRECISION_F16X3 && (rc = os2d_launch_split_fm(fm, sumsq, fsplit, A, C, H * W, st))) return rc;
+  if (precision != OS2D_PRECISION_F32 && (rc = os2d_launch_split_fm(fm, sumsq, fsplit, A, C, H * W, st))) return rc;
   for (int b0 = 0; b0 < B; b0 += Bc) {
     const int bc = (B - b0 < Bc) ? (B - b0) : Bc;
     const int NB = A * bc;
-    const bool f16 = precision == OS2D_PRECISION_F16X3;
+    const bool f16 = precision != OS2D_PRECISION_F32;
+    const int terms1 = precision == OS2D_PRECISION_F16X2 ? 2 : 3;  // 7x7 layer: weights as fp16 roundings only under f16x2
     mark(b0, 0);
     if (f16) {
       if ((rc = os2d_launch_border_zero_shb(rpad, NB, H, W, st))) return rc;
@@ -284,21 +285,21 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     mark(b0, 1);
     mark(b0, 2);
     if (f16) {
-      if ((rc = os2d_launch_conv_f16x3(1, rpad, w1, b1, ldexpf(1.0f, -scale_log2[0]), h1, NB, P, H, W, st))) return rc;
+      if ((rc = os2d_launch_conv_f16x3(1, rpad, w1, b1, ldexpf(1.0f, -scale_log2[0]), h1, NB, P, H, W, terms1, st))) return rc;
     } else {
       if ((rc = os2d_launch_conv(1, rpad, static_cast<const float*>(w1), b1, h1, NB, P, H, W, st))) return rc;
     }
     mark(b0, 3);
     mark(b0, 4);
     if (f16) {
-      if ((rc = os2d_launch_conv_f16x3(2, h1, w2, b2, ldexpf(1.0f, -scale_log2[1]), h2, NB, P, H, W, st))) return rc;
+      if ((rc = os2d_launch_conv_f16x3(2, h1, w2, b2, ldexpf(1.0f, -scale_log2[1]), h2, NB, P, H, W, 3, st))) return rc;
     } else {
       if ((rc = os2d_launch_conv(2, h1, static_cast<const float*>(w2), b2, h2, NB, P, H, W, st))) return rc;
     }
     mark(b0, 5);
     mark(b0, 6);
     if (f16) {
-      if ((rc = os2d_launch_conv_f16x3(3, h2, w3, b3, ldexpf(1.0f, -scale_log2[2]), params, NB, P, H, W, st))) return rc;
+      if ((rc = os2d_launch_conv_f16x3(3, h2, w3, b3, ldexpf(1.0f, -scale_log2[2]), params, NB, P, H, W, 3, st))) return rc;
     } else {
       if ((rc = os2d_launch_conv(3, h2, static_cast<const float*>(w3), b3, params, NB, P, H, W, st))) return rc;
     }
@@ -331,7 +332,7 @@ int os2d_class_split(const float* qp, void* qs, int B, int C, void* stream) {
 
 size_t os2d_packed_conv_bytes(int layer, int precision) {
   if (precision == OS2D_PRECISION_F32) return os2d_packed_conv_floats(layer) * sizeof(float);
-  if (precision != OS2D_PRECISION_F16X3) return 0;
+  if (precision != OS2D_PRECISION_F16X3 && precision != OS2D_PRECISION_F16X2) return 0;
   // [G][steps padded to whole stages][2][2][MT] units of 16 B (conv_f16x3.hip: layer 1 SS=5, layer 2 SS=7)
   if (layer == 1) return (size_t)OS2D_G * 25 * 4 * 128 * 16;
   if (layer == 2) return (size_t)16 * 14 * 4 * 64 * 16;

@@ -34,8 +34,11 @@ __device__ __forceinline__ void split_half(float x, _Float16& hi, _Float16& lo) 
 // MTP = output rows of the packed weights (all output channels, padded), MT = rows handled by ONE work-group
 // (blockIdx.z selects the slice): splitting the output channels over two independent 4-wave groups per CU lets one
 // group's barrier / staging bubble be filled by the other's MFMAs.
+// TERMS = 3: fp32-equivalent product (above).  TERMS = 2 drops a_lo*b_hi, i.e. the WEIGHTS enter as their fp16 roundings
+// only (activations keep both halves): two thirds of the matrix-core work.  Used for the 7x7 layer under precision
+// "f16x2", where the averaging over K = 11025 keeps the box regression within 5e-5 of the fp32 result.
 template <int KS, int MTP, int MT, int WM, int WN, int NI, int SS, bool RELU, int OUT_MODE /*0 SHB, 1 fp32 plane, 2 fp32 compact [NB][Cout][H*W]*/,
-          int NBPF /*16-byte units per thread for the input-slab prefetch*/>
+          int NBPF /*16-byte units per thread for the input-slab prefetch*/, int TERMS>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_f16x3_kernel(const u32x4* in,  // SHB [NB][G][2][PLANE] (no __restrict__: invariant loads get
                                                              const u32x4* wp,  // rematerialised BEHIND the MFMAs by the register allocator)
                                                              const float* __restrict__ bp,  // [MT] fp32 folded bias
@@ -49,7 +52,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_f16x3_kernel(const u32x4
   constexpr int NW = NI * 32, NT = WN * NW;
   constexpr int NTHR = 64 * WM * WN;
   static_assert(MW % 32 == 0 && MTP % MT == 0, "wave tile rows must be a multiple of 32");
-  constexpr int ASTAGE = SS * 4 * MT;    // 16-byte units per weight stage in LDS (this group's rows only)
+  constexpr int AP = TERMS == 3 ? 2 : 1;      // weight parts staged in LDS (hi|lo or hi only)
+  constexpr int ASTAGE = SS * 2 * AP * MT;    // 16-byte units per weight stage in LDS (this group's rows only)
   constexpr int ASTAGE_G = SS * 4 * MTP;  // ... and in the packed global layout
   constexpr int NAPF = (ASTAGE + NTHR - 1) / NTHR;
 
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_f16x3_kernel(const u32x4
     const u32x4* src_ = wp + (size_t)(S)*ASTAGE_G + mOff;                                                         \
     _Pragma("unroll") for (int k = 0; k < NAPF; ++k) {                                                            \
       const int i_ = min(tid + k * NTHR, ASTAGE - 1);                                                             \
-      pfA[k] = src_[(i_ / MT) * MTP + (i_ % MT)];                                                                 \
+      pfA[k] = src_[(i_ / MT) * (2 / AP) * MTP + (i_ % MT)];                                                      \
     }                                                                                                             \
   }
 #define F16_STORE_A(S)                                                                                            \
@@ -132,10 +136,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_f16x3_kernel(const u32x4
     const int dy0_ = t0_ / KS, dx0_ = t0_ % KS, dy1_ = t1_ / KS;                                                  \
     const int bsel_ = (t1_ == t0_) ? bLane : (dy1_ == dy0_ ? bSame : bCross);                                     \
     const u32x4* bS_ = ldsB + bsel_ + dy0_ * Ws + dx0_;                                                           \
-    const u32x4* aS_ = ldsA + (BUF)*ASTAGE + aLane + (((P)*2 + hw) * 2) * MT;                                     \
+    const u32x4* aS_ = ldsA + (BUF)*ASTAGE + aLane + (((P)*2 + hw) * AP) * MT;                                    \
     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                           \
       fah[SET][mi] = *reinterpret_cast<const half8*>(aS_ + mi * 32);                                              \
-      fal[SET][mi] = *reinterpret_cast<const half8*>(aS_ + MT + mi * 32);                                         \
+      if (TERMS == 3) fal[SET][mi] = *reinterpret_cast<const half8*>(aS_ + MT + mi * 32);                         \
     }                                                                                                             \
     _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                                           \
       fbh[SET][ni] = *reinterpret_cast<const half8*>(bS_ + ni * 32);                                              \
@@ -145,9 +149,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_f16x3_kernel(const u32x4
   // three passes over the MI x NI blocks: consecutive MFMAs never touch the same accumulator
 #define F16_MFMAS(SET)                                                                                            \
   {                                                                                                               \
-    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                             \
-      _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                           \
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[SET][mi], fbh[SET][ni], acc[mi][ni], 0, 0, 0);   \
+    if (TERMS == 3) {                                                                                             \
+      _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                           \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                         \
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[SET][mi], fbh[SET][ni], acc[mi][ni], 0, 0, 0); \
+    }                                                                                                             \
     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                             \
       _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                           \
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[SET][mi], fbl[SET][ni], acc[mi][ni], 0, 0, 0);   \
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_f16x3_kernel(const u32x4
   }
 }
 
-template <int KS, int MTP, int MT, int WM, int WN, int NI, int SS, bool RELU, int OUT_MODE, int NBPF = 0>
+template <int KS, int MTP, int MT, int WM, int WN, int NI, int SS, bool RELU, int OUT_MODE, int TERMS = 3, int NBPF = 0>
 int launch(const void* in, const void* wp, const float* bp, float unscale, void* out, int NB, int G, int CoutStore,
            int H, int W, hipStream_t stream) {
   constexpr int R = KS / 2;
@@ -293,17 +299,17 @@ int launch(const void* in, const void* wp, const float* bp, float unscale, void*
   const int SLAB = NT + 2 * HALO;
   constexpr int NTHR = 64 * WM * WN;
   if (NBPF == 0) {  // pick the slab-prefetch depth: 8 units/thread up to W = 124 (fewer registers), 12 up to W = 209
-    if (2 * SLAB <= 8 * NTHR) return launch<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE, 8>(in, wp, bp, unscale, out, NB, G, CoutStore, H, W, stream);
-    if (2 * SLAB <= 12 * NTHR) return launch<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE, 12>(in, wp, bp, unscale, out, NB, G, CoutStore, H, W, stream);
+    if (2 * SLAB <= 8 * NTHR) return launch<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE, TERMS, 8>(in, wp, bp, unscale, out, NB, G, CoutStore, H, W, stream);
+    if (2 * SLAB <= 12 * NTHR) return launch<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE, TERMS, 12>(in, wp, bp, unscale, out, NB, G, CoutStore, H, W, stream);
     os2d_set_error("conv%dx%d (f16x3): feature map too wide for the input-slab prefetch (W=%d)", KS, KS, W);
     return -3;
   }
-  const size_t lds = (size_t)(2 * SS * 4 * MT + 2 * SLAB) * 16;
+  const size_t lds = (size_t)(2 * SS * 2 * (TERMS == 3 ? 2 : 1) * MT + 2 * SLAB) * 16;
   if (lds > 160 * 1024) {
     os2d_set_error("conv%dx%d (f16x3): LDS budget exceeded (%zu B, W=%d)", KS, KS, lds, W);
     return -3;
   }
-  auto kern = conv_f16x3_kernel<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE, (NBPF ? NBPF : 8)>;
+  auto kern = conv_f16x3_kernel<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE, (NBPF ? NBPF : 8), TERMS>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) {
@@ -326,7 +332,9 @@ int launch(const void* in, const void* wp, const float* bp, float unscale, void*
 // layer 1: 7x7, 29 input groups (225 ch), 128 out, SHB out;  layer 2: 5x5, 16 groups, 64 out, SHB out;
 // layer 3: 5x5, 8 groups, P out (rows padded to 32), compact fp32 [NB][P][H*W] out.
 int os2d_launch_conv_f16x3(int layer, const void* in, const void* wp, const float* bp, float unscale, void* out, int NB,
-                           int P, int H, int W, hipStream_t stream) {
+                           int P, int H, int W, int terms, hipStream_t stream) {
+  if (layer == 1 && terms == 2)
+    return launch<7, 128, 64, 1, 4, 2, 5, true, 0, 2>(in, wp, bp, unscale, out, NB, 29, 128, H, W, stream);
   switch (layer) {
     case 1: return launch<7, 128, 64, 1, 4, 2, 5, true, 0>(in, wp, bp, unscale, out, NB, 29, 128, H, W, stream);
     case 2: return launch<5, 64, 64, 1, 4, 2, 7, true, 0>(in, wp, bp, unscale, out, NB, 16, 64, H, W, stream);

@@ -58,7 +58,7 @@ int os2d_launch_corr(const float* fm, const float* qp, const float* sumsq, float
                      int A, int B, int C, int H, int W, int shb, hipStream_t stream);
 // conv_f16x3.hip
 int os2d_launch_conv_f16x3(int layer, const void* in, const void* wp, const float* bp, float unscale, void* out, int NB,
-                           int P, int H, int W, hipStream_t stream);
+                           int P, int H, int W, int terms, hipStream_t stream);
 // conv_mfma.hip
 int os2d_launch_conv(int layer, const float* in, const float* wp, const float* bp, float* out,
                      int NB, int P, int H, int W, hipStream_t stream);

@@ -26,13 +26,15 @@ from .box_coder import BoxGridGenerator
 
 TEMPLATE = 15
 QROWS = 256
-PRECISIONS = {"f32": 0, "f16x3": 1}     # OS2D_PRECISION_* of include/os2d_hip.h
+PRECISIONS = {"f32": 0, "f16x3": 1, "f16x2": 2}     # OS2D_PRECISION_* of include/os2d_hip.h
 
 
 def resolve_precision(precision=None):
     """Arithmetic of the two large TransformNet convolutions: "f32" (exact fp32 MFMA) or "f16x3" (fp16 hi/lo split on
     the half-precision matrix cores, fp32-equivalent results: same 2.4e-7 agreement with the reference on every
-    parity case).  Default from $OS2D_PRECISION, else "f16x3"."""
+    parity case), or "f16x2" (as f16x3, but the 7x7 layer takes its weights as fp16 roundings only: 2/3 of the
+    matrix-core work, box regression within 5e-5 and scores within 1e-6 of fp32, inside the 1e-4 parity bound).
+    Default from $OS2D_PRECISION, else "f16x3"."""
     precision = precision or os.environ.get("OS2D_PRECISION", "f16x3")
     if precision not in PRECISIONS:
         raise ValueError("precision must be one of {}, got {!r}".format(sorted(PRECISIONS), precision))
@@ -140,6 +142,8 @@ class TransformationNet(nn.Module):
         precision "f32": os2d_pack_conv layouts (scales are 0); "f16x3": the split-half layout of
         os2d_pack_conv_f16x3, each layer pre-scaled by the largest power of two that keeps max|w| <= 16384."""
         precision = resolve_precision(precision)
+        if precision == "f16x2":
+            precision = "f16x3"        # same packed weights and scales; the kernel just skips the lo halves of layer 1
         key = (precision,) + self._state_key()
         cached = self._packed_cache.get(precision)
         if cached is not None and cached[0] == key:
@@ -348,7 +352,7 @@ class Os2dHead(nn.Module):
         mask[:, :, pool_border_width:TEMPLATE - pool_border_width, pool_border_width:TEMPLATE - pool_border_width] = 1
         self.class_pool_mask = mask / mask.sum(dim=(2, 3), keepdim=True)
         self.aligner = aligner
-        self.precision = None      # None: follow $OS2D_PRECISION (default "f16x3"); or "f32" / "f16x3"
+        self.precision = None      # None: follow $OS2D_PRECISION (default "f16x3"); or "f32" / "f16x3" / "f16x2"
         box = box_grid_generator_image_level
         self._stride = int(box.box_stride.w)
         # image-level box = stride*(15-1) + receptive field (head.py:223-238)
@@ -420,7 +424,7 @@ class Os2dHead(nn.Module):
             _lib.ptr(w3), _lib.ptr(b3), A, B, C, H, W, P, 1 if self.aligner.use_inverse_geom_model else 0,
             self._stride, self._rec_field, _lib.ptr(loc), _lib.ptr(cls), _lib.ptr(corners),
             _lib.ptr(ws), ws.numel(), _lib.current_stream(dev), PRECISIONS[precision],
-            _lib.ptr(self._split_class_operand()) if precision == "f16x3" else None, scales, stage_events, None),
+            _lib.ptr(self._split_class_operand()) if precision != "f32" else None, scales, stage_events, None),
             "os2d_head_forward_ex")
         return loc, cls, cls, corners
 

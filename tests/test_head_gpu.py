@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 TOL_CLS, TOL_LOC, TOL_CORNERS = 1e-5, 1e-4, 2e-3
 
 
-PRECISIONS = ["f32", "f16x3"]     # both arithmetic modes must meet the same tolerances
+PRECISIONS = ["f32", "f16x3", "f16x2"]     # every arithmetic mode must meet the same tolerances
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)

@@ -28,6 +28,7 @@ Prints ONE JSON line on rank 0 with the driver's contract fields plus
                  mean launch duration, measured with HIP events recorded on the launch stream inside the timed steps,
                  against the dense MFMA peak of the instruction it runs on
   stages_ms    - mean duration of every stage of the step (same events)
+  end_to_end   - secondary: backbone + head + decode/NMS per image, and the one-off class-head construction (N=1 only)
   cpu_baseline - the oracle (torch-CPU restatement of the reference head, driven one class at a time like the
                  reference's evaluation) timed on the host cores, rank 0 / N=1 only, on a bounded class sample.
 """
@@ -67,6 +68,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-precision", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="skip the secondary end-to-end leg (backbone + class-head build + head + decode/NMS)")
     return ap.parse_args()
 
 
@@ -100,6 +103,64 @@ def measured_traffic(B, precision):
     with open(path) as f:
         t = json.load(f)
     return int(t["bytes_per_class"] * B)
+
+
+def end_to_end(dev, B, P, inverse, state, precision, steps=5, warmup=2):
+    """Secondary number: one 1280x960 image through the PyTorch-ROCm ResNet50-C4 backbone, the
+    HIP head against B classes and the HIP decode + per-class NMS of all 4800 boxes per class (score threshold -inf,
+    the reference's eval default), random-init weights; plus the one-off construction of the class head from B
+    240x240 class images (one batched backbone pass)."""
+    from os2d_amd.engine.evaluate import build_class_head
+    from os2d_amd.modeling.model import Os2dModel
+    from os2d_amd.structures.feature_map import FeatureMapSize
+    torch.manual_seed(0)
+    net = Os2dModel(is_cuda=False, merge_branch_parameters=True, backbone_arch="resnet50",
+                    use_inverse_geom_model=inverse, simplify_affine=(P == 4))
+    net.os2d_head_creator.aligner.parameter_regressor.load_state_dict(state)
+    net.to(dev).eval()
+    g = torch.Generator().manual_seed(0)
+    img = torch.randn(1, 3, 960, 1280, generator=g).to(dev)
+    class_images = [torch.randn(3, 240, 240, generator=g).to(dev) for _ in range(B)]
+    coder = net.build_box_coder()
+    img_size = FeatureMapSize(img=img)
+    ids = list(range(B))
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    with torch.no_grad():
+        build_class_head(net, class_images)                      # warm-up (MIOpen picks its kernels here)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        head = build_class_head(net, class_images)
+        torch.cuda.synchronize(dev)
+        t_build = time.perf_counter() - t0
+        head.precision = precision
+        phases = [0.0, 0.0, 0.0]
+        n_det = 0
+        for i in range(warmup + steps):
+            if i == warmup:
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+            ev[0].record()
+            fm = net.net_feature_maps(img)
+            ev[1].record()
+            loc, cls, _, _ = head(fm)
+            ev[2].record()
+            dets = coder.decode_pyramid([loc[0].flatten(2)], [cls[0].flatten(1)], [img_size], ids,
+                                        nms_score_threshold=float("-inf"))
+            ev[3].record()
+            if i >= warmup:
+                torch.cuda.synchronize(dev)
+                for k in range(3):
+                    phases[k] += ev[k].elapsed_time(ev[k + 1])
+                n_det = len(dets)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+    return {"value": round(B * steps / dt, 2), "unit": "query-image-pairs/s", "ms_per_image": round(dt / steps * 1e3, 3),
+            "backbone_ms": round(phases[0] / steps, 3), "head_ms": round(phases[1] / steps, 3),
+            "decode_nms_ms": round(phases[2] / steps, 3), "detections_per_image": n_det,
+            "class_head_build_ms": round(t_build * 1e3, 2), "precision": precision, "steps": steps,
+            "what": "ResNet50-C4 (PyTorch-ROCm/MIOpen fp32, random init) on 1x3x960x1280 + HIP head x {} classes + HIP "
+                    "decode and per-class NMS of all 4800 boxes per class; class_head_build_ms = {} class images 240x240 "
+                    "-> backbone (one batch) -> 15x15 class maps (once per class set)".format(B, B)}
 
 
 def main():
@@ -281,6 +342,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.pyramid:
         result["cpu_baseline"] = cpu_baseline(fm_cpu, class_fms_cpu, state, inverse, args.cpu_seconds)
         result["speedup_vs_cpu_baseline"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
+    if rank == 0 and world == 1 and not args.no_end_to_end and not args.pyramid:
+        result["end_to_end"] = end_to_end(dev, B, P, inverse, state, args.precision)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if use_dist:

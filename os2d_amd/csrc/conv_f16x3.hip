@@ -43,7 +43,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_f16x3_kernel(const u32x4
                                                              const u32x4* wp,  // rematerialised BEHIND the MFMAs by the register allocator)
                                                              const float* __restrict__ bp,  // [MT] fp32 folded bias
                                                              float unscale, void* __restrict__ outv, int G,
-                                                             int CoutStore, int H, int W, int PLANE, int HALO) {
+                                                             int CoutStore, int H, int W, int PLANE, int HALO,
+                                                             int TILES, int NB) {
   constexpr int R = KS / 2;
   constexpr int TAPS = KS * KS;
   constexpr int STEPS = (TAPS + 1) / 2;
@@ -68,9 +69,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_f16x3_kernel(const u32x4
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, hw = lane >> 5;
   const int wm = wid / WN, wn = wid % WN;
-  const int nb = blockIdx.y;
-  const int n0 = BASE + blockIdx.x * NT;
-  const int mOff = blockIdx.z * MT;  // first output row of this group
+  // XCD-aware work mapping: the dispatcher places work-group L on XCD L % 8, so XCD x is given the contiguous range
+  // [x*per, (x+1)*per) of the logical order (plane, tile, channel half).  The ~40 groups of one plane - whose input slabs
+  // overlap by 2/3 (halo) and are shared by both channel halves - then run on ONE XCD at about the same time and the
+  // plane is fetched into that L2 once instead of ~6 times (FETCH_SIZE 2.0 -> 0.6 GB per launch at 64 classes).
+  constexpr int ZG = MTP / MT;
+  const int per = gridDim.x >> 3;
+  const int logical = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (logical >= TILES * NB * ZG) return;
+  const int zg = logical % ZG, tile = (logical / ZG) % TILES;
+  const int nb = logical / (ZG * TILES);
+  const int n0 = BASE + tile * NT;
+  const int mOff = zg * MT;  // first output row of this group
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -269,8 +279,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_f16x3_kernel(const u32x4
   }
   // pad rows above the data (first tile) and whatever lies beyond the last tile
   {
-    const int tail0 = BASE + gridDim.x * NT, tail = PLANE - tail0;
-    const bool first = blockIdx.x == 0 && blockIdx.z == 0, last = blockIdx.x == gridDim.x - 1 && blockIdx.z == 0;
+    const int tail0 = BASE + TILES * NT, tail = PLANE - tail0;
+    const bool first = tile == 0 && zg == 0, last = tile == TILES - 1 && zg == 0;
     if (OUT_MODE == 0) {
       const int planes = ((CoutStore + 7) >> 3) * 2;
       u32x4* o = reinterpret_cast<u32x4*>(outv) + (size_t)nb * planes * PLANE;
@@ -316,9 +326,15 @@ int launch(const void* in, const void* wp, const float* bp, float unscale, void*
     os2d_set_error("hipFuncSetAttribute(conv f16x3): %s", hipGetErrorString(e));
     return -4;
   }
-  dim3 grid((H * Ws + NT - 1) / NT, NB, MTP / MT);
+  const int tiles = (H * Ws + NT - 1) / NT;
+  const long long groups = (long long)tiles * NB * (MTP / MT);
+  if (groups + 7 > 0x7fffffffLL) {
+    os2d_set_error("conv f16x3: too many work-groups (%lld)", groups);
+    return -3;
+  }
+  dim3 grid((unsigned)((groups + 7) / 8 * 8));  // multiple of 8: every XCD gets the same number of logical slots
   hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds, stream, reinterpret_cast<const u32x4*>(in),
-                     reinterpret_cast<const u32x4*>(wp), bp, unscale, out, G, CoutStore, H, W, PLANE, HALO);
+                     reinterpret_cast<const u32x4*>(wp), bp, unscale, out, G, CoutStore, H, W, PLANE, HALO, tiles, NB);
   e = hipGetLastError();
   if (e != hipSuccess) {
     os2d_set_error("conv f16x3 launch: %s", hipGetErrorString(e));

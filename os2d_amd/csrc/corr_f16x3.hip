@@ -29,8 +29,8 @@ constexpr int NPF = CH_UNITS / NTHR;     // 4 units per thread per operand
 
 __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  // [A][CG][2][HW]   (no __restrict__, see
                                                              const u32x4* qs,  // [B][CG][2][256]    conv_f16x3.hip)
-                                                             float* __restrict__ corr, char* __restrict__ rshb, int B,
-                                                             int CG, int H, int W, int PLANE, float unscale) {
+                                                             float* __restrict__ corr, char* __restrict__ rshb, int A,
+                                                             int B, int CG, int H, int W, int PLANE, float unscale) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
   u32x4* ldsA = smem16;                 // [2][CH_UNITS]
   u32x4* ldsB = smem16 + 2 * CH_UNITS;  // [2][CH_UNITS]
@@ -40,8 +40,20 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, hw = lane >> 5;
   const int wm = wid >> 2, wn = wid & 3;  // wave tile: rows [wm*128,+128), cols [wn*64,+64)
-  const int n0 = blockIdx.x * NT;
-  const int b = blockIdx.y, a = blockIdx.z;
+  // XCD-aware work mapping (work-group L runs on XCD L % 8): XCD x gets the contiguous range [x*per, (x+1)*per) of the
+  // logical order (image, group of 4 classes, position tile, class in group).  The 32 groups resident on an XCD (one per
+  // CU) are then ~8 tiles x 4 classes marching through K together: 12 MB of distinct operand bytes per 32 groups in
+  // that XCD's L2 instead of 20+ MB with classes or tiles spread round-robin over the XCDs.
+  const int tiles = (HW + NT - 1) / NT;
+  const int per = gridDim.x >> 3;
+  const int logical = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (logical >= tiles * B * A) return;
+  const int a = logical / (tiles * B);
+  const int r_ = logical - a * tiles * B;
+  const int gb0 = (r_ / (4 * tiles)) * 4, gsz = min(4, B - gb0);
+  const int r2_ = r_ - gb0 * tiles;
+  const int b = gb0 + r2_ % gsz;
+  const int n0 = (r2_ / gsz) * NT;
   const int nb = a * B + b;
 
   f32x16 acc[4][2];
@@ -253,9 +265,10 @@ int os2d_launch_corr_f16x3(const void* fs, const void* qs, float* corr, void* rs
     os2d_set_error("hipFuncSetAttribute(corr f16x3): %s", hipGetErrorString(e));
     return -4;
   }
-  dim3 grid((HW + NT - 1) / NT, B, A);
+  const long long groups = (long long)((HW + NT - 1) / NT) * B * A;
+  dim3 grid((unsigned)((groups + 7) / 8 * 8));  // multiple of 8: every XCD gets the same number of logical slots
   hipLaunchKernelGGL(corr_f16x3_kernel, grid, dim3(NTHR), lds, stream, reinterpret_cast<const u32x4*>(fs),
-                     reinterpret_cast<const u32x4*>(qs), corr, reinterpret_cast<char*>(rshb), B, (C + 7) / 8, H, W,
+                     reinterpret_cast<const u32x4*>(qs), corr, reinterpret_cast<char*>(rshb), A, B, (C + 7) / 8, H, W,
                      os2d_plane(H, W), ldexpf(1.0f, -2 * SCALE_LOG2));
   return check("corr_f16x3");
 }

@@ -2,6 +2,8 @@
 ``make_iterator_extract_scores_from_images_batched`` (os2d/engine/evaluate.py:177-371) and the decode step of
 ``evaluate`` (:99-117) do for one image, minus datasets / dataloaders / mAP (out of scope).
 
+    class_image_views  reference evaluate.py:241-269  class-image augmentation (rotation90 / horflip / both): every
+                       view becomes one more row of the class-batched head, NMS merges the views of a class
     build_class_head   reference evaluate.py:232-274  one backbone pass per class image -> one class-batched head
                        (same-size class images go through the backbone as ONE batch instead of one call each)
     extract_scores     reference evaluate.py:306-361  per pyramid level: backbone + heads of all classes
@@ -15,10 +17,40 @@ from ..structures.feature_map import FeatureMapSize
 from .pyramid import PyramidHeadRunner
 
 
+CLASS_IMAGE_AUGMENTATIONS = ("", "rotation90", "horflip", "horflip_rotation90")
+
+
+def class_image_views(class_images, class_ids, class_image_augmentation=""):
+    """Views of every class image in the reference's order (evaluate.py:241-269): rotation90 -> [im, 90, 180, 270]
+    (``rot90`` over the two spatial dims), horflip -> [im, flipped], horflip_rotation90 -> the four rotations followed
+    by the horizontal flip of each.  Returns (views, view_class_ids, num_class_views); the id of view l is
+    ``class_ids[l // num_class_views]`` (evaluate.py:294), so ``decode_pyramid`` merges the views of a class before NMS."""
+    if class_image_augmentation not in CLASS_IMAGE_AUGMENTATIONS and class_image_augmentation is not None:
+        raise RuntimeError("Unknown value of class_image_augmentation: {}".format(class_image_augmentation))
+    views, view_ids = [], []
+    num_class_views = 1
+    for im, cid in zip(class_images, class_ids):
+        if im.dim() == 4:
+            im = im.squeeze(0)
+        mine = [im]
+        if class_image_augmentation in ("rotation90", "horflip_rotation90"):
+            for _ in range(3):
+                mine.append(mine[-1].rot90(1, [1, 2]))
+        if class_image_augmentation == "horflip":
+            mine.append(im.flip(2))
+        elif class_image_augmentation == "horflip_rotation90":
+            mine += [v.flip(2) for v in mine[:4]]
+        num_class_views = len(mine)
+        views += [v.contiguous() for v in mine]
+        view_ids += [cid] * len(mine)
+    return views, view_ids, num_class_views
+
+
 def build_class_head(net, class_images, batch_same_size=True):
     """class_images: list of [3,h,w] device tensors (already normalised).  Returns the ``Os2dHead`` of all classes in
     the given order.  The reference extracts class features one image at a time (model.py:80-88); images of equal size
-    are stacked here so the backbone sees a few large batches (identical arithmetic per image)."""
+    are stacked here so the backbone sees a few large batches (identical arithmetic per image).
+    With class-image augmentation pass the views of ``class_image_views``."""
     feats = [None] * len(class_images)
     with torch.no_grad():
         if batch_same_size:

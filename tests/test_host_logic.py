@@ -109,3 +109,23 @@ def test_boxlist_basics():
     assert len(sel) == 2 and sel.get_field("scores").tolist() == pytest.approx([0.1, 0.3])
     both = cat_boxlist([sel, sel])
     assert len(both) == 4 and BoxList(torch.tensor([[5., 5., 2., 2.]]), b.image_size, mode="cx_cy_w_h").bbox_xyxy.tolist() == [[4, 4, 6, 6]]
+
+
+def test_class_image_views_order_and_ids():
+    """reference evaluate.py:241-269,294: order of the augmented views and the id each one carries."""
+    from os2d_amd.engine.evaluate import class_image_views
+    im = torch.arange(3 * 2 * 3, dtype=torch.float32).view(3, 2, 3)
+    im2 = -im
+    v, ids, n = class_image_views([im, im2], [7, 9], "")
+    assert n == 1 and ids == [7, 9] and torch.equal(v[0], im) and torch.equal(v[1], im2)
+    v, ids, n = class_image_views([im, im2], [7, 9], "horflip")
+    assert n == 2 and ids == [7, 7, 9, 9] and torch.equal(v[1], im.flip(2)) and torch.equal(v[3], im2.flip(2))
+    v, ids, n = class_image_views([im.unsqueeze(0)], [4], "rotation90")
+    r90 = im.rot90(1, [1, 2])
+    assert n == 4 and ids == [4] * 4 and v[1].shape == (3, 3, 2)
+    assert torch.equal(v[1], r90) and torch.equal(v[2], r90.rot90(1, [1, 2])) and torch.equal(v[3], im.rot90(3, [1, 2]))
+    v, ids, n = class_image_views([im], [4], "horflip_rotation90")
+    assert n == 8 and torch.equal(v[4], im.flip(2)) and torch.equal(v[5], r90.flip(2)) and torch.equal(v[7], im.rot90(3, [1, 2]).flip(2))
+    assert all(ids[l] == [4][l // n] for l in range(8))
+    with pytest.raises(RuntimeError):
+        class_image_views([im], [4], "rot45")

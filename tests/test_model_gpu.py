@@ -104,3 +104,32 @@ def test_detect_pipeline_end_to_end(device):
     assert torch.equal(det.get_field("labels").cpu(), lab)
     assert util.maxdiff(det.get_field("scores"), sc) < 1e-5
     assert util.maxdiff(det.bbox_xyxy, b) < 1e-2
+
+
+def test_detect_with_class_image_augmentation(device):
+    """horflip_rotation90 turns 2 classes into 16 head rows; the 8 views of a class are merged before NMS
+    (reference evaluate.py:241-269,294 + box_coder.py:483-534)."""
+    from oracle import decode_oracle as D
+    from os2d_amd.engine import evaluate as E
+    net, state = _model(device, seed=6)
+    g = torch.Generator().manual_seed(3)
+    class_images = [torch.randn(3, 96, 96, generator=g).to(device), torch.randn(3, 80, 112, generator=g).to(device)]
+    levels = [torch.randn(1, 3, 128, 160, generator=g).to(device)]
+    views, view_ids, n_views = E.class_image_views(class_images, [5, 2], "horflip_rotation90")
+    assert n_views == 8 and len(views) == 16
+    head = E.build_class_head(net, views)
+    assert head.class_batch_size == 16
+    coder = net.build_box_coder()
+    det = E.detect(net, coder, levels, head, class_ids=view_ids, nms_score_threshold=0.0)
+    lab = det.get_field("labels").cpu()
+    assert set(lab.tolist()) <= {2, 5} and lab.tolist() == sorted(lab.tolist())
+    # oracle: per class, the 8 views are 8 "levels" of the same label
+    s = E.extract_scores(net, levels, head, per_level_streams=False)
+    loc, cls = s["loc"][0][0].cpu(), s["cls"][0][0].cpu()
+    fm, img = (s["fm_sizes"][0].h, s["fm_sizes"][0].w), (s["img_sizes"][0].w, s["img_sizes"][0].h)
+    expect_scores = []
+    for label, rows in ((2, range(8, 16)), (5, range(0, 8))):
+        b, sc, _ = D.decode_pyramid([loc[r:r + 1] for r in rows], [cls[r:r + 1] for r in rows], [fm] * 8, [img] * 8, None, 0.0, 0.3)
+        expect_scores.append(sc)
+        assert int((lab == label).sum()) == len(sc)
+    assert util.maxdiff(det.get_field("scores"), torch.cat(expect_scores)) < 1e-5

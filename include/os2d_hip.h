@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define OS2D_ABI_VERSION 2
+#define OS2D_ABI_VERSION 3
 
 /* arithmetic of the two large TransformNet convolutions (everything else is fp32 in both modes) */
 #define OS2D_PRECISION_F32 0   /* v_mfma_f32_32x32x2_f32: exact fp32 (k-ordered fmaf chain)                            */
@@ -132,6 +132,20 @@ int os2d_decode_boxes(const float* loc, int NB, int H, int W, int stride, int re
 int os2d_nms_workspace_bytes(int NC, int N, size_t* bytes);
 int os2d_nms(const float* boxes, const int* counts, int NC, int N, float iou_threshold, unsigned char* keep,
              int* num_keep, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- fused single-level detection: everything reference os2d/modeling/box_coder.py:448-536 does per class for ONE
+ * pyramid level, in one launch (one work-group per class, all state in LDS):
+ *   decode + clip (:319-330, bounding_box.py:261-265), drop empty boxes and scores <= score_threshold (:489-497; pass
+ *   -INFINITY to keep all), map to the output image (BoxList.resize: x * scale_x, y * scale_y; 1,1 = no mapping),
+ *   greedy NMS at iou_threshold over the boxes in decreasing score (ties in location order), survivors compacted.
+ *   loc [B,4,H*W], cls [B,H*W]  ->  out_boxes [B,H*W,4], out_scores [B,H*W], out_index [B,H*W] (source location),
+ *   of which the first out_count[b] entries of every class are valid, by decreasing score.
+ * os2d_detect_level_supported(H,W) = 1 when the level fits the kernel's LDS budget (6*pow2(H*W) + 18*H*W bytes <= 155 KB:
+ * up to about 5900 locations - 60x80 fits, 72x96 does not); otherwise use os2d_decode_boxes + os2d_nms.                                        */
+int os2d_detect_level_supported(int H, int W);
+int os2d_detect_level(const float* loc, const float* cls, int B, int H, int W, int stride, int rec_field, float img_w,
+                      float img_h, float scale_x, float scale_y, float score_threshold, float iou_threshold,
+                      float* out_boxes, float* out_scores, int* out_index, int* out_count, void* stream);
 
 #ifdef __cplusplus
 }

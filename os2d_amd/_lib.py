@@ -9,7 +9,7 @@ import os
 
 from .build import LIB_PATH
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _c_float_p = ctypes.c_void_p   # device pointers travel as raw addresses (tensor.data_ptr())
 _vp = ctypes.c_void_p
@@ -44,6 +44,8 @@ SIGNATURES = {
     "os2d_decode_boxes": (_i, [_vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp]),
     "os2d_nms_workspace_bytes": (_i, [_i, _i, ctypes.POINTER(_sz)]),
     "os2d_nms": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    "os2d_detect_level_supported": (_i, [_i, _i]),
+    "os2d_detect_level": (_i, [_vp, _vp] + [_i] * 5 + [_f] * 6 + [_vp] * 5),
 }
 
 

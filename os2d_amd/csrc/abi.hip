@@ -177,6 +177,20 @@ int os2d_decode_boxes(const float* loc, int NB, int H, int W, int stride, int re
   return os2d_launch_decode_boxes(loc, NB, H, W, stride, rec_field, img_w, img_h, boxes, S(stream));
 }
 
+int os2d_detect_level_supported(int H, int W) { return os2d_detect_level_lds_bytes(H, W) != 0 ? 1 : 0; }
+
+int os2d_detect_level(const float* loc, const float* cls, int B, int H, int W, int stride, int rec_field, float img_w,
+                      float img_h, float scale_x, float scale_y, float score_threshold, float iou_threshold,
+                      float* out_boxes, float* out_scores, int* out_index, int* out_count, void* stream) {
+  if (!loc || !cls || !out_boxes || !out_scores || !out_index || !out_count || B < 1 || H < 1 || W < 1 || stride < 1 ||
+      rec_field < 1) {
+    os2d_set_error("os2d_detect_level: bad arguments");
+    return -1;
+  }
+  return os2d_launch_detect_level(loc, cls, B, H, W, stride, rec_field, img_w, img_h, scale_x, scale_y, score_threshold,
+                                  iou_threshold, out_boxes, out_scores, out_index, out_count, S(stream));
+}
+
 int os2d_nms_workspace_bytes(int NC, int N, size_t* bytes) {
   if (!bytes || NC < 1 || N < 1) {
     os2d_set_error("os2d_nms_workspace_bytes: bad arguments");

@@ -6,9 +6,9 @@
 //
 // One 256-thread work-group per class (classes are independent), no N x N mask matrix:
 // candidates are consumed in sorted order 64 at a time;
-//   phase 1  all 4 waves test the 64 candidates against the kept list so far (kept boxes stream through L2/LDS),
-//   phase 2  the 64 x 64 intra-chunk overlaps are computed by all 4 waves (each lane ends up with the bitmask of EARLIER
-//            lanes that overlap it), then wave 0 walks the 64 candidates in order (v_readlane) to decide survivors,
+//   phase 1  all 4 waves test the 64 candidates against the kept list so far (first 2048 kept boxes in LDS, broadcast reads),
+//   phase 2  wave 0 resolves the candidates that are still alive in order: the best one is kept, every later alive
+//            candidate overlapping it dies (one 64-lane IoU test per box kept in this step), and so on,
 //   phase 3  survivors are appended to the kept list.
 // Work ~ N * kept / 256 IoU tests per class instead of N^2 / 2, and nothing but the kept list (<= N boxes) is stored.
 #include "os2d_common.h"
@@ -17,18 +17,10 @@ namespace {
 
 constexpr int KEPT_LDS = 2048;  // kept boxes cached in LDS per class (32 KB)
 
-__device__ __forceinline__ bool iou_gt(float4 a, float area_a, float4 b, float area_b, float thr) {
-  const float w = fmaxf(fminf(a.z, b.z) - fmaxf(a.x, b.x), 0.f);
-  const float h = fmaxf(fminf(a.w, b.w) - fmaxf(a.y, b.y), 0.f);
-  const float inter = w * h;
-  return inter / (area_a + area_b - inter) > thr;
-}
-
 __global__ __launch_bounds__(256) void nms_kernel(const float4* __restrict__ boxes,  // [NC][N] sorted by score desc
                                                   const int* __restrict__ counts,    // [NC]
                                                   int N, float thr, unsigned char* __restrict__ keep,  // [NC][N]
                                                   int* __restrict__ num_keep, float4* __restrict__ kept_ws) {
-  __shared__ float4 cand[64];
   __shared__ float4 kept_lds[KEPT_LDS];  // the kept list lives in LDS (broadcast reads); only its tail spills to HBM
   __shared__ int dead[4][64];
   __shared__ int kept_count;
@@ -42,7 +34,6 @@ __global__ __launch_bounds__(256) void nms_kernel(const float4* __restrict__ box
   if (tid == 0) kept_count = 0;
   __syncthreads();
 
-  __shared__ unsigned int sup_lo[4][64], sup_hi[4][64];
   float4 nxt = (lane < n) ? bx[lane] : make_float4(0.f, 0.f, 0.f, 0.f);  // candidates of the next chunk, prefetched
   for (int base = 0; base < n; base += 64) {
     const int nk = kept_count;  // kept before this chunk (uniform)
@@ -51,46 +42,39 @@ __global__ __launch_bounds__(256) void nms_kernel(const float4* __restrict__ box
     const float4 me = nxt;
     if (base + 64 + lane < n) nxt = bx[base + 64 + lane];  // in flight while this chunk is resolved
     const float my_area = (me.z - me.x) * (me.w - me.y);
-    if (wv == 0) cand[lane] = me;
     // ---- phase 1: against the kept list, 4 waves take interleaved kept boxes
     int d = 0;
     const int nk_lds = min(nk, KEPT_LDS);
     for (int j = wv; j < nk_lds; j += 4) {  // no early exit: a wave-uniform trip count keeps the loop pipelined
       const float4 k = kept_lds[j];
-      d |= iou_gt(k, (k.z - k.x) * (k.w - k.y), me, my_area, thr) ? 1 : 0;
+      d |= os2d_iou_gt(k, (k.z - k.x) * (k.w - k.y), me, my_area, thr) ? 1 : 0;
     }
     for (int j = KEPT_LDS + wv; j < nk; j += 4) {
-      const float4 k = kept[j];
-      d |= iou_gt(k, (k.z - k.x) * (k.w - k.y), me, my_area, thr) ? 1 : 0;
+      const volatile float4* kv = kept;  // written by wave 0 in earlier steps: read past this CU's L1
+      float4 k;
+      k.x = kv[j].x;
+      k.y = kv[j].y;
+      k.z = kv[j].z;
+      k.w = kv[j].w;
+      d |= os2d_iou_gt(k, (k.z - k.x) * (k.w - k.y), me, my_area, thr) ? 1 : 0;
     }
     dead[wv][lane] = d;
     __syncthreads();
-    // ---- phase 2a: 64 x 64 intra-chunk overlaps, wave w tests candidates 16w .. 16w+15 against every lane
-    {
-      unsigned int bits = 0u;
-#pragma unroll 4
-      for (int t = 0; t < 16; ++t) {
-        const int i = wv * 16 + t;
-        const float4 o = cand[i];
-        const bool hit = (i < lane) && iou_gt(o, (o.z - o.x) * (o.w - o.y), me, my_area, thr);
-        bits |= hit ? (1u << t) : 0u;
-      }
-      // bit t of wave w = candidate 16w+t: waves 0,1 fill the low word, waves 2,3 the high word
-      sup_lo[wv][lane] = (wv < 2) ? (bits << (16 * wv)) : 0u;
-      sup_hi[wv][lane] = (wv >= 2) ? (bits << (16 * (wv - 2))) : 0u;
-    }
-    __syncthreads();
-    // ---- phase 2b: in-order resolve, wave 0
+    // ---- phase 2: in-order resolve, wave 0
     if (wv == 0) {
       const bool pre_dead = (dead[0][lane] | dead[1][lane] | dead[2][lane] | dead[3][lane]) != 0 || !valid;
-      const unsigned int lo = sup_lo[0][lane] | sup_lo[1][lane], hi = sup_hi[2][lane] | sup_hi[3][lane];
-      const unsigned long long alive0 = ~__ballot(pre_dead);  // candidates not killed by the kept list
+      unsigned long long alive = ~__ballot(pre_dead);  // candidates not killed by the kept list
       unsigned long long kbits = 0ull;
-      for (int i = 0; i < 64; ++i) {
-        // readlane returns a signed int: go through unsigned int or bit 31 would sign-extend into the high word
-        const unsigned long long s = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)hi, i) << 32) |
-                                     (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)lo, i);
-        if (((alive0 >> i) & 1ull) && (s & kbits) == 0ull) kbits |= (1ull << i);
+      while (alive) {
+        const int i = __builtin_ctzll(alive);  // best-scoring candidate still alive: kept
+        kbits |= 1ull << i;
+        float4 kb;
+        kb.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, me.x), i));
+        kb.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, me.y), i));
+        kb.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, me.z), i));
+        kb.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, me.w), i));
+        const bool hit = os2d_iou_gt(kb, (kb.z - kb.x) * (kb.w - kb.y), me, my_area, thr);
+        alive &= ~(__ballot(hit) | ((2ull << i) - 1ull));  // drop lanes 0..i and everything the new box suppresses
       }
       const bool k = (kbits >> lane) & 1ull;
       if (valid) kp[idx] = k ? 1 : 0;

@@ -37,6 +37,50 @@ static inline __host__ __device__ bool os2d_interior(int n, int H, int W) {
   return r >= 0 && r < H * os2d_ws(W) && (r % os2d_ws(W)) < W;
 }
 
+// Box decode of ONE location (reference os2d/modeling/box_coder.py:319-330 = torchvision BoxCoder.decode_single with
+// weights (10,10,5,5) and the dw/dh clamp log(1000/16), then clip_boxes_to_image): shared by decode_boxes_kernel and
+// detect_level_kernel so both produce bit-identical boxes.  ``l`` points at loc[nb][0][n]; channel stride HW.
+__device__ __forceinline__ float4 os2d_decode_box(const float* __restrict__ l, int HW, int n, int W, float stride,
+                                                  float half_box, float img_w, float img_h) {
+  const int h = n / W, w = n - h * W;
+  const float ecx = stride * ((float)w + 0.5f), ecy = stride * ((float)h + 0.5f);
+  const float ax1 = ecx - half_box, ay1 = ecy - half_box;
+  const float aw = (ecx + half_box) - ax1, ah = (ecy + half_box) - ay1;
+  const float acx = ax1 + 0.5f * aw, acy = ay1 + 0.5f * ah;
+  const float clipv = 4.135166556742356f;  // log(1000/16): torchvision BoxCoder.bbox_xform_clip
+  const float dx = l[0] / 10.0f, dy = l[HW] / 10.0f;
+  const float dw = fminf(l[2 * (size_t)HW] / 5.0f, clipv), dh = fminf(l[3 * (size_t)HW] / 5.0f, clipv);
+  const float pcx = dx * aw + acx, pcy = dy * ah + acy;
+  const float pw = expf(dw) * aw, ph = expf(dh) * ah;
+  float4 o = make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph);
+  if (img_w > 0.f && img_h > 0.f) {  // clip_boxes_to_image; a non-positive size means "leave unclipped"
+    o.x = fminf(fmaxf(o.x, 0.f), img_w);
+    o.y = fminf(fmaxf(o.y, 0.f), img_h);
+    o.z = fminf(fmaxf(o.z, 0.f), img_w);
+    o.w = fminf(fmaxf(o.w, 0.f), img_h);
+  }
+  return o;
+}
+
+// IoU(a, b) > thr with torchvision's arithmetic (inter / (area_a + area_b - inter) in fp32, reference
+// os2d/structures/bounding_box.py:367 -> torchvision.ops.nms).  The IEEE division (a dozen VALU instructions) is only
+// executed when some lane of the wave is within 1e-5 (relative) of the threshold - everywhere else comparing inter with
+// thr * union gives the same answer as the rounded quotient.  The vote makes the branch wave-uniform, so it is a real
+// branch and not an if-converted select.
+__device__ __forceinline__ bool os2d_iou_gt(float4 a, float area_a, float4 b, float area_b, float thr) {
+  const float w = fmaxf(fminf(a.z, b.z) - fmaxf(a.x, b.x), 0.f);
+  const float h = fmaxf(fminf(a.w, b.w) - fmaxf(a.y, b.y), 0.f);
+  const float inter = w * h;
+  const float uni = area_a + area_b - inter;
+  const float tu = thr * uni;
+  bool res = inter > tu;
+  const bool near = !(uni > 0.f && fabsf(inter - tu) > 1e-5f * fabsf(tu));
+  if (__builtin_amdgcn_ballot_w64(near) != 0ull) {
+    if (near) res = inter / uni > thr;
+  }
+  return res;
+}
+
 // error plumbing (abi.hip)
 void os2d_set_error(const char* fmt, ...);
 
@@ -71,6 +115,11 @@ int os2d_launch_decode_boxes(const float* loc, int NB, int H, int W, int stride,
 // nms.hip
 int os2d_launch_nms(const float* boxes, const int* counts, int NC, int N, float thr, unsigned char* keep, int* num_keep,
                     void* workspace, hipStream_t stream);
+// detect.hip
+size_t os2d_detect_level_lds_bytes(int H, int W);
+int os2d_launch_detect_level(const float* loc, const float* cls, int B, int H, int W, int stride, int rec_field,
+                             float img_w, float img_h, float scale_x, float scale_y, float score_thr, float iou_thr,
+                             float* out_boxes, float* out_scores, int* out_index, int* out_count, hipStream_t stream);
 // corr_f16x3.hip
 int os2d_launch_split_fm(const float* fm, const float* sumsq, void* fs, int A, int C, int HW, hipStream_t stream);
 int os2d_launch_split_qp(const float* qp, void* qs, int B, int C, hipStream_t stream);

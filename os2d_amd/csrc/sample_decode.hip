@@ -143,24 +143,7 @@ __global__ __launch_bounds__(256) void decode_boxes_kernel(const float* __restri
   const int n = blockIdx.x * 256 + threadIdx.x;
   const int nb = blockIdx.y;
   if (n >= HW) return;
-  const int h = n / W, w = n - h * W;
-  const float ecx = stride * ((float)w + 0.5f), ecy = stride * ((float)h + 0.5f);
-  const float ax1 = ecx - half_box, ay1 = ecy - half_box;
-  const float aw = (ecx + half_box) - ax1, ah = (ecy + half_box) - ay1;
-  const float acx = ax1 + 0.5f * aw, acy = ay1 + 0.5f * ah;
-  const float* l = loc + (size_t)nb * 4 * HW + n;
-  const float clipv = 4.135166556742356f;  // log(1000/16): torchvision BoxCoder.bbox_xform_clip
-  const float dx = l[0] / 10.0f, dy = l[HW] / 10.0f;
-  const float dw = fminf(l[2 * (size_t)HW] / 5.0f, clipv), dh = fminf(l[3 * (size_t)HW] / 5.0f, clipv);
-  const float pcx = dx * aw + acx, pcy = dy * ah + acy;
-  const float pw = expf(dw) * aw, ph = expf(dh) * ah;
-  float4 o = make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph);
-  if (img_w > 0.f && img_h > 0.f) {  // clip_boxes_to_image; a non-positive size means "leave unclipped"
-    o.x = fminf(fmaxf(o.x, 0.f), img_w);
-    o.y = fminf(fmaxf(o.y, 0.f), img_h);
-    o.z = fminf(fmaxf(o.z, 0.f), img_w);
-    o.w = fminf(fmaxf(o.w, 0.f), img_h);
-  }
+  const float4 o = os2d_decode_box(loc + (size_t)nb * 4 * HW + n, HW, n, W, stride, half_box, img_w, img_h);
   reinterpret_cast<float4*>(boxes)[(size_t)nb * HW + n] = o;
 }
 

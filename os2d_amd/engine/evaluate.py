@@ -13,6 +13,7 @@ from collections import OrderedDict
 
 import torch
 
+from ..modeling.box_coder import ResizeBoxes
 from ..structures.feature_map import FeatureMapSize
 from .pyramid import PyramidHeadRunner
 
@@ -86,7 +87,7 @@ def detect(net, box_coder, image_levels, class_head, class_ids, orig_size=None, 
     a = image_index
     inverse = None
     if orig_size is not None:
-        inverse = [(lambda boxes, size=orig_size: boxes.resize(size)) for _ in image_levels]
+        inverse = [ResizeBoxes(orig_size) for _ in image_levels]
     return box_coder.decode_pyramid([l[a] for l in s["loc"]], [c[a] for c in s["cls"]], s["img_sizes"], class_ids,
                                     nms_score_threshold=nms_score_threshold, nms_iou_threshold=nms_iou_threshold,
                                     inverse_box_transforms=inverse,

@@ -2,7 +2,8 @@
 
     create_strided_boxes_columnfirst / BoxGridGenerator   reference box_coder.py:16-76
     Os2dBoxCoder.build_boxes_from_loc_scores              reference box_coder.py:319-330   (os2d_decode_boxes)
-    Os2dBoxCoder.decode_pyramid                           reference box_coder.py:448-536   (os2d_decode_boxes + os2d_nms)
+    Os2dBoxCoder.decode_pyramid                           reference box_coder.py:448-536   (os2d_detect_level for one level,
+                                                                                            os2d_decode_boxes + os2d_nms otherwise)
 
 Only the inference half of the reference class is mirrored: target encoding / anchor matching / hard-negative
 remapping are training-only and out of scope.
@@ -29,6 +30,21 @@ def create_strided_boxes_columnfirst(grid_size, box_size, box_stride):
     cy = cy.view(-1, 1).expand(grid_size.h, grid_size.w).reshape(-1)
     hw, hh = box_size.w / 2.0, box_size.h / 2.0
     return torch.stack([cx - hw, cy - hh, cx + hw, cy + hh], dim=1)
+
+
+class ResizeBoxes(object):
+    """``inverse_box_transforms`` entry that maps a level's boxes to ``target_size`` (what the reference's
+    ``TransformList`` inverse amounts to for a resized image, box_coder.py:499-503): ``boxlist.resize(target_size)``.
+    Being a recognisable type (not a lambda) lets ``decode_pyramid`` hand the two scale factors to the fused kernel."""
+
+    def __init__(self, target_size):
+        self.target_size = target_size
+
+    def __call__(self, boxlist):
+        return boxlist.resize(self.target_size)
+
+    def ratios(self, img_size):
+        return float(self.target_size.w) / img_size.w, float(self.target_size.h) / img_size.h
 
 
 class BoxGridGenerator(object):
@@ -65,6 +81,8 @@ class Os2dBoxCoder(object):
         self.remap_classification_targets_iou_pos = remap_classification_targets_iou_pos
         self.remap_classification_targets_iou_neg = remap_classification_targets_iou_neg
         self.do_nms_across_classes = do_nms_across_classes
+        self.nms_max_batch = 10000          # reference bounding_box.py:344 (``nms_max_batch_size``)
+        self.use_fused_level_kernel = True  # single-level calls go through os2d_detect_level when the level fits
         self.weights = BOX_ENCODING_WEIGHTS
         g = output_box_grid_generator
         if g is None:
@@ -170,6 +188,11 @@ class Os2dBoxCoder(object):
         Returns a BoxList with fields scores, labels, default_boxes (and transform_corners if given)."""
         num_classes = len(class_ids)
         dev = cls_scores_pyramid[0].device
+        fused = self._decode_single_level_fused(loc_scores_pyramid, cls_scores_pyramid, img_size_pyramid, class_ids,
+                                                nms_score_threshold, nms_iou_threshold, inverse_box_transforms,
+                                                transform_corners_pyramid)
+        if fused is not None:
+            return self._nms_across_classes(fused, nms_iou_threshold)
         boxes_l, scores_l, valid_l, dflt_l, corners_l = [], [], [], [], []
         for lvl, (loc, cls, img_size) in enumerate(zip(loc_scores_pyramid, cls_scores_pyramid, img_size_pyramid)):
             assert loc.device == dev and cls.device == dev, "scores and boxes should be on the same device"
@@ -220,11 +243,20 @@ class Os2dBoxCoder(object):
                 return torch.stack(out, 0)
             boxes, scores, valid, dflt = merge(boxes, 0.0), merge(scores, float("-inf")), merge(valid, False), merge(dflt, 0.0)
             corners = merge(corners, 0.0) if corners is not None else None
-        keep = self._nms_lists(boxes, scores, valid, nms_iou_threshold)
-        # per label: survivors by decreasing score (box_coder.py:431-437)
-        key = torch.where(keep, scores, torch.full_like(scores, float("-inf")))
-        order = torch.argsort(key, dim=1, descending=True, stable=True)
-        keep_sorted = torch.gather(keep, 1, order)
+        if boxes.size(1) <= self.nms_max_batch:
+            # every list fits one NMS batch (always true for a single level): ONE stable sort by score, NMS on the sorted
+            # lists, and the survivors are already in the output order - no host synchronisation before the final
+            # ``nonzero`` that sizes the result
+            key = torch.where(valid, scores, torch.full_like(scores, float("-inf")))
+            order = torch.argsort(key, dim=1, descending=True, stable=True)
+            b_sorted = torch.gather(boxes, 1, order.unsqueeze(-1).expand(-1, -1, 4))
+            keep_sorted = self.nms_sorted(b_sorted, valid.sum(1), nms_iou_threshold)
+        else:
+            keep = self._nms_lists(boxes, scores, valid, nms_iou_threshold, self.nms_max_batch)
+            # per label: survivors by decreasing score (box_coder.py:431-437)
+            key = torch.where(keep, scores, torch.full_like(scores, float("-inf")))
+            order = torch.argsort(key, dim=1, descending=True, stable=True)
+            keep_sorted = torch.gather(keep, 1, order)
         sel = keep_sorted.reshape(-1).nonzero().squeeze(1)
         flat = (order + torch.arange(order.size(0), device=dev).unsqueeze(1) * order.size(1)).reshape(-1)[sel]
         out_size = img_size_pyramid[0]
@@ -237,11 +269,78 @@ class Os2dBoxCoder(object):
         result.add_field("default_boxes", BoxList(dflt.reshape(-1, 4)[flat], out_size))
         if corners is not None:
             result.add_field("transform_corners", corners.reshape(-1, 8)[flat])
-        if self.do_nms_across_classes:
+        return self._nms_across_classes(result, nms_iou_threshold)
+
+    def _nms_across_classes(self, result, nms_iou_threshold):
+        """reference box_coder.py:530-534 (``eval.nms_across_classes``, off by default)."""
+        if self.do_nms_across_classes and len(result) > 0:
             b = result.bbox_xyxy.unsqueeze(0)
             s = result.get_field("scores").unsqueeze(0)
             k = self._nms_lists(b, s, torch.ones_like(s, dtype=torch.bool), nms_iou_threshold)[0]
             idx = k.nonzero().squeeze(1)
             idx = idx[torch.argsort(s[0][idx], descending=True, stable=True)]
             result = result[idx]
+        return result
+
+    def _decode_single_level_fused(self, loc_pyr, cls_pyr, size_pyr, class_ids, score_thr, iou_thr, inverse, corners_pyr):
+        """One level, one row per label, an identity / ``ResizeBoxes`` mapping, and a level that fits the kernel's LDS:
+        the whole per-class chain runs in ONE launch (os2d_detect_level); None when the generic path has to be used."""
+        if not self.use_fused_level_kernel or len(loc_pyr) != 1:
+            return None
+        ids = [int(c) for c in class_ids]
+        if len(set(ids)) != len(ids):
+            return None
+        t = inverse[0] if inverse is not None else None
+        if t is not None and not isinstance(t, ResizeBoxes):
+            return None
+        loc, cls, img_size = loc_pyr[0], cls_pyr[0], size_pyr[0]
+        fm = self.get_feature_map_size(img_size)
+        lib = _lib.load()
+        if not lib.os2d_detect_level_supported(fm.h, fm.w):
+            return None
+        if not (loc.is_cuda and cls.is_cuda and loc.dtype == torch.float32):
+            raise RuntimeError("decode runs on the HIP device only (no CPU fallback)")
+        dev = cls.device
+        B, HW = len(ids), fm.h * fm.w
+        loc = loc.contiguous()
+        cls = cls.float().contiguous()
+        assert tuple(loc.shape) == (B, 4, HW) and tuple(cls.shape) == (B, HW), "level tensors do not match class_ids / feature map"
+        rx, ry = t.ratios(img_size) if t is not None else (1.0, 1.0)
+        out_size = t.target_size if t is not None else img_size
+        out_boxes = torch.empty(B, HW, 4, dtype=torch.float32, device=dev)
+        out_scores = torch.empty(B, HW, dtype=torch.float32, device=dev)
+        out_index = torch.empty(B, HW, dtype=torch.int32, device=dev)
+        out_count = torch.empty(B, dtype=torch.int32, device=dev)
+        _lib.check(lib.os2d_detect_level(_lib.ptr(loc), _lib.ptr(cls), B, fm.h, fm.w, self._stride, self._rec_field,
+                                         ctypes.c_float(img_size.w), ctypes.c_float(img_size.h), ctypes.c_float(rx),
+                                         ctypes.c_float(ry), ctypes.c_float(score_thr), ctypes.c_float(iou_thr),
+                                         _lib.ptr(out_boxes), _lib.ptr(out_scores), _lib.ptr(out_index),
+                                         _lib.ptr(out_count), _lib.current_stream(dev)), "os2d_detect_level")
+        # rows in ascending label order (the reference iterates ``set(class_ids)``), survivors of a row by score
+        order = sorted(range(B), key=lambda i: ids[i])
+        counts = out_count
+        if order != list(range(B)):
+            perm = torch.tensor(order, dtype=torch.long, device=dev)
+            counts = out_count[perm]
+        else:
+            perm = None
+        mask = torch.arange(HW, device=dev).unsqueeze(0) < counts.unsqueeze(1)
+        row, pos = mask.nonzero(as_tuple=True)                   # the one host synchronisation: sizes the result
+        src_row = perm[row] if perm is not None else row
+        flat = src_row * HW + pos
+        result = BoxList(out_boxes.view(-1, 4)[flat], out_size)
+        result.add_field("scores", out_scores.view(-1)[flat])
+        result.add_field("labels", torch.tensor([ids[i] for i in order], dtype=torch.long, device=dev)[row])
+        loc_idx = out_index.view(-1)[flat].long()
+        dflt = self._get_default_boxes(img_size).bbox_xyxy.to(dev)[loc_idx]
+        scale = None
+        if t is not None:
+            scale = torch.tensor([rx, ry, rx, ry], dtype=torch.float32, device=dev) if rx != ry else rx
+            dflt = dflt * scale
+        result.add_field("default_boxes", BoxList(dflt, out_size))
+        if corners_pyr is not None:
+            corners = corners_pyr[0][src_row, :, loc_idx]                                   # [n, 8]
+            if scale is not None:
+                corners = (corners.view(-1, 4) * scale).view(-1, 8)
+            result.add_field("transform_corners", corners)
         return result

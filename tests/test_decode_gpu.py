@@ -100,3 +100,84 @@ def test_no_detections_and_single_box(device):
     res = coder.decode_pyramid([loc], [cls2], [size], class_ids=[0, 1], nms_score_threshold=0.8)
     lab = res.get_field("labels").cpu()
     assert int((lab == 1).sum()) == 1 and abs(float(res.get_field("scores")[lab.tolist().index(1)]) - 0.9) < 1e-6
+
+
+def _assert_same_detections(a, b):
+    assert len(a) == len(b) and a.image_size == b.image_size
+    assert torch.equal(a.get_field("labels"), b.get_field("labels"))
+    assert torch.equal(a.get_field("scores"), b.get_field("scores"))
+    assert torch.equal(a.bbox_xyxy, b.bbox_xyxy)
+    assert torch.equal(a.get_field("default_boxes").bbox_xyxy, b.get_field("default_boxes").bbox_xyxy)
+    if a.has_field("transform_corners"):
+        assert torch.equal(a.get_field("transform_corners"), b.get_field("transform_corners"))
+
+
+@pytest.mark.parametrize("H,W,B", [(11, 13, 5), (60, 80, 8), (1, 1, 2), (64, 80, 3)])
+@pytest.mark.parametrize("thr", [float("-inf"), 0.0, 0.4])
+def test_fused_level_kernel_equals_generic_path(H, W, B, thr, device):
+    """os2d_detect_level (decode + filter + sort + NMS + compaction in one launch) against the generic chain
+    os2d_decode_boxes -> stable sort -> os2d_nms, which the other tests pin to the reference fixture and the oracle:
+    identical boxes, scores, labels, anchors and corners, bit for bit, incl. an anisotropic resize to the original
+    image, unsorted class ids and tied scores."""
+    from os2d_amd.modeling.box_coder import ResizeBoxes
+    from os2d_amd.structures.feature_map import FeatureMapSize
+    rs = np.random.RandomState(H * 100 + W + B)
+    size = FeatureMapSize(w=16 * W, h=16 * H)
+    loc = torch.from_numpy((rs.standard_normal((B, 4, H * W)) * 1.2).astype(np.float32)).to(device)
+    cls_np = rs.uniform(-1, 1, size=(B, H * W)).astype(np.float32)
+    if H * W > 40:
+        cls_np[0, 5:25] = cls_np[0, 5]          # ties: location order must decide
+        cls_np[1, :] = 0.5                      # a whole class of equal scores
+        loc[1] *= 0.1
+    cls = torch.from_numpy(cls_np).to(device)
+    corners = torch.from_numpy(rs.uniform(0, 300, size=(B, 8, H * W)).astype(np.float32)).to(device)
+    ids = list(rs.permutation(B) * 3 + 1)
+    coder = _coder()
+    assert coder._decode_single_level_fused([loc], [cls], [size], ids, thr, 0.3, None, None) is not None, "fused path not taken"
+    for inverse in (None, [ResizeBoxes(FeatureMapSize(w=int(size.w * 1.7), h=int(size.h * 1.3) + 1))]):
+        coder.use_fused_level_kernel = True
+        fused = coder.decode_pyramid([loc], [cls], [size], ids, nms_score_threshold=thr, inverse_box_transforms=inverse,
+                                     transform_corners_pyramid=[corners])
+        coder.use_fused_level_kernel = False
+        generic = coder.decode_pyramid([loc], [cls], [size], ids, nms_score_threshold=thr, inverse_box_transforms=inverse,
+                                       transform_corners_pyramid=[corners])
+        _assert_same_detections(fused, generic)
+        assert len(fused) > 0 or thr > 0.3 or H * W == 1
+
+
+def test_fused_level_kernel_fallbacks(device):
+    """Levels too large for LDS, merged labels and unknown box transforms use the generic path."""
+    from os2d_amd import _lib
+    from os2d_amd.structures.feature_map import FeatureMapSize
+    lib = _lib.load()
+    assert lib.os2d_detect_level_supported(60, 80) == 1 and lib.os2d_detect_level_supported(96, 128) == 0
+    coder = _coder()
+    size = FeatureMapSize(w=208, h=176)
+    loc = torch.zeros(2, 4, 11 * 13, device=device)
+    cls = torch.rand(2, 11 * 13, device=device)
+    assert coder._decode_single_level_fused([loc], [cls], [size], [4, 4], 0.0, 0.3, None, None) is None
+    assert coder._decode_single_level_fused([loc], [cls], [size], [1, 2], 0.0, 0.3, [lambda b: b], None) is None
+    assert coder._decode_single_level_fused([loc, loc], [cls, cls], [size, size], [1, 2], 0.0, 0.3, None, None) is None
+    assert coder._decode_single_level_fused([loc], [cls], [size], [1, 2], 0.0, 0.3, None, None) is not None
+
+
+def test_all_boxes_survive_long_kept_lists(device):
+    """4800 disjoint 8x8 boxes per class: every box is kept, so the kept list outgrows the LDS lists of nms_kernel (2048)
+    and detect_level_kernel (pow2/4) and continues in global memory - both paths must still agree and keep everything."""
+    from os2d_amd.structures.feature_map import FeatureMapSize
+    H, W, B = 60, 80, 3
+    rs = np.random.RandomState(11)
+    size = FeatureMapSize(w=16 * W, h=16 * H)
+    loc = torch.zeros(B, 4, H * W)
+    loc[:, 2:] = 5.0 * float(np.log(8.0 / 240.0))
+    loc[2, :2] = torch.from_numpy(rs.uniform(-0.1, 0.1, size=(2, H * W)).astype(np.float32))   # jitter < 2.4 px: still disjoint
+    cls = torch.from_numpy(rs.uniform(0.1, 1, size=(B, H * W)).astype(np.float32))
+    coder = _coder()
+    out = []
+    for fused in (True, False):
+        coder.use_fused_level_kernel = fused
+        out.append(coder.decode_pyramid([loc.to(device)], [cls.to(device)], [size], [0, 1, 2], nms_score_threshold=0.0))
+    _assert_same_detections(out[0], out[1])
+    assert len(out[0]) == B * H * W
+    s = out[0].get_field("scores").view(B, H * W).cpu()
+    assert torch.equal(s, torch.sort(cls, dim=1, descending=True)[0])

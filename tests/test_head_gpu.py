@@ -193,3 +193,34 @@ def test_full_size_class_batch_invariance(precision, device):
         assert torch.equal(part[i][:, 0:2], full[i][:, 4:6]) and torch.equal(part[i][:, 2:4], full[i][:, 1:3])
     assert torch.isfinite(full[0]).all() and torch.isfinite(full[1]).all() and torch.isfinite(full[3]).all()
     assert float(full[1].min()) > 0.2 and float(full[1].max()) < 0.6      # post-ReLU features: scores 0.3-0.45
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_baseline_config_256_classes_v1_properties(precision, device):
+    """BASELINE.json configs[3] size (256 classes, V1 head, 1024x60x80) through size-independent properties:
+    * both inputs are L2-normalised by the head (reference head.py:293,339), so scaling the image features by 3 and
+      the class features by 0.25 (exact power of two / small odd factor) leaves every output unchanged to round-off;
+    * a class repeated in the batch gives bit-identical rows wherever it sits (first, middle, last chunk);
+    * the 256-class run equals the 64-class runs of its four quarters bit for bit (class chunking / XCD work mapping
+      do not leak between classes)."""
+    from os2d_amd.utils import synthetic
+    P, inverse, B = 4, False, 256
+    state = synthetic.make_transform_net_state(P, seed=2)
+    fm = synthetic.make_feature_map(1024, 60, 80, seed=3).to(device)
+    class_fms = [c.to(device) for c in synthetic.make_class_feature_maps(B, 1024, seed=2000)]
+    class_fms[100] = class_fms[0]
+    class_fms[255] = class_fms[0]
+    creator = util.make_head_creator(P, inverse, state, device)
+    with torch.no_grad():
+        head = creator.create_os2d_head(class_fms)
+        full = head(fm, precision=precision)
+        for i in (0, 1, 3):
+            assert torch.equal(full[i][:, 0], full[i][:, 100]) and torch.equal(full[i][:, 0], full[i][:, 255])
+        for q in range(4):
+            part = creator.create_os2d_head(class_fms[64 * q:64 * (q + 1)])(fm, precision=precision)
+            for i in (0, 1, 3):
+                assert torch.equal(part[i], full[i][:, 64 * q:64 * (q + 1)])
+        scaled = creator.create_os2d_head([c * 0.25 for c in class_fms])(fm * 3.0, precision=precision)
+    assert util.maxdiff(scaled[1], full[1]) < TOL_CLS
+    assert util.maxdiff(scaled[0], full[0]) < TOL_LOC
+    assert torch.isfinite(full[0]).all() and torch.isfinite(full[3]).all()

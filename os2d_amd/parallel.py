@@ -93,6 +93,50 @@ def all_gather_class_outputs(flat_local, counts, A, H, W, group=None, channels=O
     return _assemble(gathered, list(counts), A, H, W, tuple(channels))
 
 
+def all_gather_detections(detections, group=None):
+    """Class-sharded decode: every rank has decoded + NMS-ed ITS classes (``Os2dBoxCoder.decode_pyramid`` on the local
+    block; NMS is per class, reference config.py:202), and only the surviving detections cross xGMI - a few thousand
+    boxes of 18 floats instead of B x H x W score maps.  ``detections`` is the rank's ``BoxList`` (fields scores,
+    labels, default_boxes, optionally transform_corners); returns the union on every rank, ordered by label
+    (stable: rank order, then the rank's own order, i.e. decreasing score within a label).
+    Two collectives: the per-rank counts, then ONE padded all-gather of the packed rows."""
+    from .structures.bounding_box import BoxList
+    world = dist.get_world_size(group)
+    dev = detections.bbox_xyxy.device
+    has_corners = detections.has_field("transform_corners")
+    n = len(detections)
+    cols = [detections.bbox_xyxy.view(n, 4), detections.get_field("scores").view(n, 1).float(),
+            detections.get_field("default_boxes").bbox_xyxy.view(n, 4)]
+    if has_corners:
+        cols.append(detections.get_field("transform_corners").view(n, 8).float())
+    packed = torch.cat(cols, dim=1)                                   # [n, 9 or 17] float32
+    labels = detections.get_field("labels").view(n).to(torch.int64)
+    counts = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, torch.tensor([n], dtype=torch.int64, device=dev), group=group)
+    counts = counts.tolist()
+    n_max = max(counts)
+    width = packed.size(1)
+    send = torch.zeros(n_max, width + 2, dtype=torch.float32, device=dev)   # labels ride along as two exact fp32 halves
+    if n:
+        send[:n, :width] = packed
+        send[:n, width] = (labels >> 20).float()
+        send[:n, width + 1] = (labels & 0xFFFFF).float()
+    recv = torch.empty(world * n_max, width + 2, dtype=torch.float32, device=dev)
+    if n_max:
+        dist.all_gather_into_tensor(recv, send, group=group)
+    rows = torch.cat([recv[r * n_max:r * n_max + counts[r]] for r in range(world)], dim=0)
+    lab = (rows[:, width].long() << 20) | rows[:, width + 1].long()
+    order = torch.argsort(lab, stable=True)
+    rows, lab = rows[order], lab[order]
+    out = BoxList(rows[:, 0:4].contiguous(), detections.image_size)
+    out.add_field("scores", rows[:, 4].contiguous())
+    out.add_field("labels", lab)
+    out.add_field("default_boxes", BoxList(rows[:, 5:9].contiguous(), detections.image_size))
+    if has_corners:
+        out.add_field("transform_corners", rows[:, 9:17].contiguous())
+    return out
+
+
 class ClassShardedHead(object):
     """Class-parallel wrapper around ``Os2dHead``: build it on every rank with the SAME global list of class feature
     maps (or with ``local_head`` prebuilt for the rank's block); ``forward`` returns the full-size outputs on every

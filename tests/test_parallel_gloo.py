@@ -94,3 +94,54 @@ def test_class_sharded_head_world2(n_classes, gather):
     for rank, ok, shape in sorted(results):
         assert ok, "rank {} assembled a wrong result".format(rank)
         assert shape == (2, n_classes, 1, 7, 9)
+
+
+def _det_worker(rank, world, port, result_queue):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from os2d_amd.parallel import all_gather_detections
+        from os2d_amd.structures.bounding_box import BoxList
+        from os2d_amd.structures.feature_map import FeatureMapSize
+        size = FeatureMapSize(w=640, h=480)
+
+        def make(rank_):
+            g = torch.Generator().manual_seed(100 + rank_)
+            n = [5, 0, 3][rank_]                      # rank 1 has found nothing
+            det = BoxList(torch.rand(n, 4, generator=g) * 100, size)
+            det.add_field("scores", torch.rand(n, generator=g))
+            # rank 0 holds labels 0,1 ; rank 2 holds a huge label id (exact transport) and label 7
+            labels = [torch.tensor([0, 0, 1, 1, 1]), torch.zeros(0, dtype=torch.long), torch.tensor([7, 7, (1 << 33) + 5])][rank_]
+            det.add_field("labels", labels)
+            det.add_field("default_boxes", BoxList(torch.rand(n, 4, generator=g) * 50, size))
+            det.add_field("transform_corners", torch.rand(n, 8, generator=g))
+            return det
+        mine = make(rank)
+        got = all_gather_detections(mine)
+        parts = [make(r) for r in range(world)]
+        ok = len(got) == 8 and got.image_size == size
+        ok = ok and got.get_field("labels").tolist() == [0, 0, 1, 1, 1, 7, 7, (1 << 33) + 5]
+        ok = ok and torch.equal(got.bbox_xyxy, torch.cat([p.bbox_xyxy for p in parts]))
+        ok = ok and torch.equal(got.get_field("scores"), torch.cat([p.get_field("scores") for p in parts]))
+        ok = ok and torch.equal(got.get_field("default_boxes").bbox_xyxy, torch.cat([p.get_field("default_boxes").bbox_xyxy for p in parts]))
+        ok = ok and torch.equal(got.get_field("transform_corners"), torch.cat([p.get_field("transform_corners") for p in parts]))
+        result_queue.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_gather_detections_world3():
+    """Class-sharded decode: variable-length per-rank detections (incl. an empty rank) are unioned on every rank."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_det_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in results)

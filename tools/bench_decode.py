@@ -38,3 +38,26 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
                                nms_iou_threshold=0.3, transform_corners_pyramid=[cor_l])
     torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=12, max_name_column_width=60))
+
+# ---- 7-level pyramid (BASELINE.json configs[4]): all levels of a class are merged before NMS (generic path)
+if "--pyramid" in sys.argv:
+    from os2d_amd.engine.pyramid import PyramidHeadRunner
+    from os2d_amd.modeling.box_coder import ResizeBoxes
+    level_hw = [(30, 40), (38, 50), (48, 64), (60, 80), (72, 96), (84, 112), (96, 128)]
+    fms = [synthetic.make_feature_map(1024, h, w, seed=100 + i).to(dev) for i, (h, w) in enumerate(level_hw)]
+    sizes = [FeatureMapSize(w=16 * w, h=16 * h) for h, w in level_hw]
+    with torch.no_grad():
+        loc_p, cls_p, cor_p, _ = PyramidHeadRunner(head, device=dev).run(fms, inputs_are_features=True)
+    loc_p = [l[0] for l in loc_p]; cls_p = [c[0] for c in cls_p]; cor_p = [k[0] for k in cor_p]
+    inverse = [ResizeBoxes(FeatureMapSize(w=3264, h=2448)) for _ in sizes]
+    for it in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        res = coder.decode_pyramid(loc_p, cls_p, sizes, class_ids=list(range(B)), nms_score_threshold=thr,
+                                   nms_iou_threshold=0.3, inverse_box_transforms=inverse, transform_corners_pyramid=cor_p)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print("pyramid decode B={} thr={}: {:.2f} ms, {} detections".format(B, thr, dt * 1e3, len(res)))
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        res = coder.decode_pyramid(loc_p, cls_p, sizes, class_ids=list(range(B)), nms_score_threshold=thr,
+                                   nms_iou_threshold=0.3, inverse_box_transforms=inverse, transform_corners_pyramid=cor_p)
+        torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=10, max_name_column_width=60))

@@ -61,7 +61,8 @@ int os2d_class_prepare(const float* src, int C, int h, int w, int normalize, flo
  *   stride / rec_field: backbone stride and receptive field (16 / 16 for ResNet-C4, feature_extractor.py:115-117)
  *   outputs loc [A,B,4,H,W], cls [A,B,1,H,W], corners [A,B,8,H,W]  (cls_detached aliases cls in eval, head.py:400-402)
  * The workspace may be smaller than os2d_head_workspace_bytes(A,B,...) reports: classes are then processed in
- * chunks; it must hold at least os2d_head_workspace_bytes(A,1,...) bytes.  C must be a multiple of 4. */
+ * chunks; it must hold at least os2d_head_workspace_bytes(A,1,...) bytes.  C must be a multiple of 4 and W <= 209
+ * (3344-px wide images at stride 16: the 7x7 kernels keep three halo rows in LDS); both are checked before any launch. */
 int os2d_head_workspace_bytes(int A, int B, int C, int H, int W, int P, size_t* bytes);
 int os2d_head_forward(const float* fm, const float* qp, const float* w1, const float* b1, const float* w2,
                       const float* b2, const float* w3, const float* b3, int A, int B, int C, int H, int W, int P,

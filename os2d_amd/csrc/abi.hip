@@ -53,6 +53,11 @@ bool head_args_ok(int A, int B, int C, int H, int W, int P) {
                    W, P);
     return false;
   }
+  if (W > OS2D_MAX_W) {
+    os2d_set_error("feature map width %d > %d: the 7x7 kernels keep 3 halo rows of the input in LDS (images wider than %d px "
+                   "at stride 16 are not supported)", W, OS2D_MAX_W, OS2D_MAX_W * 16);
+    return false;
+  }
   return true;
 }
 }  // namespace

@@ -20,6 +20,7 @@
 #define OS2D_K 225           // T*T correlation channels
 #define OS2D_KP 226          // padded to an even channel count (MFMA 32x32x2 consumes channel pairs)
 #define OS2D_QROWS 256       // correlation GEMM M tile: 225 rows padded with zeros
+#define OS2D_MAX_W 209       // widest feature map: 256 + 2*(3*(W+3)+3) slab units must fit the conv 7x7 prefetch (<= 1536)
 #define OS2D_G 29            // 8-channel groups of the 225 correlation channels (f16x3 path)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -52,6 +52,8 @@ def test_library_loads_and_reports_abi(lib_path):
     assert lib.os2d_head_workspace_bytes(1, 1, 1023, 60, 80, 6, ctypes.byref(n)) == -1
     assert b"C%4" in lib.os2d_last_error() or b"C" in lib.os2d_last_error()
     assert lib.os2d_head_workspace_bytes(1, 1, 1024, 60, 80, 5, ctypes.byref(n)) == -1
+    assert lib.os2d_head_workspace_bytes(1, 1, 1024, 60, 209, 6, ctypes.byref(n)) == 0
+    assert lib.os2d_head_workspace_bytes(1, 1, 1024, 60, 210, 6, ctypes.byref(n)) == -1 and b"width" in lib.os2d_last_error()
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

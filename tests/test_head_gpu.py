@@ -224,3 +224,25 @@ def test_baseline_config_256_classes_v1_properties(precision, device):
     assert util.maxdiff(scaled[1], full[1]) < TOL_CLS
     assert util.maxdiff(scaled[0], full[0]) < TOL_LOC
     assert torch.isfinite(full[0]).all() and torch.isfinite(full[3]).all()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_widest_supported_level_and_clean_failure_beyond(precision, device):
+    """Maximum size: W = 209 columns (a 3344-px wide image) is the widest level the 7x7 kernels take and must match the
+    oracle; W = 210 fails loudly BEFORE anything is launched (no partial results, no CPU fallback)."""
+    from os2d_amd.utils import synthetic
+    P, inverse, C = 6, True, 16
+    state = synthetic.make_transform_net_state(P, seed=4)
+    class_fms = [c + 0.05 for c in synthetic.make_class_feature_maps(2, C, sizes=[(15, 15), (14, 16)], seed=77)]
+    creator = util.make_head_creator(P, inverse, state, device)
+    fm = synthetic.make_feature_map(C, 9, 209, seed=5) + 0.05
+    with torch.no_grad():
+        head = creator.create_os2d_head([c.to(device) for c in class_fms])
+        loc, cls, _, corners = head(fm.to(device), precision=precision)
+    ref = _oracle(fm, class_fms, state, inverse)
+    assert util.maxdiff(cls, ref[1]) < TOL_CLS
+    assert util.maxdiff(loc, ref[0]) < TOL_LOC
+    assert util.maxdiff(corners, ref[3]) < 8e-3      # coordinates up to ~3500 px
+    wide = synthetic.make_feature_map(C, 4, 210, seed=6).to(device)
+    with pytest.raises(RuntimeError, match="width"):
+        head(wide, precision=precision)

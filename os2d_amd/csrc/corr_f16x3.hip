@@ -81,6 +81,14 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
       pfB[k] = fa[(size_t)grow_ * HW + min(n0 + col_, HW - 1)];                                                   \
     }                                                                                                             \
   }
+#define CF_LOAD1(T, K)                                                                                            \
+  {                                                                                                               \
+    const int i_ = tid + (K)*NTHR;                                                                                \
+    const int row_ = i_ >> 8, col_ = i_ & 255;                                                                    \
+    const int grow_ = min((T)*GC * 2 + row_, CG * 2 - 1);                                                         \
+    pfA[K] = qb[(size_t)grow_ * 256 + col_];                                                                      \
+    pfB[K] = fa[(size_t)grow_ * HW + min(n0 + col_, HW - 1)];                                                     \
+  }
 #define CF_STORE(T)                                                                                               \
   {                                                                                                               \
     const int g0_ = (T)*GC;                                                                                       \
@@ -92,7 +100,9 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
       ldsB[((T)&1) * CH_UNITS + i_] = (rok_ && n0 + col_ < HW) ? pfB[k] : U32X4_ZERO;                             \
     }                                                                                                             \
   }
-#define CF_COMPUTE(T)                                                                                             \
+#define CF_NOHOOK(MI)
+#define CF_COMPUTE(T) CF_COMPUTE_H(T, CF_NOHOOK)
+#define CF_COMPUTE_H(T, HOOK)                                                                                     \
   {                                                                                                               \
     const u32x4* aB_ = ldsA + ((T)&1) * CH_UNITS + wm * 128 + l31;                                                \
     const u32x4* bB_ = ldsB + ((T)&1) * CH_UNITS + wn * 64 + l31;                                                 \
@@ -111,22 +121,35 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bl_[ni], acc[mi][ni], 0, 0, 0);               \
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bh_[ni], acc[mi][ni], 0, 0, 0);               \
         }                                                                                                         \
+        if (ks == 0) { HOOK(mi) }                                                                                 \
       }                                                                                                           \
     }                                                                                                             \
   }
 
+  // The global -> register prefetch of chunk t+1 is issued IN PIECES between the MFMA groups of chunk t (one class unit
+  // + one image unit per thread after each of the first four groups): eight waves bursting 72 KB of loads right after
+  // the barrier queue up behind each other in the CU's load path (the last wave needed 1.4 us just to ISSUE its loads,
+  // everyone else waited for it at the next barrier); spread out, the issue slots hide behind the matrix pipe.
+#define CF_PF_HOOK(MI)                                                                                            \
+  {                                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    CF_LOAD1(t + 1, MI)                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+  }
   CF_LOAD(0)
   CF_STORE(0)
   __syncthreads();
   for (int t = 0; t + 1 < nchunks; ++t) {
-    CF_LOAD(t + 1)
-    __builtin_amdgcn_sched_barrier(0);
-    CF_COMPUTE(t)
+    CF_COMPUTE_H(t, CF_PF_HOOK)
     __builtin_amdgcn_sched_barrier(0);
     CF_STORE(t + 1)
     __syncthreads();
   }
   CF_COMPUTE(nchunks - 1)
+#undef CF_PF_HOOK
+#undef CF_LOAD1
+#undef CF_NOHOOK
+#undef CF_COMPUTE_H
 #undef CF_LOAD
 #undef CF_STORE
 #undef CF_COMPUTE

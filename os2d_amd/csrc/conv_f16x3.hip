@@ -108,6 +108,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_f16x3_kernel(const u32x4
       pfA[k] = src_[(i_ / MT) * (2 / AP) * MTP + (i_ % MT)];                                                      \
     }                                                                                                             \
   }
+#define F16_LOAD_A1(S, K)                                                                                         \
+  {                                                                                                               \
+    const int i_ = min(tid + (K)*NTHR, ASTAGE - 1);                                                               \
+    pfA[K] = (wp + (size_t)(S)*ASTAGE_G + mOff)[(i_ / MT) * (2 / AP) * MTP + (i_ % MT)];                          \
+  }
+#define F16_LOAD_B1(GRP, K)                                                                                       \
+  {                                                                                                               \
+    const int i_ = min(tid + (K)*NTHR, 2 * SLAB - 1);                                                             \
+    const int part_ = i_ >= SLAB ? 1 : 0;                                                                         \
+    int g_ = n0 - HALO + (i_ - part_ * SLAB);                                                                     \
+    g_ = (g_ >= 0 && g_ < PLANE) ? g_ : 0;                                                                        \
+    pfB[K] = inb[((size_t)(GRP)*2 + part_) * PLANE + g_];                                                         \
+  }
 #define F16_STORE_A(S)                                                                                            \
   {                                                                                                               \
     u32x4* dst_ = ldsA + ((S)&1) * ASTAGE;                                                                        \
@@ -186,8 +199,23 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_f16x3_kernel(const u32x4
         }                                                                                                         \
         F16_MFMAS(p & 1)                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
+        F16_PF(ST, p)                                                                                             \
       }                                                                                                           \
     }                                                                                                             \
+  }
+  // Prefetch pieces issued right after the MFMAs of k-step P of stage ST: one weight unit of the next stage, and in the
+  // last stage of a channel group a share of the next group's input slab.  Spreading the loads over the stage instead
+  // of bursting them at its start keeps the CU's load path short for everybody (see corr_f16x3.hip).
+  constexpr int LASTN = STEPS - (NST - 1) * SS;        // k-steps of the last stage of a group
+  constexpr int BPS = (NBPF + LASTN - 1) / LASTN;      // slab units per k-step there
+#define F16_PF(ST, P)                                                                                             \
+  {                                                                                                               \
+    if ((P) < NAPF) F16_LOAD_A1(s1, P)                                                                            \
+    if ((ST) == NST - 1) {                                                                                        \
+      _Pragma("unroll") for (int kk = 0; kk < BPS; ++kk)                                                          \
+        if ((P)*BPS + kk < NBPF) F16_LOAD_B1(g1, (P)*BPS + kk)                                                    \
+    }                                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
   }
 
   // ---- prologue: group 0 slab + stage 0 weights
@@ -202,10 +230,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_f16x3_kernel(const u32x4
     for (int st = 0; st < NST; ++st) {
       const int s = g * NST + st;
       const int s1 = min(s + 1, nstages - 1);  // clamped: the very last iteration re-loads its own stage (harmless)
-      F16_LOAD_A(s1)
-      if (st == NST - 1) {
-        const int g1 = min(g + 1, G - 1);
-        F16_LOAD_B(g1)
+      const int g1 = min(g + 1, G - 1);
+      {  // weight units beyond this stage's k-steps (one unit rides behind each k-step) go first
+        const int nst_ = (st == NST - 1) ? (STEPS - (NST - 1) * SS) : SS;
+        _Pragma("unroll") for (int k = 0; k < NAPF; ++k)
+          if (k >= nst_) F16_LOAD_A1(s1, k)
       }
       __builtin_amdgcn_sched_barrier(0);
       F16_COMPUTE(st, (s & 1))
@@ -219,6 +248,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_f16x3_kernel(const u32x4
     }
   }
 #undef F16_LOAD_A
+#undef F16_LOAD_A1
+#undef F16_LOAD_B1
+#undef F16_PF
 #undef F16_STORE_A
 #undef F16_LOAD_B
 #undef F16_STORE_B

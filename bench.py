@@ -298,6 +298,11 @@ def main():
              "bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": peak / 1e12, "unit": "TFLOP/s",
              "frac": round(achieved / peak, 4), "traffic": measured_traffic(B, precision),
              "flops_per_launch": flops, "avg_launch_ms": round(stage_ms[1], 4)}
+        # algorithmic HBM bytes of the same launch: every input plane read once (226 fp32 planes, or 29 groups x 8
+        # channels x (hi|lo) halves) + the 128 output planes written once + the packed weights once
+        plane = int(lib.os2d_plane_floats(H_FM, W_FM))
+        in_planes = 226 if precision == "f32" else 232
+        r["algorithmic_bytes"] = int(B * (in_planes + 128) * plane * 4 + lib.os2d_packed_conv_bytes(1, {"f32": 0, "f16x3": 1, "f16x2": 2}[precision]))
         if precision != "f32":
             # every algorithmic product costs three (f16x2: two) half-precision MFMA products: the ceiling for
             # algorithmic FLOP/s on this instruction is peak/3 (peak/2); the executed rate also includes the tile /

@@ -5,6 +5,7 @@ Tolerances (north_star: score maps within 1e-4 fp32):
   loc      1e-4 absolute  (values up to ~1;   measured ~3e-6)
   corners  2e-3 absolute  (pixel coordinates up to ~600; fp32 ulp there is 6e-5; measured ~1e-4)
 """
+import numpy as np
 import pytest
 import torch
 
@@ -246,3 +247,32 @@ def test_widest_supported_level_and_clean_failure_beyond(precision, device):
     wide = synthetic.make_feature_map(C, 4, 210, seed=6).to(device)
     with pytest.raises(RuntimeError, match="width"):
         head(wide, precision=precision)
+
+
+def _random_shapes(n, seed):
+    rs = np.random.RandomState(seed)
+    shapes = [(4, 1, 1, 1, 1, 6, True), (8, 1, 64, 1, 2, 4, False), (4, 37, 1, 2, 1, 6, False)]      # degenerate maps first
+    while len(shapes) < n:
+        shapes.append((int(rs.randint(1, 17)) * 4, int(rs.randint(1, 41)), int(rs.randint(1, 61)), int(rs.randint(1, 3)),
+                       int(rs.randint(1, 10)), int(rs.choice([4, 6])), bool(rs.randint(0, 2))))
+    return shapes
+
+
+@pytest.mark.parametrize("C,H,W,A,B,P,inverse", _random_shapes(14, seed=2024))
+def test_random_shapes_all_precisions_match_oracle(C, H, W, A, B, P, inverse, device):
+    """Seeded sweep over channel counts (any multiple of 4), map sizes from 1x1 to 40x60 (partial tiles, single rows /
+    columns), image batches and class counts, both head variants: every arithmetic mode against the oracle."""
+    from os2d_amd.utils import synthetic
+    state = synthetic.make_transform_net_state(P, seed=C + H)
+    fm = synthetic.make_feature_map(C, H, W, seed=H * 100 + W, A=A) + 0.05
+    class_fms = [c + 0.05 for c in synthetic.make_class_feature_maps(B, C, sizes=[(15, 15), (9, 23), (16, 14)], seed=B * 7 + C)]
+    creator = util.make_head_creator(P, inverse, state, device)
+    ref = _oracle(fm, class_fms, state, inverse)
+    with torch.no_grad():
+        head = creator.create_os2d_head([c.to(device) for c in class_fms])
+        for precision in PRECISIONS:
+            loc, cls, _, corners = head(fm.to(device), precision=precision)
+            assert tuple(loc.shape) == (A, B, 4, H, W) and tuple(cls.shape) == (A, B, 1, H, W)
+            assert util.maxdiff(cls, ref[1]) < TOL_CLS, precision
+            assert util.maxdiff(loc, ref[0]) < TOL_LOC, precision
+            assert util.maxdiff(corners, ref[3]) < TOL_CORNERS, precision

@@ -8,6 +8,8 @@
                        (same-size class images go through the backbone as ONE batch instead of one call each)
     extract_scores     reference evaluate.py:306-361  per pyramid level: backbone + heads of all classes
     detect             reference evaluate.py:99-117   + Os2dBoxCoder.decode_pyramid (decode, clip, NMS, merge levels)
+    detect_images      reference evaluate.py:278-371  the per-image loop, with the next image's host-to-device copy
+                       prefetched on a side stream
 """
 from collections import OrderedDict
 
@@ -92,3 +94,41 @@ def detect(net, box_coder, image_levels, class_head, class_ids, orig_size=None, 
                                     nms_score_threshold=nms_score_threshold, nms_iou_threshold=nms_iou_threshold,
                                     inverse_box_transforms=inverse,
                                     transform_corners_pyramid=[k[a] for k in s["corners"]])
+
+
+def detect_images(net, box_coder, image_pyramids, class_head, class_ids, orig_sizes=None, device=None, **detect_kwargs):
+    """Generator over images: the build's counterpart of the reference's evaluation iterator (evaluate.py:278-371 +
+    :99-117) for host-resident inputs.  ``image_pyramids`` is an iterable of lists of CPU tensors [1,3,h_l,w_l] (one
+    list per image, e.g. from a dataloader); the levels of image i+1 are copied to the device on a side stream
+    (pinned staging buffers, ``non_blocking``) while image i is in the backbone / head / decode, so the PCIe transfer
+    (4.9 MB at 1280x960, ~0.1 ms) never sits in front of the compute.  Yields one ``BoxList`` per image, identical to
+    calling ``detect`` on that image."""
+    device = device or class_head.class_feature_maps.device
+    copy_stream = torch.cuda.Stream(device=device)
+
+    def upload(levels):
+        with torch.cuda.stream(copy_stream):
+            out = [(x if x.is_pinned() else x.pin_memory()).to(device, non_blocking=True) for x in levels]
+        ready = torch.cuda.Event()
+        ready.record(copy_stream)
+        return out, ready
+
+    it = iter(image_pyramids)
+    try:
+        nxt = upload(next(it))
+    except StopIteration:
+        return
+    index = 0
+    while nxt is not None:
+        levels, ready = nxt
+        try:
+            nxt = upload(next(it))          # in flight while this image is processed
+        except StopIteration:
+            nxt = None
+        main = torch.cuda.current_stream(device)
+        main.wait_event(ready)
+        for x in levels:
+            x.record_stream(main)           # allocated on the copy stream, consumed on the compute stream
+        orig = orig_sizes[index] if orig_sizes is not None else None
+        yield detect(net, box_coder, levels, class_head, class_ids, orig_size=orig, **detect_kwargs)
+        index += 1

@@ -133,3 +133,25 @@ def test_detect_with_class_image_augmentation(device):
         expect_scores.append(sc)
         assert int((lab == label).sum()) == len(sc)
     assert util.maxdiff(det.get_field("scores"), torch.cat(expect_scores)) < 1e-5
+
+
+def test_detect_images_prefetching_iterator_equals_per_image_detect(device):
+    """Host-resident image pyramids through the prefetching iterator (next image's H2D copy on a side stream) give
+    exactly the detections of per-image ``detect`` calls on device tensors."""
+    from os2d_amd.engine import evaluate as E
+    from os2d_amd.structures.feature_map import FeatureMapSize
+    net, state = _model(device, seed=7)
+    g = torch.Generator().manual_seed(4)
+    class_images = [torch.randn(3, 96, 96, generator=g).to(device) for _ in range(3)]
+    head = E.build_class_head(net, class_images)
+    coder = net.build_box_coder()
+    pyramids = [[torch.randn(1, 3, 96, 128, generator=g), torch.randn(1, 3, 128, 176, generator=g)] for _ in range(4)]
+    orig = [FeatureMapSize(w=200 + 10 * i, h=150 + 5 * i) for i in range(4)]
+    got = list(E.detect_images(net, coder, pyramids, head, [0, 1, 2], orig_sizes=orig, nms_score_threshold=0.0))
+    assert len(got) == 4 and list(E.detect_images(net, coder, [], head, [0, 1, 2])) == []
+    for i, det in enumerate(got):
+        ref = E.detect(net, coder, [x.to(device) for x in pyramids[i]], head, [0, 1, 2], orig_size=orig[i], nms_score_threshold=0.0)
+        assert len(det) == len(ref) > 0 and det.image_size == orig[i]
+        assert torch.equal(det.get_field("labels"), ref.get_field("labels"))
+        assert util.maxdiff(det.get_field("scores"), ref.get_field("scores")) < 1e-5     # MIOpen is not bit-reproducible call to call
+        assert util.maxdiff(det.bbox_xyxy, ref.bbox_xyxy) < 1e-2

@@ -181,3 +181,31 @@ def test_all_boxes_survive_long_kept_lists(device):
     assert len(out[0]) == B * H * W
     s = out[0].get_field("scores").view(B, H * W).cpu()
     assert torch.equal(s, torch.sort(cls, dim=1, descending=True)[0])
+
+
+def test_nms_decisions_at_the_iou_threshold(device):
+    """Pairs of boxes whose IoU sits within a few ulps of the threshold (0.3): the kernels only divide when
+    inter is within 1e-5 of thr * union (os2d_iou_gt) - the decision must still equal the fp32 quotient test
+    inter / union > thr of torchvision / the oracle for every pair.  One pair per class list."""
+    from oracle import decode_oracle as D
+    from os2d_amd.modeling.box_coder import Os2dBoxCoder
+    rs = np.random.RandomState(3)
+    pairs = []
+    for k in range(1500):
+        s = float(rs.uniform(0.5, 40.0))                      # scale of the pair
+        up = np.float32(np.inf if k % 2 else -np.inf)
+        y = np.float32(3.0 * s)
+        for _ in range(int(rs.randint(0, 4)) if k % 7 else 0):   # 0..3 ulps off the exact ratio
+            y = np.nextafter(y, up, dtype=np.float32)
+        pairs.append([[0.0, 0.0, 10.0 * s, 10.0 * s],          # kept (listed first = higher score)
+                      [0.0, 0.0, 10.0 * s, float(y)]])         # IoU = y / (10 s) ~ 0.3
+    b = torch.tensor(pairs, dtype=torch.float32)              # [1500, 2, 4]
+    ref = torch.zeros(b.size(0), 2, dtype=torch.bool)
+    iou = torch.zeros(b.size(0))
+    for c in range(b.size(0)):
+        ref[c, D.greedy_nms(b[c], torch.tensor([2.0, 1.0]), 0.3)] = True
+        iou[c] = D.box_iou_matrix(b[c])[0, 1]
+    assert int(((iou - 0.3).abs() < 1e-6).sum()) > 1400
+    assert bool(ref[:, 0].all()) and 100 < int(ref[:, 1].sum()) < 1400       # both outcomes occur
+    keep = Os2dBoxCoder.nms_sorted(b.to(device), torch.full((b.size(0),), 2), 0.3).cpu()
+    assert torch.equal(keep, ref)

@@ -64,41 +64,32 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
+  const u32x4* zeros = reinterpret_cast<const u32x4*>(rshb);  // pad cell 0 of plane 0: zero since border_zero_shb
   const u32x4* qb = qs + (size_t)b * CG * 2 * 256;
   const u32x4* fa = fs + (size_t)a * CG * 2 * HW;
   const int nchunks = (CG + GC - 1) / GC;
-  u32x4 pfA[NPF], pfB[NPF];
-
-  // unit i of a chunk: row = i / 256 = (group_local * 2 + part), col = i % 256
-#define CF_LOAD(T)                                                                                                \
-  {                                                                                                               \
-    const int g0_ = (T)*GC;                                                                                       \
-    _Pragma("unroll") for (int k = 0; k < NPF; ++k) {                                                             \
-      const int i_ = tid + k * NTHR;                                                                              \
-      const int row_ = i_ >> 8, col_ = i_ & 255;                                                                  \
-      const int grow_ = min(g0_ * 2 + row_, CG * 2 - 1); /* global (group, part) row, clamped */                  \
-      pfA[k] = qb[(size_t)grow_ * 256 + col_];                                                                    \
-      pfB[k] = fa[(size_t)grow_ * HW + min(n0 + col_, HW - 1)];                                                   \
-    }                                                                                                             \
-  }
-#define CF_LOAD1(T, K)                                                                                            \
+  // ---- staging: global -> LDS directly (LDS-DMA, global_load_lds_dwordx4): no staging registers, no ds_write pass.
+  // A wave instruction writes 64 consecutive 16-byte units starting at a wave-uniform LDS address, which is exactly how
+  // a chunk is laid out (unit i = row i/256 = (group, part), column i%256; 64 consecutive threads = 64 consecutive
+  // columns of one row).  The global address is per lane: rows past the last channel group and columns past H*W are
+  // pointed at a 16-byte block of zeros (`zeros`: pad cell 0 of the output planes, cleared before this kernel runs).
+  typedef const void __attribute__((address_space(1))) * gptr_t;
+  typedef void __attribute__((address_space(3))) * lptr_t;
+#define CF_DMA1(T, K)                                                                                             \
   {                                                                                                               \
     const int i_ = tid + (K)*NTHR;                                                                                \
     const int row_ = i_ >> 8, col_ = i_ & 255;                                                                    \
-    const int grow_ = min((T)*GC * 2 + row_, CG * 2 - 1);                                                         \
-    pfA[K] = qb[(size_t)grow_ * 256 + col_];                                                                      \
-    pfB[K] = fa[(size_t)grow_ * HW + min(n0 + col_, HW - 1)];                                                     \
+    const int grow_ = (T)*GC * 2 + row_;                                                                          \
+    const bool rok_ = grow_ < CG * 2;                                                                             \
+    const u32x4* ga_ = rok_ ? qb + (size_t)grow_ * 256 + col_ : zeros;                                            \
+    const u32x4* gb_ = (rok_ && n0 + col_ < HW) ? fa + (size_t)grow_ * HW + n0 + col_ : zeros;                    \
+    const int w0_ = ((T)&1) * CH_UNITS + (i_ & ~63); /* first unit of this wave's 64 */                           \
+    __builtin_amdgcn_global_load_lds((gptr_t)ga_, (lptr_t)(ldsA + w0_), 16, 0, 0);                                \
+    __builtin_amdgcn_global_load_lds((gptr_t)gb_, (lptr_t)(ldsB + w0_), 16, 0, 0);                                \
   }
-#define CF_STORE(T)                                                                                               \
+#define CF_DMA(T)                                                                                                 \
   {                                                                                                               \
-    const int g0_ = (T)*GC;                                                                                       \
-    _Pragma("unroll") for (int k = 0; k < NPF; ++k) {                                                             \
-      const int i_ = tid + k * NTHR;                                                                              \
-      const int row_ = i_ >> 8, col_ = i_ & 255;                                                                  \
-      const bool rok_ = g0_ * 2 + row_ < CG * 2;                                                                  \
-      ldsA[((T)&1) * CH_UNITS + i_] = rok_ ? pfA[k] : U32X4_ZERO;                                                 \
-      ldsB[((T)&1) * CH_UNITS + i_] = (rok_ && n0 + col_ < HW) ? pfB[k] : U32X4_ZERO;                             \
-    }                                                                                                             \
+    _Pragma("unroll") for (int k = 0; k < NPF; ++k) CF_DMA1(T, k)                                                 \
   }
 #define CF_NOHOOK(MI)
 #define CF_COMPUTE(T) CF_COMPUTE_H(T, CF_NOHOOK)
@@ -126,32 +117,29 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
     }                                                                                                             \
   }
 
-  // The global -> register prefetch of chunk t+1 is issued IN PIECES between the MFMA groups of chunk t (one class unit
-  // + one image unit per thread after each of the first four groups): eight waves bursting 72 KB of loads right after
-  // the barrier queue up behind each other in the CU's load path (the last wave needed 1.4 us just to ISSUE its loads,
-  // everyone else waited for it at the next barrier); spread out, the issue slots hide behind the matrix pipe.
+  // The DMA of chunk t+1 is issued IN PIECES between the MFMA groups of chunk t (one class unit + one image unit per
+  // thread after each of the first four groups): eight waves bursting 72 KB of loads right after the barrier queue up
+  // behind each other in the CU's load path; spread out, the issue slots hide behind the matrix pipe.  The barrier at the
+  // end of an iteration drains the wave's own DMAs (vmcnt(0), emitted by __syncthreads) and then orders them for
+  // everybody's fragment reads of the next iteration.
 #define CF_PF_HOOK(MI)                                                                                            \
   {                                                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
-    CF_LOAD1(t + 1, MI)                                                                                           \
+    CF_DMA1(t + 1, MI)                                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
   }
-  CF_LOAD(0)
-  CF_STORE(0)
+  CF_DMA(0)
   __syncthreads();
   for (int t = 0; t + 1 < nchunks; ++t) {
     CF_COMPUTE_H(t, CF_PF_HOOK)
-    __builtin_amdgcn_sched_barrier(0);
-    CF_STORE(t + 1)
     __syncthreads();
   }
   CF_COMPUTE(nchunks - 1)
 #undef CF_PF_HOOK
-#undef CF_LOAD1
+#undef CF_DMA
+#undef CF_DMA1
 #undef CF_NOHOOK
 #undef CF_COMPUTE_H
-#undef CF_LOAD
-#undef CF_STORE
 #undef CF_COMPUTE
 
   // ---- epilogue (features were normalised before the split, so only the 2^-24 operand scale is undone)

@@ -66,6 +66,26 @@ def greedy_nms(boxes, scores, iou_thr):
     return torch.tensor(keep, dtype=torch.long)
 
 
+def nms_chunked(boxes, scores, iou_thr, max_batch=10000, score_thr=float("-inf")):
+    """reference bounding_box.py:343-374 (``nms`` with ``do_separate_per_label=False``): the memory-bounded NMS.
+    Start from the ids with score > score_thr in list order; repeat { cut the current id list into consecutive chunks
+    of ``max_batch``; greedy-NMS every chunk on its own (kept ids come back by decreasing score); concatenate the
+    chunks' survivors in chunk order } until there was at most one chunk or no box was removed.  With more than one
+    chunk this is NOT a global NMS: boxes of different chunks only meet if a later pass puts them in the same chunk.
+    Returns the surviving ids in the reference's final order."""
+    ids = torch.nonzero(scores > score_thr).squeeze(1)
+    while True:
+        n = ids.numel()
+        num_batches = -(-n // max_batch)
+        survived = []
+        for start in range(0, n, max_batch):
+            chunk = ids[start:start + max_batch]
+            survived.append(chunk[greedy_nms(boxes[chunk], scores[chunk], iou_thr)])
+        ids = torch.cat(survived, 0) if survived else torch.zeros(0, dtype=torch.long)
+        if num_batches <= 1 or ids.numel() == n:
+            return ids
+
+
 def decode_pyramid(loc_pyramid, cls_pyramid, fm_sizes, img_sizes, orig_size=None,
                    score_thr=float("-inf"), iou_thr=0.3):
     """Per class: decode every level, clip, drop empty / low-score boxes, map to the original image

@@ -247,6 +247,33 @@ def make_decode_fixture():
     np.savez_compressed(os.path.join(HERE, "decode_pyramid.npz"), **arrays)
 
 
+def make_chunked_nms_fixture():
+    """The reference's memory-bounded NMS (bounding_box.py:343-374: lists longer than nms_max_batch are NMS-ed in
+    chunks of that size, survivors concatenated chunk by chunk in score order, repeated until one chunk is left or
+    nothing changes) on random boxes with batch sizes small enough that 2-3 passes with several chunks happen."""
+    from os2d.structures.bounding_box import BoxList, nms
+    from os2d.structures.feature_map import FeatureMapSize
+    rs = np.random.RandomState(123)
+    arrays = {}
+    cases = [("a", 600, 900.0, 64), ("b", 600, 250.0, 50), ("c", 257, 2000.0, 16), ("d", 90, 60.0, 100)]
+    for name, n, spread, max_batch in cases:
+        ctr = rs.uniform(0, spread, size=(n, 2))
+        wh = rs.uniform(10, 60, size=(n, 2))
+        boxes = torch.from_numpy(np.concatenate([ctr - wh / 2, ctr + wh / 2], 1).astype(np.float32))
+        scores = torch.from_numpy(rs.uniform(-1, 1, size=n).astype(np.float32))
+        bl = BoxList(boxes, FeatureMapSize(w=4000, h=4000), mode="xyxy")
+        bl.add_field("scores", scores)
+        for thr_name, score_thr in (("tinf", float("-inf")), ("t0", 0.0)):
+            keep = nms(bl, 0.3, nms_max_batch=max_batch, nms_score_threshold=score_thr)
+            arrays["ref_{}_{}".format(name, thr_name)] = keep.numpy().astype(np.int64)
+            print("chunked nms {} {}: {} of {} kept (batch {})".format(name, thr_name, keep.numel(), n, max_batch))
+        arrays["boxes_" + name] = boxes.numpy()
+        arrays["scores_" + name] = scores.numpy()
+        arrays["max_batch_" + name] = np.int64(max_batch)
+    arrays["cases"] = np.array([c[0] for c in cases])
+    np.savez_compressed(os.path.join(HERE, "nms_chunked.npz"), **arrays)
+
+
 def main():
     if not os.path.isdir(REFERENCE):
         raise SystemExit("the reference checkout {} is not present; fixtures can only be regenerated "
@@ -256,6 +283,7 @@ def main():
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     make_head_fixtures()
     make_decode_fixture()
+    make_chunked_nms_fixture()
 
 
 if __name__ == "__main__":

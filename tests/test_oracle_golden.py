@@ -1,5 +1,7 @@
 """CPU: the oracle (oracle/*.py) against the golden vectors recorded from the reference itself
 (tests/golden/make_golden.py).  This is what pins the oracle; the GPU tests then compare HIP <-> oracle/golden."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -106,3 +108,14 @@ def test_decode_pyramid_matches_reference():
         assert torch.equal(b, torch.from_numpy(d["ref_%s_boxes" % name]))
         assert torch.equal(s, torch.from_numpy(d["ref_%s_scores" % name]))
         assert torch.equal(l, torch.from_numpy(d["ref_%s_labels" % name]))
+
+
+def test_chunked_nms_oracle_matches_reference():
+    """oracle.nms_chunked against the reference's own ``nms`` run with small batch sizes (several passes, several chunks)."""
+    from oracle import decode_oracle as D
+    d = np.load(os.path.join(util.GOLDEN, "nms_chunked.npz"))
+    for name in d["cases"]:
+        boxes, scores = torch.from_numpy(d["boxes_" + name]), torch.from_numpy(d["scores_" + name])
+        for thr_name, thr in (("tinf", float("-inf")), ("t0", 0.0)):
+            got = D.nms_chunked(boxes, scores, 0.3, int(d["max_batch_" + name]), thr)
+            assert torch.equal(got, torch.from_numpy(d["ref_{}_{}".format(name, thr_name)])), (name, thr_name)

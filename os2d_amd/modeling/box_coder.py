@@ -142,40 +142,56 @@ class Os2dBoxCoder(object):
         return keep.bool()
 
     def _nms_lists(self, boxes, scores, valid, iou_threshold, nms_max_batch=10000):
-        """Batched equivalent of reference bounding_box.py:344-374 for NC independent lists padded to a common
+        """Batched equivalent of reference bounding_box.py:343-374 for NC independent lists padded to a common
         length: boxes [NC,N,4], scores [NC,N], valid [NC,N] bool.  Lists longer than ``nms_max_batch`` go through
-        the reference's chunk-and-repeat scheme (chunks of 10000 in list order until one chunk is left or
-        nothing changes), so results match it exactly.  Returns a bool keep mask [NC,N]."""
+        the reference's chunk-and-repeat scheme: the current id list (at first the valid entries in list order) is cut
+        into consecutive chunks of ``nms_max_batch``, every chunk is NMS-ed on its own, the survivors are concatenated
+        chunk by chunk in score order, until a list needed one chunk only or lost nothing.  Per pass: ONE stable sort
+        by (chunk, descending score), ONE gather and ONE ``os2d_nms`` launch over all NC x chunks lists, one host
+        synchronisation.  Lists that are finished are stable under further passes (an NMS of its own output removes
+        nothing), so all lists simply iterate until the last one is done.  Returns a bool keep mask [NC,N]."""
         NC, N = scores.shape
-        alive = valid.clone()
+        dev = scores.device
+        M = int(nms_max_batch)
+        # descending-score sort key as a non-negative int64 < 2^32 (smaller = higher score; -0 and +0 tie like in a float sort)
+        bits = (scores.float() + 0.0).contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+        asc = torch.where((bits >> 31) == 1, bits ^ 0xFFFFFFFF, bits | 0x80000000)
+        desc_key = 0xFFFFFFFF - asc
+        cnt = valid.sum(1)
+        n_max = int(cnt.max())
+        if n_max == 0:
+            return torch.zeros_like(valid)
+        ids = torch.argsort((~valid).to(torch.uint8), dim=1, stable=True)[:, :n_max]      # valid entries, list order
         while True:
-            n_alive = alive.sum(1)
-            n_max = int(n_alive.max())
-            if n_max == 0:
-                return alive
-            # position of every alive entry among the alive ones (list order) -> chunk id
-            rank = torch.cumsum(alive.int(), 1) - 1
-            chunk = torch.div(rank, nms_max_batch, rounding_mode="floor")
-            num_chunks = (n_max + nms_max_batch - 1) // nms_max_batch
-            new_alive = torch.zeros_like(alive)
-            for ch in range(num_chunks):
-                sel = alive & (chunk == ch)
-                key = torch.where(sel, scores, torch.full_like(scores, float("-inf")))
-                # selected entries first, by decreasing score (stable: ties keep list order)
-                # (a selected entry always has a finite key: it passed ``score > threshold``)
-                order = torch.argsort(key, dim=1, descending=True, stable=True)
-                cnt = sel.sum(1)
-                width = int(cnt.max())
-                if width == 0:
-                    continue
-                order = order[:, :width]
-                b_sorted = torch.gather(boxes, 1, order.unsqueeze(-1).expand(-1, -1, 4))
-                keep_sorted = self.nms_sorted(b_sorted, cnt, iou_threshold)
-                new_alive.scatter_(1, order, keep_sorted)
-            changed = bool((new_alive != alive).any())
-            alive = new_alive
-            if num_chunks <= 1 or not changed:
-                return alive
+            L = ids.size(1)
+            num_chunks = (n_max + M - 1) // M
+            pos = torch.arange(L, device=dev).unsqueeze(0)
+            inlist = pos < cnt.unsqueeze(1)
+            key = torch.where(inlist, ((pos // M) << 32) | torch.gather(desc_key, 1, ids),
+                              torch.full((1, 1), (num_chunks + 1) << 32, dtype=torch.int64, device=dev))
+            order = torch.argsort(key, dim=1, stable=True)
+            ids_sorted = torch.gather(ids, 1, order)          # chunk ch of a list = sorted positions [ch*M, ch*M + its count)
+            Lp = num_chunks * M
+            padded = ids_sorted if L == Lp else torch.cat(
+                [ids_sorted[:, :Lp], torch.zeros(NC, max(Lp - L, 0), dtype=ids.dtype, device=dev)], 1)
+            b_sorted = torch.gather(boxes, 1, padded.unsqueeze(-1).expand(-1, -1, 4)).view(NC * num_chunks, M, 4)
+            cnt_ch = (cnt.unsqueeze(1) - torch.arange(num_chunks, device=dev).unsqueeze(0) * M).clamp(0, M).reshape(-1)
+            keep_sorted = self.nms_sorted(b_sorted, cnt_ch, iou_threshold).view(NC, Lp)
+            keep_sorted = keep_sorted[:, :L] if Lp >= L else torch.cat(
+                [keep_sorted, torch.zeros(NC, L - Lp, dtype=torch.bool, device=dev)], 1)
+            new_cnt = keep_sorted.sum(1)
+            compact = torch.argsort((~keep_sorted).to(torch.uint8), dim=1, stable=True)   # survivors first, arrangement kept
+            ids = torch.gather(ids_sorted, 1, compact)
+            more = (((cnt + M - 1) // M > 1) & (new_cnt != cnt)).any()
+            new_max, more = torch.stack([new_cnt.max(), more.to(new_cnt.dtype)]).tolist()  # the pass's one synchronisation
+            cnt, n_max = new_cnt, int(new_max)
+            ids = ids[:, :max(n_max, 1)]
+            if not more:
+                break
+        alive = torch.zeros(NC, N + 1, dtype=torch.bool, device=dev)
+        pos = torch.arange(ids.size(1), device=dev).unsqueeze(0)
+        alive.scatter_(1, torch.where(pos < cnt.unsqueeze(1), ids, torch.full_like(ids, N)), True)
+        return alive[:, :N]
 
     def decode_pyramid(self, loc_scores_pyramid, cls_scores_pyramid, img_size_pyramid, class_ids,
                        nms_score_threshold=0.0, nms_iou_threshold=0.3, inverse_box_transforms=None,

@@ -209,3 +209,37 @@ def test_nms_decisions_at_the_iou_threshold(device):
     assert bool(ref[:, 0].all()) and 100 < int(ref[:, 1].sum()) < 1400       # both outcomes occur
     keep = Os2dBoxCoder.nms_sorted(b.to(device), torch.full((b.size(0),), 2), 0.3).cpu()
     assert torch.equal(keep, ref)
+
+
+def test_chunked_nms_matches_reference_fixture(device):
+    """Lists longer than ``nms_max_batch``: the reference's chunk-and-repeat NMS (bounding_box.py:343-374), recorded from
+    the reference itself with small batch sizes (golden nms_chunked.npz: several passes over several chunks), one list
+    at a time and several lists of different lengths in one batched call."""
+    import os
+    from oracle import decode_oracle as D
+    d = np.load(os.path.join(util.GOLDEN, "nms_chunked.npz"))
+    coder = _coder()
+    for name in d["cases"]:
+        boxes, scores = torch.from_numpy(d["boxes_" + name]), torch.from_numpy(d["scores_" + name])
+        for thr_name, thr in (("tinf", float("-inf")), ("t0", 0.0)):
+            keep = coder._nms_lists(boxes.unsqueeze(0).to(device), scores.unsqueeze(0).to(device),
+                                    (scores > thr).unsqueeze(0).to(device), 0.3, int(d["max_batch_" + name]))[0].cpu()
+            ref = torch.zeros_like(keep)
+            ref[torch.from_numpy(d["ref_{}_{}".format(name, thr_name)])] = True
+            assert torch.equal(keep, ref), (name, thr_name)
+    # batched: four lists of different lengths, one batch size
+    names = list(d["cases"])
+    N = max(int(d["boxes_" + n].shape[0]) for n in names)
+    B = torch.zeros(len(names), N, 4)
+    S = torch.full((len(names), N), -2.0)
+    V = torch.zeros(len(names), N, dtype=torch.bool)
+    for i, n in enumerate(names):
+        k = d["boxes_" + n].shape[0]
+        B[i, :k], S[i, :k], V[i, :k] = torch.from_numpy(d["boxes_" + n]), torch.from_numpy(d["scores_" + n]), True
+    V &= S > -0.5
+    keep = coder._nms_lists(B.to(device), S.to(device), V.to(device), 0.3, 40).cpu()
+    for i in range(len(names)):
+        sel = V[i].nonzero().squeeze(1)
+        ref = torch.zeros(N, dtype=torch.bool)
+        ref[sel[D.nms_chunked(B[i][sel], S[i][sel], 0.3, 40)]] = True
+        assert torch.equal(keep[i], ref), names[i]

@@ -87,12 +87,14 @@ def nms_chunked(boxes, scores, iou_thr, max_batch=10000, score_thr=float("-inf")
 
 
 def decode_pyramid(loc_pyramid, cls_pyramid, fm_sizes, img_sizes, orig_size=None,
-                   score_thr=float("-inf"), iou_thr=0.3):
+                   score_thr=float("-inf"), iou_thr=0.3, nms_across_classes=False):
     """Per class: decode every level, clip, drop empty / low-score boxes, map to the original image
     (ratio resize, reference bounding_box.py:138-163), concatenate levels, NMS, sort by score.
 
     loc_pyramid[l] [B,4,HW_l], cls_pyramid[l] [B,HW_l], fm_sizes[l]=(H,W), img_sizes[l]=(w,h).
-    Returns (boxes [N,4], scores [N], labels [N]) with classes in ascending order.
+    Returns (boxes [N,4], scores [N], labels [N]) with classes in ascending order; with ``nms_across_classes``
+    (reference box_coder.py:530-532, config ``eval.nms_across_classes``) a second NMS over the union of all labels,
+    result by decreasing score.
     """
     B = cls_pyramid[0].size(0)
     out_b, out_s, out_l = [], [], []
@@ -119,4 +121,8 @@ def decode_pyramid(loc_pyramid, cls_pyramid, fm_sizes, img_sizes, orig_size=None
         out_b.append(bb[keep])
         out_s.append(ss[keep])
         out_l.append(torch.full((keep.numel(),), b, dtype=torch.long))
-    return torch.cat(out_b, 0), torch.cat(out_s, 0), torch.cat(out_l, 0)
+    bb, ss, ll = torch.cat(out_b, 0), torch.cat(out_s, 0), torch.cat(out_l, 0)
+    if nms_across_classes:
+        keep = greedy_nms(bb, ss, iou_thr)          # kept ids by decreasing score (box_coder.py:425-437)
+        bb, ss, ll = bb[keep], ss[keep], ll[keep]
+    return bb, ss, ll

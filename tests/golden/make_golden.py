@@ -244,6 +244,16 @@ def make_decode_fixture():
         arrays["ref_{}_scores".format(thr_name)] = res.get_field("scores")[order].numpy()
         arrays["ref_{}_labels".format(thr_name)] = res.get_field("labels")[order].numpy()
         print("decode {}: {} detections".format(thr_name, len(order)))
+    # eval.nms_across_classes = True (config.py:202 default False): a second NMS over the union of all labels
+    # (box_coder.py:530-532), result sorted by score
+    coder_x = Os2dBoxCoder(0.5, 0.1, 0.5, 0.1, gen, fm_size, do_nms_across_classes=True)
+    res = coder_x.decode_pyramid([l.clone() for l in locs], [c.clone() for c in clss], img_sizes,
+                                 class_ids=list(range(n_cls)), nms_score_threshold=0.0,
+                                 nms_iou_threshold=0.3, inverse_box_transforms=inverse)
+    arrays["ref_across_boxes"] = res.bbox_xyxy.numpy()
+    arrays["ref_across_scores"] = res.get_field("scores").numpy()
+    arrays["ref_across_labels"] = res.get_field("labels").numpy()
+    print("decode across classes: {} detections".format(len(res)))
     np.savez_compressed(os.path.join(HERE, "decode_pyramid.npz"), **arrays)
 
 

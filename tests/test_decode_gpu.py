@@ -38,6 +38,14 @@ def test_decode_level_and_pyramid_match_reference(device):
         assert torch.equal(res.get_field("scores").cpu(), torch.from_numpy(d["ref_%s_scores" % name]))
         assert util.maxdiff(res.bbox_xyxy, torch.from_numpy(d["ref_%s_boxes" % name])) < 1e-3
         assert res.image_size == orig
+    # eval.nms_across_classes (reference box_coder.py:530-532): second NMS over the union of the labels, by score
+    from os2d_amd.modeling.box_coder import BoxGridGenerator, Os2dBoxCoder
+    coder_x = Os2dBoxCoder(output_box_grid_generator=coder.output_box_grid_generator, do_nms_across_classes=True)
+    res = coder_x.decode_pyramid(locs, clss, sizes, class_ids=list(range(int(d["n_classes"]))), nms_score_threshold=0.0,
+                                 nms_iou_threshold=0.3, inverse_box_transforms=inverse)
+    assert torch.equal(res.get_field("labels").cpu(), torch.from_numpy(d["ref_across_labels"]))
+    assert torch.equal(res.get_field("scores").cpu(), torch.from_numpy(d["ref_across_scores"]))
+    assert util.maxdiff(res.bbox_xyxy, torch.from_numpy(d["ref_across_boxes"])) < 1e-3
 
 
 @pytest.mark.parametrize("n,spread", [(1, 50.0), (63, 40.0), (64, 40.0), (65, 30.0), (700, 120.0), (4800, 400.0)])

@@ -108,6 +108,9 @@ def test_decode_pyramid_matches_reference():
         assert torch.equal(b, torch.from_numpy(d["ref_%s_boxes" % name]))
         assert torch.equal(s, torch.from_numpy(d["ref_%s_scores" % name]))
         assert torch.equal(l, torch.from_numpy(d["ref_%s_labels" % name]))
+    b, s, l = D.decode_pyramid(locs, clss, fm_sizes, img, orig, 0.0, 0.3, nms_across_classes=True)
+    assert torch.equal(b, torch.from_numpy(d["ref_across_boxes"])) and torch.equal(s, torch.from_numpy(d["ref_across_scores"]))
+    assert torch.equal(l, torch.from_numpy(d["ref_across_labels"]))
 
 
 def test_chunked_nms_oracle_matches_reference():

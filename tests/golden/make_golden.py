@@ -235,11 +235,18 @@ def make_decode_fixture():
         t = TransformList()
         t.append(lambda boxes: boxes.resize(orig_size))
         inverse.append(t)
+    # transform corners (box_coder.py:439-446,493-503): random parallelogram end points per location
+    corners = [torch.from_numpy(rs.uniform(0, 300, size=(n_cls, 8, l.shape[2])).astype(np.float32)) for l in locs]
+    for i, k in enumerate(corners):
+        arrays["corners_{}".format(i)] = k.numpy()
     for thr_name, score_thr in (("t0", 0.0), ("tinf", float("-inf")), ("t06", 0.6)):
         res = coder.decode_pyramid([l.clone() for l in locs], [c.clone() for c in clss], img_sizes,
                                    class_ids=list(range(n_cls)), nms_score_threshold=score_thr,
-                                   nms_iou_threshold=0.3, inverse_box_transforms=inverse)
+                                   nms_iou_threshold=0.3, inverse_box_transforms=inverse,
+                                   transform_corners_pyramid=[k.clone() for k in corners])
         order = torch.argsort(res.get_field("labels") * 10 - res.get_field("scores"), stable=True)
+        arrays["ref_{}_default_boxes".format(thr_name)] = res.get_field("default_boxes").bbox_xyxy[order].numpy()
+        arrays["ref_{}_corners".format(thr_name)] = res.get_field("transform_corners")[order].numpy()
         arrays["ref_{}_boxes".format(thr_name)] = res.bbox_xyxy[order].numpy()
         arrays["ref_{}_scores".format(thr_name)] = res.get_field("scores")[order].numpy()
         arrays["ref_{}_labels".format(thr_name)] = res.get_field("labels")[order].numpy()

@@ -30,9 +30,14 @@ def test_decode_level_and_pyramid_match_reference(device):
         assert util.maxdiff(boxes, torch.from_numpy(d["ref_boxes_%d" % i])) < 1e-3
     orig = FeatureMapSize(w=int(d["orig_size"][0]), h=int(d["orig_size"][1]))
     inverse = [(lambda b: b.resize(orig)) for _ in range(L)]
+    corners = [torch.from_numpy(d["corners_%d" % i]).to(device) for i in range(L)]
     for name, thr in (("t0", 0.0), ("tinf", float("-inf")), ("t06", 0.6)):
         res = coder.decode_pyramid(locs, clss, sizes, class_ids=list(range(int(d["n_classes"]))),
-                                   nms_score_threshold=thr, nms_iou_threshold=0.3, inverse_box_transforms=inverse)
+                                   nms_score_threshold=thr, nms_iou_threshold=0.3, inverse_box_transforms=inverse,
+                                   transform_corners_pyramid=corners)
+        # the anchors and the transform corners of the surviving boxes, mapped to the original image like the boxes
+        assert util.maxdiff(res.get_field("default_boxes").bbox_xyxy, torch.from_numpy(d["ref_%s_default_boxes" % name])) < 1e-3
+        assert util.maxdiff(res.get_field("transform_corners"), torch.from_numpy(d["ref_%s_corners" % name])) < 1e-3
         assert len(res) == len(d["ref_%s_scores" % name]), name
         assert torch.equal(res.get_field("labels").cpu(), torch.from_numpy(d["ref_%s_labels" % name]))
         assert torch.equal(res.get_field("scores").cpu(), torch.from_numpy(d["ref_%s_scores" % name]))

@@ -200,7 +200,8 @@ class Os2dBoxCoder(object):
         per level decode + clip (os2d_decode_boxes), score / empty-box mask, map to the original image
         (``inverse_box_transforms[l]`` is applied ONCE to a BoxList holding the level's boxes of all classes),
         concatenate levels, per-label NMS (os2d_nms), sort by score.  Entries of ``class_ids`` with the same id
-        are merged before NMS, labels appear in ascending order like the reference's ``set(class_ids)``.
+        are merged before NMS, labels appear in the iteration order of ``set(class_ids)`` like in the reference (ascending
+        for small ids).
         Returns a BoxList with fields scores, labels, default_boxes (and transform_corners if given)."""
         num_classes = len(class_ids)
         dev = cls_scores_pyramid[0].device
@@ -243,7 +244,7 @@ class Os2dBoxCoder(object):
         by_label = {}
         for i, c in enumerate(ids):
             by_label.setdefault(c, []).append(i)
-        labels_sorted = sorted(by_label)
+        labels_sorted = list(set(ids))   # the reference iterates ``set(class_ids)`` (box_coder.py:483): same order, whatever it is
         groups = [by_label[l] for l in labels_sorted]
         if len(labels_sorted) != len(ids) or labels_sorted != ids:
             width = max(len(g) for g in groups) * boxes.size(1)
@@ -332,8 +333,9 @@ class Os2dBoxCoder(object):
                                          ctypes.c_float(ry), ctypes.c_float(score_thr), ctypes.c_float(iou_thr),
                                          _lib.ptr(out_boxes), _lib.ptr(out_scores), _lib.ptr(out_index),
                                          _lib.ptr(out_count), _lib.current_stream(dev)), "os2d_detect_level")
-        # rows in ascending label order (the reference iterates ``set(class_ids)``), survivors of a row by score
-        order = sorted(range(B), key=lambda i: ids[i])
+        # rows in the label order of the reference (iteration order of ``set(class_ids)``), survivors of a row by score
+        rank = {l: k for k, l in enumerate(set(ids))}      # the reference iterates ``set(class_ids)`` (box_coder.py:483)
+        order = sorted(range(B), key=lambda i: rank[ids[i]])
         counts = out_count
         if order != list(range(B)):
             perm = torch.tensor(order, dtype=torch.long, device=dev)

@@ -256,3 +256,20 @@ def test_chunked_nms_matches_reference_fixture(device):
         ref = torch.zeros(N, dtype=torch.bool)
         ref[sel[D.nms_chunked(B[i][sel], S[i][sel], 0.3, 40)]] = True
         assert torch.equal(keep[i], ref), names[i]
+
+
+def test_label_order_follows_set_iteration_like_the_reference(device):
+    """reference box_coder.py:483 loops ``for real_label in set(class_ids)``: with ids such as [1000, 3, 70] that is NOT
+    ascending; both decode paths reproduce the same order."""
+    from os2d_amd.structures.feature_map import FeatureMapSize
+    rs = np.random.RandomState(21)
+    size = FeatureMapSize(w=208, h=176)
+    loc = torch.from_numpy(rs.standard_normal((4, 4, 11 * 13)).astype(np.float32)).to(device)
+    cls = torch.from_numpy(rs.uniform(0.1, 1, size=(4, 11 * 13)).astype(np.float32)).to(device)
+    coder = _coder()
+    for ids in ([1000, 3, 70, 5], [70, 1000, 70, 3]):           # unique ids (fused kernel) / a merged label (generic path)
+        expect = list(set(ids))
+        res = coder.decode_pyramid([loc], [cls], [size], ids, nms_score_threshold=0.0)
+        lab = res.get_field("labels").cpu().tolist()
+        seen = [l for i, l in enumerate(lab) if i == 0 or lab[i - 1] != l]
+        assert seen == expect, (ids, seen, expect)

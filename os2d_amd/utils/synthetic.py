@@ -95,3 +95,35 @@ def state_checksum(state):
         v = state[k].double()
         total += float((v * v).sum()) + float(v.sum()) * 1e-3
     return total
+
+
+def fill_model_state(state_dict, seed, P):
+    """Deterministic non-trivial weights for a whole ``Os2dModel`` state dict (backbone + TransformNet), a function of
+    the sorted key names and shapes only - the golden generator applies it to the REFERENCE model, the tests to ours,
+    so equal keys/shapes give equal weights.  Conv weights ~ N(0, sqrt(2 / fan_out)) (the ResNet initialisation scale),
+    norm layers perturbed around identity, running statistics live; the TransformNet comes from
+    ``make_transform_net_state`` so that the alignment path is exercised."""
+    rs = _rs(seed)
+    out = {}
+    tn_prefix = "os2d_head_creator.aligner.parameter_regressor."
+    tn = make_transform_net_state(P, seed=seed + 1)
+    for k in sorted(state_dict):
+        v = state_dict[k]
+        shape = tuple(v.shape)
+        if k.startswith(tn_prefix):
+            out[k] = tn[k[len(tn_prefix):]].clone().reshape(shape)
+        elif k.endswith("num_batches_tracked"):
+            out[k] = torch.ones(shape, dtype=v.dtype)
+        elif k.endswith("running_var"):
+            out[k] = torch.from_numpy(rs.uniform(0.5, 1.5, size=shape).astype(np.float32))
+        elif k.endswith("running_mean"):
+            out[k] = torch.from_numpy((0.1 * rs.standard_normal(shape)).astype(np.float32))
+        elif len(shape) == 4:
+            std = np.sqrt(2.0 / (shape[0] * shape[2] * shape[3]))
+            out[k] = torch.from_numpy((std * rs.standard_normal(shape)).astype(np.float32))
+        elif k.endswith("weight"):
+            out[k] = torch.from_numpy((1.0 + 0.1 * rs.standard_normal(shape)).astype(np.float32))
+        else:
+            out[k] = torch.from_numpy((0.1 * rs.standard_normal(shape)).astype(np.float32))
+        assert tuple(out[k].shape) == shape, k
+    return out

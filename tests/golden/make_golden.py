@@ -102,6 +102,53 @@ def _tv_nms(boxes, scores, thr):
     return torch.tensor(keep, dtype=torch.long)
 
 
+class _TvBottleneck(torch.nn.Module):
+    # torchvision.models.resnet.Bottleneck as published (ResNet v1.5: the stride sits on the 3x3 convolution)
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride, downsample, norm_layer):
+        super().__init__()
+        nn = torch.nn
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = norm_layer(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = norm_layer(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = norm_layer(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        return self.relu(self.bn3(self.conv3(out)) + idt)
+
+
+class _TvResNet(torch.nn.Module):
+    # torchvision.models.resnet.ResNet as published: conv1 7x7/2, bn1, relu, maxpool 3x3/2, layer1..4, avgpool, fc.
+    # The reference subclasses it and copies its __dict__ (os2d/modeling/feature_extractor.py:23-52).
+    def __init__(self, layers=(3, 4, 6, 3), norm_layer=None):
+        super().__init__()
+        nn = torch.nn
+        norm_layer = norm_layer or nn.BatchNorm2d
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = norm_layer(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        for i, (planes, blocks, stride) in enumerate(zip((64, 128, 256, 512), layers, (1, 2, 2, 2))):
+            down = None
+            if stride != 1 or self.inplanes != planes * 4:
+                down = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False), norm_layer(planes * 4))
+            seq = [_TvBottleneck(self.inplanes, planes, stride, down, norm_layer)]
+            self.inplanes = planes * 4
+            seq += [_TvBottleneck(self.inplanes, planes, 1, None, norm_layer) for _ in range(1, blocks)]
+            setattr(self, "layer{}".format(i + 1), nn.Sequential(*seq))
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(2048, 1000)
+
+
 def install_torchvision_standin():
     def mod(name):
         m = types.ModuleType(name)
@@ -121,11 +168,9 @@ def install_torchvision_standin():
     det._utils = utils
     ops.boxes = boxes
 
-    class ResNet(torch.nn.Module):  # placeholder: the backbone is not part of the recorded path
-        pass
-
-    resnet.ResNet = ResNet
-    resnet.resnet50 = resnet.resnet101 = lambda **kw: None
+    resnet.ResNet = _TvResNet
+    resnet.resnet50 = lambda norm_layer=None, **kw: _TvResNet([3, 4, 6, 3], norm_layer)
+    resnet.resnet101 = lambda norm_layer=None, **kw: _TvResNet([3, 4, 23, 3], norm_layer)
     utils.encode_boxes = _tv_encode_boxes
     utils.BoxCoder = _TvBoxCoder
 
@@ -264,6 +309,41 @@ def make_decode_fixture():
     np.savez_compressed(os.path.join(HERE, "decode_pyramid.npz"), **arrays)
 
 
+def make_model_fixture():
+    """Os2dModel.forward (reference model.py:235-276) end to end on CPU: images + class images -> backbone ->
+    class heads -> outputs, for the two branch layouts; also records the reference's state-dict keys and shapes.
+    The ResNet comes from the published-architecture stand-in above (torchvision is absent), weights from
+    ``synthetic.fill_model_state`` (a function of key names and shapes)."""
+    import logging
+    from os2d.modeling.model import Os2dModel
+    arrays = {}
+    g = torch.Generator().manual_seed(99)
+    image = torch.randn(1, 3, 96, 128, generator=g)
+    class_images = [torch.randn(3, 64, 64, generator=g), torch.randn(3, 48, 80, generator=g)]
+    arrays["image"] = image.numpy()
+    for i, c in enumerate(class_images):
+        arrays["class_image_{}".format(i)] = c.numpy()
+    for name, merge, simplify, inverse, arch in (("v2_merged", True, False, True, "resnet50"),
+                                                 ("v1_split", False, True, False, "resnet50")):
+        net = Os2dModel(logger=logging.getLogger("golden"), is_cuda=False, merge_branch_parameters=merge,
+                        backbone_arch=arch, use_inverse_geom_model=inverse, simplify_affine=simplify)
+        sd = net.state_dict()
+        filled = synthetic.fill_model_state(sd, seed=500, P=4 if simplify else 6)
+        net.load_state_dict(filled)
+        net.eval()
+        with torch.no_grad():
+            loc, cls, cls_det, fm_size, corners = net(images=image, class_images=class_images)
+        arrays["keys_" + name] = np.array(list(sd.keys()))
+        arrays["shapes_" + name] = np.array([",".join(str(d) for d in v.shape) for v in sd.values()])
+        arrays["checksum_" + name] = np.float64(synthetic.state_checksum(filled))
+        arrays["ref_loc_" + name] = loc.numpy()
+        arrays["ref_cls_" + name] = cls.numpy()
+        arrays["ref_corners_" + name] = corners.numpy()
+        arrays["fm_size_" + name] = np.array([fm_size.w, fm_size.h], dtype=np.int64)
+        print("model {}: {} state-dict entries, outputs {} {}".format(name, len(sd), tuple(loc.shape), tuple(cls.shape)))
+    np.savez_compressed(os.path.join(HERE, "model_forward.npz"), **arrays)
+
+
 def make_chunked_nms_fixture():
     """The reference's memory-bounded NMS (bounding_box.py:343-374: lists longer than nms_max_batch are NMS-ed in
     chunks of that size, survivors concatenated chunk by chunk in score order, repeated until one chunk is left or
@@ -301,6 +381,7 @@ def main():
     make_head_fixtures()
     make_decode_fixture()
     make_chunked_nms_fixture()
+    make_model_fixture()
 
 
 if __name__ == "__main__":

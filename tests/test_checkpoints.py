@@ -1,5 +1,8 @@
 """CPU: checkpoint compatibility of the model wrapper (reference os2d/modeling/model.py:290-426, os2d/utils/logger.py:137-160
 format: {"net": state_dict, "optimizer": ...}; backbone-only files; weakalign FeatureExtraction / FeatureRegression maps)."""
+import os
+
+import pytest
 import torch
 
 from os2d_amd.modeling.model import Os2dModel, init_from_weakalign_model
@@ -55,3 +58,18 @@ def test_weakalign_transform_mapping():
     assert torch.equal(got["linear.weight"], src["FeatureRegression.linear.weight"].view(6, 64, 5, 5))
     assert torch.equal(got["conv.0.weight"], src["FeatureRegression.conv.0.weight"])
     assert torch.equal(got["conv.4.running_var"], src["FeatureRegression.conv.4.running_var"])
+
+
+@pytest.mark.parametrize("name,merge,simplify,inverse", [("v2_merged", True, False, True), ("v1_split", False, True, False)])
+def test_state_dict_layout_equals_the_reference_model(name, merge, simplify, inverse):
+    """Keys, ORDER and shapes of ``Os2dModel.state_dict()`` against those recorded from the reference's own Os2dModel
+    (tests/golden/model_forward.npz): reference checkpoints load key for key, and aliases of shared modules
+    (merge_branch_parameters) appear under both names in the same order."""
+    import numpy as np
+    from os2d_amd.modeling.model import Os2dModel
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_forward.npz"))
+    net = Os2dModel(is_cuda=False, merge_branch_parameters=merge, backbone_arch="resnet50",
+                    use_inverse_geom_model=inverse, simplify_affine=simplify)
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in d["keys_" + name]]
+    assert [",".join(str(x) for x in v.shape) for v in sd.values()] == [str(s) for s in d["shapes_" + name]]

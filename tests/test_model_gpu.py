@@ -155,3 +155,31 @@ def test_detect_images_prefetching_iterator_equals_per_image_detect(device):
         assert torch.equal(det.get_field("labels"), ref.get_field("labels"))
         assert util.maxdiff(det.get_field("scores"), ref.get_field("scores")) < 1e-5     # MIOpen is not bit-reproducible call to call
         assert util.maxdiff(det.bbox_xyxy, ref.bbox_xyxy) < 1e-2
+
+
+@pytest.mark.parametrize("name,merge,simplify,inverse", [("v2_merged", True, False, True), ("v1_split", False, True, False)])
+def test_model_forward_matches_the_reference_model(name, merge, simplify, inverse, device):
+    """``Os2dModel.forward(images, class_images)`` end to end against the REFERENCE model's CPU outputs
+    (tests/golden/model_forward.npz): same weights (regenerated from key names and shapes, checksum-verified), backbone
+    on MIOpen, class heads built from two class images of different sizes, HIP head.  The backbone runs through a
+    different convolution library than the reference's CPU run, hence the looser tolerances."""
+    import os
+    import numpy as np
+    from os2d_amd.modeling.model import Os2dModel
+    from os2d_amd.utils import synthetic
+    d = np.load(os.path.join(util.GOLDEN, "model_forward.npz"))
+    net = Os2dModel(is_cuda=False, merge_branch_parameters=merge, backbone_arch="resnet50",
+                    use_inverse_geom_model=inverse, simplify_affine=simplify)
+    filled = synthetic.fill_model_state(net.state_dict(), seed=500, P=4 if simplify else 6)
+    assert abs(synthetic.state_checksum(filled) - float(d["checksum_" + name])) < 1e-6 * float(d["checksum_" + name])
+    net.load_state_dict(filled)
+    net.to(device).eval()
+    image = torch.from_numpy(d["image"]).to(device)
+    class_images = [torch.from_numpy(d["class_image_%d" % i]).to(device) for i in range(2)]
+    with torch.no_grad():
+        loc, cls, cls_det, fm_size, corners = net(images=image, class_images=class_images)
+    assert (fm_size.w, fm_size.h) == tuple(int(v) for v in d["fm_size_" + name])
+    assert tuple(loc.shape) == d["ref_loc_" + name].shape and tuple(cls.shape) == d["ref_cls_" + name].shape
+    assert util.maxdiff(cls, torch.from_numpy(d["ref_cls_" + name])) < 1e-4
+    assert util.maxdiff(loc, torch.from_numpy(d["ref_loc_" + name])) < 1e-3
+    assert util.maxdiff(corners, torch.from_numpy(d["ref_corners_" + name])) < 2e-2

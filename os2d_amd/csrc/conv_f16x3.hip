@@ -379,8 +379,25 @@ int launch(const void* in, const void* wp, const float* bp, float unscale, void*
 
 // layer 1: 7x7, 29 input groups (225 ch), 128 out, SHB out;  layer 2: 5x5, 16 groups, 64 out, SHB out;
 // layer 3: 5x5, 8 groups, P out (rows padded to 32), compact fp32 [NB][P][H*W] out.
+//
+// Small grids (a handful of classes: fewer work-groups of the standard shape than 1.5 per CU) use finer work-groups -
+// 128 positions instead of 256 and 32 output channels per group - so that a call with ONE class (the reference's own
+// calling pattern, evaluate.py:323-331) still spreads over 160 / 80 / 40 groups instead of 40 / 20 / 20 and a group's
+// serial K loop issues 3 instead of 12 MFMAs per k-step.  Every output element accumulates the same products in the
+// same order in both shapes, so results do not depend on which one ran (tests: small batch == slice of a large batch).
 int os2d_launch_conv_f16x3(int layer, const void* in, const void* wp, const float* bp, float unscale, void* out, int NB,
                            int P, int H, int W, int terms, hipStream_t stream) {
+  const long long std_groups = (long long)((H * os2d_ws(W) + 255) / 256) * NB;
+  if (std_groups * (layer == 1 ? 2 : 1) < 384) {  // measured crossover at 60x80: finer shapes win up to 9 classes
+    if (layer == 1 && terms == 2)
+      return launch<7, 128, 32, 1, 4, 1, 5, true, 0, 2>(in, wp, bp, unscale, out, NB, 29, 128, H, W, stream);
+    switch (layer) {
+      case 1: return launch<7, 128, 32, 1, 4, 1, 5, true, 0>(in, wp, bp, unscale, out, NB, 29, 128, H, W, stream);
+      case 2: return launch<5, 64, 32, 1, 4, 1, 7, true, 0>(in, wp, bp, unscale, out, NB, 16, 64, H, W, stream);
+      case 3: return launch<5, 32, 32, 1, 4, 1, 7, false, 2>(in, wp, bp, unscale, out, NB, 8, P, H, W, stream);
+      default: break;
+    }
+  }
   if (layer == 1 && terms == 2)
     return launch<7, 128, 64, 1, 4, 2, 5, true, 0, 2>(in, wp, bp, unscale, out, NB, 29, 128, H, W, stream);
   switch (layer) {

@@ -276,3 +276,22 @@ def test_random_shapes_all_precisions_match_oracle(C, H, W, A, B, P, inverse, de
             assert util.maxdiff(cls, ref[1]) < TOL_CLS, precision
             assert util.maxdiff(loc, ref[0]) < TOL_LOC, precision
             assert util.maxdiff(corners, ref[3]) < TOL_CORNERS, precision
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_small_batches_equal_slices_of_a_large_batch(precision, device):
+    """A handful of classes runs through finer work-group shapes than a large batch (128-position tiles, 32 output
+    channels per group); every output element still accumulates the same products in the same order, so a 1-, 2- or
+    5-class call equals the corresponding slice of a 40-class call bit for bit - at the full 1024 x 60 x 80 size."""
+    from os2d_amd.utils import synthetic
+    P, inverse = 6, True
+    state = synthetic.make_transform_net_state(P, seed=8)
+    fm = synthetic.make_feature_map(1024, 60, 80, seed=9).to(device)
+    class_fms = [c.to(device) for c in synthetic.make_class_feature_maps(40, 1024, sizes=[(15, 15), (13, 17)], seed=3000)]
+    creator = util.make_head_creator(P, inverse, state, device)
+    with torch.no_grad():
+        big = creator.create_os2d_head(class_fms)(fm, precision=precision)
+        for lo, hi in ((0, 1), (17, 19), (30, 35)):
+            small = creator.create_os2d_head(class_fms[lo:hi])(fm, precision=precision)
+            for i in (0, 1, 3):
+                assert torch.equal(small[i], big[i][:, lo:hi]), (lo, hi, i)

@@ -22,24 +22,30 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 constexpr int NTHR = 512;
-constexpr int NT = 256;
 constexpr int GC = 4;                    // 8-channel groups per K chunk (32 channels)
-constexpr int CH_UNITS = GC * 2 * 256;   // 16-byte units of one operand chunk (A and B alike): 2048 = 32 KB
-constexpr int NPF = CH_UNITS / NTHR;     // 4 units per thread per operand
+constexpr int CH_UNITS = GC * 2 * 256;   // 16-byte units of one class-operand chunk: 2048 = 32 KB
+constexpr int NPF = CH_UNITS / NTHR;     // 4 class units per thread
 
+// NI = 32-column tiles per wave: 2 -> 256 positions per work-group (the throughput shape), 1 -> 128 positions (twice the
+// work-groups, half the MFMAs per K chunk: for a handful of classes, where the chip is empty and a group's serial K loop
+// is what a call waits for).  Every output accumulates the same products in the same order in both shapes.
+template <int NI>
 __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  // [A][CG][2][HW]   (no __restrict__, see
                                                              const u32x4* qs,  // [B][CG][2][256]    conv_f16x3.hip)
                                                              float* __restrict__ corr, char* __restrict__ rshb, int A,
                                                              int B, int CG, int H, int W, int PLANE, float unscale) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
+  constexpr int NT = 128 * NI;           // positions per work-group
+  constexpr int BUNITS = GC * 2 * NT;    // 16-byte units of one image-operand chunk
+  constexpr int NPFB = BUNITS / NTHR;    // image units per thread (4 or 2)
   u32x4* ldsA = smem16;                 // [2][CH_UNITS]
-  u32x4* ldsB = smem16 + 2 * CH_UNITS;  // [2][CH_UNITS]
+  u32x4* ldsB = smem16 + 2 * CH_UNITS;  // [2][BUNITS]
   __shared__ float red[2][NT];
 
   const int HW = H * W;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, hw = lane >> 5;
-  const int wm = wid >> 2, wn = wid & 3;  // wave tile: rows [wm*128,+128), cols [wn*64,+64)
+  const int wm = wid >> 2, wn = wid & 3;  // wave tile: rows [wm*128,+128), cols [wn*32*NI,+32*NI)
   // XCD-aware work mapping (work-group L runs on XCD L % 8): XCD x gets the contiguous range [x*per, (x+1)*per) of the
   // logical order (image, group of 4 classes, position tile, class in group).  The 32 groups resident on an XCD (one per
   // CU) are then ~8 tiles x 4 classes marching through K together: 12 MB of distinct operand bytes per 32 groups in
@@ -56,11 +62,11 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
   const int n0 = (r2_ / gsz) * NT;
   const int nb = a * B + b;
 
-  f32x16 acc[4][2];
+  f32x16 acc[4][NI];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
@@ -78,14 +84,16 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
 #define CF_DMA1(T, K)                                                                                             \
   {                                                                                                               \
     const int i_ = tid + (K)*NTHR;                                                                                \
-    const int row_ = i_ >> 8, col_ = i_ & 255;                                                                    \
-    const int grow_ = (T)*GC * 2 + row_;                                                                          \
-    const bool rok_ = grow_ < CG * 2;                                                                             \
-    const u32x4* ga_ = rok_ ? qb + (size_t)grow_ * 256 + col_ : zeros;                                            \
-    const u32x4* gb_ = (rok_ && n0 + col_ < HW) ? fa + (size_t)grow_ * HW + n0 + col_ : zeros;                    \
-    const int w0_ = ((T)&1) * CH_UNITS + (i_ & ~63); /* first unit of this wave's 64 */                           \
-    __builtin_amdgcn_global_load_lds((gptr_t)ga_, (lptr_t)(ldsA + w0_), 16, 0, 0);                                \
-    __builtin_amdgcn_global_load_lds((gptr_t)gb_, (lptr_t)(ldsB + w0_), 16, 0, 0);                                \
+    {                                                                                                             \
+      const int grow_ = (T)*GC * 2 + (i_ >> 8);                                                                   \
+      const u32x4* ga_ = grow_ < CG * 2 ? qb + (size_t)grow_ * 256 + (i_ & 255) : zeros;                          \
+      __builtin_amdgcn_global_load_lds((gptr_t)ga_, (lptr_t)(ldsA + ((T)&1) * CH_UNITS + (i_ & ~63)), 16, 0, 0);  \
+    }                                                                                                             \
+    if ((K) < NPFB) {                                                                                             \
+      const int grow_ = (T)*GC * 2 + i_ / NT, col_ = i_ % NT;                                                     \
+      const u32x4* gb_ = (grow_ < CG * 2 && n0 + col_ < HW) ? fa + (size_t)grow_ * HW + n0 + col_ : zeros;        \
+      __builtin_amdgcn_global_load_lds((gptr_t)gb_, (lptr_t)(ldsB + ((T)&1) * BUNITS + (i_ & ~63)), 16, 0, 0);    \
+    }                                                                                                             \
   }
 #define CF_DMA(T)                                                                                                 \
   {                                                                                                               \
@@ -96,18 +104,18 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
 #define CF_COMPUTE_H(T, HOOK)                                                                                     \
   {                                                                                                               \
     const u32x4* aB_ = ldsA + ((T)&1) * CH_UNITS + wm * 128 + l31;                                                \
-    const u32x4* bB_ = ldsB + ((T)&1) * CH_UNITS + wn * 64 + l31;                                                 \
+    const u32x4* bB_ = ldsB + ((T)&1) * BUNITS + wn * (32 * NI) + l31;                                            \
     _Pragma("unroll") for (int ks = 0; ks < GC / 2; ++ks) {                                                       \
       const int rowh_ = ((2 * ks + hw) * 2 + 0) * 256, rowl_ = ((2 * ks + hw) * 2 + 1) * 256;                     \
-      half8 bh_[2], bl_[2];                                                                                       \
-      _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                                          \
-        bh_[ni] = *reinterpret_cast<const half8*>(bB_ + rowh_ + ni * 32);                                         \
-        bl_[ni] = *reinterpret_cast<const half8*>(bB_ + rowl_ + ni * 32);                                         \
+      half8 bh_[NI], bl_[NI];                                                                                     \
+      _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                                         \
+        bh_[ni] = *reinterpret_cast<const half8*>(bB_ + ((2 * ks + hw) * 2 + 0) * NT + ni * 32);                  \
+        bl_[ni] = *reinterpret_cast<const half8*>(bB_ + ((2 * ks + hw) * 2 + 1) * NT + ni * 32);                  \
       }                                                                                                           \
       _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                                          \
         const half8 ah_ = *reinterpret_cast<const half8*>(aB_ + rowh_ + mi * 32);                                 \
         const half8 al_ = *reinterpret_cast<const half8*>(aB_ + rowl_ + mi * 32);                                 \
-        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                                        \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                                       \
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al_, bh_[ni], acc[mi][ni], 0, 0, 0);               \
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bl_[ni], acc[mi][ni], 0, 0, 0);               \
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bh_[ni], acc[mi][ni], 0, 0, 0);               \
@@ -144,10 +152,10 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
 
   // ---- epilogue (features were normalised before the split, so only the 2^-24 operand scale is undone)
   const int Ws = os2d_ws(W), BASE = os2d_base(W);
-  float part[2];
+  float part[NI];
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int n = n0 + wn * 64 + ni * 32 + l31;
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n0 + wn * (32 * NI) + ni * 32 + l31;
     const bool nin = n < HW;
     float s = 0.f;
 #pragma unroll
@@ -165,13 +173,13 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
     part[ni] = s;
   }
   if (hw == 0) {
-    red[wm][wn * 64 + l31] = part[0];
-    red[wm][wn * 64 + 32 + l31] = part[1];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) red[wm][wn * (32 * NI) + ni * 32 + l31] = part[ni];
   }
   __syncthreads();
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int col = wn * 64 + ni * 32 + l31;
+  for (int ni = 0; ni < NI; ++ni) {
+    const int col = wn * (32 * NI) + ni * 32 + l31;
     const int n = n0 + col;
     if (n >= HW) continue;
     const float inv_r = 1.0f / (sqrtf(red[0][col] + red[1][col]) + 1e-6f);  // head.py:650,597 (eps 1e-6)
@@ -266,11 +274,15 @@ int os2d_launch_split_qp(const float* qp, void* qs, int B, int C, hipStream_t st
   return check("split_qp");
 }
 
-int os2d_launch_corr_f16x3(const void* fs, const void* qs, float* corr, void* rshb, int A, int B, int C, int H, int W,
-                           hipStream_t stream) {
+namespace {
+
+template <int NI>
+int launch_corr(const void* fs, const void* qs, float* corr, void* rshb, int A, int B, int C, int H, int W,
+                hipStream_t stream) {
+  constexpr int NT = 128 * NI;
   const int HW = H * W;
-  const size_t lds = (size_t)4 * CH_UNITS * 16;  // 128 KB dynamic (+2 KB static)
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_f16x3_kernel),
+  const size_t lds = (size_t)(2 * CH_UNITS + 2 * GC * 2 * NT) * 16;  // 128 KB (NI = 2) / 96 KB dynamic (+ static)
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_f16x3_kernel<NI>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) {
     os2d_set_error("hipFuncSetAttribute(corr f16x3): %s", hipGetErrorString(e));
@@ -278,8 +290,17 @@ int os2d_launch_corr_f16x3(const void* fs, const void* qs, float* corr, void* rs
   }
   const long long groups = (long long)((HW + NT - 1) / NT) * B * A;
   dim3 grid((unsigned)((groups + 7) / 8 * 8));  // multiple of 8: every XCD gets the same number of logical slots
-  hipLaunchKernelGGL(corr_f16x3_kernel, grid, dim3(NTHR), lds, stream, reinterpret_cast<const u32x4*>(fs),
+  hipLaunchKernelGGL(corr_f16x3_kernel<NI>, grid, dim3(NTHR), lds, stream, reinterpret_cast<const u32x4*>(fs),
                      reinterpret_cast<const u32x4*>(qs), corr, reinterpret_cast<char*>(rshb), A, B, (C + 7) / 8, H, W,
                      os2d_plane(H, W), ldexpf(1.0f, -2 * SCALE_LOG2));
   return check("corr_f16x3");
+}
+
+}  // namespace
+
+int os2d_launch_corr_f16x3(const void* fs, const void* qs, float* corr, void* rshb, int A, int B, int C, int H, int W,
+                           hipStream_t stream) {
+  // the 128-position shape as long as its work-groups still fit the chip in one round (see the kernel's comment)
+  if ((long long)((H * W + 127) / 128) * B * A <= 256) return launch_corr<1>(fs, qs, corr, rshb, A, B, C, H, W, stream);
+  return launch_corr<2>(fs, qs, corr, rshb, A, B, C, H, W, stream);
 }

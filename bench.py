@@ -15,7 +15,7 @@ in HBM before the timed region.
 Arithmetic (``--precision``):
   f16x3 (default)  every fp32 operand of the four GEMM-shaped stages is split into fp16 hi + lo and each product is
                    evaluated with three v_mfma_f32_32x32x16_f16 (fp32 accumulation): outputs agree with the reference
-                   to the same 2.4e-7 as the fp32 mode (tests/test_head_gpu.py runs every parity case in both modes);
+                   to the same 2.4e-7 as the fp32 mode (tests/test_head_gpu.py runs every parity case in all modes);
   f16x2            as f16x3, except that the dominant 7x7 layer takes its WEIGHTS as fp16 roundings only (two MFMAs per
                    product, activations still split): scores within 1e-6 and box regression within 5e-5 of the fp32
                    result - inside the 1e-4 parity bound of BASELINE.json, but no longer fp32-equivalent;

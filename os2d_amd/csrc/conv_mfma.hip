@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const float* __restri
                                                            const float* __restrict__ wp,   // [CinP/2][KS*KS][2][MT]
                                                            const float* __restrict__ bp,   // [MT]
                                                            float* __restrict__ out, int CinP, int CoutStore,
-                                                           int H, int W, int PLANE, int HALO) {
+                                                           int H, int W, int PLANE, int HALO, int TILES, int NB) {
   constexpr int R = KS / 2;
   constexpr int SP = KS / RS;  // stages per channel pair
   static_assert(SP * RS == KS, "RS must divide KS");
@@ -52,8 +52,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const float* __restri
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
   const int wm = wid / WN, wn = wid % WN;
-  const int nb = blockIdx.y;
-  const int n0 = BASE + blockIdx.x * NT;
+  // XCD-aware work mapping (see conv_f16x3.hip): XCD x = work-groups L with L % 8 == x gets a contiguous range of the
+  // logical order (plane, tile), so the tiles of one plane - whose input slabs overlap by 2/3 - share one L2
+  const int per = gridDim.x >> 3;
+  const int logical = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (logical >= TILES * NB) return;
+  const int tile = logical % TILES;
+  const int nb = logical / TILES;
+  const int n0 = BASE + tile * NT;
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -172,10 +178,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const float* __restri
   }
   if (!COMPACT) {
     // pad rows above the data (first tile) and whatever lies beyond the last tile
-    if (blockIdx.x == 0)
+    if (tile == 0)
       for (int i = tid; i < CoutStore * BASE; i += 256) out[((size_t)nb * CoutStore + i / BASE) * PLANE + i % BASE] = 0.f;
-    if (blockIdx.x == gridDim.x - 1) {
-      const int tail0 = BASE + gridDim.x * NT, tail = PLANE - tail0;
+    if (tile == TILES - 1) {
+      const int tail0 = BASE + TILES * NT, tail = PLANE - tail0;
       if (tail > 0)
         for (int i = tid; i < CoutStore * tail; i += 256)
           out[((size_t)nb * CoutStore + i / tail) * PLANE + tail0 + i % tail] = 0.f;
@@ -203,8 +209,10 @@ int launch(const float* in, const float* wp, const float* bp, float* out, int NB
     os2d_set_error("hipFuncSetAttribute(conv): %s", hipGetErrorString(e));
     return -4;
   }
-  dim3 grid((H * Ws + NT - 1) / NT, NB);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, in, wp, bp, out, CinP, CoutStore, H, W, PLANE, HALO);
+  const int tiles = (H * Ws + NT - 1) / NT;
+  const long long groups = (long long)tiles * NB;
+  dim3 grid((unsigned)((groups + 7) / 8 * 8));  // multiple of 8: every XCD gets the same number of logical slots
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, in, wp, bp, out, CinP, CoutStore, H, W, PLANE, HALO, tiles, NB);
   e = hipGetLastError();
   if (e != hipSuccess) {
     os2d_set_error("conv launch: %s", hipGetErrorString(e));

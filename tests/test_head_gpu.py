@@ -295,3 +295,25 @@ def test_small_batches_equal_slices_of_a_large_batch(precision, device):
             small = creator.create_os2d_head(class_fms[lo:hi])(fm, precision=precision)
             for i in (0, 1, 3):
                 assert torch.equal(small[i], big[i][:, lo:hi]), (lo, hi, i)
+
+
+@pytest.mark.parametrize("B,iters", [(64, 150), (2, 400)])
+def test_repeated_calls_are_bit_identical(B, iters, device):
+    """Soak test of the asynchronous staging (LDS-DMA in the correlation, register prefetch pipelines in the convolutions,
+    both work-group shapes): hundreds of back-to-back calls at the full 1024 x 60 x 80 size must reproduce the first
+    result bit for bit - a read that races a DMA or a prefetch shows up as a rare wrong tile."""
+    from os2d_amd.utils import synthetic
+    P, inverse = 6, True
+    state = synthetic.make_transform_net_state(P, seed=12)
+    fm = synthetic.make_feature_map(1024, 60, 80, seed=13).to(device)
+    class_fms = [c.to(device) for c in synthetic.make_class_feature_maps(B, 1024, seed=4000)]
+    creator = util.make_head_creator(P, inverse, state, device)
+    with torch.no_grad():
+        head = creator.create_os2d_head(class_fms)
+        first = [t.clone() for t in head(fm)]
+        bad = torch.zeros((), dtype=torch.int64, device=device)
+        for _ in range(iters):
+            out = head(fm)
+            for i in (0, 1, 3):
+                bad += (out[i] != first[i]).sum()
+    assert int(bad) == 0

@@ -302,6 +302,8 @@ def main():
         # channels x (hi|lo) halves) + the 128 output planes written once + the packed weights once
         plane = int(lib.os2d_plane_floats(H_FM, W_FM))
         in_planes = 226 if precision == "f32" else 232
+        if r["traffic"]:
+            r["hbm_gbps"] = round(r["traffic"] / (stage_ms[1] * 1e-3) / 1e9, 1)      # 8000 GB/s peak: far from HBM-bound
         r["algorithmic_bytes"] = int(B * (in_planes + 128) * plane * 4 + lib.os2d_packed_conv_bytes(1, {"f32": 0, "f16x3": 1, "f16x2": 2}[precision]))
         if precision != "f32":
             # every algorithmic product costs three (f16x2: two) half-precision MFMA products: the ceiling for

@@ -26,7 +26,8 @@ The primary line is measured in the selected mode; the other modes are timed rig
 Prints ONE JSON line on rank 0 with the driver's contract fields plus
   roofline     - the dominant kernel (conv 7x7 225->128 MFMA implicit GEMM): ALGORITHMIC FLOPs per launch divided by its
                  mean launch duration, measured with HIP events recorded on the launch stream inside the timed steps,
-                 against the dense MFMA peak of the instruction it runs on
+                 against the dense MFMA peak of the instruction it runs on; `traffic` / `hbm_gbps` / `mfma_pipe_busy` are the
+                 HBM bytes, HBM rate and matrix-pipe utilisation of that kernel from the committed rocprofv3 PMC passes
   stages_ms    - mean duration of every stage of the step (same events)
   end_to_end   - secondary: backbone + head + decode/NMS per image, and the one-off class-head construction (N=1 only)
   cpu_baseline - the oracle (torch-CPU restatement of the reference head, driven one class at a time like the
@@ -101,6 +102,16 @@ def cpu_baseline(fm_cpu, class_fms_cpu, state, inverse, budget_s):
                       "60x80x1024 feature map, {:.1f} s, torch CPU fp32, best of {} threads ({}) on {} hw threads"
                       .format(best[2], best[3], "/".join(str(r[1]) for r in results),
                               ", ".join("{}: {:.1f} pairs/s".format(r[1], r[0]) for r in results), ncores)}
+
+
+def measured_mfma_busy(precision):
+    """Matrix-pipe utilisation of the conv 7x7 kernel from the committed rocprofv3 SQ pass
+    (SQ_VALU_MFMA_BUSY_CYCLES x 32 / (1024 SIMDs x GRBM_GUI_ACTIVE)); None if not recorded."""
+    path = os.path.join(REPO, "profiles", "conv1_traffic_{}.json".format(precision))
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get("mfma_pipe_busy")
 
 
 def measured_traffic(B, precision):
@@ -302,6 +313,7 @@ def main():
         # channels x (hi|lo) halves) + the 128 output planes written once + the packed weights once
         plane = int(lib.os2d_plane_floats(H_FM, W_FM))
         in_planes = 226 if precision == "f32" else 232
+        r["mfma_pipe_busy"] = measured_mfma_busy(precision)
         if r["traffic"]:
             r["hbm_gbps"] = round(r["traffic"] / (stage_ms[1] * 1e-3) / 1e9, 1)      # 8000 GB/s peak: far from HBM-bound
         r["algorithmic_bytes"] = int(B * (in_planes + 128) * plane * 4 + lib.os2d_packed_conv_bytes(1, {"f32": 0, "f16x3": 1, "f16x2": 2}[precision]))

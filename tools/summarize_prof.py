@@ -63,10 +63,24 @@ def conv1_traffic(root, classes, out_path):
             vals[name] = row[0]
     if len(vals) == 2 and all(v is not None for v in vals.values()):
         total = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+        # matrix-pipe utilisation of the same kernel from the SQ pass: SQ_VALU_MFMA_BUSY_CYCLES counts units of 32 cycles
+        # summed over the SIMDs (= one per 32x32x16 f16 MFMA, two per 32x32x2 f32 MFMA); 1024 SIMDs on the chip
+        busy = {}
+        for path in glob.glob(os.path.join(root, "pmc_sq", "*.db")):
+            cur = sqlite3.connect(path).cursor()
+            for name in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
+                row = cur.execute(
+                    "select avg(e.value) from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id = p.id "
+                    "join rocpd_kernel_dispatch d on e.event_id = d.event_id join rocpd_info_kernel_symbol s on d.kernel_id = s.id "
+                    "where p.name = ? and (s.kernel_name like '%conv_mfma_kernelILi7%' or s.kernel_name like '%conv_f16x3_kernelILi7%')", (name,)).fetchone()
+                busy[name] = row[0]
         with open(out_path, "w") as f:
             json.dump({"kernel": "TransformNet conv 7x7 (conv_mfma_kernel<7,..> or conv_f16x3_kernel<7,..>)", "classes_profiled": classes, "fetch_kib": vals["FETCH_SIZE"],
                        "write_kib": vals["WRITE_SIZE"], "fetch_correction": 2.0, "bytes_per_launch": total,
-                       "bytes_per_class": total / classes, "source": os.path.basename(os.path.normpath(root))}, f, indent=1)
+                       "bytes_per_class": total / classes, "source": os.path.basename(os.path.normpath(root)),
+                       "mfma_busy_cycles_x32": busy.get("SQ_VALU_MFMA_BUSY_CYCLES"), "grbm_gui_active": busy.get("GRBM_GUI_ACTIVE"),
+                       "mfma_pipe_busy": (round(busy["SQ_VALU_MFMA_BUSY_CYCLES"] * 32 / (1024 * busy["GRBM_GUI_ACTIVE"]), 4)
+                                          if busy.get("SQ_VALU_MFMA_BUSY_CYCLES") and busy.get("GRBM_GUI_ACTIVE") else None)}, f, indent=1)
         print("conv1 traffic: {:.1f} MB per launch ({} classes) -> {}".format(total / 1e6, classes, out_path))
 
 

@@ -129,3 +129,16 @@ def test_class_image_views_order_and_ids():
     assert all(ids[l] == [4][l // n] for l in range(8))
     with pytest.raises(RuntimeError):
         class_image_views([im], [4], "rot45")
+
+
+def test_bench_refuses_to_run_without_a_device():
+    """No CPU fallback anywhere near the measured path: without a HIP device bench.py stops with a clear message."""
+    import os
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    repo = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--steps", "1"], cwd=repo, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode != 0 and "HIP device" in (out.stderr + out.stdout)

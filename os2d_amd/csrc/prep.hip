@@ -8,22 +8,32 @@
 
 namespace {
 
-// ---- fm_sumsq: one block per 64 positions, 1024 threads = 64 positions x 16 channel lanes, fixed-order LDS tree
-// (deterministic: no atomics, so repeated calls and class chunking give bit-identical results)
-constexpr int SUMSQ_LANES = 16;
+// ---- fm_sumsq: one block per 16 positions (300 blocks at 60x80, so every CU streams), 256 threads = 16 positions x 16
+// channel lanes (64-byte row segments), fixed-order LDS tree (deterministic: no atomics, so repeated calls and class
+// chunking give bit-identical results)
+constexpr int SUMSQ_LANES = 16, SUMSQ_POS = 16;
 
-__global__ __launch_bounds__(1024) void fm_sumsq_kernel(const float* __restrict__ fm, float* __restrict__ sumsq, int C,
-                                                        int HW) {
-  __shared__ float red[SUMSQ_LANES][64];
-  const int col = threadIdx.x & 63, cl = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + col;
+__global__ __launch_bounds__(SUMSQ_LANES * SUMSQ_POS) void fm_sumsq_kernel(const float* __restrict__ fm,
+                                                                           float* __restrict__ sumsq, int C, int HW) {
+  __shared__ float red[SUMSQ_LANES][SUMSQ_POS];
+  const int col = threadIdx.x % SUMSQ_POS, cl = threadIdx.x / SUMSQ_POS;
+  const int n = blockIdx.x * SUMSQ_POS + col;
   const int a = blockIdx.y;
   float s = 0.f;
-  if (n < HW)
-    for (int c = cl; c < C; c += SUMSQ_LANES) {
-      const float v = fm[((size_t)a * C + c) * HW + n];
-      s += v * v;
+  if (n < HW) {
+    const float* p = fm + (size_t)a * C * HW + n;
+    for (int c0 = cl; c0 < C; c0 += SUMSQ_LANES * 8) {  // 8 independent loads in flight, accumulated in channel order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + u * SUMSQ_LANES;
+        v[u] = p[(size_t)min(c, C - 1) * HW];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (c0 + u * SUMSQ_LANES < C) s += v[u] * v[u];
     }
+  }
   red[cl][col] = s;
   __syncthreads();
   if (cl == 0 && n < HW) {
@@ -218,7 +228,8 @@ int check_launch(const char* what) {
 }  // namespace
 
 int os2d_launch_fm_sumsq(const float* fm, float* sumsq, int A, int C, int HW, hipStream_t stream) {
-  hipLaunchKernelGGL(fm_sumsq_kernel, dim3((HW + 63) / 64, A), dim3(1024), 0, stream, fm, sumsq, C, HW);
+  hipLaunchKernelGGL(fm_sumsq_kernel, dim3((HW + SUMSQ_POS - 1) / SUMSQ_POS, A), dim3(SUMSQ_LANES * SUMSQ_POS), 0, stream,
+                     fm, sumsq, C, HW);
   return check_launch("fm_sumsq");
 }
 

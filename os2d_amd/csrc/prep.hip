@@ -210,10 +210,21 @@ __global__ __launch_bounds__(256) void pack_conv_f16_kernel(const float* __restr
 }
 
 // border cells of the split-half blocked normalised-correlation buffer [NB][29][2][PLANE] x 16 B
+// (the pad cells are enumerated directly: the BASE cells in front, the 3 cells after every row, the tail)
 __global__ __launch_bounds__(256) void border_zero_shb_kernel(uint4* __restrict__ p, int H, int W, int PLANE) {
   uint4* q = p + (size_t)blockIdx.x * PLANE;
-  for (int i = threadIdx.x; i < PLANE; i += 256)
-    if (!os2d_interior(i, H, W)) q[i] = make_uint4(0u, 0u, 0u, 0u);
+  const int Ws = os2d_ws(W), BASE = os2d_base(W);
+  const int rows = H * OS2D_PAD, tail0 = BASE + H * Ws;
+  const int npad = BASE + rows + (PLANE - tail0);
+  for (int k = threadIdx.x; k < npad; k += 256) {
+    int cell;
+    if (k < BASE) cell = k;
+    else if (k < BASE + rows) {
+      const int j = k - BASE;
+      cell = BASE + (j / OS2D_PAD) * Ws + W + j % OS2D_PAD;
+    } else cell = tail0 + (k - BASE - rows);
+    q[cell] = make_uint4(0u, 0u, 0u, 0u);
+  }
 }
 
 int check_launch(const char* what) {

@@ -21,7 +21,6 @@ Two statements are provided:
                                    (no 15x15x2 grid tensor, 121 taps, 4 corners, analytic inverse): an
                                    independent derivation used as high-precision truth for error budgets.
 """
-import math
 
 import torch
 import torch.nn.functional as F

@@ -8,7 +8,6 @@ stride on the 3x3 convolution, as torchvision >= 0.5) is defined here with torch
 """
 from itertools import chain
 
-import torch
 import torch.nn as nn
 
 from ..structures.feature_map import FeatureMapSize

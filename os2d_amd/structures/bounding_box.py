@@ -3,8 +3,6 @@
 xyxy storage, image size, named per-box fields, indexing, resize, clipping and the empty-box mask."""
 import torch
 
-from .feature_map import FeatureMapSize
-
 
 class BoxList(object):
     def __init__(self, bbox, image_size, mode="xyxy"):

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Stage-by-stage diagnostic of the HIP path against the oracle on one golden fixture (GPU box).
 Prints max abs errors of: class maps, sumsq, corr, normalised corr, conv1, conv2, params, final outputs."""
-import ctypes
 import os
 import sys
 

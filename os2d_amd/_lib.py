@@ -71,7 +71,12 @@ def load():
         # HIP library, not a fallback implementation; if hipcc is missing the error below still fires.
         try:
             from . import build as _build
-            _build.build(verbose=False)
+            import fcntl
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path + ".lock", "w") as lock:      # one builder at a time (torchrun starts N ranks at once)
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                if not os.path.exists(path):
+                    _build.build(verbose=False)
         except Exception as e:  # noqa: BLE001
             raise Os2dLibraryError("libos2d_hip.so is not built and building it failed ({}); the OS2D head has no "
                                    "CPU or PyTorch fallback".format(e))

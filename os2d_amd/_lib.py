@@ -9,7 +9,7 @@ import os
 
 from .build import LIB_PATH
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c_float_p = ctypes.c_void_p   # device pointers travel as raw addresses (tensor.data_ptr())
 _vp = ctypes.c_void_p
@@ -28,10 +28,16 @@ SIGNATURES = {
     "os2d_head_workspace_bytes": (_i, [_i, _i, _i, _i, _i, _i, ctypes.POINTER(_sz)]),
     "os2d_head_forward": (_i, [_vp] * 8 + [_i] * 9 + [_vp, _vp, _vp, _vp, _sz, _vp]),
     "os2d_packed_conv_bytes": (_sz, [_i, _i]),
-    "os2d_pack_conv_f16x3": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),
+    "os2d_pack_conv_f16x3": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp]),
+    "os2d_rnorm_exp": (_i, []),
+    "os2d_class_prepare_batch": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "os2d_shb_bytes": (_sz, [_i, _i, _i]),
+    "os2d_corr_normalize_f16x3": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "os2d_transform_conv_f16x3": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "os2d_alignment_grids": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "os2d_class_split": (_i, [_vp, _vp, _i, _i, _vp]),
     "os2d_head_forward_ex": (_i, [_vp] * 8 + [_i] * 9 + [_vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, ctypes.POINTER(_i),
-                                  ctypes.POINTER(_vp), ctypes.POINTER(_i)]),
+                                  ctypes.POINTER(_vp), ctypes.POINTER(_i), _vp]),
     "os2d_prof_event_create": (_i, [ctypes.POINTER(_vp)]),
     "os2d_prof_event_destroy": (_i, [_vp]),
     "os2d_prof_event_elapsed_ms": (_i, [_vp, _vp, ctypes.POINTER(_f)]),
@@ -66,20 +72,22 @@ def load():
     if _LIB is not None:
         return _LIB
     path = lib_path()
-    if not os.path.exists(path) and "OS2D_HIP_LIB" not in os.environ:
-        # a fresh checkout (the .so is a build artefact, not tracked): compile it in-tree once.  This is the same
-        # HIP library, not a fallback implementation; if hipcc is missing the error below still fires.
-        try:
-            from . import build as _build
-            import fcntl
-            os.makedirs(os.path.dirname(path), exist_ok=True)
-            with open(path + ".lock", "w") as lock:      # one builder at a time (torchrun starts N ranks at once)
-                fcntl.flock(lock, fcntl.LOCK_EX)
-                if not os.path.exists(path):
-                    _build.build(verbose=False)
-        except Exception as e:  # noqa: BLE001
-            raise Os2dLibraryError("libos2d_hip.so is not built and building it failed ({}); the OS2D head has no "
-                                   "CPU or PyTorch fallback".format(e))
+    if "OS2D_HIP_LIB" not in os.environ:
+        # The .so is a build artefact (not tracked): compile it in-tree when it is missing OR was built from other
+        # sources than the ones in the tree (content hash, os2d_amd/build.py - an edited kernel never runs stale).
+        # This is the same HIP library, not a fallback implementation; if hipcc is missing the error below fires.
+        from . import build as _build
+        if not _build.up_to_date():
+            try:
+                import fcntl
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                with open(path + ".lock", "w") as lock:      # one builder at a time (torchrun starts N ranks at once);
+                    fcntl.flock(lock, fcntl.LOCK_EX)         # the check is repeated under the lock
+                    if not _build.up_to_date():
+                        _build.build(verbose=False)
+            except Exception as e:  # noqa: BLE001
+                raise Os2dLibraryError("libos2d_hip.so is missing or stale and building it failed ({}); the OS2D head "
+                                       "has no CPU or PyTorch fallback".format(e))
     if not os.path.exists(path):
         raise Os2dLibraryError(
             "libos2d_hip.so not found at {} - the OS2D head has no CPU or PyTorch fallback; build the HIP "
@@ -119,6 +127,16 @@ def ptr(t):
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype in (torch.float32, torch.uint8, torch.int32, torch.int64) and t.is_contiguous()):
         raise ValueError("expected a contiguous device tensor, got {}".format(
             (type(t).__name__, getattr(t, "device", None), getattr(t, "dtype", None))))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def host_ptr(t):
+    """Address of a PINNED host tensor (hipHostMalloc memory is mapped into the device address space under the same
+    address: kernels may store to it); None -> NULL."""
+    if t is None:
+        return None
+    if not t.is_pinned():
+        raise ValueError("expected a pinned host tensor")
     return ctypes.c_void_p(t.data_ptr())
 
 

@@ -3,6 +3,7 @@
     python -m os2d_amd.build          # build if stale
     python -m os2d_amd.build --force
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -24,6 +25,29 @@ def _hipcc():
         if cand and os.path.exists(cand):
             return cand
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
+
+
+STAMP_PATH = LIB_PATH + ".srchash"
+
+
+def source_hash():
+    """sha256 over every source, header and the compiler flags: what decides whether the library is up to date
+    (mtimes do not survive a copy of the tree to another machine, contents do)."""
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS).encode())
+    for path in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def up_to_date():
+    """True when libos2d_hip.so exists and was built from exactly the sources in the tree."""
+    if not (os.path.exists(LIB_PATH) and os.path.exists(STAMP_PATH)):
+        return False
+    with open(STAMP_PATH) as f:
+        return f.read().strip() == source_hash()
 
 
 def _stale(target, deps):
@@ -49,11 +73,17 @@ def build(force=False, verbose=True):
             if verbose:
                 print("[os2d_amd.build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-    if force or _stale(LIB_PATH, objs):
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    digest = source_hash()
+    if force or _stale(LIB_PATH, objs) or not up_to_date():
+        tmp = LIB_PATH + ".tmp.{}".format(os.getpid())          # link aside, then rename: a concurrent loader never
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs   # maps a half-written file
         if verbose:
             print("[os2d_amd.build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        os.replace(tmp, LIB_PATH)
+        with open(STAMP_PATH + ".tmp", "w") as f:
+            f.write(digest + "\n")
+        os.replace(STAMP_PATH + ".tmp", STAMP_PATH)
     return LIB_PATH
 
 

@@ -182,7 +182,10 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
     const int col = wn * (32 * NI) + ni * 32 + l31;
     const int n = n0 + col;
     if (n >= HW) continue;
-    const float inv_r = 1.0f / (sqrtf(red[0][col] + red[1][col]) + 1e-6f);  // head.py:650,597 (eps 1e-6)
+    // head.py:650,597 (eps 1e-6); the normalised values (<= 1) are stored scaled by 2^OS2D_RNORM_EXP so that their lo halves
+    // stay normal fp16 numbers (the conv 7x7 epilogue undoes the scale exactly)
+    const float inv_r = 1.0f / (sqrtf(red[0][col] + red[1][col]) + 1e-6f);
+    const float rscale = ldexpf(1.0f, OS2D_RNORM_EXP);
     const int h = n / W, w = n - h * W;
     const size_t cell = (size_t)BASE + (size_t)h * Ws + w;
 #pragma unroll
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
         half4 h4, l4;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float v = (m0 + k < OS2D_K) ? fmaxf(acc[mi][ni][4 * q + k], 0.f) * inv_r : 0.f;
+          const float v = (m0 + k < OS2D_K) ? fmaxf(acc[mi][ni][4 * q + k], 0.f) * inv_r * rscale : 0.f;
           const _Float16 hv = (_Float16)v;
           h4[k] = hv;
           l4[k] = (_Float16)(v - (float)hv);

@@ -22,6 +22,8 @@
 #define OS2D_QROWS 256       // correlation GEMM M tile: 225 rows padded with zeros
 #define OS2D_MAX_W 209       // widest feature map: 256 + 2*(3*(W+3)+3) slab units must fit the conv 7x7 prefetch (<= 1536)
 #define OS2D_G 29            // 8-channel groups of the 225 correlation channels (f16x3 path)
+#define OS2D_RNORM_EXP 12    // the relu+L2-normalised correlation (|x| <= 1) is stored as fp16 hi|lo of x * 2^12
+#define OS2D_STATUS_F16_RANGE 1  // sticky status bit: a split-fp16 activation left the fp16 range (non-finite input)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -97,13 +99,16 @@ int os2d_launch_pack_conv(const float* w, const float* b, const float* bn_w, con
 int os2d_launch_border_zero_shb(void* rnorm, int NB, int H, int W, hipStream_t stream);
 int os2d_launch_pack_conv_f16(const float* w, const float* b, const float* bn_w, const float* bn_b, const float* bn_mean,
                               const float* bn_var, float bn_eps, int Cout, int Cin, int KS, int MT, int steps_padded,
-                              int scale_log2, void* wp, float* bp, hipStream_t stream);
+                              const int* wexp, int in_exp, void* wp, float* bp, hipStream_t stream);
+int os2d_launch_class_prepare_batch(const float* const* srcs, const int* sizes, int B, int C, int normalize, float* q15,
+                                    float* qp, hipStream_t stream);
+int os2d_launch_corr_normalize_shb(const float* corr, void* rshb, int NB, int H, int W, hipStream_t stream);
 // corr_mfma.hip (shb != 0: rnorm is written in the split-half blocked layout of conv_f16x3.hip)
 int os2d_launch_corr(const float* fm, const float* qp, const float* sumsq, float* corr, void* rnorm,
                      int A, int B, int C, int H, int W, int shb, hipStream_t stream);
 // conv_f16x3.hip
-int os2d_launch_conv_f16x3(int layer, const void* in, const void* wp, const float* bp, float unscale, void* out, int NB,
-                           int P, int H, int W, int terms, hipStream_t stream);
+int os2d_launch_conv_f16x3(int layer, const void* in, const void* wp, const float* bp, float out_scale, int* status,
+                           void* out, int NB, int P, int H, int W, int terms, hipStream_t stream);
 // conv_mfma.hip
 int os2d_launch_conv(int layer, const float* in, const float* wp, const float* bp, float* out,
                      int NB, int P, int H, int W, hipStream_t stream);
@@ -113,6 +118,8 @@ int os2d_launch_sample_decode(const float* corr, const float* params, int NB, in
                               float* corners, hipStream_t stream);
 int os2d_launch_decode_boxes(const float* loc, int NB, int H, int W, int stride, int rec_field, float img_w,
                              float img_h, float* boxes, hipStream_t stream);
+int os2d_launch_alignment_grids(const float* params, int NB, int H, int W, int P, int inverse, float* theta,
+                                float* grids, hipStream_t stream);
 // nms.hip
 int os2d_launch_nms(const float* boxes, const int* counts, int NC, int N, float thr, unsigned char* keep, int* num_keep,
                     void* workspace, hipStream_t stream);

@@ -73,10 +73,9 @@ __global__ __launch_bounds__(256) void corr_normalize_kernel(const float* __rest
   for (int k = 0; k < OS2D_K; ++k) o[(size_t)k * PLANE] = fmaxf(c[(size_t)k * HW], 0.f) * inv;
 }
 
-// ---- class_prepare: grid 225 (one block per template cell), block 256 loops over channels
-__global__ __launch_bounds__(256) void class_prepare_kernel(const float* __restrict__ src, int C, int h, int w, int normalize,
-                                                            float* __restrict__ q15, float* __restrict__ qp) {
-  __shared__ float red[4];
+// ---- class_prepare: grid 225 (one block per template cell) x classes, block 256 loops over channels
+__device__ __forceinline__ void class_prepare_body(const float* __restrict__ src, int C, int h, int w, int normalize,
+                                                   float* __restrict__ q15, float* __restrict__ qp, float* red) {
   const int cell = blockIdx.x;  // i*15 + j  (row i, col j)
   const int i = cell / OS2D_T, j = cell - i * OS2D_T;
   // sampling position of the identity grid, as F.affine_grid(align_corners=True) + F.grid_sample build it
@@ -122,6 +121,58 @@ __global__ __launch_bounds__(256) void class_prepare_kernel(const float* __restr
     }
 }
 
+__global__ __launch_bounds__(256) void class_prepare_kernel(const float* __restrict__ src, int C, int h, int w, int normalize,
+                                                            float* __restrict__ q15, float* __restrict__ qp) {
+  __shared__ float red[4];
+  class_prepare_body(src, C, h, w, normalize, q15, qp, red);
+}
+
+// all classes of a head in ONE launch: class b's map (its own h x w) is srcs[b]; sizes = [B][2] (h, w)
+__global__ __launch_bounds__(256) void class_prepare_batch_kernel(const float* const* __restrict__ srcs,
+                                                                  const int* __restrict__ sizes, int C, int normalize,
+                                                                  float* __restrict__ q15, float* __restrict__ qp) {
+  __shared__ float red[4];
+  const int b = blockIdx.y;
+  class_prepare_body(srcs[b], C, sizes[2 * b], sizes[2 * b + 1], normalize, q15 + (size_t)b * C * OS2D_K,
+                     qp + (size_t)b * C * OS2D_QROWS, red);
+}
+
+// ---- corr_normalize_shb: standalone relu -> L2 over the 225 channels (head.py:650) of an arbitrary correlation tensor
+// [NB][225][HW] into the split-half blocked layout of the f16x3 convolutions ([NB][29][hi|lo][PLANE] units of 8 halves,
+// values scaled by 2^OS2D_RNORM_EXP); the fused path does this in the correlation epilogue.  Border cells are cleared
+// by border_zero_shb before.
+__global__ __launch_bounds__(256) void corr_normalize_shb_kernel(const float* __restrict__ corr, uint4* __restrict__ rshb,
+                                                                 int H, int W, int PLANE) {
+  typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+  const int HW = H * W, Ws = os2d_ws(W);
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int nb = blockIdx.y;
+  if (n >= HW) return;
+  const float* c = corr + (size_t)nb * OS2D_K * HW + n;
+  float s = 0.f;
+  for (int k = 0; k < OS2D_K; ++k) {
+    const float v = fmaxf(c[(size_t)k * HW], 0.f);
+    s += v * v;
+  }
+  const float inv = 1.0f / (sqrtf(s) + 1e-6f);
+  const float scale = ldexpf(1.0f, OS2D_RNORM_EXP);
+  const int h = n / W, w = n - h * W;
+  uint4* o = rshb + (size_t)nb * OS2D_G * 2 * PLANE + (size_t)os2d_base(W) + (size_t)h * Ws + w;
+  for (int g = 0; g < OS2D_G; ++g) {
+    half8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = g * 8 + j;
+      const float v = k < OS2D_K ? fmaxf(c[(size_t)k * HW], 0.f) * inv * scale : 0.f;
+      const _Float16 hv = (_Float16)v;
+      hi[j] = hv;
+      lo[j] = (_Float16)(v - (float)hv);
+    }
+    *reinterpret_cast<half8*>(o + (size_t)(2 * g) * PLANE) = hi;
+    *reinterpret_cast<half8*>(o + (size_t)(2 * g + 1) * PLANE) = lo;
+  }
+}
+
 // ---- pack_conv: wp[cp][tap][half][o] = w[o][2cp+half][tap] * bn_scale[o]; bp[o] = folded bias
 __global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict__ w, const float* __restrict__ b,
                                                         const float* __restrict__ bn_w, const float* __restrict__ bn_b,
@@ -161,14 +212,15 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict_
 }
 
 // ---- f16x3 path (conv_f16x3.hip): packed weights [G][steps_padded][2 half-wave][2 hi|lo][MT] units of 8 halves.
-// Unit (g, ps, hw, part, o) holds channels 8g..8g+7 of output o at tap 2*ps+hw, scaled by 2^scale_log2 and BN-folded;
+// Unit (g, ps, hw, part, o) holds channels 8g..8g+7 of output o at tap 2*ps+hw, BN-folded and scaled by 2^wexp[o] (one exponent per output channel);
 // part 0 = rn16(x), part 1 = rn16(x - hi).  Taps / channels / outputs past the real sizes are zero.
 __global__ __launch_bounds__(256) void pack_conv_f16_kernel(const float* __restrict__ w, const float* __restrict__ b,
                                                             const float* __restrict__ bn_w,
                                                             const float* __restrict__ bn_b,
                                                             const float* __restrict__ bn_mean,
                                                             const float* __restrict__ bn_var, float bn_eps, int Cout,
-                                                            int Cin, int KS, int MT, int steps_padded, float scale,
+                                                            int Cin, int KS, int MT, int steps_padded,
+                                                            const int* __restrict__ wexp, int in_exp,
                                                             _Float16* __restrict__ wp, float* __restrict__ bp) {
   const int taps = KS * KS;
   const int G = (Cin + 7) / 8;
@@ -189,7 +241,7 @@ __global__ __launch_bounds__(256) void pack_conv_f16_kernel(const float* __restr
     float v = 0.f;
     if (o < Cout && c < Cin && tap < taps) {
       const float s = bn_w ? bn_w[o] / sqrtf(bn_var[o] + bn_eps) : 1.0f;
-      v = w[((size_t)o * Cin + c) * taps + tap] * s * scale;
+      v = ldexpf(w[((size_t)o * Cin + c) * taps + tap] * s, wexp[o]);  // exact: a power-of-two scale per output channel
     }
     const _Float16 hi = (_Float16)v;
     wp[idx] = part ? (_Float16)(v - (float)hi) : hi;
@@ -206,6 +258,7 @@ __global__ __launch_bounds__(256) void pack_conv_f16_kernel(const float* __restr
         }
       }
       bp[o] = v;
+      bp[MT + o] = o < Cout ? ldexpf(1.0f, -(wexp[o] + in_exp)) : 0.f;  // undoes the weight and the input scale
     }
 }
 
@@ -257,9 +310,9 @@ int os2d_launch_border_zero_shb(void* rnorm, int NB, int H, int W, hipStream_t s
 
 int os2d_launch_pack_conv_f16(const float* w, const float* b, const float* bn_w, const float* bn_b, const float* bn_mean,
                               const float* bn_var, float bn_eps, int Cout, int Cin, int KS, int MT, int steps_padded,
-                              int scale_log2, void* wp, float* bp, hipStream_t stream) {
+                              const int* wexp, int in_exp, void* wp, float* bp, hipStream_t stream) {
   hipLaunchKernelGGL(pack_conv_f16_kernel, dim3(1024), dim3(256), 0, stream, w, b, bn_w, bn_b, bn_mean, bn_var, bn_eps,
-                     Cout, Cin, KS, MT, steps_padded, ldexpf(1.0f, scale_log2), reinterpret_cast<_Float16*>(wp), bp);
+                     Cout, Cin, KS, MT, steps_padded, wexp, in_exp, reinterpret_cast<_Float16*>(wp), bp);
   return check_launch("pack_conv_f16");
 }
 
@@ -274,6 +327,20 @@ int os2d_launch_corr_normalize(const float* corr, float* rpad, int NB, int H, in
 int os2d_launch_class_prepare(const float* src, int C, int h, int w, int normalize, float* q15, float* qp, hipStream_t stream) {
   hipLaunchKernelGGL(class_prepare_kernel, dim3(OS2D_K), dim3(256), 0, stream, src, C, h, w, normalize, q15, qp);
   return check_launch("class_prepare");
+}
+
+int os2d_launch_class_prepare_batch(const float* const* srcs, const int* sizes, int B, int C, int normalize, float* q15,
+                                    float* qp, hipStream_t stream) {
+  hipLaunchKernelGGL(class_prepare_batch_kernel, dim3(OS2D_K, B), dim3(256), 0, stream, srcs, sizes, C, normalize, q15, qp);
+  return check_launch("class_prepare_batch");
+}
+
+int os2d_launch_corr_normalize_shb(const float* corr, void* rshb, int NB, int H, int W, hipStream_t stream) {
+  int rc = os2d_launch_border_zero_shb(rshb, NB, H, W, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(corr_normalize_shb_kernel, dim3((H * W + 255) / 256, NB), dim3(256), 0, stream, corr,
+                     reinterpret_cast<uint4*>(rshb), H, W, os2d_plane(H, W));
+  return check_launch("corr_normalize_shb");
 }
 
 int os2d_launch_pack_conv(const float* w, const float* b, const float* bn_w, const float* bn_b, const float* bn_mean,

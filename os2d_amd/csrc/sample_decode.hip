@@ -20,23 +20,10 @@ namespace {
 
 constexpr int POOL_LO = 2, POOL_HI = OS2D_T - 2;  // head.py:280,296-302: pool_border_width = 2
 
-__global__ __launch_bounds__(256) void sample_decode_kernel(const float* __restrict__ corr,    // [NB][225][HW]
-                                                            const float* __restrict__ params,  // [NB][P][HW]
-                                                            int H, int W, int P, int inverse, float stride,
-                                                            float half_box, int Bc, int Btot, int b0,
-                                                            float* __restrict__ loc, float* __restrict__ cls,
-                                                            float* __restrict__ corners) {
-  const int HW = H * W;
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  const int nb = blockIdx.y;  // index inside the class chunk: a*Bc + b_local
-  if (n >= HW) return;
-  // output slot in the full [A,Btot,...] tensors
-  const int img = nb / Bc;
-  const size_t ob = (size_t)img * Btot + b0 + (nb - img * Bc);
-  const int h = n / W, w = n - h * W;
-
-  const float* pp = params + (size_t)nb * P * HW + n;
-  float t00, t01, t02, t10, t11, t12;
+// Transformation parameters of one location -> the 2x3 affine map used for sampling (reference head.py:81-153):
+// P = 6 full affine, P = 4 scale + translation; optional inverse of the homogeneous 3x3 matrix.
+__device__ __forceinline__ void os2d_theta(const float* __restrict__ pp, int HW, int P, int inverse, float& t00,
+                                           float& t01, float& t02, float& t10, float& t11, float& t12) {
   if (P == 6) {  // head.py:98-100
     t00 = pp[0];
     t01 = pp[HW];
@@ -74,6 +61,25 @@ __global__ __launch_bounds__(256) void sample_decode_kernel(const float* __restr
     t11 = i11;
     t12 = i12;
   }
+}
+
+__global__ __launch_bounds__(256) void sample_decode_kernel(const float* __restrict__ corr,    // [NB][225][HW]
+                                                            const float* __restrict__ params,  // [NB][P][HW]
+                                                            int H, int W, int P, int inverse, float stride,
+                                                            float half_box, int Bc, int Btot, int b0,
+                                                            float* __restrict__ loc, float* __restrict__ cls,
+                                                            float* __restrict__ corners) {
+  const int HW = H * W;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int nb = blockIdx.y;  // index inside the class chunk: a*Bc + b_local
+  if (n >= HW) return;
+  // output slot in the full [A,Btot,...] tensors
+  const int img = nb / Bc;
+  const size_t ob = (size_t)img * Btot + b0 + (nb - img * Bc);
+  const int h = n / W, w = n - h * W;
+
+  float t00, t01, t02, t10, t11, t12;
+  os2d_theta(params + (size_t)nb * P * HW + n, HW, P, inverse, t00, t01, t02, t10, t11, t12);
 
   // ---- resample + pool: 11x11 inner template points, channel = j*15 + i (x-major)
   const float step = 2.0f / (OS2D_T - 1);
@@ -147,6 +153,37 @@ __global__ __launch_bounds__(256) void decode_boxes_kernel(const float* __restri
   reinterpret_cast<float4*>(boxes)[(size_t)nb * HW + n] = o;
 }
 
+
+// Os2dAlignment.forward as the reference returns it (head.py:155-193): the transformed 15x15 template grid of every
+// location in LOCAL coordinates, grids [NB][H][W][15][15][2] (x, y in [-1,1]), i.e. F.affine_grid(theta,
+// align_corners=True) - and / or the prepared theta [NB*H*W][2][3] (prepare_transform_parameters_for_grid_sampler,
+// head.py:81-153).  The fused head never materialises either; this kernel exists for callers of the class API.
+__global__ __launch_bounds__(256) void alignment_grids_kernel(const float* __restrict__ params, int HW, int P, int inverse,
+                                                              float* __restrict__ theta, float* __restrict__ grids) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int nb = blockIdx.y;
+  if (n >= HW) return;
+  float t00, t01, t02, t10, t11, t12;
+  os2d_theta(params + (size_t)nb * P * HW + n, HW, P, inverse, t00, t01, t02, t10, t11, t12);
+  const size_t loc = (size_t)nb * HW + n;
+  if (theta) {
+    float* o = theta + loc * 6;
+    o[0] = t00, o[1] = t01, o[2] = t02, o[3] = t10, o[4] = t11, o[5] = t12;
+  }
+  if (grids) {
+    float2* g = reinterpret_cast<float2*>(grids) + loc * (OS2D_T * OS2D_T);
+    const float step = 2.0f / (OS2D_T - 1);
+    for (int i = 0; i < OS2D_T; ++i) {
+      // torch.linspace(-1, 1, 15): symmetric evaluation from both ends
+      const float yi = (i < (OS2D_T + 1) / 2) ? (-1.0f + step * i) : (1.0f - step * (OS2D_T - 1 - i));
+#pragma unroll
+      for (int j = 0; j < OS2D_T; ++j) {
+        const float xj = (j < (OS2D_T + 1) / 2) ? (-1.0f + step * j) : (1.0f - step * (OS2D_T - 1 - j));
+        g[i * OS2D_T + j] = make_float2(t00 * xj + t01 * yi + t02, t10 * xj + t11 * yi + t12);
+      }
+    }
+  }
+}
 }  // namespace
 
 int os2d_launch_sample_decode(const float* corr, const float* params, int NB, int H, int W, int P, int inverse,
@@ -173,6 +210,18 @@ int os2d_launch_decode_boxes(const float* loc, int NB, int H, int W, int stride,
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     os2d_set_error("decode_boxes launch: %s", hipGetErrorString(e));
+    return -4;
+  }
+  return 0;
+}
+
+int os2d_launch_alignment_grids(const float* params, int NB, int H, int W, int P, int inverse, float* theta,
+                                float* grids, hipStream_t stream) {
+  dim3 grid((H * W + 255) / 256, NB);
+  hipLaunchKernelGGL(alignment_grids_kernel, grid, dim3(256), 0, stream, params, H * W, P, inverse, theta, grids);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    os2d_set_error("alignment_grids launch: %s", hipGetErrorString(e));
     return -4;
   }
   return 0;

@@ -17,6 +17,21 @@ from ..structures.feature_map import FeatureMapSize
 DEFAULT_SCALES = (0.5, 0.625, 0.8, 1.0, 1.2, 1.4, 1.6)   # reference os2d/config.py:194
 
 
+# One pool of side streams per device, shared by every runner: level slot i always maps to the same HIP stream, so the
+# per-stream head workspaces (os2d_amd/modeling/head.py: one grow-only buffer per stream) stay at one per slot however
+# many runners / images come and go.  (torch hands out fresh Stream objects round-robin from 32 native streams; a new
+# set per image would eventually grow 32 workspaces to the size of the largest level.)
+_STREAM_POOL = {}
+
+
+def level_stream(device, slot):
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    pool = _STREAM_POOL.setdefault(index, [])
+    while len(pool) <= slot:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[slot]
+
+
 def pyramid_sizes(img_size, scales=DEFAULT_SCALES):
     """reference dataloader.py:326: level size = (int(w*s), int(h*s))."""
     return [FeatureMapSize(w=int(img_size.w * s), h=int(img_size.h * s)) for s in scales]
@@ -31,24 +46,26 @@ class PyramidHeadRunner(object):
         self.head = head
         self.features = features
         self.device = device or (head.class_feature_maps.device if hasattr(head, "class_feature_maps") else torch.device("cuda"))
-        self._streams = []
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self._num_streams = num_streams
 
     def _stream(self, i):
         n = self._num_streams
         if n is not None and n <= 1:
             return torch.cuda.current_stream(self.device)
-        slot = i if n is None else i % n
-        while len(self._streams) <= slot:
-            self._streams.append(torch.cuda.Stream(device=self.device))
-        return self._streams[slot]
+        return level_stream(self.device, i if n is None else i % n)
 
     def run(self, level_inputs, inputs_are_features=False):
         """level_inputs: list of image tensors [A,3,h_l,w_l] (or feature maps [A,C,H_l,W_l] if
         ``inputs_are_features``).  Returns per level lists (loc [A,B,4,HW], cls [A,B,HW], corners [A,B,8,HW],
-        FeatureMapSize), laid out like ``Os2dModel.forward``.  The calling stream waits for all levels on return
+        FeatureMapSize), laid out like ``Os2dModel.forward``; loc / corners entries are None when the head gathers score
+        maps only (``ClassShardedHead(gather="scores")``).  The calling stream waits for all levels on return
         (stream-ordered, no host synchronisation)."""
         main = torch.cuda.current_stream(self.device)
+        if hasattr(self.head, "prepare"):
+            self.head.prepare()       # cached operands (packed weights, fp16 class split) are built on the caller's
+                                      # stream, BEFORE the event every level stream waits on
         ready = torch.cuda.Event()
         ready.record(main)
         locs, clss, corners_l, sizes = [], [], [], []
@@ -61,7 +78,7 @@ class PyramidHeadRunner(object):
                     fm = x if inputs_are_features else self.features(x)
                     loc, cls, _, corners = self.head(fm)
                     A, B = cls.size(0), cls.size(1)
-                    locs.append(loc.reshape(A, B, 4, -1))
+                    locs.append(loc.reshape(A, B, 4, -1) if loc is not None else None)
                     clss.append(cls.reshape(A, B, -1))
                     corners_l.append(corners.reshape(A, B, 8, -1) if corners is not None else None)
                     sizes.append(FeatureMapSize(img=fm))

@@ -108,9 +108,10 @@ class Os2dBoxCoder(object):
         NB, four, HW = loc_scores.shape
         assert four == 4 and HW == fm.w * fm.h, "loc_scores {} do not match the feature map {}".format(tuple(loc_scores.shape), fm)
         boxes = torch.empty(NB, HW, 4, dtype=torch.float32, device=loc_scores.device)
-        _lib.check(lib.os2d_decode_boxes(_lib.ptr(loc_scores), NB, fm.h, fm.w, self._stride, self._rec_field,
-                                         ctypes.c_float(img_size.w), ctypes.c_float(img_size.h), _lib.ptr(boxes),
-                                         _lib.current_stream(loc_scores.device)), "os2d_decode_boxes")
+        with torch.cuda.device(loc_scores.device):       # launches act on the CURRENT device
+            _lib.check(lib.os2d_decode_boxes(_lib.ptr(loc_scores), NB, fm.h, fm.w, self._stride, self._rec_field,
+                                             ctypes.c_float(img_size.w), ctypes.c_float(img_size.h), _lib.ptr(boxes),
+                                             _lib.current_stream(loc_scores.device)), "os2d_decode_boxes")
         return boxes
 
     def build_boxes_from_loc_scores(self, loc_scores, default_boxes):
@@ -136,9 +137,10 @@ class Os2dBoxCoder(object):
         nbytes = ctypes.c_size_t()
         _lib.check(lib.os2d_nms_workspace_bytes(NC, N, ctypes.byref(nbytes)), "os2d_nms_workspace_bytes")
         ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-        _lib.check(lib.os2d_nms(_lib.ptr(boxes_sorted), _lib.ptr(counts), NC, N, ctypes.c_float(iou_threshold),
-                                _lib.ptr(keep), _lib.ptr(num_keep), _lib.ptr(ws), ws.numel(),
-                                _lib.current_stream(dev)), "os2d_nms")
+        with torch.cuda.device(dev):
+            _lib.check(lib.os2d_nms(_lib.ptr(boxes_sorted), _lib.ptr(counts), NC, N, ctypes.c_float(iou_threshold),
+                                    _lib.ptr(keep), _lib.ptr(num_keep), _lib.ptr(ws), ws.numel(),
+                                    _lib.current_stream(dev)), "os2d_nms")
         return keep.bool()
 
     def _nms_lists(self, boxes, scores, valid, iou_threshold, nms_max_batch=10000):
@@ -328,11 +330,12 @@ class Os2dBoxCoder(object):
         out_scores = torch.empty(B, HW, dtype=torch.float32, device=dev)
         out_index = torch.empty(B, HW, dtype=torch.int32, device=dev)
         out_count = torch.empty(B, dtype=torch.int32, device=dev)
-        _lib.check(lib.os2d_detect_level(_lib.ptr(loc), _lib.ptr(cls), B, fm.h, fm.w, self._stride, self._rec_field,
-                                         ctypes.c_float(img_size.w), ctypes.c_float(img_size.h), ctypes.c_float(rx),
-                                         ctypes.c_float(ry), ctypes.c_float(score_thr), ctypes.c_float(iou_thr),
-                                         _lib.ptr(out_boxes), _lib.ptr(out_scores), _lib.ptr(out_index),
-                                         _lib.ptr(out_count), _lib.current_stream(dev)), "os2d_detect_level")
+        with torch.cuda.device(dev):     # hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device
+            _lib.check(lib.os2d_detect_level(_lib.ptr(loc), _lib.ptr(cls), B, fm.h, fm.w, self._stride, self._rec_field,
+                                             ctypes.c_float(img_size.w), ctypes.c_float(img_size.h), ctypes.c_float(rx),
+                                             ctypes.c_float(ry), ctypes.c_float(score_thr), ctypes.c_float(iou_thr),
+                                             _lib.ptr(out_boxes), _lib.ptr(out_scores), _lib.ptr(out_index),
+                                             _lib.ptr(out_count), _lib.current_stream(dev)), "os2d_detect_level")
         # rows in the label order of the reference (iteration order of ``set(class_ids)``), survivors of a row by score
         rank = {l: k for k, l in enumerate(set(ids))}      # the reference iterates ``set(class_ids)`` (box_coder.py:483)
         order = sorted(range(B), key=lambda i: rank[ids[i]])

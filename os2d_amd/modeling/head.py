@@ -14,7 +14,7 @@ memory, the stream and the parameter containers.  There is no CPU / eager fallba
 Training through the head (autograd) is out of scope and raises as well.
 """
 import ctypes
-import math
+import logging
 import os
 
 import torch
@@ -74,6 +74,25 @@ def get_workspace(device, wanted, minimum):
 
 def release_workspaces():
     _WORKSPACES.clear()
+
+
+class _StreamOrdered(object):
+    """A cached device operand together with the event that marks the end of the kernels that produced it.  Consumers on
+    OTHER streams (the per-level streams of the pyramid runner) wait for that event before their kernels read the
+    buffers; on the producing stream plain stream order is enough."""
+
+    def __init__(self, key, value, device):
+        self.key, self.value = key, value
+        stream = torch.cuda.current_stream(device)
+        self._stream = stream.cuda_stream
+        self._event = torch.cuda.Event()
+        self._event.record(stream)
+
+    def get(self, device):
+        stream = torch.cuda.current_stream(device)
+        if stream.cuda_stream != self._stream:
+            stream.wait_event(self._event)
+        return self.value
 
 
 def _require_device_f32(t, name):
@@ -137,82 +156,146 @@ class TransformationNet(nn.Module):
         ts = list(self.parameters()) + list(self.buffers())
         return tuple((t.data_ptr(), t._version, str(t.device)) for t in ts)
 
+    def _folded(self):
+        """Eval-mode BatchNorm folded into the convolutions, in float64: [(w [Cout,Cin,k,k], b [Cout])] x 3
+        (head.py:619-629).  Used for the range analysis of the split-fp16 path only; the kernels fold in fp32."""
+        out = []
+        for conv, bn in ((self.conv[0], self.conv[1]), (self.conv[3], self.conv[4]), (self.linear, None)):
+            w, b = conv.weight.detach().double(), conv.bias.detach().double()
+            if bn is not None:
+                s = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+                w = w * s.view(-1, 1, 1, 1)
+                b = (b - bn.running_mean.detach().double()) * s + bn.bias.detach().double()
+            out.append((w, b))
+        return out
+
+    def range_plan(self):
+        """Scales of the split-fp16 ("f16x3") path, chosen so that NO value can leave the fp16 range for finite inputs.
+
+        Every fp32 value x of the path is stored as fp16 hi + lo of x * 2^e; hi must stay below 65504 and, for the full
+        22 bits, above 2^-3 (so that lo is a normal fp16 number).  Returns dict(weight_exp=[int tensors per layer],
+        act_exp=(e1, e2), bounds=(B1, B2)):
+          * weights: one exponent PER OUTPUT CHANNEL, the largest with max|w_folded[o]| * 2^e <= 16384 - BatchNorm scales
+            that differ by orders of magnitude between channels cost no precision;
+          * activations: the TransformNet input is L2-normalised over its 225 channels (head.py:650), so by
+            Cauchy-Schwarz |conv1[o]| <= 7 * ||w1[o]||_2 + |b1[o]| at every location (49 taps, each seeing a vector of norm
+            <= 1), and with N1 = ||(bound1[o])_o||_2 bounding the 128-vector after ReLU, |conv2[o]| <= 5 * N1 * ||w2[o]||_2
+            + |b2[o]|.  The activation exponents put those bounds at <= 2^15: overflow is impossible, and values down to
+            2^-18 of the bound keep all 22 bits (typical activations sit 2^7 .. 2^13 below the bound).
+        """
+        (w1, b1), (w2, b2), (w3, b3) = self._folded()
+
+        def wexp(w):
+            amax = w.abs().amax(dim=(1, 2, 3))
+            e = torch.floor(torch.log2(16384.0 / amax.clamp_min(1e-300)))
+            e = torch.where(amax > 0, e, torch.zeros_like(e)).clamp(-60, 60)
+            return e.to(torch.int32)
+
+        def act_exp(bound):
+            bmax = float(bound.max())
+            if not (bmax > 0.0) or bmax != bmax or bmax == float("inf"):
+                return 0
+            import math
+            return int(max(-60, min(60, math.floor(math.log2(32768.0 / bmax)))))
+
+        bound1 = 7.0 * w1.flatten(1).norm(dim=1) + b1.abs()
+        n1 = bound1.norm()
+        bound2 = 5.0 * n1 * w2.flatten(1).norm(dim=1) + b2.abs()
+        return dict(weight_exp=[wexp(w1), wexp(w2), wexp(w3)], act_exp=(act_exp(bound1), act_exp(bound2)),
+                    bounds=(float(bound1.max()), float(bound2.max())))
+
     def packed(self, precision=None):
-        """Packed TransformNet for the kernels: (w1, b1, w2, b2, w3, b3, scale_log2[3]).
-        precision "f32": os2d_pack_conv layouts (scales are 0); "f16x3": the split-half layout of
-        os2d_pack_conv_f16x3, each layer pre-scaled by the largest power of two that keeps max|w| <= 16384."""
+        """Packed TransformNet for the kernels: (w1, b1, w2, b2, w3, b3, act_exp[2]).
+        precision "f32": os2d_pack_conv layouts (act_exp zeros); "f16x3": the split-half layout of os2d_pack_conv_f16x3
+        with the scales of ``range_plan``.  Cached until a parameter changes; the cache entry carries an event so that
+        other streams never read half-written buffers."""
         precision = resolve_precision(precision)
         if precision == "f16x2":
             precision = "f16x3"        # same packed weights and scales; the kernel just skips the lo halves of layer 1
         key = (precision,) + self._state_key()
-        cached = self._packed_cache.get(precision)
-        if cached is not None and cached[0] == key:
-            return cached[1]
-        lib = _lib.load()
         dev = self.linear.weight.device
+        cached = self._packed_cache.get(precision)
+        if cached is not None and cached.key == key:
+            return cached.get(dev)
+        lib = _lib.load()
         if dev.type != "cuda":
             raise RuntimeError("TransformationNet parameters are on {}: move the model to the HIP device "
                                "(no CPU fallback)".format(dev))
         if self.training and any(isinstance(m, nn.BatchNorm2d) and m.training for m in self.modules()):
             raise RuntimeError("TransformationNet is in training mode: the HIP path implements eval-mode "
                                "BatchNorm (running statistics) only; call .eval()")
-        stream = _lib.current_stream(dev)
-        out, scales = [], []
-        P = self.output_dim
-        layers = ((1, self.conv[0], self.conv[1]), (2, self.conv[3], self.conv[4]), (3, self.linear, None))
-        for layer, conv, bn in layers:
-            w = _require_device_f32(conv.weight.detach(), "conv weight")
-            b = _require_device_f32(conv.bias.detach(), "conv bias")
-            pb = torch.empty(lib.os2d_packed_bias_floats(layer), dtype=torch.float32, device=dev)
-            if bn is not None:
-                bnp = [_require_device_f32(t.detach(), "bn") for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
-                eps = float(bn.eps)
-            else:
-                bnp, eps = [None] * 4, 0.0
-            if precision == "f16x3":
-                wmax = w.abs().amax(dim=(1, 2, 3))
+        with torch.cuda.device(dev):
+            stream = _lib.current_stream(dev)
+            out = []
+            P = self.output_dim
+            plan = self.range_plan() if precision == "f16x3" else None
+            in_exps = (lib.os2d_rnorm_exp(),) + plan["act_exp"] if plan else (0, 0, 0)
+            layers = ((1, self.conv[0], self.conv[1]), (2, self.conv[3], self.conv[4]), (3, self.linear, None))
+            for layer, conv, bn in layers:
+                w = _require_device_f32(conv.weight.detach(), "conv weight")
+                b = _require_device_f32(conv.bias.detach(), "conv bias")
+                pb = torch.zeros(lib.os2d_packed_bias_floats(layer), dtype=torch.float32, device=dev)
                 if bn is not None:
-                    wmax = wmax * (bnp[0] / torch.sqrt(bnp[3] + eps)).abs()
-                folded_max = float(wmax.max())
-                scale_log2 = int(math.floor(math.log2(16384.0 / folded_max))) if folded_max > 0 else 0
-                scale_log2 = max(-60, min(60, scale_log2))
-                pw = torch.empty(lib.os2d_packed_conv_bytes(layer, PRECISIONS[precision]), dtype=torch.uint8, device=dev)
-                _lib.check(lib.os2d_pack_conv_f16x3(layer, P, _lib.ptr(w), _lib.ptr(b), *[_lib.ptr(t) for t in bnp],
-                                                    ctypes.c_float(eps), scale_log2, _lib.ptr(pw), _lib.ptr(pb), stream),
-                           "os2d_pack_conv_f16x3")
-                scales.append(scale_log2)
-            else:
-                pw = torch.empty(lib.os2d_packed_conv_floats(layer), dtype=torch.float32, device=dev)
-                _lib.check(lib.os2d_pack_conv(layer, P, _lib.ptr(w), _lib.ptr(b), *[_lib.ptr(t) for t in bnp],
-                                              ctypes.c_float(eps), _lib.ptr(pw), _lib.ptr(pb), stream), "os2d_pack_conv")
-                scales.append(0)
-            out += [pw, pb]
-        result = tuple(out) + ((ctypes.c_int * 3)(*scales),)
-        self._packed_cache[precision] = (key, result)
+                    bnp = [_require_device_f32(t.detach(), "bn") for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
+                    eps = float(bn.eps)
+                else:
+                    bnp, eps = [None] * 4, 0.0
+                if precision == "f16x3":
+                    we = plan["weight_exp"][layer - 1].to(dev).contiguous()
+                    pw = torch.empty(lib.os2d_packed_conv_bytes(layer, PRECISIONS[precision]), dtype=torch.uint8, device=dev)
+                    _lib.check(lib.os2d_pack_conv_f16x3(layer, P, _lib.ptr(w), _lib.ptr(b), *[_lib.ptr(t) for t in bnp],
+                                                        ctypes.c_float(eps), _lib.ptr(we), in_exps[layer - 1],
+                                                        _lib.ptr(pw), _lib.ptr(pb), stream), "os2d_pack_conv_f16x3")
+                    we.record_stream(torch.cuda.current_stream(dev))
+                else:
+                    pw = torch.empty(lib.os2d_packed_conv_floats(layer), dtype=torch.float32, device=dev)
+                    _lib.check(lib.os2d_pack_conv(layer, P, _lib.ptr(w), _lib.ptr(b), *[_lib.ptr(t) for t in bnp],
+                                                  ctypes.c_float(eps), _lib.ptr(pw), _lib.ptr(pb), stream), "os2d_pack_conv")
+                out += [pw, pb]
+            act = plan["act_exp"] if plan else (0, 0)
+            result = tuple(out) + ((ctypes.c_int * 2)(*act),)
+            self._packed_cache[precision] = _StreamOrdered(key, result, dev)
         return result
 
-    def forward(self, corr_maps):
-        """corr_maps [N,225,H,W] -> transform parameters [N,P,H,W] (reference head.py:648-655), via
-        os2d_corr_normalize + the three MFMA conv kernels."""
+    def forward(self, corr_maps, precision="f32"):
+        """corr_maps [N,225,H,W] -> transform parameters [N,P,H,W] (reference head.py:648-655): input normalisation + the
+        three convolution kernels of the selected arithmetic ("f32": os2d_corr_normalize + os2d_transform_conv;
+        "f16x3" / "f16x2": os2d_corr_normalize_f16x3 + os2d_transform_conv_f16x3 - the kernels the fused head runs)."""
         corr_maps = _require_device_f32(corr_maps, "corr_maps")
         if corr_maps.dim() != 4 or corr_maps.size(1) != 225:
             raise RuntimeError("corr_maps must be [N,225,H,W], got {}".format(tuple(corr_maps.shape)))
         if torch.is_grad_enabled() and (corr_maps.requires_grad or any(p.requires_grad for p in self.parameters())) and self.training:
             raise RuntimeError("autograd through the HIP TransformNet is not implemented (training is out of scope)")
+        precision = resolve_precision(precision)
         lib = _lib.load()
         N, _, H, W = corr_maps.shape
         dev = corr_maps.device
-        w1, b1, w2, b2, w3, b3 = self.packed("f32")[:6]
-        plane = lib.os2d_plane_floats(H, W)
-        stream = _lib.current_stream(dev)
-        r = torch.empty(N * 226 * plane, dtype=torch.float32, device=dev)
-        h1 = torch.empty(N * 128 * plane, dtype=torch.float32, device=dev)
-        h2 = torch.empty(N * 64 * plane, dtype=torch.float32, device=dev)
-        out = torch.empty(N, self.output_dim, H, W, dtype=torch.float32, device=dev)
-        _lib.check(lib.os2d_corr_normalize(_lib.ptr(corr_maps), _lib.ptr(r), N, H, W, stream), "os2d_corr_normalize")
-        _lib.check(lib.os2d_transform_conv(1, _lib.ptr(r), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(h1), N, self.output_dim, H, W, stream), "conv1")
-        _lib.check(lib.os2d_transform_conv(2, _lib.ptr(h1), _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(h2), N, self.output_dim, H, W, stream), "conv2")
-        _lib.check(lib.os2d_transform_conv(3, _lib.ptr(h2), _lib.ptr(w3), _lib.ptr(b3), _lib.ptr(out), N, self.output_dim, H, W, stream), "conv3")
+        P = self.output_dim
+        w1, b1, w2, b2, w3, b3, act = self.packed(precision)
+        out = torch.empty(N, P, H, W, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            stream = _lib.current_stream(dev)
+            if precision == "f32":
+                plane = lib.os2d_plane_floats(H, W)
+                r = torch.empty(N * 226 * plane, dtype=torch.float32, device=dev)
+                h1 = torch.empty(N * 128 * plane, dtype=torch.float32, device=dev)
+                h2 = torch.empty(N * 64 * plane, dtype=torch.float32, device=dev)
+                _lib.check(lib.os2d_corr_normalize(_lib.ptr(corr_maps), _lib.ptr(r), N, H, W, stream), "os2d_corr_normalize")
+                _lib.check(lib.os2d_transform_conv(1, _lib.ptr(r), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(h1), N, P, H, W, stream), "conv1")
+                _lib.check(lib.os2d_transform_conv(2, _lib.ptr(h1), _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(h2), N, P, H, W, stream), "conv2")
+                _lib.check(lib.os2d_transform_conv(3, _lib.ptr(h2), _lib.ptr(w3), _lib.ptr(b3), _lib.ptr(out), N, P, H, W, stream), "conv3")
+            else:
+                terms1 = 2 if precision == "f16x2" else 3
+                r = torch.empty(N * lib.os2d_shb_bytes(225, H, W), dtype=torch.uint8, device=dev)
+                h1 = torch.empty(N * lib.os2d_shb_bytes(128, H, W), dtype=torch.uint8, device=dev)
+                h2 = torch.empty(N * lib.os2d_shb_bytes(64, H, W), dtype=torch.uint8, device=dev)
+                status = torch.zeros(1, dtype=torch.int32, device=dev)
+                _lib.check(lib.os2d_corr_normalize_f16x3(_lib.ptr(corr_maps), _lib.ptr(r), N, H, W, stream), "os2d_corr_normalize_f16x3")
+                for layer, src, wp, bp, dst, terms, oexp in ((1, r, w1, b1, h1, terms1, act[0]), (2, h1, w2, b2, h2, 3, act[1]),
+                                                            (3, h2, w3, b3, out, 3, 0)):
+                    _lib.check(lib.os2d_transform_conv_f16x3(layer, _lib.ptr(src), _lib.ptr(wp), _lib.ptr(bp), _lib.ptr(dst), N, P,
+                                                             H, W, terms, oexp, _lib.ptr(status), stream), "os2d_transform_conv_f16x3")
+                self.last_status = status      # device int32: OS2D_STATUS_F16_RANGE if an activation left the fp16 range
         return out
 
 
@@ -240,10 +323,35 @@ class Os2dAlignment(nn.Module):
     def num_transform_params(self):
         return self.parameter_regressor.output_dim
 
-    def forward(self, corr_maps):
-        raise NotImplementedError("Os2dAlignment.forward would materialise the [N,H,W,15,15,2] sampling grids; the "
-                                  "HIP path fuses them into Os2dHead.forward (use parameter_regressor(corr_maps) "
-                                  "for the raw transform parameters)")
+    def prepare_transform_parameters_for_grid_sampler(self, transform_parameters):
+        """reference head.py:81-153: [N,P,H,W] regressed parameters -> theta [N*H*W,2,3] (full / simplified affine,
+        optionally inverted), with os2d_alignment_grids."""
+        return self._grids(transform_parameters, want_theta=True, want_grids=False)[0]
+
+    def _grids(self, params, want_theta, want_grids):
+        params = _require_device_f32(params, "transform_parameters")
+        N, P, H, W = params.shape
+        assert P == self.num_transform_params, \
+            "Tranformation parameter vector has to be of dimension {0}, have {1} instead".format(self.num_transform_params, P)
+        lib = _lib.load()
+        dev = params.device
+        theta = torch.empty(N * H * W, 2, 3, dtype=torch.float32, device=dev) if want_theta else None
+        grids = torch.empty(N, H, W, TEMPLATE, TEMPLATE, 2, dtype=torch.float32, device=dev) if want_grids else None
+        with torch.cuda.device(dev):
+            _lib.check(lib.os2d_alignment_grids(_lib.ptr(params), N, H, W, P, 1 if self.use_inverse_geom_model else 0,
+                                                _lib.ptr(theta), _lib.ptr(grids), _lib.current_stream(dev)),
+                       "os2d_alignment_grids")
+        return theta, grids
+
+    def forward(self, corr_maps, precision="f32"):
+        """reference head.py:155-193: corr_maps [N,225,H,W] -> resampling grids in local coordinates
+        [N,H,W,15,15,2] (TransformNet -> theta -> F.affine_grid(align_corners=True)).  ``Os2dHead.forward`` never
+        materialises these grids (they are fused into os2d_sample_decode); this entry point serves callers of the class
+        API that want them (6.2 MB per class at 60x80)."""
+        assert corr_maps.size(1) == self.input_feature_dim, \
+            "The dimension 1 of corr_maps={0} should be equal to self.input_feature_dim={1}".format(corr_maps.size(1), self.input_feature_dim)
+        transform_parameters = self.parameter_regressor(corr_maps, precision=precision)
+        return self._grids(transform_parameters, want_theta=False, want_grids=True)[1]
 
 
 # --------------------------------------------------------------------------------------------- head creator
@@ -304,14 +412,27 @@ def _prepare_class_maps(class_feature_maps, normalise=True):
     C = maps[0].size(0)
     dev = maps[0].device
     B = len(maps)
-    q15 = torch.empty(B, C, TEMPLATE, TEMPLATE, dtype=torch.float32, device=dev)
-    qp = torch.empty(B, C, QROWS, dtype=torch.float32, device=dev)
-    stream = _lib.current_stream(dev)
-    for b, fm in enumerate(maps):
+    for fm in maps:
         if fm.size(0) != C:
             raise RuntimeError("class feature maps disagree on the feature dimension: {} vs {}".format(fm.size(0), C))
-        _lib.check(lib.os2d_class_prepare(_lib.ptr(fm), C, fm.size(1), fm.size(2), 1 if normalise else 0,
-                                          _lib.ptr(q15[b]), _lib.ptr(qp[b]), stream), "os2d_class_prepare")
+        if fm.device != dev:
+            raise RuntimeError("class feature maps are on different devices: {} vs {}".format(fm.device, dev))
+    q15 = torch.empty(B, C, TEMPLATE, TEMPLATE, dtype=torch.float32, device=dev)
+    qp = torch.empty(B, C, QROWS, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        stream = _lib.current_stream(dev)
+        # ONE launch for all classes (the reference loops them, head.py:261-268): pointer + size tables on the device
+        for b0 in range(0, B, 65535):
+            chunk = maps[b0:b0 + 65535]
+            ptrs = torch.tensor([m.data_ptr() for m in chunk], dtype=torch.int64).to(dev, non_blocking=False)
+            sizes = torch.tensor([[m.size(1), m.size(2)] for m in chunk], dtype=torch.int32).to(dev, non_blocking=False)
+            _lib.check(lib.os2d_class_prepare_batch(_lib.ptr(ptrs), _lib.ptr(sizes), len(chunk), C, 1 if normalise else 0,
+                                                    _lib.ptr(q15[b0:b0 + len(chunk)]), _lib.ptr(qp[b0:b0 + len(chunk)]),
+                                                    stream), "os2d_class_prepare_batch")
+            cur = torch.cuda.current_stream(dev)
+            ptrs.record_stream(cur), sizes.record_stream(cur)
+            for m in chunk:
+                m.record_stream(cur)
     return q15, qp
 
 
@@ -353,6 +474,11 @@ class Os2dHead(nn.Module):
         self.class_pool_mask = mask / mask.sum(dim=(2, 3), keepdim=True)
         self.aligner = aligner
         self.precision = None      # None: follow $OS2D_PRECISION (default "f16x3"); or "f32" / "f16x3" / "f16x2"
+        # sticky status word of the split-fp16 kernels in mapped pinned host memory: the kernels store to it only when an
+        # activation leaves the fp16 range (impossible for finite inputs, see TransformationNet.range_plan), the host
+        # reads it without synchronising
+        self._status = None
+        self.strict_range = os.environ.get("OS2D_STRICT_RANGE", "0") not in ("0", "", "false")
         box = box_grid_generator_image_level
         self._stride = int(box.box_stride.w)
         # image-level box = stride*(15-1) + receptive field (head.py:223-238)
@@ -361,15 +487,51 @@ class Os2dHead(nn.Module):
             raise RuntimeError("anisotropic strides / receptive fields are not supported by the HIP head")
 
     def _split_class_operand(self):
-        """qs [B, C/8, hi|lo, 256] x 8 halves for the f16x3 correlation (os2d_class_split), built on first use."""
+        """qs [B, C/8, hi|lo, 256] x 8 halves for the f16x3 correlation (os2d_class_split), built on first use; carries
+        the event of the kernel that wrote it so that other streams can consume it safely."""
+        dev = self._qp.device
         if self._qs is None:
             lib = _lib.load()
             B, C = self._qp.size(0), self._qp.size(1)
-            qs = torch.empty(B * ((C + 7) // 8) * 2 * 256 * 16, dtype=torch.uint8, device=self._qp.device)
-            _lib.check(lib.os2d_class_split(_lib.ptr(self._qp), _lib.ptr(qs), B, C, _lib.current_stream(self._qp.device)),
-                       "os2d_class_split")
-            self._qs = qs
-        return self._qs
+            qs = torch.empty(B * ((C + 7) // 8) * 2 * 256 * 16, dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.os2d_class_split(_lib.ptr(self._qp), _lib.ptr(qs), B, C, _lib.current_stream(dev)),
+                           "os2d_class_split")
+            self._qs = _StreamOrdered(None, qs, dev)
+        return self._qs.get(dev)
+
+    def prepare(self, precision=None):
+        """Build everything ``forward`` caches on first use (packed TransformNet of the selected arithmetic, the fp16
+        split of the class operand) on the CURRENT stream.  Callers that fan out over several streams (the pyramid
+        runner) call this first; the caches are event-tracked either way."""
+        precision = resolve_precision(precision or self.precision)
+        self.aligner.parameter_regressor.packed(precision)
+        if precision != "f32":
+            self._split_class_operand()
+        return self
+
+    def _status_word(self):
+        if self._status is None:
+            self._status = torch.zeros(1, dtype=torch.int32).pin_memory()
+        return self._status
+
+    def range_status(self, synchronize=False):
+        """Sticky status bits raised by the split-fp16 kernels (OS2D_STATUS_F16_RANGE = 1: an activation left the fp16
+        range).  Without ``synchronize`` this reads the mapped host word as it is (kernels in flight may still set it)."""
+        if self._status is None:
+            return 0
+        if synchronize:
+            torch.cuda.synchronize(self._qp.device)
+        return int(self._status[0])
+
+    def _handle_range_flag(self):
+        """A previous split-fp16 call overflowed (non-finite inputs): from now on this head computes in exact fp32."""
+        self._status[0] = 0
+        if resolve_precision(self.precision) != "f32":
+            logging.getLogger("OS2D").warning(
+                "OS2D head: a split-fp16 activation left the fp16 range (non-finite or out-of-bound input); switching "
+                "this head to precision='f32'")
+            self.precision = "f32"
 
     @classmethod
     def cat(cls, heads):
@@ -380,12 +542,15 @@ class Os2dHead(nn.Module):
         return cls(q15, h0.aligner, h0.box_grid_generator_image_level, h0.box_grid_generator_feature_map_level,
                    _prepared=qp)
 
-    def forward(self, feature_maps, out=None, stage_events=None, precision=None):
+    def forward(self, feature_maps, out=None, stage_events=None, precision=None, strict_range=None):
         """feature_maps [A,C,H,W] -> (loc [A,B,4,H,W], cls [A,B,1,H,W], cls_detached (same), corners [A,B,8,H,W]).
 
         ``out``: optional preallocated (loc, cls, corners) device tensors of exactly those shapes (contiguous) - used
         by the class-sharded wrapper to let the kernels write straight into the all-gather buffer.
-        ``stage_events``: optional ctypes array of 10 event handles for os2d_head_forward_profiled (bench.py)."""
+        ``stage_events``: optional ctypes array of 10 event handles for os2d_head_forward_profiled (bench.py).
+        ``strict_range`` (default $OS2D_STRICT_RANGE, off): synchronise after a split-fp16 call and, if the range flag
+        was raised, re-run it in exact fp32 before returning.  Without it the flag is looked at when the next call
+        starts (no synchronisation): the head then switches itself to "f32" for good."""
         feature_maps = _require_device_f32(feature_maps, "feature_maps")
         if feature_maps.dim() != 4:
             raise RuntimeError("feature_maps must be [A,C,H,W], got {}".format(tuple(feature_maps.shape)))
@@ -403,8 +568,12 @@ class Os2dHead(nn.Module):
         dev = feature_maps.device
         regressor = self.aligner.parameter_regressor
         P = regressor.output_dim
+        if self._status is not None and int(self._status[0]) != 0:
+            self._handle_range_flag()
+            if precision is not None and resolve_precision(precision) != "f32":
+                precision = "f32"
         precision = resolve_precision(precision or self.precision)
-        w1, b1, w2, b2, w3, b3, scales = regressor.packed(precision)
+        w1, b1, w2, b2, w3, b3, act_exp = regressor.packed(precision)
         if out is None:
             loc = torch.empty(A, B, 4, H, W, dtype=torch.float32, device=dev)
             cls = torch.empty(A, B, 1, H, W, dtype=torch.float32, device=dev)
@@ -418,14 +587,22 @@ class Os2dHead(nn.Module):
         one = ctypes.c_size_t()
         _lib.check(lib.os2d_head_workspace_bytes(A, B, C, H, W, P, ctypes.byref(full)), "os2d_head_workspace_bytes")
         _lib.check(lib.os2d_head_workspace_bytes(A, 1, C, H, W, P, ctypes.byref(one)), "os2d_head_workspace_bytes")
-        ws = get_workspace(dev, full.value, one.value)
-        _lib.check(lib.os2d_head_forward_ex(
-            _lib.ptr(feature_maps), _lib.ptr(self._qp), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2),
-            _lib.ptr(w3), _lib.ptr(b3), A, B, C, H, W, P, 1 if self.aligner.use_inverse_geom_model else 0,
-            self._stride, self._rec_field, _lib.ptr(loc), _lib.ptr(cls), _lib.ptr(corners),
-            _lib.ptr(ws), ws.numel(), _lib.current_stream(dev), PRECISIONS[precision],
-            _lib.ptr(self._split_class_operand()) if precision != "f32" else None, scales, stage_events, None),
-            "os2d_head_forward_ex")
+        with torch.cuda.device(dev):     # hipFuncSetAttribute / launches act on the CURRENT device
+            ws = get_workspace(dev, full.value, one.value)
+            status = self._status_word() if precision != "f32" else None
+            _lib.check(lib.os2d_head_forward_ex(
+                _lib.ptr(feature_maps), _lib.ptr(self._qp), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2),
+                _lib.ptr(w3), _lib.ptr(b3), A, B, C, H, W, P, 1 if self.aligner.use_inverse_geom_model else 0,
+                self._stride, self._rec_field, _lib.ptr(loc), _lib.ptr(cls), _lib.ptr(corners),
+                _lib.ptr(ws), ws.numel(), _lib.current_stream(dev), PRECISIONS[precision],
+                _lib.ptr(self._split_class_operand()) if precision != "f32" else None, act_exp, stage_events, None,
+                _lib.host_ptr(status)), "os2d_head_forward_ex")
+        strict = self.strict_range if strict_range is None else strict_range
+        if strict and precision != "f32":
+            torch.cuda.current_stream(dev).synchronize()
+            if int(self._status[0]) != 0:
+                self._handle_range_flag()
+                return self.forward(feature_maps, out=out, stage_events=stage_events, precision="f32")
         return loc, cls, cls, corners
 
 

@@ -130,26 +130,47 @@ class Os2dModel(nn.Module):
                             do_nms_across_classes=do_nms_across_classes)
 
     def init_model_from_file(self, path, init_affine_transform_path=""):
-        """reference model.py:290-345: full ``{"net":..., "optimizer":...}`` checkpoint first, then backbone-only
-        formats; optionally a weakalign TransformNet.  Returns the optimizer state (or None)."""
+        """reference model.py:290-345: full ``{"net":..., "optimizer":...}`` checkpoint first; if ANYTHING about that
+        fails (no 'net' key, keys that do not fit the whole model - e.g. a checkpoint whose 'net' holds only a feature
+        extractor) fall through to the backbone-only chain of ``_load_network`` like the reference does; optionally a
+        weakalign TransformNet afterwards, whose failure is logged and ignored (reference model.py:331-345).
+        Returns the optimizer state (or None)."""
         optimizer = None
         checkpoint = None
-        if path:
-            self.logger.info("Reading model file {}".format(path))
-            checkpoint = torch.load(path, map_location="cpu")
-        if checkpoint is not None and "net" in checkpoint:
-            self.load_state_dict(checkpoint["net"])
-            self.logger.info("Loaded complete model from checkpoint")
-            optimizer = checkpoint.get("optimizer")
-        elif checkpoint is not None:
-            self.logger.info("Cannot find 'net' in the checkpoint file, trying to init feature extractors")
-            self._load_network(self.net_label_features.net_class_features, checkpoint)
-            if not self.merge_branch_parameters:
-                self.net_feature_maps.load_state_dict(self.net_label_features.net_class_features.state_dict())
+        try:
+            if path:
+                self.logger.info("Reading model file {}".format(path))
+                checkpoint = torch.load(path, map_location="cpu")
+            if checkpoint and "net" in checkpoint:
+                self.load_state_dict(checkpoint["net"])
+                self.logger.info("Loaded complete model from checkpoint")
+            else:
+                self.logger.info("Cannot find 'net' in the checkpoint file")
+                raise RuntimeError()
+            if "optimizer" in checkpoint:
+                optimizer = checkpoint["optimizer"]
+                self.logger.info("Loaded optimizer from checkpoint")
+            else:
+                self.logger.info("Cannot find 'optimizer' in the checkpoint file. Initializing optimizer from scratch.")
+        except (KeyboardInterrupt, SystemExit):
+            raise
+        except Exception:   # noqa: BLE001 - the reference's permissive loader (bare except, model.py:321)
+            self.logger.info("Failed to load the full model, trying to init feature extractors")
+            if checkpoint is not None:
+                self._load_network(self.net_label_features.net_class_features, checkpoint)
+                if not self.merge_branch_parameters:
+                    self._load_network(self.net_feature_maps, self.net_label_features.net_class_features.state_dict())
         if init_affine_transform_path:
-            data = torch.load(init_affine_transform_path, map_location="cpu")
-            init_from_weakalign_model(data["state_dict"], None,
-                                      affine_regressor=self.os2d_head_creator.aligner.parameter_regressor)
+            try:
+                self.logger.info("Trying to init affine transform from {}".format(init_affine_transform_path))
+                data = torch.load(init_affine_transform_path, map_location="cpu")
+                init_from_weakalign_model(data["state_dict"], None,
+                                          affine_regressor=self.os2d_head_creator.aligner.parameter_regressor)
+                self.logger.info("Successfully initialized the affine transform from the provided weakalign model.")
+            except (KeyboardInterrupt, SystemExit):
+                raise
+            except Exception:   # noqa: BLE001 - reference model.py:344
+                self.logger.info("Could not init affine transform from {0}.".format(init_affine_transform_path))
         return optimizer
 
     def _load_network(self, net, model_data):

@@ -169,6 +169,12 @@ class ClassShardedHead(object):
             assert local_head.class_batch_size == e - s, "local head holds {} classes, shard is {}".format(local_head.class_batch_size, e - s)
         self.counts = [e - s for s, e in self.bounds]
 
+    def prepare(self, precision=None):
+        """Build the local head's cached operands on the current stream (see ``Os2dHead.prepare``)."""
+        if hasattr(self.local_head, "prepare"):
+            self.local_head.prepare(precision)
+        return self
+
     def forward(self, feature_maps, async_gather=False):
         """Full-size (loc, cls, cls, corners) on every rank; with ``async_gather`` a zero-argument callable is returned
         instead that waits for the collective and yields that tuple (call it after queueing more work)."""

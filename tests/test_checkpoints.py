@@ -73,3 +73,30 @@ def test_state_dict_layout_equals_the_reference_model(name, merge, simplify, inv
     sd = net.state_dict()
     assert list(sd.keys()) == [str(k) for k in d["keys_" + name]]
     assert [",".join(str(x) for x in v.shape) for v in sd.values()] == [str(s) for s in d["shapes_" + name]]
+
+
+def test_checkpoint_whose_net_holds_only_a_backbone_falls_back(tmp_path):
+    """{"net": <feature extractor only>}: the whole-model load fails and the reference falls through to the backbone
+    chain (model.py:321-325 -> _load_network step 2: net.load_state_dict(model_data["net"], strict=False))."""
+    src = _perturbed(Os2dModel(is_cuda=False, merge_branch_parameters=False, backbone_arch="resnet50"), 5)
+    path = tmp_path / "backbone_ckpt.pth"
+    torch.save({"net": src.net_feature_maps.state_dict(), "epoch": 1, "loss": 0.5}, str(path))
+    dst = Os2dModel(is_cuda=False, merge_branch_parameters=False, backbone_arch="resnet50")
+    assert dst.init_model_from_file(str(path)) is None
+    for k, v in src.net_feature_maps.state_dict().items():
+        assert torch.equal(dst.net_label_features.net_class_features.state_dict()[k], v)
+        assert torch.equal(dst.net_feature_maps.state_dict()[k], v)
+
+
+def test_unreadable_affine_transform_file_is_ignored(tmp_path):
+    """A missing / malformed init_affine_transform_path is logged and ignored (reference model.py:331-345)."""
+    src = _perturbed(Os2dModel(is_cuda=False, merge_branch_parameters=True, backbone_arch="resnet50"), 6)
+    path = tmp_path / "checkpoint.pth"
+    torch.save({"net": src.state_dict()}, str(path))
+    bad = tmp_path / "weakalign.pth"
+    torch.save({"not_state_dict": 1}, str(bad))
+    for affine in (str(bad), str(tmp_path / "does_not_exist.pth")):
+        dst = Os2dModel(is_cuda=False, merge_branch_parameters=True, backbone_arch="resnet50")
+        dst.init_model_from_file(str(path), init_affine_transform_path=affine)
+        a, b = src.state_dict(), dst.state_dict()
+        assert all(torch.equal(a[k], b[k]) for k in a)

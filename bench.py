@@ -1,34 +1,52 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X OS2D head: query-image-pairs/s (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--classes B_per_gpu] [--precision f16x3|f16x2|f32] [--pyramid]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--classes B_per_gpu | --classes-total B] [--variant v2|v1]
+                    [--precision f16x3|f16x2|f32] [--pyramid] [--gather all|scores|detections]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 One "step" = the whole head (correlation -> TransformNet -> resample/pool -> box encode) for ONE 1280x960 image
-feature map [1,1024,60,80] against B classes per GPU (default 64 = BASELINE.json configs[1]); with N GPUs the classes
-are sharded (weak scaling: N*B classes in total) and every step ends with the RCCL all-gather of the per-class SCORE
-maps (north_star: "all-gather ... of per-class score maps before NMS"), as ``os2d_amd.parallel.ClassShardedHead``
-does it.  Inputs are synthetic (post-ReLU Gaussian features, perturbed TransformNet) and resident
-in HBM before the timed region.
+feature map [1,1024,60,80] against the classes of the run.  Inputs are synthetic (post-ReLU Gaussian features, perturbed
+TransformNet) and resident in HBM before the timed region.
+
+Workloads
+  N = 1 (default)  BASELINE.json configs[1]: 64 classes, V2 head.  The same run also times, with the driver's clock
+                   running, the other single-GPU readings of BASELINE.json's configs and reports them under "sweep":
+                   256 classes V1 head (configs[3]), all 1024 classes on one GPU (configs[2], N = 1) and the 7-level
+                   pyramid with one HIP stream per level at 128 classes (the per-GPU share of configs[4]); each entry
+                   carries its own roofline object.
+  N > 1 (default)  BASELINE.json configs[2]: STRONG scaling of 1024 classes, block-sharded over the N ranks (128 per GPU
+                   at N = 8); every step ends with the RCCL all-gather of the per-class output maps so that every rank
+                   holds a result it can decode (--gather all: loc | cls | corners, 250 KB per class; issued
+                   asynchronously and waited for after the next step's kernels are queued, every gather completing inside
+                   the timed region).  The lighter exchanges are timed right after and reported under "other_gathers":
+                   "scores" (north_star: "all-gather ... of per-class score maps before NMS", 19 KB per class) and
+                   "detections" (every rank decodes + NMS-es its own classes, only surviving boxes cross xGMI).
+                   --classes B keeps B classes per GPU instead (weak scaling).
 
 Arithmetic (``--precision``):
   f16x3 (default)  every fp32 operand of the four GEMM-shaped stages is split into fp16 hi + lo and each product is
-                   evaluated with three v_mfma_f32_32x32x16_f16 (fp32 accumulation): outputs agree with the reference
-                   to the same 2.4e-7 as the fp32 mode (tests/test_head_gpu.py runs every parity case in all modes);
+                   evaluated with three v_mfma_f32_32x32x16_f16 (fp32 accumulation); per-channel power-of-two scales
+                   derived from rigorous bounds make fp16 overflow impossible for finite inputs (a sticky status flag
+                   reports anything else).  Outputs agree with the reference to the same 2.4e-7 as the fp32 mode
+                   (tests/test_head_gpu.py runs every parity case, incl. the hostile-range networks, in all modes);
+                   "max_abs_diff_vs_f32" in the JSON line is measured on the benchmarked tensors in this very run;
   f16x2            as f16x3, except that the dominant 7x7 layer takes its WEIGHTS as fp16 roundings only (two MFMAs per
-                   product, activations still split): scores within 1e-6 and box regression within 5e-5 of the fp32
-                   result - inside the 1e-4 parity bound of BASELINE.json, but no longer fp32-equivalent;
+                   product): scores within 1e-6 and box regression within 5e-5 of fp32 - inside the 1e-4 parity bound of
+                   BASELINE.json, but no longer fp32-equivalent;
   f32              v_mfma_f32_32x32x2_f32, exact fp32.
 The primary line is measured in the selected mode; the other modes are timed right after and reported under
 "other_precisions" so all are always on record.
 
 Prints ONE JSON line on rank 0 with the driver's contract fields plus
   roofline     - the dominant kernel (conv 7x7 225->128 MFMA implicit GEMM): ALGORITHMIC FLOPs per launch divided by its
-                 mean launch duration, measured with HIP events recorded on the launch stream inside the timed steps,
-                 against the dense MFMA peak of the instruction it runs on; `traffic` / `hbm_gbps` / `mfma_pipe_busy` are the
-                 HBM bytes, HBM rate and matrix-pipe utilisation of that kernel from the committed rocprofv3 PMC passes
+                 mean launch duration, measured LIVE with HIP events recorded on the launch stream inside the timed
+                 steps, against the dense MFMA peak of the instruction it runs on.  `traffic` / `hbm_gbps` /
+                 `mfma_pipe_busy` / `effective_clock_ghz` are REPLAYED from the committed rocprofv3 PMC passes
+                 (profiles/conv1_traffic_<precision>.json, see `counters_source`), scaled to the class count of the run
   stages_ms    - mean duration of every stage of the step (same events)
+  sweep        - see above (N = 1)
   end_to_end   - secondary: backbone + head + decode/NMS per image, and the one-off class-head construction (N=1 only)
   cpu_baseline - the oracle (torch-CPU restatement of the reference head, driven one class at a time like the
                  reference's evaluation) timed on the host cores, rank 0 / N=1 only, on a bounded class sample.
@@ -46,9 +64,15 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 C_FEAT, H_FM, W_FM = 1024, 60, 80          # ResNet50-C4 features of a 1280x960 input
+LEVEL_HW = [(30, 40), (38, 50), (48, 64), (60, 80), (72, 96), (84, 112), (96, 128)]   # 7 scales 0.5-1.6
 FLOP_PER_LOC = {"corr": 2 * 225 * 1024, "conv1": 2 * 128 * 225 * 49, "conv2": 2 * 64 * 128 * 25}
 PEAK = {"f32": 157.3e12, "f16x3": 2.5e15, "f16x2": 2.5e15}  # dense MFMA peaks (MI355X_MICROARCH.md): fp32-input MFMA; fp16/bf16 MFMA
 STAGES = ("corr", "conv1", "conv2", "conv3", "sample")
+PREC_ID = {"f32": 0, "f16x3": 1, "f16x2": 2}
+DTYPE = {"f32": "f32",
+         "f16x3": "f16x3 (fp32 operands split into fp16 hi+lo, 3 half MFMAs per product, fp32 accumulate)",
+         "f16x2": "f16x2 (as f16x3; the 7x7 layer's weights enter as fp16 roundings only, 2 half MFMAs per product)"}
+DISTINCT_CLASS_MAPS = 64     # synthetic class maps are generated for 64 seeds and repeated (separate device copies)
 
 
 def parse():
@@ -56,18 +80,23 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--classes", type=int, default=64, help="classes per GPU")
+    ap.add_argument("--classes", type=int, default=None, help="classes PER GPU (weak scaling); default 64 at N=1")
+    ap.add_argument("--classes-total", type=int, default=None,
+                    help="classes in total, block-sharded over the ranks (strong scaling); default 1024 at N>1")
     ap.add_argument("--variant", default="v2", choices=["v2", "v1"], help="v2: affine+inverse (P=6); v1: simplified (P=4)")
     ap.add_argument("--precision", default=os.environ.get("OS2D_PRECISION", "f16x3"), choices=["f32", "f16x3", "f16x2"])
     ap.add_argument("--pyramid", action="store_true",
                     help="BASELINE configs[4]: 7-scale pyramid (0.5-1.6) of the 1280x960 image, one HIP stream per level; "
                          "a pair then means one (image, class) over all 7 levels")
-    ap.add_argument("--gather", default="scores", choices=["scores", "all"], help="what the N>1 all-gather moves")
+    ap.add_argument("--gather", default="all", choices=["all", "scores", "detections"],
+                    help="what the N>1 step exchanges (see the module docstring)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and use the class-sharded path even with one rank "
                          "(smoke test of the N>1 code path on a single-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-precision", action="store_true")
+    ap.add_argument("--no-other-gather", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the 256-class V1 / 1024-class / pyramid lines (N=1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="skip the secondary end-to-end leg (backbone + class-head build + head + decode/NMS)")
@@ -104,30 +133,21 @@ def cpu_baseline(fm_cpu, class_fms_cpu, state, inverse, budget_s):
                               ", ".join("{}: {:.1f} pairs/s".format(r[1], r[0]) for r in results), ncores)}
 
 
-def measured_mfma_busy(precision):
-    """Matrix-pipe utilisation of the conv 7x7 kernel from the committed rocprofv3 SQ pass
-    (SQ_VALU_MFMA_BUSY_CYCLES x 32 / (1024 SIMDs x GRBM_GUI_ACTIVE)); None if not recorded."""
-    path = os.path.join(REPO, "profiles", "conv1_traffic_{}.json".format(precision))
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        return json.load(f).get("mfma_pipe_busy")
-
-
-def measured_traffic(B, precision):
-    """HBM bytes per conv1 launch from the committed rocprofv3 PMC passes (profiles/conv1_traffic_<precision>.json,
-    written by tools/summarize_prof.py --traffic: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate
-    passes), scaled to the class count of this run; None if no profile has been recorded."""
+def replayed_counters(precision):
+    """The committed rocprofv3 PMC passes of the conv 7x7 kernel (profiles/conv1_traffic_<precision>.json, written by
+    tools/summarize_prof.py --traffic: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, SQ / GRBM pass;
+    separate passes).  These are NOT measured in this run."""
     path = os.path.join(REPO, "profiles", "conv1_traffic_{}.json".format(precision))
     if not os.path.exists(path):
         return None
     with open(path) as f:
         t = json.load(f)
-    return int(t["bytes_per_class"] * B)
+    t["path"] = os.path.relpath(path, REPO)
+    return t
 
 
-def end_to_end(dev, B, P, inverse, state, precision, steps=5, warmup=2):
-    """Secondary number: one 1280x960 image through the PyTorch-ROCm ResNet50-C4 backbone, the
+def end_to_end(dev, B, P, inverse, state, precision, arch="resnet50", steps=5, warmup=2):
+    """Secondary number: one 1280x960 image through the PyTorch-ROCm ResNet-C4 backbone, the
     HIP head against B classes and the HIP decode + per-class NMS of all 4800 boxes per class (score threshold -inf,
     the reference's eval default), random-init weights; plus the one-off construction of the class head from B
     240x240 class images (one batched backbone pass)."""
@@ -135,7 +155,7 @@ def end_to_end(dev, B, P, inverse, state, precision, steps=5, warmup=2):
     from os2d_amd.modeling.model import Os2dModel
     from os2d_amd.structures.feature_map import FeatureMapSize
     torch.manual_seed(0)
-    net = Os2dModel(is_cuda=False, merge_branch_parameters=True, backbone_arch="resnet50",
+    net = Os2dModel(is_cuda=False, merge_branch_parameters=True, backbone_arch=arch,
                     use_inverse_geom_model=inverse, simplify_affine=(P == 4))
     net.os2d_head_creator.aligner.parameter_regressor.load_state_dict(state)
     net.to(dev).eval()
@@ -176,12 +196,260 @@ def end_to_end(dev, B, P, inverse, state, precision, steps=5, warmup=2):
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
     return {"value": round(B * steps / dt, 2), "unit": "query-image-pairs/s", "ms_per_image": round(dt / steps * 1e3, 3),
-            "backbone_ms": round(phases[0] / steps, 3), "head_ms": round(phases[1] / steps, 3),
+            "backbone": arch, "backbone_ms": round(phases[0] / steps, 3), "head_ms": round(phases[1] / steps, 3),
             "decode_nms_ms": round(phases[2] / steps, 3), "detections_per_image": n_det,
             "class_head_build_ms": round(t_build * 1e3, 2), "precision": precision, "steps": steps,
-            "what": "ResNet50-C4 (PyTorch-ROCm/MIOpen fp32, random init) on 1x3x960x1280 + HIP head x {} classes + HIP "
+            "what": "{}-C4 (PyTorch-ROCm/MIOpen fp32, random init) on 1x3x960x1280 + HIP head x {} classes + HIP "
                     "decode and per-class NMS of all 4800 boxes per class; class_head_build_ms = {} class images 240x240 "
-                    "-> backbone (one batch) -> 15x15 class maps (once per class set)".format(B, B)}
+                    "-> backbone (one batch) -> 15x15 class maps (once per class set)".format(arch, B, B)}
+
+
+class Workload(object):
+    """One benchmark configuration resident in HBM: feature map(s), the class head of this rank's classes and, with
+    several ranks, the class-sharded wrapper."""
+
+    def __init__(self, dev, rank, world, classes_total, variant, pyramid, use_dist, gather):
+        from os2d_amd import _lib
+        from os2d_amd.modeling.head import build_os2d_head_creator
+        from os2d_amd.parallel import ClassShardedHead, shard_bounds
+        from os2d_amd.structures.feature_map import FeatureMapSize
+        from os2d_amd.utils import synthetic
+        self.lib = _lib.load()
+        self._lib_mod = _lib
+        self.dev, self.rank, self.world, self.use_dist, self.gather = dev, rank, world, use_dist, gather
+        self.P, self.inverse = (6, True) if variant == "v2" else (4, False)
+        self.variant, self.pyramid = variant, pyramid
+        self.classes_total = classes_total
+        self.bounds = shard_bounds(classes_total, world)
+        s, e = self.bounds[rank]
+        self.B_local = e - s
+        self.state = synthetic.make_transform_net_state(self.P, seed=1)
+        self.fm_cpu = synthetic.make_feature_map(C_FEAT, H_FM, W_FM, seed=0)
+        # global class id c uses seed 1000 + (c % 64): 64 distinct synthetic class maps, every class its own device copy
+        distinct = {}
+        for c in range(s, e):
+            distinct.setdefault(c % DISTINCT_CLASS_MAPS, None)
+        for k in distinct:
+            distinct[k] = synthetic.make_class_feature_maps(1, C_FEAT, sizes=[(15, 15)], seed=1000 + k)[0]
+        self.class_fms_cpu = [distinct[c % DISTINCT_CLASS_MAPS] for c in range(s, min(e, s + DISTINCT_CLASS_MAPS))]
+        self.creator = build_os2d_head_creator(self.P == 4, False, self.inverse, FeatureMapSize(w=16, h=16), FeatureMapSize(w=16, h=16))
+        self.creator.aligner.parameter_regressor.load_state_dict(self.state)
+        self.creator.to(dev).eval()
+        self.fm = self.fm_cpu.to(dev)
+        with torch.no_grad():
+            self.head = self.creator.create_os2d_head([distinct[c % DISTINCT_CLASS_MAPS].to(dev) for c in range(s, e)])
+        self.sharded = None
+        if use_dist:
+            self.sharded = ClassShardedHead(self.creator, group=None, gather="scores" if gather == "scores" else "all",
+                                            num_classes=classes_total, local_head=self.head)
+        self.runner, self.level_fms = None, None
+        if pyramid:
+            from os2d_amd.engine.pyramid import PyramidHeadRunner
+            self.level_fms = [synthetic.make_feature_map(C_FEAT, h, w, seed=100 + i).to(dev) for i, (h, w) in enumerate(LEVEL_HW)]
+            self.runner = PyramidHeadRunner(self.sharded if (self.sharded is not None and gather != "detections") else self.head, device=dev)
+        self.coder = None
+        if gather == "detections" and use_dist:
+            from os2d_amd.modeling.box_coder import Os2dBoxCoder
+            self.coder = Os2dBoxCoder(output_box_grid_generator=self.creator.box_grid_generator_image_level)
+            self.img_sizes = [FeatureMapSize(w=16 * w, h=16 * h) for h, w in (LEVEL_HW if pyramid else [(H_FM, W_FM)])]
+            self.local_ids = list(range(s, e))
+
+    @property
+    def locations(self):
+        return sum(h * w for h, w in LEVEL_HW) if self.pyramid else H_FM * W_FM
+
+    def set_gather(self, gather):
+        """Switch what the N>1 step exchanges (same resident data)."""
+        w = Workload.__new__(Workload)
+        w.__dict__.update(self.__dict__)
+        w.gather = gather
+        from os2d_amd.parallel import ClassShardedHead
+        w.sharded = ClassShardedHead(self.creator, group=None, gather="scores" if gather == "scores" else "all",
+                                     num_classes=self.classes_total, local_head=self.head)
+        w.coder = None
+        if self.pyramid:
+            from os2d_amd.engine.pyramid import PyramidHeadRunner
+            w.runner = PyramidHeadRunner(w.sharded if gather != "detections" else self.head, device=self.dev)
+        if gather == "detections":
+            from os2d_amd.modeling.box_coder import Os2dBoxCoder
+            from os2d_amd.structures.feature_map import FeatureMapSize
+            w.coder = Os2dBoxCoder(output_box_grid_generator=self.creator.box_grid_generator_image_level)
+            w.img_sizes = [FeatureMapSize(w=16 * ww, h=16 * hh) for hh, ww in (LEVEL_HW if self.pyramid else [(H_FM, W_FM)])]
+            s, e = self.bounds[self.rank]
+            w.local_ids = list(range(s, e))
+        return w
+
+    def _new_event_set(self):
+        arr = (ctypes.c_void_p * 10)()
+        for i in range(10):
+            ev = ctypes.c_void_p()
+            self._lib_mod.check(self.lib.os2d_prof_event_create(ctypes.byref(ev)), "os2d_prof_event_create")
+            arr[i] = ev.value
+        return arr
+
+    def sync_all(self):
+        import torch.distributed as dist
+        torch.cuda.synchronize(self.dev)
+        if self.use_dist:
+            dist.barrier()
+            torch.cuda.synchronize(self.dev)
+
+    def run(self, precision, steps, warmup):
+        """W warm-up + exactly K timed steps in one arithmetic mode; returns (seconds (max over ranks), per-stage mean
+        ms or None)."""
+        import torch.distributed as dist
+        head, sharded, runner = self.head, self.sharded, self.runner
+        head.precision = precision
+        staged = sharded is None and runner is None
+        # one set of 10 stage events per timed step, so nothing has to be read back inside the timed region
+        event_sets = [self._new_event_set() for _ in range(steps)] if staged else []
+        pending = []
+
+        def step(events):
+            with torch.no_grad():
+                if self.coder is not None:
+                    # class-sharded decode: the rank's own classes through head + decode + per-class NMS, then the union of
+                    # the surviving detections (two small collectives)
+                    from os2d_amd.parallel import all_gather_detections
+                    if runner is not None:
+                        loc, cls, _, _ = runner.run(self.level_fms, inputs_are_features=True)
+                        loc, cls = [l[0] for l in loc], [c[0] for c in cls]
+                    else:
+                        l, c, _, _ = head(self.fm)
+                        loc, cls = [l[0].flatten(2)], [c[0].flatten(1)]
+                    dets = self.coder.decode_pyramid(loc, cls, self.img_sizes, self.local_ids,
+                                                     nms_score_threshold=float("-inf"))      # reference eval default (config.py:198)
+                    return all_gather_detections(dets)
+                if runner is not None:
+                    return runner.run(self.level_fms, inputs_are_features=True)
+                if sharded is not None:
+                    # the all-gather of this step runs asynchronously (RCCL stream) and is waited for only after the
+                    # NEXT step's kernels have been queued, so the xGMI transfer hides behind compute
+                    pending.append(sharded(self.fm, async_gather=True))
+                    if len(pending) > 1:
+                        pending.pop(0)()
+                    return None
+                return head(self.fm, stage_events=events)
+
+        for _ in range(warmup):
+            step(None)
+        while pending:
+            pending.pop(0)()
+        self.sync_all()
+        # ---- timed region: exactly K steps; stage events are recorded on the launch stream inside these steps
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(event_sets[i] if event_sets else None)
+        while pending:
+            pending.pop(0)()          # every gather of the timed steps completes inside the timed region
+        self.sync_all()
+        dt = time.perf_counter() - t0
+        if self.use_dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        stage_ms = None
+        if event_sets:
+            ms = ctypes.c_float()
+            rows = []
+            for evs in event_sets:
+                row = []
+                for st in range(5):
+                    self._lib_mod.check(self.lib.os2d_prof_event_elapsed_ms(evs[2 * st], evs[2 * st + 1], ctypes.byref(ms)), "elapsed")
+                    row.append(ms.value)
+                rows.append(row)
+                for ev in evs:
+                    self.lib.os2d_prof_event_destroy(ev)
+            stage_ms = [sum(r[st] for r in rows) / len(rows) for st in range(5)]
+        return dt, stage_ms
+
+    def whole_head_flops_per_class(self):
+        per_loc = FLOP_PER_LOC["corr"] + FLOP_PER_LOC["conv1"] + FLOP_PER_LOC["conv2"] + 2 * self.P * 64 * 25
+        return per_loc * self.locations
+
+    def roofline(self, precision, stage_ms=None, seconds_per_step=None):
+        """Roofline object.  With stage events: the conv 7x7 kernel alone (algorithmic FLOPs of one launch / its mean
+        duration).  Without (several streams / ranks): the whole head of this rank (algorithmic FLOPs of a step / step
+        time) - `kernel` says which."""
+        peak = PEAK[precision]
+        B = self.B_local
+        if stage_ms is not None:
+            flops = FLOP_PER_LOC["conv1"] * H_FM * W_FM * B            # algorithmic FLOPs of ONE conv1 launch
+            seconds = stage_ms[1] * 1e-3
+            kernel = "TransformNet conv 7x7 225->128 ({})".format(
+                "conv_mfma_kernel<7,...>, v_mfma_f32_32x32x2_f32" if precision == "f32"
+                else "conv_f16x3_kernel<7,...>, v_mfma_f32_32x32x16_f16 x{} per product".format(precision[-1]))
+        else:
+            flops = self.whole_head_flops_per_class() * B
+            seconds = seconds_per_step
+            kernel = "whole head of one rank (correlation + 3 TransformNet convolutions, all MFMA kernels of a step{})".format(
+                ", 7 levels on 7 HIP streams" if self.pyramid else "")
+        achieved = flops / seconds
+        r = {"kernel": kernel, "bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": peak / 1e12, "unit": "TFLOP/s",
+             "frac": round(achieved / peak, 4), "traffic": None, "flops_per_launch": flops,
+             "avg_launch_ms": round(seconds * 1e3, 4), "timing": "HIP events on the launch stream, this run" if stage_ms is not None
+             else "wall clock of the timed steps, this run"}
+        if stage_ms is not None:
+            c = replayed_counters(precision)
+            if c:
+                r["traffic"] = int(c["bytes_per_class"] * B)
+                r["hbm_gbps"] = round(r["traffic"] / seconds / 1e9, 1)      # 8000 GB/s peak: far from HBM-bound
+                r["mfma_pipe_busy"] = c.get("mfma_pipe_busy")
+                if c.get("grbm_gui_active") and c.get("avg_launch_us"):
+                    clk = c["grbm_gui_active"] / (c["avg_launch_us"] * 1e-6) / 1e9
+                    r["effective_clock_ghz"] = round(clk, 3)
+                    r["frac_clock_adjusted"] = round(achieved / (peak * clk / 2.4), 4)   # against the peak at the sustained clock
+                r["counters_source"] = "REPLAYED from {} (rocprofv3 PMC passes recorded at {} classes, {}); not measured in this run".format(
+                    c["path"], c.get("classes_profiled"), c.get("source"))
+            # algorithmic HBM bytes of the same launch: every input plane read once (226 fp32 planes, or 29 groups x 8
+            # channels x (hi|lo) halves) + the 128 output planes written once + the packed weights once
+            plane = int(self.lib.os2d_plane_floats(H_FM, W_FM))
+            in_planes = 226 if precision == "f32" else 232
+            r["algorithmic_bytes"] = int(B * (in_planes + 128) * plane * 4 + self.lib.os2d_packed_conv_bytes(1, PREC_ID[precision]))
+        if precision != "f32":
+            # every algorithmic product costs three (f16x2: two, 7x7 layer only) half-precision MFMA products: the ceiling for
+            # algorithmic FLOP/s on this instruction is peak/3 (peak/2); the executed rate also includes the tile /
+            # channel-group padding (x1.118 for the 7x7 kernel)
+            terms = int(precision[-1]) if stage_ms is not None else 3
+            r["algorithmic_ceiling"] = round(peak / terms / 1e12, 1)
+            r["frac_of_algorithmic_ceiling"] = round(achieved / (peak / terms), 4)
+            if stage_ms is not None:
+                r["executed_mfma_tflops"] = round(terms * achieved * 1.118 / 1e12, 1)
+                r["executed_frac_of_peak"] = round(terms * achieved * 1.118 / peak, 4)
+        return r
+
+    def describe(self):
+        return ("OS2D head, ResNet50-C4 features of one 1280x960 image ({}), {} classes in total ({} on this GPU), {}, {} "
+                "(P={}, inverse={}), head only, features resident in HBM".format(
+                    "7-level pyramid 30x40..96x128, 39580 locations" if self.pyramid else "1x1024x60x80",
+                    self.classes_total, self.B_local, "7 scales 0.5-1.6, one HIP stream per level" if self.pyramid else "single scale",
+                    self.variant.upper(), self.P, int(self.inverse)))
+
+
+def precision_deviation(w):
+    """max |mode - f32| of the head outputs on the benchmarked tensors (this run, this workload)."""
+    out = {}
+    with torch.no_grad():
+        ref = [t.clone() for t in w.head(w.fm, precision="f32")]
+        for p in ("f16x3", "f16x2"):
+            o = w.head(w.fm, precision=p)
+            out[p] = {"cls": float((o[1] - ref[1]).abs().max()), "loc": float((o[0] - ref[0]).abs().max()),
+                      "corners_px": float((o[3] - ref[3]).abs().max())}
+        out["range_flag"] = w.head.range_status(synchronize=True)
+    return out
+
+
+def sweep_entry(dev, name, classes, variant, pyramid, precision, steps, warmup):
+    w = Workload(dev, 0, 1, classes, variant, pyramid, False, "all")
+    dt, stage_ms = w.run(precision, steps, warmup)
+    e = {"name": name, "workload": w.describe(), "classes": classes, "variant": variant, "pyramid": pyramid,
+         "precision": precision, "steps": steps, "warmup": warmup, "value": round(classes * steps / dt, 2),
+         "unit": "query-image-pairs/s", "ms_per_step": round(dt / steps * 1e3, 4)}
+    if stage_ms:
+        e["stages_ms"] = {k: round(v, 4) for k, v in zip(STAGES, stage_ms)}
+    e["roofline"] = w.roofline(precision, stage_ms, dt / steps)
+    e["head_tflops_algorithmic"] = round(w.whole_head_flops_per_class() * classes * steps / dt / 1e12, 3)
+    return e, w
 
 
 def main():
@@ -204,175 +472,98 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from os2d_amd import _lib
-    from os2d_amd.modeling.head import build_os2d_head_creator
-    from os2d_amd.parallel import ClassShardedHead
-    from os2d_amd.structures.feature_map import FeatureMapSize
-    from os2d_amd.utils import synthetic
-    lib = _lib.load()
+    # ---- workload of the primary line
+    if args.classes is not None and args.classes_total is not None:
+        raise SystemExit("give --classes (per GPU, weak scaling) or --classes-total (strong scaling), not both")
+    if args.classes is not None:
+        classes_total, scaling = args.classes * world, "weak"
+    elif args.classes_total is not None:
+        classes_total, scaling = args.classes_total, "strong"
+    elif world > 1:
+        classes_total, scaling = 1024, "strong"          # BASELINE.json configs[2]
+    else:
+        classes_total, scaling = 64, "weak"              # BASELINE.json configs[1]
+    if classes_total < world:
+        raise SystemExit("need at least one class per rank")
+    w = Workload(dev, rank, world, classes_total, args.variant, args.pyramid, use_dist, args.gather)
 
-    P, inverse = (6, True) if args.variant == "v2" else (4, False)
-    B = args.classes
-    state = synthetic.make_transform_net_state(P, seed=1)
-    fm_cpu = synthetic.make_feature_map(C_FEAT, H_FM, W_FM, seed=0)
-    # this rank's classes: global class ids rank*B .. rank*B+B-1 (seeds 1000+id)
-    class_fms_cpu = synthetic.make_class_feature_maps(B, C_FEAT, sizes=[(15, 15)], seed=1000 + rank * B)
-    creator = build_os2d_head_creator(P == 4, False, inverse, FeatureMapSize(w=16, h=16), FeatureMapSize(w=16, h=16))
-    creator.aligner.parameter_regressor.load_state_dict(state)
-    creator.to(dev).eval()
-    fm = fm_cpu.to(dev)
-    with torch.no_grad():
-        head = creator.create_os2d_head([c.to(dev) for c in class_fms_cpu])
-    sharded = ClassShardedHead(creator, group=None, gather=args.gather, num_classes=B * world, local_head=head) if use_dist else None
-
-    def new_event_set():
-        arr = (ctypes.c_void_p * 10)()
-        for i in range(10):
-            ev = ctypes.c_void_p()
-            _lib.check(lib.os2d_prof_event_create(ctypes.byref(ev)), "os2d_prof_event_create")
-            arr[i] = ev.value
-        return arr
-
-    runner, level_fms = None, None
-    if args.pyramid:
-        from os2d_amd.engine.pyramid import PyramidHeadRunner
-        level_hw = [(30, 40), (38, 50), (48, 64), (60, 80), (72, 96), (84, 112), (96, 128)]
-        level_fms = [synthetic.make_feature_map(C_FEAT, h, w, seed=100 + i).to(dev) for i, (h, w) in enumerate(level_hw)]
-        runner = PyramidHeadRunner(sharded if sharded is not None else head, device=dev)
-
-    def sync_all():
-        torch.cuda.synchronize(dev)
-        if use_dist:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    def run_mode(precision, steps, warmup):
-        """W warm-up + exactly K timed steps in one arithmetic mode; returns (seconds, per-stage mean ms or None)."""
-        head.precision = precision
-        # one set of 10 stage events per timed step, so nothing has to be read back inside the timed region
-        event_sets = [new_event_set() for _ in range(steps)] if (sharded is None and runner is None) else []
-
-        pending = []
-
-        def step(events):
-            with torch.no_grad():
-                if runner is not None:
-                    return runner.run(level_fms, inputs_are_features=True)
-                if sharded is not None:
-                    # the all-gather of this step runs asynchronously (RCCL stream) and is waited for only after the
-                    # NEXT step's kernels have been queued, so the xGMI transfer hides behind compute
-                    pending.append(sharded(fm, async_gather=True))
-                    if len(pending) > 1:
-                        pending.pop(0)()
-                    return None
-                return head(fm, stage_events=events)
-
-        for _ in range(warmup):
-            step(None)
-        while pending:
-            pending.pop(0)()
-        sync_all()
-        # ---- timed region: exactly K steps; stage events are recorded on the launch stream inside these steps
-        t0 = time.perf_counter()
-        for i in range(steps):
-            step(event_sets[i] if event_sets else None)
-        while pending:
-            pending.pop(0)()          # every gather of the timed steps completes inside the timed region
-        sync_all()
-        dt = time.perf_counter() - t0
-        if use_dist:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        stage_ms = None
-        if event_sets:
-            ms = ctypes.c_float()
-            rows = []
-            for evs in event_sets:
-                row = []
-                for st in range(5):
-                    _lib.check(lib.os2d_prof_event_elapsed_ms(evs[2 * st], evs[2 * st + 1], ctypes.byref(ms)), "elapsed")
-                    row.append(ms.value)
-                rows.append(row)
-                for ev in evs:
-                    lib.os2d_prof_event_destroy(ev)
-            stage_ms = [sum(r[st] for r in rows) / len(rows) for st in range(5)]
-        return dt, stage_ms
-
-    def roofline(precision, stage_ms):
-        flops = FLOP_PER_LOC["conv1"] * H_FM * W_FM * B            # algorithmic FLOPs of ONE conv1 launch
-        achieved = flops / (stage_ms[1] * 1e-3)
-        peak = PEAK[precision]
-        r = {"kernel": "TransformNet conv 7x7 225->128 ({})".format(
-                 "conv_mfma_kernel<7,...>, v_mfma_f32_32x32x2_f32" if precision == "f32"
-                 else "conv_f16x3_kernel<7,...>, v_mfma_f32_32x32x16_f16 x{} per product".format(precision[-1])),
-             "bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": peak / 1e12, "unit": "TFLOP/s",
-             "frac": round(achieved / peak, 4), "traffic": measured_traffic(B, precision),
-             "flops_per_launch": flops, "avg_launch_ms": round(stage_ms[1], 4)}
-        # algorithmic HBM bytes of the same launch: every input plane read once (226 fp32 planes, or 29 groups x 8
-        # channels x (hi|lo) halves) + the 128 output planes written once + the packed weights once
-        plane = int(lib.os2d_plane_floats(H_FM, W_FM))
-        in_planes = 226 if precision == "f32" else 232
-        r["mfma_pipe_busy"] = measured_mfma_busy(precision)
-        if r["traffic"]:
-            r["hbm_gbps"] = round(r["traffic"] / (stage_ms[1] * 1e-3) / 1e9, 1)      # 8000 GB/s peak: far from HBM-bound
-        r["algorithmic_bytes"] = int(B * (in_planes + 128) * plane * 4 + lib.os2d_packed_conv_bytes(1, {"f32": 0, "f16x3": 1, "f16x2": 2}[precision]))
-        if precision != "f32":
-            # every algorithmic product costs three (f16x2: two) half-precision MFMA products: the ceiling for
-            # algorithmic FLOP/s on this instruction is peak/3 (peak/2); the executed rate also includes the tile /
-            # channel-group padding (x1.118)
-            terms = int(precision[-1])
-            r["algorithmic_ceiling"] = round(peak / terms / 1e12, 1)
-            r["frac_of_algorithmic_ceiling"] = round(achieved / (peak / terms), 4)
-            r["executed_mfma_tflops"] = round(terms * achieved * 1.118 / 1e12, 1)
-            r["executed_frac_of_peak"] = round(terms * achieved * 1.118 / peak, 4)
-        return r
-
-    whole = (FLOP_PER_LOC["corr"] + FLOP_PER_LOC["conv1"] + FLOP_PER_LOC["conv2"] + 2 * P * 64 * 25) * H_FM * W_FM
-    pairs_per_step = B * world
-    dt, stage_ms = run_mode(args.precision, args.steps, args.warmup)
-    value = pairs_per_step * args.steps / dt
-    dtype = {"f32": "f32", "f16x3": "f16x3 (fp32 operands split into fp16 hi+lo, 3 half MFMAs per product, fp32 accumulate)",
-             "f16x2": "f16x2 (as f16x3; the 7x7 layer's weights enter as fp16 roundings only, 2 half MFMAs per product)"}
+    dt, stage_ms = w.run(args.precision, args.steps, args.warmup)
+    value = classes_total * args.steps / dt
+    gather_desc = {"all": "loc | cls | corners maps (every rank can decode every class)", "scores": "score maps only",
+                   "detections": "local decode + per-class NMS, then the surviving detections"}
     result = {
         "metric": "query-image-pairs/s (1280-px input, ResNet50, N-class)",
         "value": round(value, 2),
         "unit": "query-image-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": dtype[args.precision], "data": "synthetic",
-        "config": {"workload": "OS2D head, ResNet50-C4 features of one 1280x960 image ({}), {} classes per GPU "
-                               "({} total), {}, {} (P={}, inverse={}), head only, features resident in HBM"
-                               .format("7-level pyramid 30x40..96x128, 39580 locations" if args.pyramid else "1x1024x60x80",
-                                       B, B * world, "7 scales 0.5-1.6, one HIP stream per level" if args.pyramid else "single scale",
-                                       args.variant.upper(), P, int(inverse)),
-                   "classes_per_gpu": B, "classes_total": B * world, "feature_map": [C_FEAT, H_FM, W_FM],
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "dtype": DTYPE[args.precision], "data": "synthetic",
+        "config": {"workload": ("BASELINE.json configs[{}]: ".format(
+                                    4 if args.pyramid else (2 if classes_total == 1024 and args.variant == "v2" else
+                                                            (1 if classes_total == 64 and world == 1 and args.variant == "v2" else "-")))
+                                + w.describe()),
+                   "classes_per_gpu": w.B_local if scaling == "weak" else [e - s for s, e in w.bounds],
+                   "classes_total": classes_total, "feature_map": [C_FEAT, H_FM, W_FM],
                    "precision": args.precision,
-                   "parallelism": "class-sharded x{} + all-gather of {}".format(world, "score maps" if args.gather == "scores" else "loc|cls|corners")
-                                  if world > 1 else "single GPU"},
+                   "parallelism": ("class-sharded x{} ({} scaling) + RCCL all-gather per step of the {}".format(world, scaling, gather_desc[args.gather])
+                                   if use_dist else "single GPU")},
     }
     if stage_ms:
         result["stages_ms"] = {k: round(v, 4) for k, v in zip(STAGES, stage_ms)}
-        result["roofline"] = roofline(args.precision, stage_ms)
-    if not args.pyramid:
-        result["head_tflops_algorithmic"] = round(whole * value / 1e12, 3)
+    result["roofline"] = w.roofline(args.precision, stage_ms, dt / args.steps)
+    result["head_tflops_algorithmic"] = round(w.whole_head_flops_per_class() * value / 1e12, 3)
     if not args.no_other_precision:
         result["other_precisions"] = []
         for other in ("f16x3", "f16x2", "f32"):
             if other == args.precision:
                 continue
-            dt2, stage2 = run_mode(other, args.steps, 1)
-            o = {"precision": other, "value": round(pairs_per_step * args.steps / dt2, 2), "ms_per_step": round(dt2 / args.steps * 1e3, 4)}
+            dt2, stage2 = w.run(other, max(2, min(args.steps, 10)), 1)
+            n2 = max(2, min(args.steps, 10))
+            o = {"precision": other, "value": round(classes_total * n2 / dt2, 2), "ms_per_step": round(dt2 / n2 * 1e3, 4), "steps": n2}
             if stage2:
                 o["stages_ms"] = {k: round(v, 4) for k, v in zip(STAGES, stage2)}
-                o["roofline"] = roofline(other, stage2)
+            o["roofline"] = w.roofline(other, stage2, dt2 / n2)
             result["other_precisions"].append(o)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.pyramid:
-        result["cpu_baseline"] = cpu_baseline(fm_cpu, class_fms_cpu, state, inverse, args.cpu_seconds)
+        if not args.pyramid:
+            result["max_abs_diff_vs_f32"] = precision_deviation(w)
+    if use_dist and not args.no_other_gather:
+        result["other_gathers"] = []
+        for g in ("all", "scores", "detections"):
+            if g == args.gather:
+                continue
+            wg = w.set_gather(g)
+            n2 = max(2, min(args.steps, 10))
+            dt2, _ = wg.run(args.precision, n2, 1)
+            result["other_gathers"].append({"gather": g, "what": gather_desc[g], "value": round(classes_total * n2 / dt2, 2),
+                                            "ms_per_step": round(dt2 / n2 * 1e3, 4), "steps": n2})
+    single = rank == 0 and world == 1 and not args.force_dist
+    if single and not args.no_sweep and not args.pyramid:
+        # the other single-GPU readings of BASELINE.json's configs, timed in this very run
+        n = max(2, min(args.steps, 5))
+        result["sweep"] = []
+        for name, classes, variant, pyr in (("configs[3]: 256 classes, V1 simplified-affine head", 256, "v1", False),
+                                            ("configs[2] on one GPU: 1024 classes", 1024, "v2", False),
+                                            ("configs[4] per-GPU share: 7-level pyramid, 128 classes, one HIP stream per level", 128, "v2", True)):
+            e, ws = sweep_entry(dev, name, classes, variant, pyr, args.precision, n, 1)
+            result["sweep"].append(e)
+            if name.startswith("configs[2]"):
+                result["scaling_reference"] = {"what": "all 1024 classes of configs[2] on ONE GPU (the N=1 point of the strong-scaling curve "
+                                                       "bench.py --gpus N measures)", "value": e["value"], "ms_per_step": e["ms_per_step"]}
+            del ws
+            from os2d_amd.modeling import head as head_mod
+            head_mod.release_workspaces()
+            torch.cuda.empty_cache()
+    if single and not args.no_cpu_baseline and not args.pyramid:
+        result["cpu_baseline"] = cpu_baseline(w.fm_cpu, w.class_fms_cpu, w.state, w.inverse, args.cpu_seconds)
         result["speedup_vs_cpu_baseline"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
-    if rank == 0 and world == 1 and not args.no_end_to_end and not args.pyramid:
-        result["end_to_end"] = end_to_end(dev, B, P, inverse, state, args.precision)
+    if single and not args.no_end_to_end and not args.pyramid:
+        result["end_to_end"] = end_to_end(dev, min(classes_total, 256), w.P, w.inverse, w.state, args.precision)
+        if not args.no_sweep:
+            # configs[3] names a ResNet101 backbone: the same leg with it and the V1 head at 256 classes
+            from os2d_amd.utils import synthetic
+            result["end_to_end_resnet101_v1_256"] = end_to_end(dev, 256, 4, False, synthetic.make_transform_net_state(4, seed=1),
+                                                               args.precision, arch="resnet101", steps=3, warmup=1)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if use_dist:

@@ -42,7 +42,7 @@ const char* os2d_last_error(void);
  * conv.0/conv.1(BN)/conv.3/conv.4(BN)/linear; eval-mode BatchNorm (head.py:623) is folded here and the filters are
  * re-laid-out for the MFMA implicit-GEMM kernels.  Sizes of the packed buffers (in floats): */
 size_t os2d_packed_conv_floats(int layer /*1|2|3*/);       /* weights */
-size_t os2d_packed_bias_floats(int layer /*1|2|3*/);       /* bias (+ the per-row unscale factors of the f16x3 packing) */
+size_t os2d_packed_bias_floats(int layer /*1|2|3*/);       /* bias (+ the per-row scale factors of the f16x3 packing) */
 /* layer 1: w[128,225,7,7]; layer 2: w[64,128,5,5]; layer 3: w[P,64,5,5] (bn_* = NULL, P = 6 or 4).
  * bn_eps is BatchNorm2d.eps (1e-5 in the reference). */
 int os2d_pack_conv(int layer, int P, const float* w, const float* b, const float* bn_weight, const float* bn_bias,
@@ -74,29 +74,30 @@ int os2d_head_forward(const float* fm, const float* qp, const float* w1, const f
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- f16x3 weight packing (bn_* = NULL for layer 3, as in os2d_pack_conv).  Range handling, so that no value of the
- * path can leave the fp16 range for finite inputs ("range safety"):
- *   weight_exp  DEVICE int[Cout]: output channel o's folded weights are multiplied by 2^weight_exp[o] before the fp16
- *               hi/lo split; choose the largest exponent with max|w_folded[o]| * 2^weight_exp[o] <= 16384;
- *   in_exp      the layer's INPUT activations are stored as fp16 hi|lo of x * 2^in_exp (layer 1: os2d_rnorm_exp() = 12,
- *               layers 2 / 3: the out_exp the previous layer runs with);
- * packed_b [2*MT] receives the folded bias and the per-row factor 2^-(weight_exp[o] + in_exp) that the epilogue applies
- * to the accumulator (power-of-two scales: exact).  Buffer sizes: os2d_packed_conv_bytes, os2d_packed_bias_floats.     */
+ * path can leave the fp16 range for finite inputs and every value keeps its 22 bits ("range safety"):
+ * all three are DEVICE int arrays of power-of-two exponents, applied exactly:
+ *   in_exp  [Cin]   input channel c of the layer is stored as fp16 hi|lo of x[c] * 2^in_exp[c] (layer 1: os2d_rnorm_exp()
+ *                   = 12 for all 225 channels; layers 2 / 3: the previous layer's out_exp);
+ *   out_exp [Cout]  output channel o is written as fp16 hi|lo of y[o] * 2^out_exp[o] (NULL for layer 3, whose output is
+ *                   fp32); the binding derives it from a rigorous bound of |y[o]| so that finite inputs cannot overflow;
+ *   weight_exp [Cout]  the folded weights w[o][c] * 2^-in_exp[c] of output channel o are multiplied by 2^weight_exp[o]
+ *                   before the hi/lo split; choose the largest exponent that keeps their maximum <= 16384.
+ * packed_b [3*MT] receives per output row the folded bias, 2^-weight_exp (applied to the accumulator) and 2^out_exp.
+ * Buffer sizes: os2d_packed_conv_bytes, os2d_packed_bias_floats.                                                      */
 size_t os2d_packed_conv_bytes(int layer, int precision);
 int os2d_rnorm_exp(void);
 int os2d_pack_conv_f16x3(int layer /*1|2|3*/, int P, const float* w, const float* b, const float* bn_weight,
                          const float* bn_bias, const float* bn_running_mean, const float* bn_running_var, float bn_eps,
-                         const int* weight_exp, int in_exp, void* packed_w, float* packed_b, void* stream);
+                         const int* weight_exp, const int* in_exp, const int* out_exp, void* packed_w, float* packed_b,
+                         void* stream);
 
 /* split class operand for the f16x3 correlation: qp [B,C,256] fp32 (os2d_class_prepare) -> qs [B, C/8, hi|lo, 256] units
  * of 8 halves (B * ceil(C/8) * 2 * 256 * 16 bytes), scaled by 2^12.                                                 */
 int os2d_class_split(const float* qp, void* qs, int B, int C, void* stream);
 
 /* ---- extended head entry point: identical to os2d_head_forward, plus
- *   precision     OS2D_PRECISION_F32 (w1..w3 from os2d_pack_conv; qs / act_exp ignored) or OS2D_PRECISION_F16X3 / _F16X2
+ *   precision     OS2D_PRECISION_F32 (w1..w3 from os2d_pack_conv; qs ignored) or OS2D_PRECISION_F16X3 / _F16X2
  *                 (w1..w3 from os2d_pack_conv_f16x3, qs [B, C/8, 2, 256, 8] halves from os2d_class_split);
- *   act_exp       host int[2]: the activations after conv 7x7 / conv 5x5 are stored as fp16 hi|lo of x * 2^act_exp[0|1]
- *                 (the in_exp the NEXT layer's weights were packed with; the binding derives them from a rigorous bound
- *                 of the layer outputs, so finite inputs cannot overflow);
  *   stage_events  NULL, or an array of 10 hipEvent_t (from os2d_prof_event_create); events [2s] / [2s+1] are recorded
  *                 on `stream` right before / after stage s of the FIRST class chunk
  *                 (s = 0 correlation, 1 conv 7x7, 2 conv 5x5 128->64, 3 conv 5x5 64->P, 4 resample+encode);
@@ -109,7 +110,7 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
                          const float* b2, const void* w3, const float* b3, int A, int B, int C, int H, int W, int P,
                          int inverse, int stride, int rec_field, float* loc, float* cls, float* corners,
                          void* workspace, size_t workspace_bytes, void* stream, int precision, const void* qs,
-                         const int* act_exp /*[2], host memory*/, void** stage_events, int* chunk_classes, int* status);
+                         void** stage_events, int* chunk_classes, int* status);
 int os2d_prof_event_create(void** ev);
 int os2d_prof_event_destroy(void* ev);
 int os2d_prof_event_elapsed_ms(void* begin, void* end, float* ms);   /* both events must have completed */
@@ -133,12 +134,12 @@ int os2d_transform_conv(int layer, const float* in, const float* packed_w, const
 /* The same two stages on the half-precision matrix cores (the kernels the f16x3 / f16x2 head runs), for stage-level parity
  * tests: activations are "split-half blocked" buffers [NB][ceil(ch/8)][hi|lo][PLANE] of 16-byte units (os2d_shb_bytes).
  *   os2d_corr_normalize_f16x3  corr [NB,225,H*W] fp32 -> relu + L2 (eps 1e-6), scaled by 2^os2d_rnorm_exp(), split
- *   os2d_transform_conv_f16x3  layer 1 / 2: SHB in -> SHB out holding x * 2^out_exp; layer 3: SHB in -> fp32 [NB,P,H*W];
+ *   os2d_transform_conv_f16x3  layer 1 / 2: SHB in -> SHB out (channel scales as packed); layer 3: SHB in -> fp32 [NB,P,H*W];
  *                              terms = 3 (fp32-equivalent) or 2 (layer 1 only: weights as fp16 roundings, f16x2 mode)   */
 size_t os2d_shb_bytes(int channels, int H, int W);
 int os2d_corr_normalize_f16x3(const float* corr, void* rshb, int NB, int H, int W, void* stream);
 int os2d_transform_conv_f16x3(int layer, const void* in, const void* packed_w, const float* packed_b, void* out, int NB,
-                              int P, int H, int W, int terms, int out_exp, int* status, void* stream);
+                              int P, int H, int W, int terms, int* status, void* stream);
 /* Os2dAlignment.forward / prepare_transform_parameters_for_grid_sampler as the reference returns them (head.py:81-193):
  * params [NB,P,H*W] -> theta [NB*H*W,2,3] (NULL to skip) and the transformed template grids in local coordinates
  * grids [NB,H,W,15,15,2] (NULL to skip; F.affine_grid, align_corners=True).  The fused head materialises neither.     */

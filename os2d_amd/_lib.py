@@ -28,15 +28,15 @@ SIGNATURES = {
     "os2d_head_workspace_bytes": (_i, [_i, _i, _i, _i, _i, _i, ctypes.POINTER(_sz)]),
     "os2d_head_forward": (_i, [_vp] * 8 + [_i] * 9 + [_vp, _vp, _vp, _vp, _sz, _vp]),
     "os2d_packed_conv_bytes": (_sz, [_i, _i]),
-    "os2d_pack_conv_f16x3": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp]),
+    "os2d_pack_conv_f16x3": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "os2d_rnorm_exp": (_i, []),
     "os2d_class_prepare_batch": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "os2d_shb_bytes": (_sz, [_i, _i, _i]),
     "os2d_corr_normalize_f16x3": (_i, [_vp, _vp, _i, _i, _i, _vp]),
-    "os2d_transform_conv_f16x3": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "os2d_transform_conv_f16x3": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "os2d_alignment_grids": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "os2d_class_split": (_i, [_vp, _vp, _i, _i, _vp]),
-    "os2d_head_forward_ex": (_i, [_vp] * 8 + [_i] * 9 + [_vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, ctypes.POINTER(_i),
+    "os2d_head_forward_ex": (_i, [_vp] * 8 + [_i] * 9 + [_vp, _vp, _vp, _vp, _sz, _vp, _i, _vp,
                                   ctypes.POINTER(_vp), ctypes.POINTER(_i), _vp]),
     "os2d_prof_event_create": (_i, [ctypes.POINTER(_vp)]),
     "os2d_prof_event_destroy": (_i, [_vp]),

@@ -82,7 +82,7 @@ size_t os2d_packed_conv_floats(int layer) {
 size_t os2d_packed_bias_floats(int layer) {
   ConvShape s;
   if (!conv_shape(layer, 6, &s)) return 0;
-  return (size_t)2 * s.mt;  // folded bias | per-row unscale (f16x3 packing; the fp32 packing uses the first half)
+  return (size_t)3 * s.mt;  // folded bias | per-row 2^-weight_exp | per-row 2^out_exp (f16x3 packing; fp32: first third)
 }
 
 int os2d_pack_conv(int layer, int P, const float* w, const float* b, const float* bn_weight, const float* bn_bias,
@@ -240,7 +240,7 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
                          const float* b2, const void* w3, const float* b3, int A, int B, int C, int H, int W, int P,
                          int inverse, int stride, int rec_field, float* loc, float* cls, float* corners,
                          void* workspace, size_t workspace_bytes, void* stream, int precision, const void* qs,
-                         const int* act_exp, void** stage_events, int* chunk_classes, int* status) {
+                         void** stage_events, int* chunk_classes, int* status) {
   if (!fm || !qp || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !loc || !cls || !corners || !workspace) {
     os2d_set_error("os2d_head_forward: null pointer");
     return -1;
@@ -249,13 +249,8 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     os2d_set_error("os2d_head_forward: unknown precision %d", precision);
     return -1;
   }
-  if (precision != OS2D_PRECISION_F32 && (!qs || !act_exp)) {
-    os2d_set_error("os2d_head_forward: precision f16x3 / f16x2 needs the split class operand (os2d_class_split) and the "
-                   "two activation exponents the weights were packed for");
-    return -1;
-  }
-  if (precision != OS2D_PRECISION_F32 && (act_exp[0] < -100 || act_exp[0] > 100 || act_exp[1] < -100 || act_exp[1] > 100)) {
-    os2d_set_error("os2d_head_forward: activation exponents %d / %d out of range", act_exp[0], act_exp[1]);
+  if (precision != OS2D_PRECISION_F32 && !qs) {
+    os2d_set_error("os2d_head_forward: precision f16x3 / f16x2 needs the split class operand (os2d_class_split)");
     return -1;
   }
   if (!head_args_ok(A, B, C, H, W, P)) return -1;
@@ -322,21 +317,21 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     mark(b0, 1);
     mark(b0, 2);
     if (f16) {
-      if ((rc = os2d_launch_conv_f16x3(1, rpad, w1, b1, ldexpf(1.0f, act_exp[0]), status, h1, NB, P, H, W, terms1, st))) return rc;
+      if ((rc = os2d_launch_conv_f16x3(1, rpad, w1, b1, status, h1, NB, P, H, W, terms1, st))) return rc;
     } else {
       if ((rc = os2d_launch_conv(1, rpad, static_cast<const float*>(w1), b1, h1, NB, P, H, W, st))) return rc;
     }
     mark(b0, 3);
     mark(b0, 4);
     if (f16) {
-      if ((rc = os2d_launch_conv_f16x3(2, h1, w2, b2, ldexpf(1.0f, act_exp[1]), status, h2, NB, P, H, W, 3, st))) return rc;
+      if ((rc = os2d_launch_conv_f16x3(2, h1, w2, b2, status, h2, NB, P, H, W, 3, st))) return rc;
     } else {
       if ((rc = os2d_launch_conv(2, h1, static_cast<const float*>(w2), b2, h2, NB, P, H, W, st))) return rc;
     }
     mark(b0, 5);
     mark(b0, 6);
     if (f16) {
-      if ((rc = os2d_launch_conv_f16x3(3, h2, w3, b3, 1.0f, status, params, NB, P, H, W, 3, st))) return rc;
+      if ((rc = os2d_launch_conv_f16x3(3, h2, w3, b3, status, params, NB, P, H, W, 3, st))) return rc;
     } else {
       if ((rc = os2d_launch_conv(3, h2, static_cast<const float*>(w3), b3, params, NB, P, H, W, st))) return rc;
     }
@@ -356,7 +351,7 @@ int os2d_head_forward(const float* fm, const float* qp, const float* w1, const f
                       size_t workspace_bytes, void* stream) {
   return os2d_head_forward_ex(fm, qp, w1, b1, w2, b2, w3, b3, A, B, C, H, W, P, inverse, stride, rec_field, loc, cls,
                               corners, workspace, workspace_bytes, stream, OS2D_PRECISION_F32, nullptr, nullptr, nullptr,
-                              nullptr, nullptr);
+                              nullptr);
 }
 
 int os2d_class_split(const float* qp, void* qs, int B, int C, void* stream) {
@@ -379,25 +374,22 @@ size_t os2d_packed_conv_bytes(int layer, int precision) {
 
 int os2d_pack_conv_f16x3(int layer, int P, const float* w, const float* b, const float* bn_weight, const float* bn_bias,
                          const float* bn_running_mean, const float* bn_running_var, float bn_eps, const int* weight_exp,
-                         int in_exp, void* packed_w, float* packed_b, void* stream) {
+                         const int* in_exp, const int* out_exp, void* packed_w, float* packed_b, void* stream) {
   const bool has_bn = bn_weight || bn_bias || bn_running_mean || bn_running_var;
-  if (layer < 1 || layer > 3 || !w || !b || !packed_w || !packed_b || !weight_exp ||
-      (has_bn && !(bn_weight && bn_bias && bn_running_mean && bn_running_var)) || (layer == 3 && P != 6 && P != 4)) {
+  if (layer < 1 || layer > 3 || !w || !b || !packed_w || !packed_b || !weight_exp || !in_exp ||
+      (layer != 3 && !out_exp) || (has_bn && !(bn_weight && bn_bias && bn_running_mean && bn_running_var)) ||
+      (layer == 3 && P != 6 && P != 4)) {
     os2d_set_error("os2d_pack_conv_f16x3: bad arguments (layer %d, P %d)", layer, P);
-    return -1;
-  }
-  if (in_exp < -100 || in_exp > 100) {
-    os2d_set_error("os2d_pack_conv_f16x3: in_exp %d out of range", in_exp);
     return -1;
   }
   if (layer == 1)
     return os2d_launch_pack_conv_f16(w, b, bn_weight, bn_bias, bn_running_mean, bn_running_var, bn_eps, 128, OS2D_K, 7,
-                                     128, 25, weight_exp, in_exp, packed_w, packed_b, S(stream));
+                                     128, 25, weight_exp, in_exp, out_exp, packed_w, packed_b, S(stream));
   if (layer == 2)
     return os2d_launch_pack_conv_f16(w, b, bn_weight, bn_bias, bn_running_mean, bn_running_var, bn_eps, 64, 128, 5, 64,
-                                     14, weight_exp, in_exp, packed_w, packed_b, S(stream));
+                                     14, weight_exp, in_exp, out_exp, packed_w, packed_b, S(stream));
   return os2d_launch_pack_conv_f16(w, b, bn_weight, bn_bias, bn_running_mean, bn_running_var, bn_eps, P, 64, 5, 32, 14,
-                                   weight_exp, in_exp, packed_w, packed_b, S(stream));
+                                   weight_exp, in_exp, nullptr, packed_w, packed_b, S(stream));
 }
 
 int os2d_rnorm_exp(void) { return OS2D_RNORM_EXP; }
@@ -411,19 +403,17 @@ int os2d_corr_normalize_f16x3(const float* corr, void* rshb, int NB, int H, int 
 }
 
 int os2d_transform_conv_f16x3(int layer, const void* in, const void* packed_w, const float* packed_b, void* out, int NB,
-                              int P, int H, int W, int terms, int out_exp, int* status, void* stream) {
+                              int P, int H, int W, int terms, int* status, void* stream) {
   if (!in || !packed_w || !packed_b || !out || NB < 1 || H < 1 || W < 1 || layer < 1 || layer > 3 ||
-      (layer == 3 && P != 6 && P != 4) || (terms != 3 && !(terms == 2 && layer == 1)) || out_exp < -100 || out_exp > 100) {
-    os2d_set_error("os2d_transform_conv_f16x3: bad arguments (layer=%d NB=%d P=%d terms=%d out_exp=%d)", layer, NB, P,
-                   terms, out_exp);
+      (layer == 3 && P != 6 && P != 4) || (terms != 3 && !(terms == 2 && layer == 1))) {
+    os2d_set_error("os2d_transform_conv_f16x3: bad arguments (layer=%d NB=%d P=%d terms=%d)", layer, NB, P, terms);
     return -1;
   }
   if (W > OS2D_MAX_W) {
     os2d_set_error("os2d_transform_conv_f16x3: feature map width %d > %d", W, OS2D_MAX_W);
     return -1;
   }
-  return os2d_launch_conv_f16x3(layer, in, packed_w, packed_b, layer == 3 ? 1.0f : ldexpf(1.0f, out_exp), status, out,
-                                NB, P, H, W, terms, S(stream));
+  return os2d_launch_conv_f16x3(layer, in, packed_w, packed_b, status, out, NB, P, H, W, terms, S(stream));
 }
 
 int os2d_alignment_grids(const float* params, int NB, int H, int W, int P, int inverse, float* theta, float* grids,

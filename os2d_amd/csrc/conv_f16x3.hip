@@ -41,8 +41,8 @@ template <int KS, int MTP, int MT, int WM, int WN, int NI, int SS, bool RELU, in
           int NBPF /*16-byte units per thread for the input-slab prefetch*/, int TERMS>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_f16x3_kernel(const u32x4* in,  // SHB [NB][G][2][PLANE] (no __restrict__: invariant loads get
                                                              const u32x4* wp,  // rematerialised BEHIND the MFMAs by the register allocator)
-                                                             const float* __restrict__ bp,  // [2][MTP] fp32: folded bias | per-row 2^-(weight exp + input exp)
-                                                             float out_scale, int* __restrict__ status,
+                                                             const float* __restrict__ bp,  // [3][MTP] fp32 per output row: folded bias | 2^-weight_exp | 2^out_exp
+                                                             int* __restrict__ status,
                                                              void* __restrict__ outv, int G,
                                                              int CoutStore, int H, int W, int PLANE, int HALO,
                                                              int TILES, int NB) {
@@ -259,11 +259,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_f16x3_kernel(const u32x4
 #undef F16_FRAGS
 #undef F16_MFMAS
 
-  // ---- epilogue: undo the (per output channel) weight scale and the input scale, bias (+ReLU), apply the output
-  // scale of the split activation buffer; pad cells are written as exact zeros.  The output scale is chosen on the host
-  // from a rigorous bound of the layer's outputs (os2d_amd/modeling/head.py: TransformationNet.packed), so a FINITE
-  // input cannot leave the fp16 range; anything that still does (Inf / NaN inputs) raises the sticky status flag
-  // instead of being clamped silently.
+  // ---- epilogue: undo the weight scale of the output channel (the input channels' scales are folded into the packed
+  // weights), bias (+ReLU), apply the output channel's scale of the split activation buffer; pad cells are written as
+  // exact zeros.  The output scales come from a rigorous per-channel bound of the layer's outputs
+  // (os2d_amd/modeling/head.py: TransformationNet.range_plan), so a FINITE input cannot leave the fp16 range; anything
+  // that still does (Inf / NaN inputs) raises the sticky status flag instead of being clamped silently.
   bool out_of_range = false;
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_f16x3_kernel(const u32x4
           if (RELU) t = fmaxf(t, 0.f);
           const bool live = valid && m0 + k < CoutStore;
           if (OUT_MODE == 0) {
-            t *= out_scale;
+            t *= bp[2 * MTP + m0 + k];
             if (live && !(fabsf(t) <= 65504.f)) out_of_range = true;  // also true for NaN
           }
           v[k] = live ? t : 0.f;
@@ -347,8 +347,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_f16x3_kernel(const u32x4
 }
 
 template <int KS, int MTP, int MT, int WM, int WN, int NI, int SS, bool RELU, int OUT_MODE, int TERMS = 3, int NBPF = 0>
-int launch(const void* in, const void* wp, const float* bp, float out_scale, int* status, void* out, int NB, int G,
-           int CoutStore, int H, int W, hipStream_t stream) {
+int launch(const void* in, const void* wp, const float* bp, int* status, void* out, int NB, int G, int CoutStore, int H,
+           int W, hipStream_t stream) {
   constexpr int R = KS / 2;
   constexpr int NT = WN * NI * 32;
   const int Ws = os2d_ws(W), PLANE = os2d_plane(H, W);
@@ -356,8 +356,8 @@ int launch(const void* in, const void* wp, const float* bp, float out_scale, int
   const int SLAB = NT + 2 * HALO;
   constexpr int NTHR = 64 * WM * WN;
   if (NBPF == 0) {  // pick the slab-prefetch depth: 8 units/thread up to W = 124 (fewer registers), 12 up to W = 209
-    if (2 * SLAB <= 8 * NTHR) return launch<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE, TERMS, 8>(in, wp, bp, out_scale, status, out, NB, G, CoutStore, H, W, stream);
-    if (2 * SLAB <= 12 * NTHR) return launch<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE, TERMS, 12>(in, wp, bp, out_scale, status, out, NB, G, CoutStore, H, W, stream);
+    if (2 * SLAB <= 8 * NTHR) return launch<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE, TERMS, 8>(in, wp, bp, status, out, NB, G, CoutStore, H, W, stream);
+    if (2 * SLAB <= 12 * NTHR) return launch<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE, TERMS, 12>(in, wp, bp, status, out, NB, G, CoutStore, H, W, stream);
     os2d_set_error("conv%dx%d (f16x3): feature map too wide for the input-slab prefetch (W=%d)", KS, KS, W);
     return -3;
   }
@@ -381,8 +381,7 @@ int launch(const void* in, const void* wp, const float* bp, float out_scale, int
   }
   dim3 grid((unsigned)((groups + 7) / 8 * 8));  // multiple of 8: every XCD gets the same number of logical slots
   hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds, stream, reinterpret_cast<const u32x4*>(in),
-                     reinterpret_cast<const u32x4*>(wp), bp, out_scale, status, out, G, CoutStore, H, W, PLANE, HALO, tiles,
-                     NB);
+                     reinterpret_cast<const u32x4*>(wp), bp, status, out, G, CoutStore, H, W, PLANE, HALO, tiles, NB);
   e = hipGetLastError();
   if (e != hipSuccess) {
     os2d_set_error("conv f16x3 launch: %s", hipGetErrorString(e));
@@ -401,25 +400,25 @@ int launch(const void* in, const void* wp, const float* bp, float out_scale, int
 // calling pattern, evaluate.py:323-331) still spreads over 160 / 80 / 40 groups instead of 40 / 20 / 20 and a group's
 // serial K loop issues 3 instead of 12 MFMAs per k-step.  Every output element accumulates the same products in the
 // same order in both shapes, so results do not depend on which one ran (tests: small batch == slice of a large batch).
-int os2d_launch_conv_f16x3(int layer, const void* in, const void* wp, const float* bp, float out_scale, int* status,
-                           void* out, int NB, int P, int H, int W, int terms, hipStream_t stream) {
+int os2d_launch_conv_f16x3(int layer, const void* in, const void* wp, const float* bp, int* status, void* out, int NB,
+                           int P, int H, int W, int terms, hipStream_t stream) {
   const long long std_groups = (long long)((H * os2d_ws(W) + 255) / 256) * NB;
   if (std_groups * (layer == 1 ? 2 : 1) < 384) {  // measured crossover at 60x80: finer shapes win up to 9 classes
     if (layer == 1 && terms == 2)
-      return launch<7, 128, 32, 1, 4, 1, 5, true, 0, 2>(in, wp, bp, out_scale, status, out, NB, 29, 128, H, W, stream);
+      return launch<7, 128, 32, 1, 4, 1, 5, true, 0, 2>(in, wp, bp, status, out, NB, 29, 128, H, W, stream);
     switch (layer) {
-      case 1: return launch<7, 128, 32, 1, 4, 1, 5, true, 0>(in, wp, bp, out_scale, status, out, NB, 29, 128, H, W, stream);
-      case 2: return launch<5, 64, 32, 1, 4, 1, 7, true, 0>(in, wp, bp, out_scale, status, out, NB, 16, 64, H, W, stream);
-      case 3: return launch<5, 32, 32, 1, 4, 1, 7, false, 2>(in, wp, bp, out_scale, status, out, NB, 8, P, H, W, stream);
+      case 1: return launch<7, 128, 32, 1, 4, 1, 5, true, 0>(in, wp, bp, status, out, NB, 29, 128, H, W, stream);
+      case 2: return launch<5, 64, 32, 1, 4, 1, 7, true, 0>(in, wp, bp, status, out, NB, 16, 64, H, W, stream);
+      case 3: return launch<5, 32, 32, 1, 4, 1, 7, false, 2>(in, wp, bp, status, out, NB, 8, P, H, W, stream);
       default: break;
     }
   }
   if (layer == 1 && terms == 2)
-    return launch<7, 128, 64, 1, 4, 2, 5, true, 0, 2>(in, wp, bp, out_scale, status, out, NB, 29, 128, H, W, stream);
+    return launch<7, 128, 64, 1, 4, 2, 5, true, 0, 2>(in, wp, bp, status, out, NB, 29, 128, H, W, stream);
   switch (layer) {
-    case 1: return launch<7, 128, 64, 1, 4, 2, 5, true, 0>(in, wp, bp, out_scale, status, out, NB, 29, 128, H, W, stream);
-    case 2: return launch<5, 64, 64, 1, 4, 2, 7, true, 0>(in, wp, bp, out_scale, status, out, NB, 16, 64, H, W, stream);
-    case 3: return launch<5, 32, 32, 1, 4, 2, 7, false, 2>(in, wp, bp, out_scale, status, out, NB, 8, P, H, W, stream);
+    case 1: return launch<7, 128, 64, 1, 4, 2, 5, true, 0>(in, wp, bp, status, out, NB, 29, 128, H, W, stream);
+    case 2: return launch<5, 64, 64, 1, 4, 2, 7, true, 0>(in, wp, bp, status, out, NB, 16, 64, H, W, stream);
+    case 3: return launch<5, 32, 32, 1, 4, 2, 7, false, 2>(in, wp, bp, status, out, NB, 8, P, H, W, stream);
     default: os2d_set_error("os2d_launch_conv_f16x3: bad layer %d", layer); return -1;
   }
 }

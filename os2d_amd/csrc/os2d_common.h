@@ -99,7 +99,8 @@ int os2d_launch_pack_conv(const float* w, const float* b, const float* bn_w, con
 int os2d_launch_border_zero_shb(void* rnorm, int NB, int H, int W, hipStream_t stream);
 int os2d_launch_pack_conv_f16(const float* w, const float* b, const float* bn_w, const float* bn_b, const float* bn_mean,
                               const float* bn_var, float bn_eps, int Cout, int Cin, int KS, int MT, int steps_padded,
-                              const int* wexp, int in_exp, void* wp, float* bp, hipStream_t stream);
+                              const int* wexp, const int* in_exp, const int* out_exp, void* wp, float* bp,
+                              hipStream_t stream);
 int os2d_launch_class_prepare_batch(const float* const* srcs, const int* sizes, int B, int C, int normalize, float* q15,
                                     float* qp, hipStream_t stream);
 int os2d_launch_corr_normalize_shb(const float* corr, void* rshb, int NB, int H, int W, hipStream_t stream);
@@ -107,8 +108,8 @@ int os2d_launch_corr_normalize_shb(const float* corr, void* rshb, int NB, int H,
 int os2d_launch_corr(const float* fm, const float* qp, const float* sumsq, float* corr, void* rnorm,
                      int A, int B, int C, int H, int W, int shb, hipStream_t stream);
 // conv_f16x3.hip
-int os2d_launch_conv_f16x3(int layer, const void* in, const void* wp, const float* bp, float out_scale, int* status,
-                           void* out, int NB, int P, int H, int W, int terms, hipStream_t stream);
+int os2d_launch_conv_f16x3(int layer, const void* in, const void* wp, const float* bp, int* status, void* out, int NB,
+                           int P, int H, int W, int terms, hipStream_t stream);
 // conv_mfma.hip
 int os2d_launch_conv(int layer, const float* in, const float* wp, const float* bp, float* out,
                      int NB, int P, int H, int W, hipStream_t stream);

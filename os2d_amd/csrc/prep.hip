@@ -79,9 +79,10 @@ __device__ __forceinline__ void class_prepare_body(const float* __restrict__ src
   const int cell = blockIdx.x;  // i*15 + j  (row i, col j)
   const int i = cell / OS2D_T, j = cell - i * OS2D_T;
   // sampling position of the identity grid, as F.affine_grid(align_corners=True) + F.grid_sample build it
+  // (torch.linspace(-1, 1, 15) on the CPU: fused multiply-adds from the start for k < 7, from the end for k >= 7)
   const float step = 2.0f / (OS2D_T - 1);
-  const float xu = (j < (OS2D_T + 1) / 2) ? (-1.0f + step * j) : (1.0f - step * (OS2D_T - 1 - j));
-  const float yu = (i < (OS2D_T + 1) / 2) ? (-1.0f + step * i) : (1.0f - step * (OS2D_T - 1 - i));
+  const float xu = (j < OS2D_T / 2) ? __fmaf_rn(step, (float)j, -1.0f) : __fmaf_rn(-step, (float)(OS2D_T - 1 - j), 1.0f);
+  const float yu = (i < OS2D_T / 2) ? __fmaf_rn(step, (float)i, -1.0f) : __fmaf_rn(-step, (float)(OS2D_T - 1 - i), 1.0f);
   const float ix = ((xu + 1.0f) * 0.5f) * (float)(w - 1);
   const float iy = ((yu + 1.0f) * 0.5f) * (float)(h - 1);
   const float fx0 = floorf(ix), fy0 = floorf(iy);
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict_
 }
 
 // ---- f16x3 path (conv_f16x3.hip): packed weights [G][steps_padded][2 half-wave][2 hi|lo][MT] units of 8 halves.
-// Unit (g, ps, hw, part, o) holds channels 8g..8g+7 of output o at tap 2*ps+hw, BN-folded and scaled by 2^wexp[o] (one exponent per output channel);
+// Unit (g, ps, hw, part, o) holds channels 8g..8g+7 of output o at tap 2*ps+hw, BN-folded and scaled by 2^(wexp[o] - in_exp[c]) (one exponent per output and per input channel);
 // part 0 = rn16(x), part 1 = rn16(x - hi).  Taps / channels / outputs past the real sizes are zero.
 __global__ __launch_bounds__(256) void pack_conv_f16_kernel(const float* __restrict__ w, const float* __restrict__ b,
                                                             const float* __restrict__ bn_w,
@@ -220,7 +221,9 @@ __global__ __launch_bounds__(256) void pack_conv_f16_kernel(const float* __restr
                                                             const float* __restrict__ bn_mean,
                                                             const float* __restrict__ bn_var, float bn_eps, int Cout,
                                                             int Cin, int KS, int MT, int steps_padded,
-                                                            const int* __restrict__ wexp, int in_exp,
+                                                            const int* __restrict__ wexp,
+                                                            const int* __restrict__ in_exp,
+                                                            const int* __restrict__ out_exp,
                                                             _Float16* __restrict__ wp, float* __restrict__ bp) {
   const int taps = KS * KS;
   const int G = (Cin + 7) / 8;
@@ -241,7 +244,9 @@ __global__ __launch_bounds__(256) void pack_conv_f16_kernel(const float* __restr
     float v = 0.f;
     if (o < Cout && c < Cin && tap < taps) {
       const float s = bn_w ? bn_w[o] / sqrtf(bn_var[o] + bn_eps) : 1.0f;
-      v = ldexpf(w[((size_t)o * Cin + c) * taps + tap] * s, wexp[o]);  // exact: a power-of-two scale per output channel
+      // exact power-of-two scales: 2^wexp[o] per output channel, 2^-in_exp[c] per input channel (the input buffer holds
+      // x[c] * 2^in_exp[c]); one ldexpf of the summed exponents, so no intermediate can over- or underflow
+      v = ldexpf(w[((size_t)o * Cin + c) * taps + tap] * s, wexp[o] - in_exp[c]);
     }
     const _Float16 hi = (_Float16)v;
     wp[idx] = part ? (_Float16)(v - (float)hi) : hi;
@@ -258,7 +263,8 @@ __global__ __launch_bounds__(256) void pack_conv_f16_kernel(const float* __restr
         }
       }
       bp[o] = v;
-      bp[MT + o] = o < Cout ? ldexpf(1.0f, -(wexp[o] + in_exp)) : 0.f;  // undoes the weight and the input scale
+      bp[MT + o] = o < Cout ? ldexpf(1.0f, -wexp[o]) : 0.f;                            // undoes the weight scale
+      bp[2 * MT + o] = (o < Cout && out_exp) ? ldexpf(1.0f, out_exp[o]) : (o < Cout ? 1.0f : 0.f);  // output buffer scale
     }
 }
 
@@ -310,9 +316,10 @@ int os2d_launch_border_zero_shb(void* rnorm, int NB, int H, int W, hipStream_t s
 
 int os2d_launch_pack_conv_f16(const float* w, const float* b, const float* bn_w, const float* bn_b, const float* bn_mean,
                               const float* bn_var, float bn_eps, int Cout, int Cin, int KS, int MT, int steps_padded,
-                              const int* wexp, int in_exp, void* wp, float* bp, hipStream_t stream) {
+                              const int* wexp, const int* in_exp, const int* out_exp, void* wp, float* bp,
+                              hipStream_t stream) {
   hipLaunchKernelGGL(pack_conv_f16_kernel, dim3(1024), dim3(256), 0, stream, w, b, bn_w, bn_b, bn_mean, bn_var, bn_eps,
-                     Cout, Cin, KS, MT, steps_padded, wexp, in_exp, reinterpret_cast<_Float16*>(wp), bp);
+                     Cout, Cin, KS, MT, steps_padded, wexp, in_exp, out_exp, reinterpret_cast<_Float16*>(wp), bp);
   return check_launch("pack_conv_f16");
 }
 

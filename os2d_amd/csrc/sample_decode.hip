@@ -20,6 +20,14 @@ namespace {
 
 constexpr int POOL_LO = 2, POOL_HI = OS2D_T - 2;  // head.py:280,296-302: pool_border_width = 2
 
+// Coordinate k of the 15-point template grid exactly as torch.linspace(-1, 1, 15) (the base grid of F.affine_grid with
+// align_corners=True, head.py:184) produces it on the CPU: fused multiply-adds from the start for the first half, from
+// the end for the second (so the middle element is -4.47e-08, not 0) - it matters once a transform zooms 1000x.
+__device__ __forceinline__ float os2d_template_coord(int k) {
+  const float step = 2.0f / (OS2D_T - 1);
+  return k < OS2D_T / 2 ? __fmaf_rn(step, (float)k, -1.0f) : __fmaf_rn(-step, (float)(OS2D_T - 1 - k), 1.0f);
+}
+
 // Transformation parameters of one location -> the 2x3 affine map used for sampling (reference head.py:81-153):
 // P = 6 full affine, P = 4 scale + translation; optional inverse of the homogeneous 3x3 matrix.
 __device__ __forceinline__ void os2d_theta(const float* __restrict__ pp, int HW, int P, int inverse, float& t00,
@@ -40,26 +48,30 @@ __device__ __forceinline__ void os2d_theta(const float* __restrict__ pp, int HW,
     t12 = pp[3 * (size_t)HW];
   }
   if (inverse) {  // head.py:111-151: inverse of [[A t],[0 0 1]] = [[A^-1, -A^-1 t],[0 0 1]]
-    float det = t00 * t11 - t01 * t10;
-    float hom = 1.0f;
-    if (det == 0.0f) {
+    // Evaluated in fp64 (a dozen operations per location): for ill-conditioned matrices (det ~ 1e-6 with entries ~ 1)
+    // the fp32 determinant loses every digit to cancellation, while the reference's pivoted LU (torch.inverse) does
+    // not; fp64 keeps the closed form within round-off of the exact inverse of the fp32 parameters.
+    double a = t00, b = t01, c = t10, d = t11;
+    double det = a * d - b * c;
+    double hom = 1.0;
+    if (det == 0.0) {
       // torch.inverse raises on an exactly singular matrix and the reference then retries the whole chunk with
       // +1e-5 on the diagonal (head.py:125-134).  We regularise only the singular matrix itself.
-      t00 += 1e-5f;
-      t11 += 1e-5f;
-      hom = 1.0f + 1e-5f;
-      det = t00 * t11 - t01 * t10;
+      a = (double)(t00 + 1e-5f);
+      d = (double)(t11 + 1e-5f);
+      hom = (double)(1.0f + 1e-5f);
+      det = a * d - b * c;
     }
-    const float r = 1.0f / det;
-    const float i00 = t11 * r, i01 = -t01 * r, i10 = -t10 * r, i11 = t00 * r;
-    const float i02 = -(i00 * t02 + i01 * t12) / hom;
-    const float i12 = -(i10 * t02 + i11 * t12) / hom;
-    t00 = i00;
-    t01 = i01;
-    t02 = i02;
-    t10 = i10;
-    t11 = i11;
-    t12 = i12;
+    const double r = 1.0 / det;
+    const double i00 = d * r, i01 = -b * r, i10 = -c * r, i11 = a * r;
+    const double i02 = -(i00 * (double)t02 + i01 * (double)t12) / hom;
+    const double i12 = -(i10 * (double)t02 + i11 * (double)t12) / hom;
+    t00 = (float)i00;
+    t01 = (float)i01;
+    t02 = (float)i02;
+    t10 = (float)i10;
+    t11 = (float)i11;
+    t12 = (float)i12;
   }
 }
 
@@ -82,17 +94,16 @@ __global__ __launch_bounds__(256) void sample_decode_kernel(const float* __restr
   os2d_theta(params + (size_t)nb * P * HW + n, HW, P, inverse, t00, t01, t02, t10, t11, t12);
 
   // ---- resample + pool: 11x11 inner template points, channel = j*15 + i (x-major)
-  const float step = 2.0f / (OS2D_T - 1);
   const float half_t = 0.5f * OS2D_T;  // feature-map level anchor: box 15, stride 1, centre (w+.5, h+.5)
   const float cx = (float)w + 0.5f, cy = (float)h + 0.5f;
   const float wmax = (float)(W - 1), hmax = (float)(H - 1);
   const float* cbase = corr + (size_t)nb * OS2D_K * HW;
   float sum = 0.f;
   for (int j = POOL_LO; j < POOL_HI; ++j) {
-    const float xj = -1.0f + step * (float)j;
+    const float xj = os2d_template_coord(j);
 #pragma unroll
     for (int i = POOL_LO; i < POOL_HI; ++i) {
-      const float yi = -1.0f + step * (float)i;
+      const float yi = os2d_template_coord(i);
       const float gx = t00 * xj + t01 * yi + t02;
       const float gy = t10 * xj + t11 * yi + t12;
       const float X = fminf(fmaxf(gx * half_t + cx, 0.f), wmax);
@@ -172,13 +183,11 @@ __global__ __launch_bounds__(256) void alignment_grids_kernel(const float* __res
   }
   if (grids) {
     float2* g = reinterpret_cast<float2*>(grids) + loc * (OS2D_T * OS2D_T);
-    const float step = 2.0f / (OS2D_T - 1);
     for (int i = 0; i < OS2D_T; ++i) {
-      // torch.linspace(-1, 1, 15): symmetric evaluation from both ends
-      const float yi = (i < (OS2D_T + 1) / 2) ? (-1.0f + step * i) : (1.0f - step * (OS2D_T - 1 - i));
+      const float yi = os2d_template_coord(i);
 #pragma unroll
       for (int j = 0; j < OS2D_T; ++j) {
-        const float xj = (j < (OS2D_T + 1) / 2) ? (-1.0f + step * j) : (1.0f - step * (OS2D_T - 1 - j));
+        const float xj = os2d_template_coord(j);
         g[i * OS2D_T + j] = make_float2(t00 * xj + t01 * yi + t02, t10 * xj + t11 * yi + t12);
       }
     }

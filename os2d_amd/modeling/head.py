@@ -53,18 +53,29 @@ _WORKSPACES = {}
 
 
 def workspace_cap_bytes():
-    """Upper bound of the per-device scratch buffer (classes are processed in chunks that fit).  An MI355X has
-    288 GB of HBM3E, so the default is generous: 32 GiB holds ~2300 classes at 60x80 in one chunk."""
-    return int(float(os.environ.get("OS2D_WORKSPACE_GB", "32")) * (1 << 30))
+    """Upper bound of ONE scratch buffer (classes are processed in chunks that fit).  An MI355X has 288 GB of HBM3E, so
+    the default is generous: 16 GiB holds ~1150 classes at 60x80 in one chunk (all 1024 classes of BASELINE.json's
+    configs[2] in a single pass of large launches)."""
+    return int(float(os.environ.get("OS2D_WORKSPACE_GB", "16")) * (1 << 30))
+
+
+def workspace_total_cap_bytes():
+    """Upper bound of ALL scratch buffers of a device together (one per HIP stream in use: 7 for the pyramid runner)."""
+    return int(float(os.environ.get("OS2D_WORKSPACE_TOTAL_GB", "96")) * (1 << 30))
 
 
 def get_workspace(device, wanted, minimum):
     """Grow-only scratch buffer, one per (device, stream): concurrent heads on different HIP streams (the pyramid
-    runner) must not share intermediates."""
-    size = max(min(wanted, workspace_cap_bytes()), minimum)
+    runner) must not share intermediates.  The pyramid runner draws its streams from a fixed pool
+    (os2d_amd/engine/pyramid.py), so the number of buffers is bounded by the number of level slots; their total is kept
+    below ``workspace_total_cap_bytes`` by shrinking what a NEW or growing buffer may take (never below ``minimum``, the
+    footprint of one class)."""
     index = device.index if device.index is not None else torch.cuda.current_device()
     key = (device.type, index, torch.cuda.current_stream(device).cuda_stream)
     buf = _WORKSPACES.get(key)
+    others = sum(b.numel() for k, b in _WORKSPACES.items() if b is not None and k != key and k[1] == index)
+    room = max(workspace_total_cap_bytes() - others, 0)
+    size = max(min(wanted, workspace_cap_bytes(), room), minimum)
     if buf is None or buf.numel() < size:
         _WORKSPACES[key] = None
         buf = torch.empty(size, dtype=torch.uint8, device=device)
@@ -170,45 +181,52 @@ class TransformationNet(nn.Module):
         return out
 
     def range_plan(self):
-        """Scales of the split-fp16 ("f16x3") path, chosen so that NO value can leave the fp16 range for finite inputs.
+        """Power-of-two scales of the split-fp16 ("f16x3") path, chosen so that NO value can leave the fp16 range for
+        finite inputs and every operand keeps its 22 bits.
 
         Every fp32 value x of the path is stored as fp16 hi + lo of x * 2^e; hi must stay below 65504 and, for the full
-        22 bits, above 2^-3 (so that lo is a normal fp16 number).  Returns dict(weight_exp=[int tensors per layer],
-        act_exp=(e1, e2), bounds=(B1, B2)):
-          * weights: one exponent PER OUTPUT CHANNEL, the largest with max|w_folded[o]| * 2^e <= 16384 - BatchNorm scales
-            that differ by orders of magnitude between channels cost no precision;
+        22 bits, above 2^-3 (so that lo is a normal fp16 number).  Exponents are per CHANNEL:
           * activations: the TransformNet input is L2-normalised over its 225 channels (head.py:650), so by
-            Cauchy-Schwarz |conv1[o]| <= 7 * ||w1[o]||_2 + |b1[o]| at every location (49 taps, each seeing a vector of norm
-            <= 1), and with N1 = ||(bound1[o])_o||_2 bounding the 128-vector after ReLU, |conv2[o]| <= 5 * N1 * ||w2[o]||_2
-            + |b2[o]|.  The activation exponents put those bounds at <= 2^15: overflow is impossible, and values down to
-            2^-18 of the bound keep all 22 bits (typical activations sit 2^7 .. 2^13 below the bound).
-        """
+            Cauchy-Schwarz |conv1[o]| <= B1[o] = 7 * ||w1[o]||_2 + |b1[o]| at every location (49 taps, each seeing a vector
+            of norm <= 1); then |conv2[o]| <= B2[o] = min(sum_c B1[c] * ||w2[o,c]||_1, 5 * ||B1||_2 * ||w2[o]||_2) + |b2[o]|
+            (ReLU only shrinks).  Channel o of a layer's output is stored with the exponent that puts its bound at <= 2^15:
+            overflow is impossible, values down to 2^-18 of the bound keep all 22 bits (typical activations sit 2^7 ..
+            2^13 below their bound);
+          * weights: w[o][c] meets the input channel c stored with exponent e_in[c], so it is packed as
+            w[o][c] * 2^(-e_in[c] + e_w[o]) with e_w[o] the largest exponent keeping that row's maximum <= 16384.
+        Channel-wise rescalings of the network (BatchNorm scales differing by orders of magnitude, compensated in the
+        next layer) therefore cost no precision: the exponents undo them up to a factor of two.
+        Returns dict(in_exp=[3 int tensors], out_exp=[2 int tensors, None], weight_exp=[3 int tensors], bounds=(B1, B2))."""
         (w1, b1), (w2, b2), (w3, b3) = self._folded()
 
-        def wexp(w):
-            amax = w.abs().amax(dim=(1, 2, 3))
-            e = torch.floor(torch.log2(16384.0 / amax.clamp_min(1e-300)))
-            e = torch.where(amax > 0, e, torch.zeros_like(e)).clamp(-60, 60)
-            return e.to(torch.int32)
+        def floor_log2(x):     # float64 tensor -> int tensor, 0 where x is 0 / non-finite
+            ok = torch.isfinite(x) & (x > 0)
+            e = torch.floor(torch.log2(torch.where(ok, x, torch.ones_like(x))))
+            return torch.where(ok, e, torch.zeros_like(e)).clamp(-60, 60).to(torch.int32)
 
-        def act_exp(bound):
-            bmax = float(bound.max())
-            if not (bmax > 0.0) or bmax != bmax or bmax == float("inf"):
-                return 0
-            import math
-            return int(max(-60, min(60, math.floor(math.log2(32768.0 / bmax)))))
+        def out_exp(bound):
+            return floor_log2(32768.0 / bound.clamp_min(1e-300)) * (bound > 0).to(torch.int32)
 
+        def weight_exp(w, in_exp):
+            eff = w * torch.exp2(-in_exp.double()).view(1, -1, 1, 1)
+            amax = eff.abs().amax(dim=(1, 2, 3))
+            return floor_log2(16384.0 / amax.clamp_min(1e-300)) * (amax > 0).to(torch.int32)
+
+        lib = _lib.load()
         bound1 = 7.0 * w1.flatten(1).norm(dim=1) + b1.abs()
-        n1 = bound1.norm()
-        bound2 = 5.0 * n1 * w2.flatten(1).norm(dim=1) + b2.abs()
-        return dict(weight_exp=[wexp(w1), wexp(w2), wexp(w3)], act_exp=(act_exp(bound1), act_exp(bound2)),
-                    bounds=(float(bound1.max()), float(bound2.max())))
+        l1 = (w2.abs().sum(dim=(2, 3)) * bound1.view(1, -1)).sum(dim=1)
+        l2 = 5.0 * bound1.norm() * w2.flatten(1).norm(dim=1)
+        bound2 = torch.minimum(l1, l2) + b2.abs()
+        e0 = torch.full((225,), lib.os2d_rnorm_exp(), dtype=torch.int32, device=w1.device)
+        e1, e2 = out_exp(bound1), out_exp(bound2)
+        return dict(in_exp=[e0, e1, e2], out_exp=[e1, e2, None],
+                    weight_exp=[weight_exp(w1, e0), weight_exp(w2, e1), weight_exp(w3, e2)], bounds=(bound1, bound2))
 
     def packed(self, precision=None):
-        """Packed TransformNet for the kernels: (w1, b1, w2, b2, w3, b3, act_exp[2]).
-        precision "f32": os2d_pack_conv layouts (act_exp zeros); "f16x3": the split-half layout of os2d_pack_conv_f16x3
-        with the scales of ``range_plan``.  Cached until a parameter changes; the cache entry carries an event so that
-        other streams never read half-written buffers."""
+        """Packed TransformNet for the kernels: (w1, b1, w2, b2, w3, b3).
+        precision "f32": os2d_pack_conv layouts; "f16x3": the split-half layout of os2d_pack_conv_f16x3 with the scales
+        of ``range_plan``.  Cached until a parameter changes; the cache entry carries an event so that other streams never
+        read half-written buffers."""
         precision = resolve_precision(precision)
         if precision == "f16x2":
             precision = "f16x3"        # same packed weights and scales; the kernel just skips the lo halves of layer 1
@@ -226,10 +244,10 @@ class TransformationNet(nn.Module):
                                "BatchNorm (running statistics) only; call .eval()")
         with torch.cuda.device(dev):
             stream = _lib.current_stream(dev)
+            cur = torch.cuda.current_stream(dev)
             out = []
             P = self.output_dim
             plan = self.range_plan() if precision == "f16x3" else None
-            in_exps = (lib.os2d_rnorm_exp(),) + plan["act_exp"] if plan else (0, 0, 0)
             layers = ((1, self.conv[0], self.conv[1]), (2, self.conv[3], self.conv[4]), (3, self.linear, None))
             for layer, conv, bn in layers:
                 w = _require_device_f32(conv.weight.detach(), "conv weight")
@@ -241,19 +259,21 @@ class TransformationNet(nn.Module):
                 else:
                     bnp, eps = [None] * 4, 0.0
                 if precision == "f16x3":
-                    we = plan["weight_exp"][layer - 1].to(dev).contiguous()
+                    exps = [plan[k][layer - 1] for k in ("weight_exp", "in_exp", "out_exp")]
+                    exps = [e.to(dev).contiguous() if e is not None else None for e in exps]
                     pw = torch.empty(lib.os2d_packed_conv_bytes(layer, PRECISIONS[precision]), dtype=torch.uint8, device=dev)
                     _lib.check(lib.os2d_pack_conv_f16x3(layer, P, _lib.ptr(w), _lib.ptr(b), *[_lib.ptr(t) for t in bnp],
-                                                        ctypes.c_float(eps), _lib.ptr(we), in_exps[layer - 1],
+                                                        ctypes.c_float(eps), *[_lib.ptr(e) for e in exps],
                                                         _lib.ptr(pw), _lib.ptr(pb), stream), "os2d_pack_conv_f16x3")
-                    we.record_stream(torch.cuda.current_stream(dev))
+                    for e in exps:
+                        if e is not None:
+                            e.record_stream(cur)
                 else:
                     pw = torch.empty(lib.os2d_packed_conv_floats(layer), dtype=torch.float32, device=dev)
                     _lib.check(lib.os2d_pack_conv(layer, P, _lib.ptr(w), _lib.ptr(b), *[_lib.ptr(t) for t in bnp],
                                                   ctypes.c_float(eps), _lib.ptr(pw), _lib.ptr(pb), stream), "os2d_pack_conv")
                 out += [pw, pb]
-            act = plan["act_exp"] if plan else (0, 0)
-            result = tuple(out) + ((ctypes.c_int * 2)(*act),)
+            result = tuple(out)
             self._packed_cache[precision] = _StreamOrdered(key, result, dev)
         return result
 
@@ -271,7 +291,7 @@ class TransformationNet(nn.Module):
         N, _, H, W = corr_maps.shape
         dev = corr_maps.device
         P = self.output_dim
-        w1, b1, w2, b2, w3, b3, act = self.packed(precision)
+        w1, b1, w2, b2, w3, b3 = self.packed(precision)
         out = torch.empty(N, P, H, W, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             stream = _lib.current_stream(dev)
@@ -291,10 +311,9 @@ class TransformationNet(nn.Module):
                 h2 = torch.empty(N * lib.os2d_shb_bytes(64, H, W), dtype=torch.uint8, device=dev)
                 status = torch.zeros(1, dtype=torch.int32, device=dev)
                 _lib.check(lib.os2d_corr_normalize_f16x3(_lib.ptr(corr_maps), _lib.ptr(r), N, H, W, stream), "os2d_corr_normalize_f16x3")
-                for layer, src, wp, bp, dst, terms, oexp in ((1, r, w1, b1, h1, terms1, act[0]), (2, h1, w2, b2, h2, 3, act[1]),
-                                                            (3, h2, w3, b3, out, 3, 0)):
+                for layer, src, wp, bp, dst, terms in ((1, r, w1, b1, h1, terms1), (2, h1, w2, b2, h2, 3), (3, h2, w3, b3, out, 3)):
                     _lib.check(lib.os2d_transform_conv_f16x3(layer, _lib.ptr(src), _lib.ptr(wp), _lib.ptr(bp), _lib.ptr(dst), N, P,
-                                                             H, W, terms, oexp, _lib.ptr(status), stream), "os2d_transform_conv_f16x3")
+                                                             H, W, terms, _lib.ptr(status), stream), "os2d_transform_conv_f16x3")
                 self.last_status = status      # device int32: OS2D_STATUS_F16_RANGE if an activation left the fp16 range
         return out
 
@@ -573,7 +592,7 @@ class Os2dHead(nn.Module):
             if precision is not None and resolve_precision(precision) != "f32":
                 precision = "f32"
         precision = resolve_precision(precision or self.precision)
-        w1, b1, w2, b2, w3, b3, act_exp = regressor.packed(precision)
+        w1, b1, w2, b2, w3, b3 = regressor.packed(precision)
         if out is None:
             loc = torch.empty(A, B, 4, H, W, dtype=torch.float32, device=dev)
             cls = torch.empty(A, B, 1, H, W, dtype=torch.float32, device=dev)
@@ -595,7 +614,7 @@ class Os2dHead(nn.Module):
                 _lib.ptr(w3), _lib.ptr(b3), A, B, C, H, W, P, 1 if self.aligner.use_inverse_geom_model else 0,
                 self._stride, self._rec_field, _lib.ptr(loc), _lib.ptr(cls), _lib.ptr(corners),
                 _lib.ptr(ws), ws.numel(), _lib.current_stream(dev), PRECISIONS[precision],
-                _lib.ptr(self._split_class_operand()) if precision != "f32" else None, act_exp, stage_events, None,
+                _lib.ptr(self._split_class_operand()) if precision != "f32" else None, stage_events, None,
                 _lib.host_ptr(status)), "os2d_head_forward_ex")
         strict = self.strict_range if strict_range is None else strict_range
         if strict and precision != "f32":

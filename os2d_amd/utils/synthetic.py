@@ -30,6 +30,11 @@ def relu_randn(shape, seed):
     return torch.from_numpy(np.maximum(x, 0.0))
 
 
+def randn_tensor(shape, seed, scale=1.0):
+    """Sign-mixed Gaussian tensor (NOT post-ReLU), float32: negative correlations / scores."""
+    return torch.from_numpy((scale * _rs(seed).standard_normal(size=tuple(shape))).astype(np.float32))
+
+
 def make_feature_map(C, H, W, seed=0, A=1):
     """Image feature map [A, C, H, W] (stand-in for the ResNet-C4 output)."""
     return relu_randn((A, C, H, W), seed)
@@ -46,12 +51,13 @@ def make_class_feature_maps(B, C, sizes=None, seed=1000):
     return out
 
 
-def make_transform_net_state(P, seed=1, linear_std=0.02):
+def make_transform_net_state(P, seed=1, linear_std=0.02, linear_bias=None):
     """State dict of the TransformNet (keys as in reference head.py:612-629):
 
     conv.0 (Conv 225->128 k7), conv.1 (BN 128), conv.3 (Conv 128->64 k5), conv.4 (BN 64),
     linear (Conv 64->P k5).  Conv weights ~ U(+-1/sqrt(fan_in)) (the PyTorch default scale),
-    BN perturbed, linear.weight ~ N(0, linear_std), linear.bias = identity transform + N(0, 0.02).
+    BN perturbed, linear.weight ~ N(0, linear_std), linear.bias = identity transform + N(0, 0.02), or ``linear_bias``
+    verbatim when given (the random stream is consumed identically either way).
     """
     rs = _rs(seed)
     sd = {}
@@ -85,6 +91,8 @@ def make_transform_net_state(P, seed=1, linear_std=0.02):
     else:
         raise ValueError("P must be 6 (affine) or 4 (simplified affine), got {}".format(P))
     sd["linear.bias"] = (bias + 0.02 * rs.standard_normal(P)).astype(np.float32)
+    if linear_bias is not None:     # a chosen transform instead of (identity + noise): fixtures far from the identity
+        sd["linear.bias"] = np.asarray(linear_bias, dtype=np.float32).reshape(P)
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
 
 

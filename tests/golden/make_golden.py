@@ -196,6 +196,60 @@ HEAD_CASES = [
 ]
 
 
+# Cases that LEAVE the identity neighbourhood (the five above have theta within +-0.18 of identity and scores in
+# [0.30, 0.45]): the last TransformNet layer's bias is set to the wanted transform (linear.weight ~ N(0, linear_std) adds a
+# small location-dependent part), so every location sees a strongly deformed template.
+#   name, P, inverse, C, H, W, class map sizes, seeds (fm, cls, net), linear.bias, linear_std, feature kind
+EXTREME_CASES = [
+    # box scales 0.2x .. 4x (head.py:405-419), with shear
+    ("x_scale_small",      6, False, 32,  9, 11, [(15, 15), (13, 17)], (31, 3100, 41), [0.20, 0.02, 0.05, -0.03, 0.25, -0.04], 0.004, "relu"),
+    ("x_scale_large",      6, False, 32,  9, 11, [(15, 15), (13, 17)], (32, 3200, 42), [4.0, 0.3, 0.3, -0.2, 3.0, -0.2], 0.004, "relu"),
+    ("x_scale_inv",        6, True,  32,  9, 11, [(15, 15), (17, 13)], (33, 3300, 43), [0.30, 0.05, 0.10, -0.04, 0.25, -0.20], 0.002, "relu"),
+    # +-90 degree rotations and reflections (det < 0), with and without the inverse (head.py:111-151)
+    ("x_rot90_inv",        6, True,  32, 10,  9, [(15, 15), (12, 18)], (34, 3400, 44), [0.0, -1.0, 0.1, 1.0, 0.0, -0.1], 0.004, "relu"),
+    ("x_rotm90",           6, False, 32, 10,  9, [(15, 15), (12, 18)], (35, 3500, 45), [0.0, 1.1, 0.0, -0.9, 0.0, 0.05], 0.004, "relu"),
+    ("x_reflect_inv",      6, True,  32,  8, 12, [(15, 15), (16, 14)], (36, 3600, 46), [-1.0, 0.1, 0.0, 0.05, 1.0, 0.0], 0.004, "relu"),
+    ("x_reflect_v1",       4, False, 32,  8, 12, [(15, 15), (16, 14)], (37, 3700, 47), [-0.8, 0.1, 1.2, -0.1], 0.004, "relu"),
+    # det ~ 1e-6 under use_inverse_geom_model: well conditioned (1e-3 * identity -> boxes 1000x the anchor) ...
+    ("x_tiny_scale_inv",   6, True,  16,  7,  8, [(15, 15), (14, 16)], (38, 3800, 48), [1e-3, 0.0, 0.0, 0.0, 1e-3, 0.0], 0.0, "relu"),
+    # ... and ill conditioned (cond ~ 2e6: the fp32 LU of torch.inverse is only good to ~10 % there)
+    ("x_near_singular_inv", 6, True, 16,  7,  8, [(15, 15), (14, 16)], (39, 3900, 49), [1.0, 1.0, 0.1, 1.0, 1.000002, -0.1], 0.0, "relu"),
+    # transformed boxes below one pixel: clip_to_min_size (bounding_box.py:267-277)
+    ("x_min_size",         6, False, 32,  9, 11, [(15, 15), (13, 17)], (40, 4000, 50), [0.002, 0.0, 0.3, 0.0, 0.003, -0.2], 0.0002, "relu"),
+    ("x_min_size_v1_inv",  4, True,  32,  9, 11, [(15, 15), (13, 17)], (41, 4100, 51), [900.0, 0.3, 700.0, -0.2], 0.0, "relu"),
+    # sampling grids (almost) entirely outside the feature map: every tap clamps to the border (head.py:371-384)
+    ("x_outside_v1",       4, False, 32,  9, 11, [(15, 15), (13, 17)], (42, 4200, 52), [1.0, 3.0, 1.1, -2.5], 0.004, "relu"),
+    # sign-mixed, unnormalised features: negative correlations and scores (the ReLU of head.py:650 is live)
+    ("x_neg_scores",       6, True,  32, 10, 12, [(15, 15), (13, 17), (16, 15)], (43, 4300, 53), None, 0.02, "randn"),
+]
+
+
+def make_extreme_fixtures():
+    for name, P, inverse, C, H, W, sizes, (s_fm, s_cls, s_net), bias, std, kind in EXTREME_CASES:
+        if kind == "relu":
+            fm = synthetic.make_feature_map(C, H, W, seed=s_fm)
+            class_fms = synthetic.make_class_feature_maps(len(sizes), C, sizes=sizes, seed=s_cls)
+        else:
+            fm = synthetic.randn_tensor((1, C, H, W), seed=s_fm, scale=3.0)
+            class_fms = [synthetic.randn_tensor((1, C, h, w), seed=s_cls + b, scale=0.5) for b, (h, w) in enumerate(sizes)]
+        state = synthetic.make_transform_net_state(P, seed=s_net, linear_std=std, linear_bias=bias)
+        out = run_reference_head(P, inverse, fm, class_fms, state)
+        p = out["params"]
+        print("{:20s} cls[{:+.4f},{:+.4f}] params[{:+.3g},{:+.3g}] loc[{:+.3f},{:+.3f}] |corners| max {:.4g}".format(
+            name, float(out["cls"].min()), float(out["cls"].max()), float(p.min()), float(p.max()),
+            float(out["loc"].min()), float(out["loc"].max()), float(out["corners"].abs().max())))
+        arrays = dict(P=np.int64(P), inverse=np.int64(inverse), seed_net=np.int64(s_net),
+                      net_checksum=np.float64(synthetic.state_checksum(state)), linear_std=np.float64(std),
+                      fm=fm.numpy(), n_classes=np.int64(len(class_fms)))
+        if bias is not None:
+            arrays["linear_bias"] = np.asarray(bias, dtype=np.float32)
+        for b, c in enumerate(class_fms):
+            arrays["class_fm_{}".format(b)] = c.numpy()
+        for k in ("loc", "cls", "corners", "params"):      # corr / q15 are covered by the five base cases
+            arrays["ref_" + k] = out[k].numpy()
+        np.savez_compressed(os.path.join(HERE, "head_{}.npz".format(name)), **arrays)
+
+
 def run_reference_head(P, inverse, fm, class_fms, state):
     from os2d.modeling.head import build_os2d_head_creator
     from os2d.structures.feature_map import FeatureMapSize
@@ -379,6 +433,7 @@ def main():
     sys.path.insert(0, REFERENCE)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     make_head_fixtures()
+    make_extreme_fixtures()
     make_decode_fixture()
     make_chunked_nms_fixture()
     make_model_fixture()

@@ -42,7 +42,7 @@ def test_library_loads_and_reports_abi(lib_path):
     assert lib.os2d_packed_conv_floats(1) == 113 * 49 * 2 * 128
     assert lib.os2d_packed_conv_floats(2) == 64 * 25 * 2 * 64
     assert lib.os2d_packed_conv_floats(3) == 32 * 25 * 2 * 32
-    assert lib.os2d_packed_bias_floats(1) == 2 * 128      # folded bias | per-row unscale
+    assert lib.os2d_packed_bias_floats(1) == 3 * 128      # folded bias | 2^-weight_exp | 2^out_exp per row
     assert lib.os2d_plane_floats(60, 80) % 64 == 0 and lib.os2d_plane_floats(60, 80) >= 63 * 83
     n = ctypes.c_size_t()
     assert lib.os2d_head_workspace_bytes(1, 64, 1024, 60, 80, 6, ctypes.byref(n)) == 0 and n.value > 0

@@ -17,7 +17,9 @@ def head_fixture_names():
 def load_head_fixture(name):
     d = np.load(os.path.join(GOLDEN, "head_{}.npz".format(name)))
     P, inverse = int(d["P"]), bool(d["inverse"])
-    state = synthetic.make_transform_net_state(P, seed=int(d["seed_net"]))
+    state = synthetic.make_transform_net_state(P, seed=int(d["seed_net"]),
+                                               linear_std=float(d["linear_std"]) if "linear_std" in d.files else 0.02,
+                                               linear_bias=d["linear_bias"] if "linear_bias" in d.files else None)
     assert abs(synthetic.state_checksum(state) - float(d["net_checksum"])) < 1e-9, "regenerated weights differ"
     fx = dict(P=P, inverse=inverse, state=state, fm=torch.from_numpy(d["fm"]),
               class_fms=[torch.from_numpy(d["class_fm_{}".format(b)]) for b in range(int(d["n_classes"]))])
@@ -41,3 +43,57 @@ def make_head_creator(P, inverse, state, device, stride=16, rec_field=16):
 
 def maxdiff(a, b):
     return float((a.double().cpu() - b.double().cpu()).abs().max())
+
+
+# ---- tolerances of the head parity tests (north_star: score maps within 1e-4 fp32)
+#   cls      1e-5 absolute  (values ~0.3-0.45; measured ~3e-7)
+#   loc      1e-4 absolute + 1e-5 relative (values up to ~1 near the identity; up to 35 / 5e5 for the extreme fixtures)
+#   corners  2e-3 absolute + 2e-6 relative (pixel coordinates: ~600 near the identity, up to 1e5 .. 1e8 for the 1000x
+#            zoom / near-singular fixtures, where one fp32 ulp is 0.008 .. 8 px)
+TOL_CLS, TOL_LOC, TOL_CORNERS = 1e-5, 1e-4, 2e-3
+RTOL_LOC, RTOL_CORNERS = 1e-5, 2e-6
+# x_tiny_scale_inv zooms the template 1000x: a 1e-7 difference in the template grid coordinate (torch.linspace's middle
+# element vs -1 + 7 * (2/14) in fp32) moves the sampling point by 1e-3 cells, i.e. the score by ~1e-5
+CLS_TOL_OVERRIDE = {"x_tiny_scale_inv": 5e-5}
+
+
+def assert_close(got, ref, atol, rtol=0.0, what=""):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    assert got.shape == ref.shape, "{}: shape {} vs {}".format(what, tuple(got.shape), tuple(ref.shape))
+    excess = (got - ref).abs() - (atol + rtol * ref.abs())
+    assert torch.isfinite(got).all(), "{}: non-finite values".format(what)
+    assert float(excess.max()) <= 0.0, "{}: max |diff| {:.3e} (worst excess over atol {:.1e} + rtol {:.1e}: {:.3e})".format(
+        what, float((got - ref).abs().max()), atol, rtol, float(excess.max()))
+
+
+def assert_head_outputs_close(name, loc, cls, corners, ref_loc, ref_cls, ref_corners, scale=1.0):
+    """The one place the head tolerances live; ``scale`` loosens all of them together (e.g. 2.5 for 1400-px coordinates)."""
+    assert_close(cls, ref_cls, CLS_TOL_OVERRIDE.get(name, TOL_CLS) * scale, 0.0, name + " cls")
+    assert_close(loc, ref_loc, TOL_LOC * scale, RTOL_LOC * scale, name + " loc")
+    assert_close(corners, ref_corners, TOL_CORNERS * scale, RTOL_CORNERS * scale, name + " corners")
+
+
+def adversarial_transform_net_state(P, seed, lo1=-3.0, hi1=6.0, lo2=-3.0, hi2=3.0):
+    """A TransformNet that computes the SAME function as ``make_transform_net_state(P, seed)`` but whose intermediate
+    ranges are hostile to a fixed-range number format:
+      * output channel o of conv 7x7 (+BN+ReLU) is scaled by s1[o] in 10^[lo1, hi1] (BN weight and bias; ReLU is
+        positively homogeneous) and the 5x5 layer's input channel o by 1/s1[o]: activations span 1e-5 .. 1e5 (below 2^-14
+        and beyond 65504), folded BN scales and the rows / columns of the weight tensors span nine decades;
+      * the same between conv 5x5 128->64 and the last layer with s2 in 10^[lo2, hi2];
+      * every fourth BatchNorm channel has running_var = 1e-6 (BN weight compensated so the folded scale is unchanged).
+    In exact arithmetic the outputs are identical to the base network's; fp32 (the reference) loses nothing either."""
+    import numpy as np
+    st = {k: v.clone() for k, v in synthetic.make_transform_net_state(P, seed=seed).items()}
+    rs = np.random.RandomState(seed + 7919)
+    for bn, nxt, lo, hi in (("conv.1", "conv.3.weight", lo1, hi1), ("conv.4", "linear.weight", lo2, hi2)):
+        c = st[bn + ".weight"].numel()
+        s = torch.from_numpy((10.0 ** rs.uniform(lo, hi, size=c)).astype(np.float32))
+        s[0], s[1] = 10.0 ** hi, 10.0 ** lo                     # both extremes are always present
+        var = st[bn + ".running_var"].clone()
+        small = torch.arange(c) % 4 == 0
+        comp = torch.sqrt((torch.full_like(var, 1e-6) + 1e-5) / (var + 1e-5))
+        st[bn + ".running_var"] = torch.where(small, torch.full_like(var, 1e-6), var)
+        st[bn + ".weight"] = st[bn + ".weight"] * torch.where(small, comp, torch.ones_like(comp)) * s
+        st[bn + ".bias"] = st[bn + ".bias"] * s
+        st[nxt] = st[nxt] / s.view(1, -1, 1, 1)
+    return st

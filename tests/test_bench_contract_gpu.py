@@ -13,7 +13,7 @@ REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 def test_bench_line_contract(device):
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "1", "--classes", "8",
-                          "--cpu-seconds", "1.5", "--no-end-to-end"], cwd=REPO, capture_output=True, text=True, timeout=600)
+                          "--cpu-seconds", "1.5", "--no-end-to-end", "--no-sweep"], cwd=REPO, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]

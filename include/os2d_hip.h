@@ -91,8 +91,10 @@ int os2d_pack_conv_f16x3(int layer /*1|2|3*/, int P, const float* w, const float
                          const int* weight_exp, const int* in_exp, const int* out_exp, void* packed_w, float* packed_b,
                          void* stream);
 
-/* split class operand for the f16x3 correlation: qp [B,C,256] fp32 (os2d_class_prepare) -> qs [B, C/8, hi|lo, 256] units
- * of 8 halves (B * ceil(C/8) * 2 * 256 * 16 bytes), scaled by 2^12.                                                 */
+/* split class operand for the f16x3 correlation: qp [B,C,256] fp32 (os2d_class_prepare) -> qs [B, G, hi|lo, 256] units
+ * of 8 halves, scaled by 2^12; G = ceil(C/8) padded with zero groups to a multiple of 4 (whole 32-channel K chunks of
+ * the correlation kernel): os2d_class_split_bytes(B, C) bytes.                                                       */
+size_t os2d_class_split_bytes(int B, int C);
 int os2d_class_split(const float* qp, void* qs, int B, int C, void* stream);
 
 /* ---- extended head entry point: identical to os2d_head_forward, plus

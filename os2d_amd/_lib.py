@@ -36,6 +36,7 @@ SIGNATURES = {
     "os2d_transform_conv_f16x3": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "os2d_alignment_grids": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "os2d_class_split": (_i, [_vp, _vp, _i, _i, _vp]),
+    "os2d_class_split_bytes": (_sz, [_i, _i]),
     "os2d_head_forward_ex": (_i, [_vp] * 8 + [_i] * 9 + [_vp, _vp, _vp, _vp, _sz, _vp, _i, _vp,
                                   ctypes.POINTER(_vp), ctypes.POINTER(_i), _vp]),
     "os2d_prof_event_create": (_i, [ctypes.POINTER(_vp)]),

@@ -18,6 +18,7 @@ SOURCES = ["abi.hip", "prep.hip", "corr_mfma.hip", "conv_mfma.hip", "conv_f16x3.
 HEADERS = [os.path.join(CSRC, "os2d_common.h"), os.path.join(HERE, "..", "include", "os2d_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("OS2D_EXTRA_HIPCC_FLAGS", "").split()      # kernel experiments (-DOS2D_DIAG_...); part of the source hash
 
 
 def _hipcc():

@@ -23,6 +23,9 @@ bool conv_shape(int layer, int P, ConvShape* s) {
 }
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// k-steps of one channel group of the packed 7x7 weights (49 taps in pairs), = 5 LDS stages of 5 in conv_f16x3.hip
+int os2d_conv1_steps_padded() { return 25; }
+
 // workspace carve for a chunk of Bc classes
 struct Carve {
   size_t sumsq, fs, corr, rpad, h1, h2, params, total;
@@ -37,7 +40,7 @@ Carve carve(int A, int Bc, int C, int H, int W, int P) {
     return o;
   };
   c.sumsq = take((size_t)A * HW);
-  c.fs = take((size_t)A * ((C + 7) / 8) * 2 * HW * 4);  // f16x3: split image features, 16 B per (group, part, cell)
+  c.fs = take((size_t)A * os2d_corr_groups(C) * 2 * HW * 4);  // f16x3: split image features, 16 B per (group, part, cell)
   c.corr = take(NB * OS2D_K * HW);
   c.rpad = take(NB * (OS2D_G * 2 * 4) * PL);  // fp32: 226 planes; f16x3: 29 groups x (hi|lo) x 16 B = 232 floats
   c.h1 = take(NB * 128 * PL);
@@ -308,7 +311,7 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
       if ((rc = os2d_launch_border_zero(rpad, NB * OS2D_KP, H, W, st))) return rc;
     }
     if (f16) {
-      const char* qsb = static_cast<const char*>(qs) + (size_t)b0 * ((C + 7) / 8) * 2 * 256 * 16;
+      const char* qsb = static_cast<const char*>(qs) + (size_t)b0 * os2d_corr_groups(C) * 2 * 256 * 16;
       if ((rc = os2d_launch_corr_f16x3(fsplit, qsb, corr, rpad, A, bc, C, H, W, st))) return rc;
     } else {
       if ((rc = os2d_launch_corr(fm, qp + (size_t)b0 * C * OS2D_QROWS, sumsq, corr, rpad, A, bc, C, H, W, 0, st)))
@@ -354,6 +357,11 @@ int os2d_head_forward(const float* fm, const float* qp, const float* w1, const f
                               nullptr);
 }
 
+size_t os2d_class_split_bytes(int B, int C) {
+  if (B < 1 || C < 1) return 0;
+  return (size_t)B * os2d_corr_groups(C) * 2 * 256 * 16;
+}
+
 int os2d_class_split(const float* qp, void* qs, int B, int C, void* stream) {
   if (!qp || !qs || B < 1 || C < 1) {
     os2d_set_error("os2d_class_split: bad arguments");
@@ -366,7 +374,7 @@ size_t os2d_packed_conv_bytes(int layer, int precision) {
   if (precision == OS2D_PRECISION_F32) return os2d_packed_conv_floats(layer) * sizeof(float);
   if (precision != OS2D_PRECISION_F16X3 && precision != OS2D_PRECISION_F16X2) return 0;
   // [G][steps padded to whole stages][2][2][MT] units of 16 B (conv_f16x3.hip: layer 1 SS=5, layer 2 SS=7)
-  if (layer == 1) return (size_t)OS2D_G * 25 * 4 * 128 * 16;
+  if (layer == 1) return (size_t)OS2D_G * os2d_conv1_steps_padded() * 4 * 128 * 16;
   if (layer == 2) return (size_t)16 * 14 * 4 * 64 * 16;
   if (layer == 3) return (size_t)8 * 14 * 4 * 32 * 16;
   return 0;
@@ -384,7 +392,8 @@ int os2d_pack_conv_f16x3(int layer, int P, const float* w, const float* b, const
   }
   if (layer == 1)
     return os2d_launch_pack_conv_f16(w, b, bn_weight, bn_bias, bn_running_mean, bn_running_var, bn_eps, 128, OS2D_K, 7,
-                                     128, 25, weight_exp, in_exp, out_exp, packed_w, packed_b, S(stream));
+                                     128, os2d_conv1_steps_padded(), weight_exp, in_exp, out_exp, packed_w, packed_b,
+                                     S(stream));
   if (layer == 2)
     return os2d_launch_pack_conv_f16(w, b, bn_weight, bn_bias, bn_running_mean, bn_running_var, bn_eps, 64, 128, 5, 64,
                                      14, weight_exp, in_exp, out_exp, packed_w, packed_b, S(stream));

@@ -38,8 +38,8 @@ __device__ __forceinline__ void split_half(float x, _Float16& hi, _Float16& lo) 
 // only (activations keep both halves): two thirds of the matrix-core work.  Used for the 7x7 layer under precision
 // "f16x2", where the averaging over K = 11025 keeps the box regression within 5e-5 of the fp32 result.
 template <int KS, int MTP, int MT, int WM, int WN, int NI, int SS, bool RELU, int OUT_MODE /*0 SHB, 1 fp32 plane, 2 fp32 compact [NB][Cout][H*W]*/,
-          int NBPF /*16-byte units per thread for the input-slab prefetch*/, int TERMS>
-__global__ __launch_bounds__(64 * WM * WN, 2) void conv_f16x3_kernel(const u32x4* in,  // SHB [NB][G][2][PLANE] (no __restrict__: invariant loads get
+          int NBPF /*16-byte units per thread for the input-slab prefetch*/, int TERMS, int MINW /*waves per SIMD the register budget allows*/>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void conv_f16x3_kernel(const u32x4* in,  // SHB [NB][G][2][PLANE] (no __restrict__: invariant loads get
                                                              const u32x4* wp,  // rematerialised BEHIND the MFMAs by the register allocator)
                                                              const float* __restrict__ bp,  // [3][MTP] fp32 per output row: folded bias | 2^-weight_exp | 2^out_exp
                                                              int* __restrict__ status,
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_f16x3_kernel(const u32x4
   }
 }
 
-template <int KS, int MTP, int MT, int WM, int WN, int NI, int SS, bool RELU, int OUT_MODE, int TERMS = 3, int NBPF = 0>
+template <int KS, int MTP, int MT, int WM, int WN, int NI, int SS, bool RELU, int OUT_MODE, int TERMS = 3, int NBPF = 0, int MINW = 2>
 int launch(const void* in, const void* wp, const float* bp, int* status, void* out, int NB, int G, int CoutStore, int H,
            int W, hipStream_t stream) {
   constexpr int R = KS / 2;
@@ -356,8 +356,8 @@ int launch(const void* in, const void* wp, const float* bp, int* status, void* o
   const int SLAB = NT + 2 * HALO;
   constexpr int NTHR = 64 * WM * WN;
   if (NBPF == 0) {  // pick the slab-prefetch depth: 8 units/thread up to W = 124 (fewer registers), 12 up to W = 209
-    if (2 * SLAB <= 8 * NTHR) return launch<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE, TERMS, 8>(in, wp, bp, status, out, NB, G, CoutStore, H, W, stream);
-    if (2 * SLAB <= 12 * NTHR) return launch<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE, TERMS, 12>(in, wp, bp, status, out, NB, G, CoutStore, H, W, stream);
+    if (2 * SLAB <= 8 * NTHR) return launch<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE, TERMS, 8, MINW>(in, wp, bp, status, out, NB, G, CoutStore, H, W, stream);
+    if (2 * SLAB <= 12 * NTHR) return launch<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE, TERMS, 12, MINW>(in, wp, bp, status, out, NB, G, CoutStore, H, W, stream);
     os2d_set_error("conv%dx%d (f16x3): feature map too wide for the input-slab prefetch (W=%d)", KS, KS, W);
     return -3;
   }
@@ -366,7 +366,7 @@ int launch(const void* in, const void* wp, const float* bp, int* status, void* o
     os2d_set_error("conv%dx%d (f16x3): LDS budget exceeded (%zu B, W=%d)", KS, KS, lds, W);
     return -3;
   }
-  auto kern = conv_f16x3_kernel<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE, (NBPF ? NBPF : 8), TERMS>;
+  auto kern = conv_f16x3_kernel<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE, (NBPF ? NBPF : 8), TERMS, MINW>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) {

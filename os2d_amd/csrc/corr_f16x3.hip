@@ -5,6 +5,7 @@
 // (values are L2-normalised, |x| <= 1, so hi <= 4096 and lo stays a normal fp16 number):
 //   fs [A][C/8][hi|lo][H*W]  units of 8 halves   image features, ALREADY L2-normalised over channels (split_fm_kernel)
 //   qs [B][C/8][hi|lo][256]  units of 8 halves   class features in the x-major channel order, rows 225..255 zero
+// Both are padded with ZERO channel groups to a multiple of 4 groups (one K chunk of 32 channels: os2d_corr_groups(C)).
 // One v_mfma_f32_32x32x16_f16 k-step = 16 channels = two 8-channel groups (lanes 0-31 / 32-63).
 //
 // Work-group = 512 threads (8 waves as 2 x 4), tile = 256 rows (one class) x 256 positions, wave tile 128 x 64.
@@ -30,10 +31,11 @@ constexpr int NPF = CH_UNITS / NTHR;     // 4 class units per thread
 // work-groups, half the MFMAs per K chunk: for a handful of classes, where the chip is empty and a group's serial K loop
 // is what a call waits for).  Every output accumulates the same products in the same order in both shapes.
 template <int NI>
-__global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  // [A][CG][2][HW]   (no __restrict__, see
-                                                             const u32x4* qs,  // [B][CG][2][256]    conv_f16x3.hip)
+__global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  // [A][CGP][2][HW]  (no __restrict__, see
+                                                             const u32x4* qs,  // [B][CGP][2][256]   conv_f16x3.hip)
                                                              float* __restrict__ corr, char* __restrict__ rshb, int A,
-                                                             int B, int CG, int H, int W, int PLANE, float unscale) {
+                                                             int B, int CGP /*channel groups, padded to a multiple of GC*/,
+                                                             int H, int W, int PLANE, float unscale) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
   constexpr int NT = 128 * NI;           // positions per work-group
   constexpr int BUNITS = GC * 2 * NT;    // 16-byte units of one image-operand chunk
@@ -70,29 +72,35 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  const u32x4* zeros = reinterpret_cast<const u32x4*>(rshb);  // pad cell 0 of plane 0: zero since border_zero_shb
-  const u32x4* qb = qs + (size_t)b * CG * 2 * 256;
-  const u32x4* fa = fs + (size_t)a * CG * 2 * HW;
-  const int nchunks = (CG + GC - 1) / GC;
+  const u32x4* qb = qs + (size_t)b * CGP * 2 * 256;
+  const u32x4* fa = fs + (size_t)a * CGP * 2 * HW;
+  const int nchunks = CGP / GC;
   // ---- staging: global -> LDS directly (LDS-DMA, global_load_lds_dwordx4): no staging registers, no ds_write pass.
   // A wave instruction writes 64 consecutive 16-byte units starting at a wave-uniform LDS address, which is exactly how
   // a chunk is laid out (unit i = row i/256 = (group, part), column i%256; 64 consecutive threads = 64 consecutive
-  // columns of one row).  The global address is per lane: rows past the last channel group and columns past H*W are
-  // pointed at a 16-byte block of zeros (`zeros`: pad cell 0 of the output planes, cleared before this kernel runs).
+  // columns of one row).  Everything but the lane's column is WAVE-UNIFORM and kept in scalar registers: the global
+  // address is (scalar base of the chunk / row) + (per-lane byte offset, loop invariant), the LDS address goes to M0
+  // from a scalar - one DMA costs a few SALU instructions and no VALU (the per-lane 64-bit pointer + v_readfirstlane
+  // form cost ~14 instructions and an M0 dependency stall each).  Both operands are padded with zero channel groups to a
+  // whole number of chunks (split_fm / split_qp), columns past H*W read the last valid column instead: their products
+  // land in accumulator columns that are never stored.
   typedef const void __attribute__((address_space(1))) * gptr_t;
   typedef void __attribute__((address_space(3))) * lptr_t;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index as a scalar
+  const unsigned voffA = (unsigned)lane * 16u;
+  const int colB = (wv * 64) % NT + lane;
+  const unsigned voffB = (unsigned)min(colB, HW - 1 - n0) * 16u;
+  const char* baseA0 = reinterpret_cast<const char*>(qb) + (size_t)wv * 64 * 16;
+  const char* baseB0 = reinterpret_cast<const char*>(fa) + ((size_t)((wv * 64) / NT) * HW + n0) * 16;
 #define CF_DMA1(T, K)                                                                                             \
   {                                                                                                               \
-    const int i_ = tid + (K)*NTHR;                                                                                \
     {                                                                                                             \
-      const int grow_ = (T)*GC * 2 + (i_ >> 8);                                                                   \
-      const u32x4* ga_ = grow_ < CG * 2 ? qb + (size_t)grow_ * 256 + (i_ & 255) : zeros;                          \
-      __builtin_amdgcn_global_load_lds((gptr_t)ga_, (lptr_t)(ldsA + ((T)&1) * CH_UNITS + (i_ & ~63)), 16, 0, 0);  \
+      const char* ga_ = baseA0 + ((size_t)(T)*CH_UNITS + (size_t)(K)*NTHR) * 16;                                  \
+      __builtin_amdgcn_global_load_lds((gptr_t)(ga_ + voffA), (lptr_t)(ldsA + ((T)&1) * CH_UNITS + (K)*NTHR + wv * 64), 16, 0, 0); \
     }                                                                                                             \
     if ((K) < NPFB) {                                                                                             \
-      const int grow_ = (T)*GC * 2 + i_ / NT, col_ = i_ % NT;                                                     \
-      const u32x4* gb_ = (grow_ < CG * 2 && n0 + col_ < HW) ? fa + (size_t)grow_ * HW + n0 + col_ : zeros;        \
-      __builtin_amdgcn_global_load_lds((gptr_t)gb_, (lptr_t)(ldsB + ((T)&1) * BUNITS + (i_ & ~63)), 16, 0, 0);    \
+      const char* gb_ = baseB0 + ((size_t)((T)*GC * 2 + ((K)*NTHR) / NT) * HW) * 16;                              \
+      __builtin_amdgcn_global_load_lds((gptr_t)(gb_ + voffB), (lptr_t)(ldsB + ((T)&1) * BUNITS + (K)*NTHR + wv * 64), 16, 0, 0); \
     }                                                                                                             \
   }
 #define CF_DMA(T)                                                                                                 \
@@ -101,6 +109,14 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
   }
 #define CF_NOHOOK(MI)
 #define CF_COMPUTE(T) CF_COMPUTE_H(T, CF_NOHOOK)
+#if defined(OS2D_DIAG_CORR_NO_MFMA)  /* diagnostic builds only: DMA + barriers, no fragment reads / MFMAs */
+#define CF_COMPUTE_H(T, HOOK)                                                                                     \
+  {                                                                                                               \
+    const int ks = 0;                                                                                             \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) { HOOK(mi) }                                                 \
+    (void)ks;                                                                                                     \
+  }
+#else
 #define CF_COMPUTE_H(T, HOOK)                                                                                     \
   {                                                                                                               \
     const u32x4* aB_ = ldsA + ((T)&1) * CH_UNITS + wm * 128 + l31;                                                \
@@ -124,18 +140,23 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
       }                                                                                                           \
     }                                                                                                             \
   }
+#endif
 
   // The DMA of chunk t+1 is issued IN PIECES between the MFMA groups of chunk t (one class unit + one image unit per
   // thread after each of the first four groups): eight waves bursting 72 KB of loads right after the barrier queue up
   // behind each other in the CU's load path; spread out, the issue slots hide behind the matrix pipe.  The barrier at the
   // end of an iteration drains the wave's own DMAs (vmcnt(0), emitted by __syncthreads) and then orders them for
   // everybody's fragment reads of the next iteration.
+#if defined(OS2D_DIAG_CORR_NO_DMA)   /* diagnostic builds only (tools/diag_corr.sh): results are garbage */
+#define CF_PF_HOOK(MI)
+#else
 #define CF_PF_HOOK(MI)                                                                                            \
   {                                                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
     CF_DMA1(t + 1, MI)                                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
   }
+#endif
   CF_DMA(0)
   __syncthreads();
   for (int t = 0; t + 1 < nchunks; ++t) {
@@ -216,7 +237,7 @@ __global__ __launch_bounds__(256) void split_fm_kernel(const float* __restrict__
   const int n = blockIdx.x * 256 + threadIdx.x;
   const int g = blockIdx.y, a = blockIdx.z;
   if (n >= HW) return;
-  const int CG = (C + 7) / 8;
+  const int CG = os2d_round_up((C + 7) / 8, GC);  // zero groups pad the channel dimension to whole K chunks
   const float inv = scale / (sqrtf(sumsq[(size_t)a * HW + n]) + 1e-5f);
   half8 hi, lo;
 #pragma unroll
@@ -237,7 +258,7 @@ __global__ __launch_bounds__(256) void split_qp_kernel(const float* __restrict__
                                                        float scale) {
   const int m = threadIdx.x;  // 0..255
   const int g = blockIdx.x, b = blockIdx.y;
-  const int CG = (C + 7) / 8;
+  const int CG = os2d_round_up((C + 7) / 8, GC);
   half8 hi, lo;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -265,14 +286,16 @@ int check(const char* what) {
 
 }  // namespace
 
+int os2d_corr_groups(int C) { return os2d_round_up((C + 7) / 8, GC); }
+
 int os2d_launch_split_fm(const float* fm, const float* sumsq, void* fs, int A, int C, int HW, hipStream_t stream) {
-  hipLaunchKernelGGL(split_fm_kernel, dim3((HW + 255) / 256, (C + 7) / 8, A), dim3(256), 0, stream, fm, sumsq,
+  hipLaunchKernelGGL(split_fm_kernel, dim3((HW + 255) / 256, os2d_round_up((C + 7) / 8, GC), A), dim3(256), 0, stream, fm, sumsq,
                      reinterpret_cast<u32x4*>(fs), C, HW, ldexpf(1.0f, SCALE_LOG2));
   return check("split_fm");
 }
 
 int os2d_launch_split_qp(const float* qp, void* qs, int B, int C, hipStream_t stream) {
-  hipLaunchKernelGGL(split_qp_kernel, dim3((C + 7) / 8, B), dim3(256), 0, stream, qp, reinterpret_cast<u32x4*>(qs), C,
+  hipLaunchKernelGGL(split_qp_kernel, dim3(os2d_round_up((C + 7) / 8, GC), B), dim3(256), 0, stream, qp, reinterpret_cast<u32x4*>(qs), C,
                      ldexpf(1.0f, SCALE_LOG2));
   return check("split_qp");
 }
@@ -294,7 +317,8 @@ int launch_corr(const void* fs, const void* qs, float* corr, void* rshb, int A, 
   const long long groups = (long long)((HW + NT - 1) / NT) * B * A;
   dim3 grid((unsigned)((groups + 7) / 8 * 8));  // multiple of 8: every XCD gets the same number of logical slots
   hipLaunchKernelGGL(corr_f16x3_kernel<NI>, grid, dim3(NTHR), lds, stream, reinterpret_cast<const u32x4*>(fs),
-                     reinterpret_cast<const u32x4*>(qs), corr, reinterpret_cast<char*>(rshb), A, B, (C + 7) / 8, H, W,
+                     reinterpret_cast<const u32x4*>(qs), corr, reinterpret_cast<char*>(rshb), A, B,
+                     os2d_round_up((C + 7) / 8, GC), H, W,
                      os2d_plane(H, W), ldexpf(1.0f, -2 * SCALE_LOG2));
   return check("corr_f16x3");
 }

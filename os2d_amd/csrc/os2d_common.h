@@ -130,6 +130,7 @@ int os2d_launch_detect_level(const float* loc, const float* cls, int B, int H, i
                              float img_w, float img_h, float scale_x, float scale_y, float score_thr, float iou_thr,
                              float* out_boxes, float* out_scores, int* out_index, int* out_count, hipStream_t stream);
 // corr_f16x3.hip
+int os2d_corr_groups(int C);  // 8-channel groups of the split correlation operands, padded to whole K chunks
 int os2d_launch_split_fm(const float* fm, const float* sumsq, void* fs, int A, int C, int HW, hipStream_t stream);
 int os2d_launch_split_qp(const float* qp, void* qs, int B, int C, hipStream_t stream);
 int os2d_launch_corr_f16x3(const void* fs, const void* qs, float* corr, void* rshb, int A, int B, int C, int H, int W,

@@ -512,7 +512,7 @@ class Os2dHead(nn.Module):
         if self._qs is None:
             lib = _lib.load()
             B, C = self._qp.size(0), self._qp.size(1)
-            qs = torch.empty(B * ((C + 7) // 8) * 2 * 256 * 16, dtype=torch.uint8, device=dev)
+            qs = torch.empty(lib.os2d_class_split_bytes(B, C), dtype=torch.uint8, device=dev)
             with torch.cuda.device(dev):
                 _lib.check(lib.os2d_class_split(_lib.ptr(self._qp), _lib.ptr(qs), B, C, _lib.current_stream(dev)),
                            "os2d_class_split")

@@ -68,6 +68,10 @@ def conv1_traffic(root, classes, out_path):
         busy = {}
         for path in glob.glob(os.path.join(root, "pmc_sq", "*.db")):
             cur = sqlite3.connect(path).cursor()
+            row = cur.execute(
+                "select avg(d.end - d.start) from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id "
+                "where (s.kernel_name like '%conv_mfma_kernelILi7%' or s.kernel_name like '%conv_f16x3_kernelILi7%')").fetchone()
+            busy["avg_launch_us"] = row[0] / 1e3 if row and row[0] else None     # duration in the SAME (profiled) pass
             for name in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
                 row = cur.execute(
                     "select avg(e.value) from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id = p.id "
@@ -79,6 +83,9 @@ def conv1_traffic(root, classes, out_path):
                        "write_kib": vals["WRITE_SIZE"], "fetch_correction": 2.0, "bytes_per_launch": total,
                        "bytes_per_class": total / classes, "source": os.path.basename(os.path.normpath(root)),
                        "mfma_busy_cycles_x32": busy.get("SQ_VALU_MFMA_BUSY_CYCLES"), "grbm_gui_active": busy.get("GRBM_GUI_ACTIVE"),
+                       "avg_launch_us": busy.get("avg_launch_us"),
+                       "effective_clock_ghz": (round(busy["GRBM_GUI_ACTIVE"] / busy["avg_launch_us"] / 1e3, 3)
+                                               if busy.get("GRBM_GUI_ACTIVE") and busy.get("avg_launch_us") else None),
                        "mfma_pipe_busy": (round(busy["SQ_VALU_MFMA_BUSY_CYCLES"] * 32 / (1024 * busy["GRBM_GUI_ACTIVE"]), 4)
                                           if busy.get("SQ_VALU_MFMA_BUSY_CYCLES") and busy.get("GRBM_GUI_ACTIVE") else None)}, f, indent=1)
         print("conv1 traffic: {:.1f} MB per launch ({} classes) -> {}".format(total / 1e6, classes, out_path))

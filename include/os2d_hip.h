@@ -54,10 +54,12 @@ int os2d_pack_conv(int layer, int P, const float* w, const float* b, const float
  *   q15 [C,15,15]  resized + L2-normalised map (what Os2dHead.class_feature_maps holds)
  *   qp  [C,256]    the same values as the correlation GEMM operand: row m = x_T*15 + y_T, rows 225..255 zero. */
 int os2d_class_prepare(const float* src, int C, int h, int w, int normalize, float* q15, float* qp, void* stream);
-/* The same for all B classes of a head in ONE launch (reference head.py:261-268 loops the maps): srcs = DEVICE array of
- * B device pointers to maps [C,h_b,w_b], sizes = DEVICE int array [B][2] = (h_b, w_b); q15 [B,C,15,15], qp [B,C,256].   */
+/* The same for all B classes of a head in two launches (reference head.py:261-268 loops the maps): srcs = DEVICE array of
+ * B device pointers to maps [C,h_b,w_b], sizes = DEVICE int array [B][2] = (h_b, w_b); q15 [B,C,15,15], qp [B,C,256];
+ * workspace: os2d_class_prepare_workspace_floats(B, C) floats (per-channel-block partial sums of squares).             */
+size_t os2d_class_prepare_workspace_floats(int B, int C);
 int os2d_class_prepare_batch(const float* const* srcs, const int* sizes, int B, int C, int normalize, float* q15,
-                             float* qp, void* stream);
+                             float* qp, float* workspace, void* stream);
 
 /* ---- the head: reference head.py:308-435 (Os2dHead.forward, eval mode) for B classes on A image feature maps.
  *   fm [A,C,H,W] raw backbone features; qp [B,C,256] from os2d_class_prepare; packed TransformNet from os2d_pack_conv
@@ -180,6 +182,30 @@ int os2d_detect_level_supported(int H, int W);
 int os2d_detect_level(const float* loc, const float* cls, int B, int H, int W, int stride, int rec_field, float img_w,
                       float img_h, float scale_x, float scale_y, float score_threshold, float iou_threshold,
                       float* out_boxes, float* out_scores, int* out_index, int* out_count, void* stream);
+
+/* ---- detection over a whole image pyramid: reference os2d/modeling/box_coder.py:448-536 per label for L levels, incl. the
+ * reference's memory-bounded NMS (os2d/structures/bounding_box.py:343-374: lists longer than nms_max_batch are NMS-ed in
+ * consecutive chunks of the list, survivors concatenated, repeated until one chunk is left or a pass removes nothing; final
+ * sort by score) - decisions identical to the reference's, one launch per pass with a work-group per (chunk, class).
+ *   loc / cls   HOST arrays of L device pointers: loc[l] [B,4,H_l*W_l], cls[l] [B,H_l*W_l];  hw HOST int [L][2] = (H_l, W_l)
+ *   corners     NULL, or a HOST array of L device pointers [B,8,H_l*W_l] (transform corners, box_coder.py:493-503)
+ *   img_wh      HOST float [L][2]: level image size (clip);  scale_xy HOST float [L][2]: level -> output image (BoxList.resize)
+ *   passes      NMS passes to launch (3 covers 39,580 -> a few thousand -> done); classes that would need more get
+ *               out_count = -1 and are counted in *unfinished (device int): the caller re-runs those through
+ *               os2d_decode_boxes + os2d_nms (the Python binding does)
+ *   outputs     [B,N,...] with N = sum of H_l*W_l: the first out_count[b] entries of a class are its detections by decreasing
+ *               score; out_index = candidate number in list order (level offsets as in hw); out_default [B,N,4] the
+ *               detection's anchor and out_corners [B,N,8] (NULL iff corners is) its transform corners, both mapped to the
+ *               output image like the box
+ * Limits (os2d_detect_pyramid_supported): L <= 16, nms_max_batch <= 12288, at most 64 chunks per class.                   */
+#define OS2D_PYRAMID_MAX_LEVELS 16
+int os2d_detect_pyramid_supported(int L, int N, int nms_max_batch);
+int os2d_detect_pyramid_workspace_bytes(int B, int N, int passes, size_t* bytes);
+int os2d_detect_pyramid(const float* const* loc, const float* const* cls, const float* const* corners, int B, int L,
+                        const int* hw, int stride, int rec_field, const float* img_wh, const float* scale_xy,
+                        float score_threshold, float iou_threshold, int nms_max_batch, int passes, float* out_boxes,
+                        float* out_scores, int* out_index, float* out_default, float* out_corners, int* out_count,
+                        int* unfinished, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -30,7 +30,8 @@ SIGNATURES = {
     "os2d_packed_conv_bytes": (_sz, [_i, _i]),
     "os2d_pack_conv_f16x3": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "os2d_rnorm_exp": (_i, []),
-    "os2d_class_prepare_batch": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "os2d_class_prepare_batch": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "os2d_class_prepare_workspace_floats": (_sz, [_i, _i]),
     "os2d_shb_bytes": (_sz, [_i, _i, _i]),
     "os2d_corr_normalize_f16x3": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "os2d_transform_conv_f16x3": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -53,6 +54,10 @@ SIGNATURES = {
     "os2d_nms": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "os2d_detect_level_supported": (_i, [_i, _i]),
     "os2d_detect_level": (_i, [_vp, _vp] + [_i] * 5 + [_f] * 6 + [_vp] * 5),
+    "os2d_detect_pyramid_supported": (_i, [_i, _i, _i]),
+    "os2d_detect_pyramid_workspace_bytes": (_i, [_i, _i, _i, ctypes.POINTER(_sz)]),
+    "os2d_detect_pyramid": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                 _vp, _vp, _sz, _vp]),
 }
 
 

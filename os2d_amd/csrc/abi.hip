@@ -117,13 +117,18 @@ int os2d_class_prepare(const float* src, int C, int h, int w, int normalize, flo
   return os2d_launch_class_prepare(src, C, h, w, normalize, q15, qp, S(stream));
 }
 
+size_t os2d_class_prepare_workspace_floats(int B, int C) {
+  if (B < 1 || C < 1) return 0;
+  return (size_t)os2d_class_prepare_partial_floats(B, C);
+}
+
 int os2d_class_prepare_batch(const float* const* srcs, const int* sizes, int B, int C, int normalize, float* q15,
-                             float* qp, void* stream) {
-  if (!srcs || !sizes || !q15 || !qp || B < 1 || C < 1 || B > 65535) {
+                             float* qp, float* workspace, void* stream) {
+  if (!srcs || !sizes || !q15 || !qp || !workspace || B < 1 || C < 1 || B > 65535) {
     os2d_set_error("os2d_class_prepare_batch: bad arguments (B=%d C=%d; at most 65535 classes per call)", B, C);
     return -1;
   }
-  return os2d_launch_class_prepare_batch(srcs, sizes, B, C, normalize, q15, qp, S(stream));
+  return os2d_launch_class_prepare_batch(srcs, sizes, B, C, normalize, q15, qp, workspace, S(stream));
 }
 
 size_t os2d_plane_floats(int H, int W) { return (size_t)os2d_plane(H, W); }

@@ -101,8 +101,9 @@ int os2d_launch_pack_conv_f16(const float* w, const float* b, const float* bn_w,
                               const float* bn_var, float bn_eps, int Cout, int Cin, int KS, int MT, int steps_padded,
                               const int* wexp, const int* in_exp, const int* out_exp, void* wp, float* bp,
                               hipStream_t stream);
+int os2d_class_prepare_partial_floats(int B, int C);
 int os2d_launch_class_prepare_batch(const float* const* srcs, const int* sizes, int B, int C, int normalize, float* q15,
-                                    float* qp, hipStream_t stream);
+                                    float* qp, float* partial, hipStream_t stream);
 int os2d_launch_corr_normalize_shb(const float* corr, void* rshb, int NB, int H, int W, hipStream_t stream);
 // corr_mfma.hip (shb != 0: rnorm is written in the split-half blocked layout of conv_f16x3.hip)
 int os2d_launch_corr(const float* fm, const float* qp, const float* sumsq, float* corr, void* rnorm,

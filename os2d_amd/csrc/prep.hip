@@ -128,14 +128,75 @@ __global__ __launch_bounds__(256) void class_prepare_kernel(const float* __restr
   class_prepare_body(src, C, h, w, normalize, q15, qp, red);
 }
 
-// all classes of a head in ONE launch: class b's map (its own h x w) is srcs[b]; sizes = [B][2] (h, w)
-__global__ __launch_bounds__(256) void class_prepare_batch_kernel(const float* const* __restrict__ srcs,
-                                                                  const int* __restrict__ sizes, int C, int normalize,
-                                                                  float* __restrict__ q15, float* __restrict__ qp) {
-  __shared__ float red[4];
-  const int b = blockIdx.y;
-  class_prepare_body(srcs[b], C, sizes[2 * b], sizes[2 * b + 1], normalize, q15 + (size_t)b * C * OS2D_K,
-                     qp + (size_t)b * C * OS2D_QROWS, red);
+// ---- all classes of a head in TWO launches (class b's map, of its own size h x w, is srcs[b]; sizes = [B][2] (h, w)).
+// A block owns 32 channels of one class and walks them one at a time with a thread per template cell, so the 4 bilinear
+// taps of neighbouring threads are neighbours in the 0.9 KB source plane and every store is a contiguous 900-byte /
+// 1 KB row (the one-block-per-cell kernel above reads and writes 4 bytes per 900-byte stride: fine for one class, 0.66 ms
+// for 64).  Pass 1 writes the resized, not yet normalised values and the block's partial sums of squares per cell;
+// pass 2 adds the partials of all channel blocks in a fixed order and rescales in place.
+constexpr int CPB = 32;  // channels per block
+
+__device__ __forceinline__ float class_resize_sample(const float* __restrict__ p, int h, int w, int cell) {
+  const int i = cell / OS2D_T, j = cell - i * OS2D_T;
+  const float step = 2.0f / (OS2D_T - 1);
+  const float xu = (j < OS2D_T / 2) ? __fmaf_rn(step, (float)j, -1.0f) : __fmaf_rn(-step, (float)(OS2D_T - 1 - j), 1.0f);
+  const float yu = (i < OS2D_T / 2) ? __fmaf_rn(step, (float)i, -1.0f) : __fmaf_rn(-step, (float)(OS2D_T - 1 - i), 1.0f);
+  const float ix = ((xu + 1.0f) * 0.5f) * (float)(w - 1);
+  const float iy = ((yu + 1.0f) * 0.5f) * (float)(h - 1);
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  const float ax = ix - fx0, ay = iy - fy0;
+  const bool x0in = x0 >= 0 && x0 < w, x1in = x0 + 1 >= 0 && x0 + 1 < w;
+  const bool y0in = y0 >= 0 && y0 < h, y1in = y0 + 1 >= 0 && y0 + 1 < h;
+  const float v00 = (x0in && y0in) ? p[y0 * w + x0] : 0.f;
+  const float v01 = (x1in && y0in) ? p[y0 * w + x0 + 1] : 0.f;
+  const float v10 = (x0in && y1in) ? p[(y0 + 1) * w + x0] : 0.f;
+  const float v11 = (x1in && y1in) ? p[(y0 + 1) * w + x0 + 1] : 0.f;
+  return v00 * (1.f - ax) * (1.f - ay) + v01 * ax * (1.f - ay) + v10 * (1.f - ax) * ay + v11 * ax * ay;
+}
+
+__global__ __launch_bounds__(256) void class_resize_batch_kernel(const float* const* __restrict__ srcs,
+                                                                 const int* __restrict__ sizes, int C,
+                                                                 float* __restrict__ q15, float* __restrict__ qp,
+                                                                 float* __restrict__ partial) {
+  const int b = blockIdx.y, cb = blockIdx.x, cell = threadIdx.x;
+  const int h = sizes[2 * b], w = sizes[2 * b + 1];
+  const float* src = srcs[b];
+  const int i = cell / OS2D_T, j = cell - i * OS2D_T;
+  const int m = j * OS2D_T + i;  // x-major correlation channel (head.py:342-344)
+  float s = 0.f;
+  const int c1 = min(C, (cb + 1) * CPB);
+  for (int c = cb * CPB; c < c1; ++c) {
+    float v = 0.f;
+    if (cell < OS2D_K) {
+      v = class_resize_sample(src + (size_t)c * h * w, h, w, cell);
+      q15[((size_t)b * C + c) * OS2D_K + cell] = v;
+      qp[((size_t)b * C + c) * OS2D_QROWS + m] = v;
+      s += v * v;
+    } else {
+      qp[((size_t)b * C + c) * OS2D_QROWS + cell] = 0.f;  // the 31 pad rows of the GEMM operand
+    }
+  }
+  if (cell < OS2D_K) partial[((size_t)b * gridDim.x + cb) * OS2D_K + cell] = s;
+}
+
+__global__ __launch_bounds__(256) void class_normalize_batch_kernel(int C, int nblocks, float* __restrict__ q15,
+                                                                    float* __restrict__ qp,
+                                                                    const float* __restrict__ partial) {
+  const int b = blockIdx.y, cb = blockIdx.x, cell = threadIdx.x;
+  if (cell >= OS2D_K) return;
+  float s = 0.f;
+  for (int k = 0; k < nblocks; ++k) s += partial[((size_t)b * nblocks + k) * OS2D_K + cell];  // fixed order: deterministic
+  const float inv = 1.0f / (sqrtf(s) + 1e-5f);  // head.py:293
+  const int i = cell / OS2D_T, j = cell - i * OS2D_T;
+  const int m = j * OS2D_T + i;
+  const int c1 = min(C, (cb + 1) * CPB);
+  for (int c = cb * CPB; c < c1; ++c) {
+    const size_t o = ((size_t)b * C + c) * OS2D_K + cell;
+    const float v = q15[o] * inv;
+    q15[o] = v;
+    qp[((size_t)b * C + c) * OS2D_QROWS + m] = v;
+  }
 }
 
 // ---- corr_normalize_shb: standalone relu -> L2 over the 225 channels (head.py:650) of an arbitrary correlation tensor
@@ -336,10 +397,16 @@ int os2d_launch_class_prepare(const float* src, int C, int h, int w, int normali
   return check_launch("class_prepare");
 }
 
+int os2d_class_prepare_partial_floats(int B, int C) { return B * ((C + CPB - 1) / CPB) * OS2D_K; }
+
 int os2d_launch_class_prepare_batch(const float* const* srcs, const int* sizes, int B, int C, int normalize, float* q15,
-                                    float* qp, hipStream_t stream) {
-  hipLaunchKernelGGL(class_prepare_batch_kernel, dim3(OS2D_K, B), dim3(256), 0, stream, srcs, sizes, C, normalize, q15, qp);
-  return check_launch("class_prepare_batch");
+                                    float* qp, float* partial, hipStream_t stream) {
+  const int nblocks = (C + CPB - 1) / CPB;
+  hipLaunchKernelGGL(class_resize_batch_kernel, dim3(nblocks, B), dim3(256), 0, stream, srcs, sizes, C, q15, qp, partial);
+  int rc = check_launch("class_resize_batch");
+  if (rc || !normalize) return rc;
+  hipLaunchKernelGGL(class_normalize_batch_kernel, dim3(nblocks, B), dim3(256), 0, stream, C, nblocks, q15, qp, partial);
+  return check_launch("class_normalize_batch");
 }
 
 int os2d_launch_corr_normalize_shb(const float* corr, void* rshb, int NB, int H, int W, hipStream_t stream) {

@@ -82,7 +82,9 @@ class Os2dBoxCoder(object):
         self.remap_classification_targets_iou_neg = remap_classification_targets_iou_neg
         self.do_nms_across_classes = do_nms_across_classes
         self.nms_max_batch = 10000          # reference bounding_box.py:344 (``nms_max_batch_size``)
-        self.use_fused_level_kernel = True  # single-level calls go through os2d_detect_level when the level fits
+        self.use_fused_level_kernel = True  # single-level calls go through os2d_detect_level when the level fits,
+                                            # several levels through os2d_detect_pyramid
+        self.fused_pyramid_passes = 3       # chunked-NMS passes launched by os2d_detect_pyramid (more -> generic path)
         self.weights = BOX_ENCODING_WEIGHTS
         g = output_box_grid_generator
         if g is None:
@@ -210,6 +212,10 @@ class Os2dBoxCoder(object):
         fused = self._decode_single_level_fused(loc_scores_pyramid, cls_scores_pyramid, img_size_pyramid, class_ids,
                                                 nms_score_threshold, nms_iou_threshold, inverse_box_transforms,
                                                 transform_corners_pyramid)
+        if fused is None:
+            fused = self._decode_pyramid_fused(loc_scores_pyramid, cls_scores_pyramid, img_size_pyramid, class_ids,
+                                               nms_score_threshold, nms_iou_threshold, inverse_box_transforms,
+                                               transform_corners_pyramid)
         if fused is not None:
             return self._nms_across_classes(fused, nms_iou_threshold)
         boxes_l, scores_l, valid_l, dflt_l, corners_l = [], [], [], [], []
@@ -364,4 +370,86 @@ class Os2dBoxCoder(object):
             if scale is not None:
                 corners = (corners.view(-1, 4) * scale).view(-1, 8)
             result.add_field("transform_corners", corners)
+        return result
+
+    def _decode_pyramid_fused(self, loc_pyr, cls_pyr, size_pyr, class_ids, score_thr, iou_thr, inverse, corners_pyr):
+        """Several levels, one row per label, identity / ``ResizeBoxes`` mappings: the whole per-label chain, incl. the
+        reference's chunk-and-repeat NMS for lists longer than ``nms_max_batch``, runs on the device (os2d_detect_pyramid:
+        one launch per NMS pass, a work-group per (chunk, class)); None when the generic path has to be used."""
+        if not self.use_fused_level_kernel or len(loc_pyr) < 2:
+            return None
+        ids = [int(c) for c in class_ids]
+        if len(set(ids)) != len(ids):
+            return None
+        ts = list(inverse) if inverse is not None else [None] * len(loc_pyr)
+        if any(t is not None and not isinstance(t, ResizeBoxes) for t in ts) or len({t is None for t in ts}) != 1:
+            return None
+        if ts[0] is not None and len({(t.target_size.w, t.target_size.h) for t in ts}) != 1:
+            return None
+        lib = _lib.load()
+        L = len(loc_pyr)
+        fms = [self.get_feature_map_size(s) for s in size_pyr]
+        hws = [fm.h * fm.w for fm in fms]
+        N = sum(hws)
+        if not lib.os2d_detect_pyramid_supported(L, N, int(self.nms_max_batch)):
+            return None
+        dev = cls_pyr[0].device
+        B = len(ids)
+        locs, clss = [], []
+        for loc, cls, hw in zip(loc_pyr, cls_pyr, hws):
+            if not (loc.is_cuda and cls.is_cuda and loc.dtype == torch.float32):
+                raise RuntimeError("decode runs on the HIP device only (no CPU fallback)")
+            assert loc.device == dev and cls.device == dev, "scores and boxes should be on the same device"
+            loc, cls = loc.contiguous(), cls.float().contiguous()
+            assert tuple(loc.shape) == (B, 4, hw) and tuple(cls.shape) == (B, hw), "level tensors do not match class_ids / feature map"
+            locs.append(loc)
+            clss.append(cls)
+        ratios = [t.ratios(s) if t is not None else (1.0, 1.0) for t, s in zip(ts, size_pyr)]
+        out_size = ts[0].target_size if ts[0] is not None else size_pyr[0]
+        passes = int(self.fused_pyramid_passes)
+        nbytes = ctypes.c_size_t()
+        _lib.check(lib.os2d_detect_pyramid_workspace_bytes(B, N, passes, ctypes.byref(nbytes)), "os2d_detect_pyramid_workspace_bytes")
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        out_boxes = torch.empty(B, N, 4, dtype=torch.float32, device=dev)
+        out_scores = torch.empty(B, N, dtype=torch.float32, device=dev)
+        out_index = torch.empty(B, N, dtype=torch.int32, device=dev)
+        out_count = torch.empty(B, dtype=torch.int32, device=dev)
+        out_default = torch.empty(B, N, 4, dtype=torch.float32, device=dev)
+        unfinished = torch.empty(1, dtype=torch.int32, device=dev)
+        c_loc = (ctypes.c_void_p * L)(*[t.data_ptr() for t in locs])
+        c_cls = (ctypes.c_void_p * L)(*[t.data_ptr() for t in clss])
+        c_cor, out_corners, cors = None, None, None
+        if corners_pyr is not None:
+            cors = [k.reshape(B, 8, hw).float().contiguous() for k, hw in zip(corners_pyr, hws)]
+            c_cor = (ctypes.c_void_p * L)(*[t.data_ptr() for t in cors])
+            out_corners = torch.empty(B, N, 8, dtype=torch.float32, device=dev)
+        c_hw = (ctypes.c_int * (2 * L))(*[v for fm in fms for v in (fm.h, fm.w)])
+        c_img = (ctypes.c_float * (2 * L))(*[float(v) for s_ in size_pyr for v in (s_.w, s_.h)])
+        c_scale = (ctypes.c_float * (2 * L))(*[float(v) for r in ratios for v in r])
+        with torch.cuda.device(dev):
+            _lib.check(lib.os2d_detect_pyramid(c_loc, c_cls, c_cor, B, L, c_hw, self._stride, self._rec_field, c_img, c_scale,
+                                               ctypes.c_float(score_thr), ctypes.c_float(iou_thr), int(self.nms_max_batch),
+                                               passes, _lib.ptr(out_boxes), _lib.ptr(out_scores), _lib.ptr(out_index),
+                                               _lib.ptr(out_default), _lib.ptr(out_corners), _lib.ptr(out_count),
+                                               _lib.ptr(unfinished), _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
+                       "os2d_detect_pyramid")
+        rank = {l: k for k, l in enumerate(set(ids))}      # the reference iterates ``set(class_ids)`` (box_coder.py:483)
+        order = sorted(range(B), key=lambda i: rank[ids[i]])
+        counts = out_count
+        perm = None
+        if order != list(range(B)):
+            perm = torch.tensor(order, dtype=torch.long, device=dev)
+            counts = out_count[perm]
+        mask = torch.arange(N, device=dev).unsqueeze(0) < counts.unsqueeze(1)
+        row, pos = mask.nonzero(as_tuple=True)                   # the one host synchronisation: sizes the result
+        if int(unfinished.item()) != 0:
+            return None          # some class needs more NMS passes than were launched: generic path (exact, slower)
+        src_row = perm[row] if perm is not None else row
+        flat = src_row * N + pos
+        result = BoxList(out_boxes.view(-1, 4)[flat], out_size)
+        result.add_field("scores", out_scores.view(-1)[flat])
+        result.add_field("labels", torch.tensor([ids[i] for i in order], dtype=torch.long, device=dev)[row])
+        result.add_field("default_boxes", BoxList(out_default.view(-1, 4)[flat], out_size))
+        if out_corners is not None:
+            result.add_field("transform_corners", out_corners.view(-1, 8)[flat])
         return result

@@ -445,11 +445,12 @@ def _prepare_class_maps(class_feature_maps, normalise=True):
             chunk = maps[b0:b0 + 65535]
             ptrs = torch.tensor([m.data_ptr() for m in chunk], dtype=torch.int64).to(dev, non_blocking=False)
             sizes = torch.tensor([[m.size(1), m.size(2)] for m in chunk], dtype=torch.int32).to(dev, non_blocking=False)
+            ws = torch.empty(lib.os2d_class_prepare_workspace_floats(len(chunk), C), dtype=torch.float32, device=dev)
             _lib.check(lib.os2d_class_prepare_batch(_lib.ptr(ptrs), _lib.ptr(sizes), len(chunk), C, 1 if normalise else 0,
                                                     _lib.ptr(q15[b0:b0 + len(chunk)]), _lib.ptr(qp[b0:b0 + len(chunk)]),
-                                                    stream), "os2d_class_prepare_batch")
+                                                    _lib.ptr(ws), stream), "os2d_class_prepare_batch")
             cur = torch.cuda.current_stream(dev)
-            ptrs.record_stream(cur), sizes.record_stream(cur)
+            ptrs.record_stream(cur), sizes.record_stream(cur), ws.record_stream(cur)
             for m in chunk:
                 m.record_stream(cur)
     return q15, qp

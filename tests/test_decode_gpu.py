@@ -273,3 +273,112 @@ def test_label_order_follows_set_iteration_like_the_reference(device):
         lab = res.get_field("labels").cpu().tolist()
         seen = [l for i, l in enumerate(lab) if i == 0 or lab[i - 1] != l]
         assert seen == expect, (ids, seen, expect)
+
+
+# ------------------------------------------------------------------------------------------------ pyramid on the device
+def test_fused_pyramid_matches_reference_fixture(device):
+    """The reference's decode_pyramid fixture (2 levels, 3 classes, 3 score thresholds) through os2d_detect_pyramid
+    (``ResizeBoxes`` mappings are what lets decode_pyramid take the device path)."""
+    from os2d_amd.modeling.box_coder import ResizeBoxes
+    from os2d_amd.structures.feature_map import FeatureMapSize
+    d = np.load(util.GOLDEN + "/decode_pyramid.npz")
+    L = int(d["n_levels"])
+    sizes = [FeatureMapSize(w=int(w), h=int(h)) for w, h in d["img_sizes"]]
+    locs = [torch.from_numpy(d["loc_%d" % i]).to(device) for i in range(L)]
+    clss = [torch.from_numpy(d["cls_%d" % i]).to(device) for i in range(L)]
+    corners = [torch.from_numpy(d["corners_%d" % i]).to(device) for i in range(L)]
+    orig = FeatureMapSize(w=int(d["orig_size"][0]), h=int(d["orig_size"][1]))
+    inverse = [ResizeBoxes(orig) for _ in range(L)]
+    coder = _coder()
+    ids = list(range(int(d["n_classes"])))
+    assert coder._decode_pyramid_fused(locs, clss, sizes, ids, 0.0, 0.3, inverse, corners) is not None, "device path not taken"
+    for name, thr in (("t0", 0.0), ("tinf", float("-inf")), ("t06", 0.6)):
+        res = coder.decode_pyramid(locs, clss, sizes, class_ids=ids, nms_score_threshold=thr, nms_iou_threshold=0.3,
+                                   inverse_box_transforms=inverse, transform_corners_pyramid=corners)
+        assert len(res) == len(d["ref_%s_scores" % name]), name
+        assert torch.equal(res.get_field("labels").cpu(), torch.from_numpy(d["ref_%s_labels" % name]))
+        assert torch.equal(res.get_field("scores").cpu(), torch.from_numpy(d["ref_%s_scores" % name]))
+        assert util.maxdiff(res.bbox_xyxy, torch.from_numpy(d["ref_%s_boxes" % name])) < 1e-3
+        assert util.maxdiff(res.get_field("default_boxes").bbox_xyxy, torch.from_numpy(d["ref_%s_default_boxes" % name])) < 1e-3
+        assert util.maxdiff(res.get_field("transform_corners"), torch.from_numpy(d["ref_%s_corners" % name])) < 1e-3
+        assert res.image_size == orig
+
+
+def _pyramid_inputs(levels, B, seed, device, loc_scale=1.2):
+    from os2d_amd.structures.feature_map import FeatureMapSize
+    rs = np.random.RandomState(seed)
+    sizes = [FeatureMapSize(w=16 * w, h=16 * h) for h, w in levels]
+    locs = [torch.from_numpy((rs.standard_normal((B, 4, h * w)) * loc_scale).astype(np.float32)).to(device) for h, w in levels]
+    clss = [torch.from_numpy(rs.uniform(-1, 1, size=(B, h * w)).astype(np.float32)).to(device) for h, w in levels]
+    corners = [torch.from_numpy(rs.uniform(0, 300, size=(B, 8, h * w)).astype(np.float32)).to(device) for h, w in levels]
+    return sizes, locs, clss, corners
+
+
+@pytest.mark.parametrize("max_batch", [10000, 300, 97])
+@pytest.mark.parametrize("thr", [float("-inf"), 0.0, 0.5])
+def test_fused_pyramid_equals_generic_path(max_batch, thr, device):
+    """os2d_detect_pyramid against the generic chain (os2d_decode_boxes -> sorts -> os2d_nms per pass, pinned to the
+    reference's chunked-NMS fixture by test_chunked_nms_matches_reference_fixture): identical detections bit for bit on a
+    4-level pyramid (1,863 candidates per class) with small ``nms_max_batch`` values that force several passes over
+    several chunks, tied scores across levels, unsorted class ids and an anisotropic resize to the original image."""
+    from os2d_amd.modeling.box_coder import ResizeBoxes
+    from os2d_amd.structures.feature_map import FeatureMapSize
+    levels = [(9, 12), (15, 20), (23, 30), (27, 31)]
+    B = 5
+    sizes, locs, clss, corners = _pyramid_inputs(levels, B, 77, device)
+    clss[0][0, 3:30] = clss[1][0, 7]                 # ties inside a level and across levels: list order decides
+    clss[2][0, 100:140] = clss[1][0, 7]
+    clss[3][1, :] = 0.25                             # a whole level of equal scores
+    ids = [11, 3, 8, 40, 5]
+    orig = FeatureMapSize(w=700, h=433)
+    for inverse in (None, [ResizeBoxes(orig) for _ in levels]):
+        coder = _coder()
+        coder.nms_max_batch = max_batch
+        coder.fused_pyramid_passes = 6
+        assert coder._decode_pyramid_fused(locs, clss, sizes, ids, thr, 0.3, inverse, corners) is not None
+        fused = coder.decode_pyramid(locs, clss, sizes, ids, nms_score_threshold=thr, inverse_box_transforms=inverse,
+                                     transform_corners_pyramid=corners)
+        coder.use_fused_level_kernel = False
+        generic = coder.decode_pyramid(locs, clss, sizes, ids, nms_score_threshold=thr, inverse_box_transforms=inverse,
+                                       transform_corners_pyramid=corners)
+        _assert_same_detections(fused, generic)
+        assert len(fused) > 0
+
+
+def test_fused_pyramid_falls_back_when_more_passes_are_needed(device):
+    """Sparse boxes + a tiny ``nms_max_batch``: the chunk-and-repeat scheme needs more passes than the device path was
+    told to launch -> `unfinished` is reported and decode_pyramid transparently uses the generic path; with enough passes
+    the device path gives the same result."""
+    levels = [(12, 16), (20, 24)]
+    sizes, locs, clss, corners = _pyramid_inputs(levels, 2, 5, device, loc_scale=0.3)
+    coder = _coder()
+    coder.nms_max_batch = 64
+    coder.use_fused_level_kernel = False
+    generic = coder.decode_pyramid(locs, clss, sizes, [0, 1], nms_score_threshold=-1.0)
+    coder.use_fused_level_kernel = True
+    coder.fused_pyramid_passes = 1
+    assert coder._decode_pyramid_fused(locs, clss, sizes, [0, 1], -1.0, 0.3, None, None) is None
+    _assert_same_detections(coder.decode_pyramid(locs, clss, sizes, [0, 1], nms_score_threshold=-1.0), generic)
+    coder.fused_pyramid_passes = 12
+    fused = coder._decode_pyramid_fused(locs, clss, sizes, [0, 1], -1.0, 0.3, None, None)
+    assert fused is not None
+    _assert_same_detections(fused, generic)
+
+
+def test_fused_pyramid_full_size_seven_levels(device):
+    """BASELINE.json configs[4] shape: the 7 levels of a 1280x960 image (39,580 candidates per class), 6 classes, the
+    reference's defaults (score threshold -inf, nms_max_batch 10000: four chunks in the first pass)."""
+    from os2d_amd.modeling.box_coder import ResizeBoxes
+    from os2d_amd.structures.feature_map import FeatureMapSize
+    levels = [(30, 40), (38, 50), (48, 64), (60, 80), (72, 96), (84, 112), (96, 128)]
+    sizes, locs, clss, corners = _pyramid_inputs(levels, 6, 9, device, loc_scale=1.0)
+    inverse = [ResizeBoxes(FeatureMapSize(w=1280, h=960)) for _ in levels]
+    ids = [4, 1, 9, 2, 7, 3]
+    coder = _coder()
+    fused = coder._decode_pyramid_fused(locs, clss, sizes, ids, float("-inf"), 0.3, inverse, corners)
+    assert fused is not None
+    coder.use_fused_level_kernel = False
+    generic = coder.decode_pyramid(locs, clss, sizes, ids, nms_score_threshold=float("-inf"), inverse_box_transforms=inverse,
+                                   transform_corners_pyramid=corners)
+    _assert_same_detections(fused, generic)
+    assert len(fused) > 100

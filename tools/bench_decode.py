@@ -50,12 +50,15 @@ if "--pyramid" in sys.argv:
         loc_p, cls_p, cor_p, _ = PyramidHeadRunner(head, device=dev).run(fms, inputs_are_features=True)
     loc_p = [l[0] for l in loc_p]; cls_p = [c[0] for c in cls_p]; cor_p = [k[0] for k in cor_p]
     inverse = [ResizeBoxes(FeatureMapSize(w=3264, h=2448)) for _ in sizes]
-    for it in range(3):
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        res = coder.decode_pyramid(loc_p, cls_p, sizes, class_ids=list(range(B)), nms_score_threshold=thr,
-                                   nms_iou_threshold=0.3, inverse_box_transforms=inverse, transform_corners_pyramid=cor_p)
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print("pyramid decode B={} thr={}: {:.2f} ms, {} detections".format(B, thr, dt * 1e3, len(res)))
+    for fused in (False, True):
+        coder.use_fused_level_kernel = fused
+        for it in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            res = coder.decode_pyramid(loc_p, cls_p, sizes, class_ids=list(range(B)), nms_score_threshold=thr,
+                                       nms_iou_threshold=0.3, inverse_box_transforms=inverse, transform_corners_pyramid=cor_p)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            print("pyramid decode ({}) B={} thr={}: {:.2f} ms, {} detections".format(
+                "os2d_detect_pyramid" if fused else "generic chain", B, thr, dt * 1e3, len(res)))
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
         res = coder.decode_pyramid(loc_p, cls_p, sizes, class_ids=list(range(B)), nms_score_threshold=thr,
                                    nms_iou_threshold=0.3, inverse_box_transforms=inverse, transform_corners_pyramid=cor_p)

@@ -128,6 +128,13 @@ int os2d_fm_sumsq(const float* fm, float* sumsq, int A, int C, int H, int W, voi
 size_t os2d_plane_floats(int H, int W);
 int os2d_corr(const float* fm, const float* qp, const float* sumsq, float* corr, float* rnorm, int A, int B, int C,
               int H, int W, void* stream);
+/* The same stage on the half-precision matrix cores (the kernels of the f16x3 / f16x2 head): fm [A,C,H,W] raw features, qs
+ * from os2d_class_split -> corr [A*B,225,H*W] fp32 and the relu + L2-normalised tensor in the split-half blocked layout
+ * (A*B * os2d_shb_bytes(225,H,W) bytes, values scaled by 2^os2d_rnorm_exp()).  workspace: os2d_corr_f16x3_workspace_bytes
+ * (per-position norms + the split image operand), 256-byte aligned.                                                       */
+size_t os2d_corr_f16x3_workspace_bytes(int A, int C, int H, int W);
+int os2d_corr_f16x3(const float* fm, const void* qs, float* corr, void* rshb, int A, int B, int C, int H, int W,
+                    void* workspace, size_t workspace_bytes, void* stream);
 /* standalone TransformNet input normalisation head.py:650 (relu, L2 over 225 channels, eps 1e-6) of an arbitrary
  * correlation tensor corr [NB,225,H*W] -> rnorm [NB,226,PLANE]; used by TransformationNet.forward.               */
 int os2d_corr_normalize(const float* corr, float* rnorm, int NB, int H, int W, void* stream);

@@ -168,6 +168,31 @@ int os2d_corr(const float* fm, const float* qp, const float* sumsq, float* corr,
   return os2d_launch_corr(fm, qp, sumsq, corr, rnorm, A, B, C, H, W, 0, S(stream));
 }
 
+size_t os2d_corr_f16x3_workspace_bytes(int A, int C, int H, int W) {
+  if (A < 1 || C < 1 || H < 1 || W < 1) return 0;
+  return align_up((size_t)A * H * W * sizeof(float), 256) + (size_t)A * os2d_corr_groups(C) * 2 * H * W * 16;
+}
+
+int os2d_corr_f16x3(const float* fm, const void* qs, float* corr, void* rshb, int A, int B, int C, int H, int W,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+  if (!fm || !qs || !corr || !rshb || !workspace) {
+    os2d_set_error("os2d_corr_f16x3: null pointer");
+    return -1;
+  }
+  if (!head_args_ok(A, B, C, H, W, 6)) return -1;
+  if (workspace_bytes < os2d_corr_f16x3_workspace_bytes(A, C, H, W) || (reinterpret_cast<uintptr_t>(workspace) & 255)) {
+    os2d_set_error("os2d_corr_f16x3: workspace too small or not 256-byte aligned");
+    return -2;
+  }
+  float* sumsq = static_cast<float*>(workspace);
+  void* fs = static_cast<char*>(workspace) + align_up((size_t)A * H * W * sizeof(float), 256);
+  int rc = os2d_launch_fm_sumsq(fm, sumsq, A, C, H * W, S(stream));
+  if (!rc) rc = os2d_launch_split_fm(fm, sumsq, fs, A, C, H * W, S(stream));
+  if (!rc) rc = os2d_launch_border_zero_shb(rshb, A * B, H, W, S(stream));
+  if (!rc) rc = os2d_launch_corr_f16x3(fs, qs, corr, rshb, A, B, C, H, W, S(stream));
+  return rc;
+}
+
 int os2d_corr_normalize(const float* corr, float* rnorm, int NB, int H, int W, void* stream) {
   if (!corr || !rnorm || NB < 1 || H < 1 || W < 1) {
     os2d_set_error("os2d_corr_normalize: bad arguments");

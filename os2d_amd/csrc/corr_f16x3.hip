@@ -171,25 +171,77 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
 #undef CF_COMPUTE_H
 #undef CF_COMPUTE
 
-  // ---- epilogue (features were normalised before the split, so only the 2^-24 operand scale is undone)
+  // ---- epilogue (features were normalised before the split, so only the 2^-24 operand scale is undone).
+  // A lane holds a 32x32 block as 4 consecutive rows x ONE column per register quadruple: stored as is, that is 128 dword
+  // stores for the correlation and 64 eight-byte stores for the normalised tensor per lane, and the epilogue (17 % of a
+  // work-group's life) is bound by issuing them.  Both go out as 16-byte stores instead:
+  //   * correlation: every 4x4 block (4 rows in 4 registers x the 4 lanes of a quad) is transposed inside the quad with
+  //     two DPP exchange stages, after which a lane owns ONE row and 4 consecutive columns - one dwordx4 store
+  //     (needs H*W % 4 == 0 for the alignment; otherwise the scalar stores);
+  //   * normalised tensor: lanes l and l+32 hold channels 0-3 / 4-7 of the same 8-channel unit; they swap halves
+  //     (ds_bpermute) so that the lower lane stores the complete hi unit and the upper lane the complete lo unit.
   const int Ws = os2d_ws(W), BASE = os2d_base(W);
+  const bool vec4 = (HW & 3) == 0;
+  const int qc = lane & 3;                    // column of this lane inside its quad = the row it owns after the transpose
   float part[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
-    const int n = n0 + wn * (32 * NI) + ni * 32 + l31;
+    const int ncol0 = n0 + wn * (32 * NI) + ni * 32;
+    const int n = ncol0 + l31;
     const bool nin = n < HW;
     float s = 0.f;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = acc[mi][ni][r] * unscale;
         acc[mi][ni][r] = v;
-        const int m = wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hw;
-        if (nin && m < OS2D_K) corr[((size_t)nb * OS2D_K + m) * HW + n] = v;
         const float rl = fmaxf(v, 0.f);
         s += rl * rl;
       }
+      if (vec4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          // (copies first: __builtin_bit_cast applied directly to an ext-vector ELEMENT reads the wrong element with hipcc 7.2)
+          const float f0 = acc[mi][ni][4 * q + 0], f1 = acc[mi][ni][4 * q + 1];
+          const float f2 = acc[mi][ni][4 * q + 2], f3 = acc[mi][ni][4 * q + 3];
+          int t0 = __float_as_int(f0), t1 = __float_as_int(f1), t2 = __float_as_int(f2), t3 = __float_as_int(f3);
+          {  // stage 1: 2x2 blocks, lanes c <-> c^1 (quad_perm [1,0,3,2])
+            const bool odd = qc & 1;
+            const int x01 = odd ? t0 : t1, x23 = odd ? t2 : t3;
+            const int y01 = __builtin_amdgcn_update_dpp(0, x01, 0xB1, 0xF, 0xF, false);
+            const int y23 = __builtin_amdgcn_update_dpp(0, x23, 0xB1, 0xF, 0xF, false);
+            t0 = odd ? y01 : t0;
+            t1 = odd ? t1 : y01;
+            t2 = odd ? y23 : t2;
+            t3 = odd ? t3 : y23;
+          }
+          {  // stage 2: lanes c <-> c^2 (quad_perm [2,3,0,1])
+            const bool up = qc & 2;
+            const int x02 = up ? t0 : t2, x13 = up ? t1 : t3;
+            const int y02 = __builtin_amdgcn_update_dpp(0, x02, 0x4E, 0xF, 0xF, false);
+            const int y13 = __builtin_amdgcn_update_dpp(0, x13, 0x4E, 0xF, 0xF, false);
+            t0 = up ? y02 : t0;
+            t2 = up ? t2 : y02;
+            t1 = up ? y13 : t1;
+            t3 = up ? t3 : y13;
+          }
+          // this lane now holds row (.. + qc) at the 4 columns of its quad
+          const int m = wm * 128 + mi * 32 + 8 * q + 4 * hw + qc;
+          const int nq = ncol0 + (l31 & ~3);
+          if (m < OS2D_K && nq < HW) {
+            f32x4 o4 = {__int_as_float(t0), __int_as_float(t1), __int_as_float(t2), __int_as_float(t3)};
+            *reinterpret_cast<f32x4*>(corr + ((size_t)nb * OS2D_K + m) * HW + nq) = o4;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hw;
+          if (nin && m < OS2D_K) corr[((size_t)nb * OS2D_K + m) * HW + n] = acc[mi][ni][r];
+        }
+      }
+    }
     s += __shfl_xor(s, 32);
     part[ni] = s;
   }
@@ -202,12 +254,13 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
   for (int ni = 0; ni < NI; ++ni) {
     const int col = wn * (32 * NI) + ni * 32 + l31;
     const int n = n0 + col;
-    if (n >= HW) continue;
+    const bool nin = n < HW;   // lanes l and l+32 share n: both take part in the exchange below or neither stores
     // head.py:650,597 (eps 1e-6); the normalised values (<= 1) are stored scaled by 2^OS2D_RNORM_EXP so that their lo halves
     // stay normal fp16 numbers (the conv 7x7 epilogue undoes the scale exactly)
     const float inv_r = 1.0f / (sqrtf(red[0][col] + red[1][col]) + 1e-6f);
     const float rscale = ldexpf(1.0f, OS2D_RNORM_EXP);
-    const int h = n / W, w = n - h * W;
+    const int nc = nin ? n : 0;
+    const int h = nc / W, w = nc - h * W;
     const size_t cell = (size_t)BASE + (size_t)h * Ws + w;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -215,7 +268,7 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
       for (int q = 0; q < 4; ++q) {
         const int m0 = wm * 128 + mi * 32 + 8 * q + 4 * hw;
         const int grp = m0 >> 3;
-        if (grp >= OS2D_G) continue;
+        if (grp >= OS2D_G) continue;   // wave-uniform (depends on wm, mi, q only)
         half4 h4, l4;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -224,9 +277,19 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
           h4[k] = hv;
           l4[k] = (_Float16)(v - (float)hv);
         }
-        char* o = rshb + (((size_t)nb * OS2D_G + grp) * 2 * PLANE + cell) * 16 + hw * 8;
-        *reinterpret_cast<half4*>(o) = h4;
-        *reinterpret_cast<half4*>(o + (size_t)PLANE * 16) = l4;
+        // lower half-wave: channels 0-3, upper: channels 4-7 of the unit.  The lower lane sends its lo half and receives the
+        // partner's hi half; the upper lane sends its hi half and receives the partner's lo half.
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 send = hw ? __builtin_bit_cast(u32x2, h4) : __builtin_bit_cast(u32x2, l4);
+        u32x2 recv;
+        recv[0] = (unsigned)__shfl_xor((int)send[0], 32);
+        recv[1] = (unsigned)__shfl_xor((int)send[1], 32);
+        const u32x2 keep = hw ? __builtin_bit_cast(u32x2, l4) : __builtin_bit_cast(u32x2, h4);
+        const u32x4 unit = hw ? u32x4{recv[0], recv[1], keep[0], keep[1]} : u32x4{keep[0], keep[1], recv[0], recv[1]};
+        if (nin) {
+          char* o = rshb + ((((size_t)nb * OS2D_G + grp) * 2 + hw) * PLANE + cell) * 16;   // part hw: 0 = hi plane, 1 = lo
+          *reinterpret_cast<u32x4*>(o) = unit;
+        }
       }
   }
 }

@@ -509,3 +509,59 @@ def test_baseline_config_pyramid_streams_128_classes(device):
                     assert torch.equal(par[k][lvl], serial[k][lvl]), (lvl, k)
     from os2d_amd.modeling import head as head_mod
     assert len(head_mod._WORKSPACES) <= len(levels) + 1          # one workspace per level stream (+ the caller's)
+
+
+# ------------------------------------------------------------------------------------------------ correlation stage
+@pytest.mark.parametrize("name", ["v2_affine_inv", "affine_noinv", "v2_c256_wide"])
+def test_correlation_stage_matches_reference(name, device):
+    """Stage-level parity of BOTH correlation kernels against the correlation tensor the reference computed
+    (``ref_corr``, the TransformNet input recorded by a forward hook in tests/golden/make_golden.py): os2d_fm_sumsq +
+    os2d_corr (fp32 MFMA) and os2d_corr_f16x3 (split-fp16 MFMA, LDS-DMA staging, wide-store epilogue) through the C ABI;
+    their normalised outputs (zero-bordered planes / split-half blocked units) against relu + L2 of the same tensor."""
+    import ctypes
+    import torch.nn.functional as F
+    from os2d_amd import _lib
+    lib = _lib.load()
+    fx = util.load_head_fixture(name)
+    creator = util.make_head_creator(fx["P"], fx["inverse"], fx["state"], device)
+    fm = fx["fm"].to(device)
+    A, C, H, W = fm.shape
+    HW = H * W
+    with torch.no_grad():
+        head = creator.create_os2d_head([c.to(device) for c in fx["class_fms"]])
+    B = head.class_batch_size
+    NB = A * B
+    st = _lib.current_stream(device)
+    ref = fx["ref_corr"].reshape(NB, 225, HW)
+    r = F.relu(fx["ref_corr"])
+    rn_ref = (r / (r.norm(dim=1, keepdim=True) + 1e-6)).reshape(NB, 225, H, W)
+    plane = lib.os2d_plane_floats(H, W)
+    Ws, base = W + 3, (3 * (W + 3) + 3 + 3) // 4 * 4
+    # ---- fp32 kernels
+    sumsq = torch.empty(A * HW, device=device)
+    corr = torch.empty(NB, 225, HW, device=device)
+    rnorm = torch.empty(NB * 226 * plane, device=device)
+    _lib.check(lib.os2d_fm_sumsq(_lib.ptr(fm), _lib.ptr(sumsq), A, C, H, W, st), "os2d_fm_sumsq")
+    _lib.check(lib.os2d_corr(_lib.ptr(fm), _lib.ptr(head._qp), _lib.ptr(sumsq), _lib.ptr(corr), _lib.ptr(rnorm), A, B, C, H, W, st), "os2d_corr")
+    assert util.maxdiff(corr, ref) < 2e-6
+    got = rnorm.view(NB, 226, plane)[:, :225, base:base + H * Ws].reshape(NB, 225, H, Ws)[..., :W]
+    assert util.maxdiff(got, rn_ref) < 2e-6
+    # ---- split-fp16 kernels
+    nbytes = lib.os2d_corr_f16x3_workspace_bytes(A, C, H, W)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    corr16 = torch.full((NB, 225, HW), float("nan"), device=device)
+    shb_bytes = lib.os2d_shb_bytes(225, H, W)
+    rshb = torch.empty(NB * shb_bytes, dtype=torch.uint8, device=device)
+    _lib.check(lib.os2d_corr_f16x3(_lib.ptr(fm), _lib.ptr(head._split_class_operand()), _lib.ptr(corr16), _lib.ptr(rshb), A, B, C, H, W,
+                                   _lib.ptr(ws), ws.numel(), st), "os2d_corr_f16x3")
+    assert util.maxdiff(corr16, ref) < 2e-6
+    # split-half blocked units: [NB][29][hi|lo][PLANE][8 halves], value = (hi + lo) * 2^-rnorm_exp
+    units = rshb.view(torch.float16).view(NB, 29, 2, plane, 8).float()
+    val = (units[:, :, 0] + units[:, :, 1]) * 2.0 ** -lib.os2d_rnorm_exp()                     # [NB,29,PLANE,8]
+    val = val.permute(0, 1, 3, 2).reshape(NB, 232, plane)
+    got16 = val[:, :225, base:base + H * Ws].reshape(NB, 225, H, Ws)[..., :W]
+    assert util.maxdiff(got16, rn_ref) < 2e-6
+    assert float(val[:, 225:].abs().max()) == 0.0                                              # padding channels of the last group
+    border = val.clone()
+    border[:, :, base:base + H * Ws].view(NB, 232, H, Ws)[..., :W] = 0
+    assert float(border.abs().max()) == 0.0                                                    # zero borders baked in

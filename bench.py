@@ -66,12 +66,13 @@ sys.path.insert(0, REPO)
 C_FEAT, H_FM, W_FM = 1024, 60, 80          # ResNet50-C4 features of a 1280x960 input
 LEVEL_HW = [(30, 40), (38, 50), (48, 64), (60, 80), (72, 96), (84, 112), (96, 128)]   # 7 scales 0.5-1.6
 FLOP_PER_LOC = {"corr": 2 * 225 * 1024, "conv1": 2 * 128 * 225 * 49, "conv2": 2 * 64 * 128 * 25}
-PEAK = {"f32": 157.3e12, "f16x3": 2.5e15, "f16x2": 2.5e15}  # dense MFMA peaks (MI355X_MICROARCH.md): fp32-input MFMA; fp16/bf16 MFMA
+PEAK = {"f32": 157.3e12, "f16x3": 2.5e15, "f16x2": 2.5e15, "fft": 157.3e12}  # dense MFMA peaks (MI355X_MICROARCH.md): fp32-input MFMA; fp16/bf16 MFMA
 STAGES = ("corr", "conv1", "conv2", "conv3", "sample")
-PREC_ID = {"f32": 0, "f16x3": 1, "f16x2": 2}
+PREC_ID = {"f32": 0, "f16x3": 1, "f16x2": 2, "fft": 3}
 DTYPE = {"f32": "f32",
          "f16x3": "f16x3 (fp32 operands split into fp16 hi+lo, 3 half MFMAs per product, fp32 accumulate)",
-         "f16x2": "f16x2 (as f16x3; the 7x7 layer's weights enter as fp16 roundings only, 2 half MFMAs per product)"}
+         "f16x2": "f16x2 (as f16x3; the 7x7 layer's weights enter as fp16 roundings only, 2 half MFMAs per product)",
+         "fft": "fft (as f16x3; the 7x7 layer in the frequency domain in fp32: real FFT, complex GEMM per bin on the fp32 MFMA, inverse FFT)"}
 DISTINCT_CLASS_MAPS = 64     # synthetic class maps are generated for 64 seeds and repeated (separate device copies)
 
 
@@ -84,7 +85,7 @@ def parse():
     ap.add_argument("--classes-total", type=int, default=None,
                     help="classes in total, block-sharded over the ranks (strong scaling); default 1024 at N>1")
     ap.add_argument("--variant", default="v2", choices=["v2", "v1"], help="v2: affine+inverse (P=6); v1: simplified (P=4)")
-    ap.add_argument("--precision", default=os.environ.get("OS2D_PRECISION", "f16x3"), choices=["f32", "f16x3", "f16x2"])
+    ap.add_argument("--precision", default=os.environ.get("OS2D_PRECISION", "f16x3"), choices=["f32", "f16x3", "f16x2", "fft"])
     ap.add_argument("--pyramid", action="store_true",
                     help="BASELINE configs[4]: 7-scale pyramid (0.5-1.6) of the 1280x960 image, one HIP stream per level; "
                          "a pair then means one (image, class) over all 7 levels")
@@ -378,6 +379,8 @@ class Workload(object):
             seconds = stage_ms[1] * 1e-3
             kernel = "TransformNet conv 7x7 225->128 ({})".format(
                 "conv_mfma_kernel<7,...>, v_mfma_f32_32x32x2_f32" if precision == "f32"
+                else "frequency domain: fft_forward + spectral_gemm (v_mfma_f32_32x32x2_f32) + fft_inverse; the FLOPs are the "
+                     "DIRECT layer's (the transform route executes 16.7x fewer), so frac may exceed 1" if precision == "fft"
                 else "conv_f16x3_kernel<7,...>, v_mfma_f32_32x32x16_f16 x{} per product".format(precision[-1]))
         else:
             flops = self.whole_head_flops_per_class() * B
@@ -389,7 +392,7 @@ class Workload(object):
              "frac": round(achieved / peak, 4), "traffic": None, "flops_per_launch": flops,
              "avg_launch_ms": round(seconds * 1e3, 4), "timing": "HIP events on the launch stream, this run" if stage_ms is not None
              else "wall clock of the timed steps, this run"}
-        if stage_ms is not None:
+        if stage_ms is not None and precision != "fft":
             c = replayed_counters(precision)
             if c:
                 r["traffic"] = int(c["bytes_per_class"] * B)
@@ -405,8 +408,8 @@ class Workload(object):
             # channels x (hi|lo) halves) + the 128 output planes written once + the packed weights once
             plane = int(self.lib.os2d_plane_floats(H_FM, W_FM))
             in_planes = 226 if precision == "f32" else 232
-            r["algorithmic_bytes"] = int(B * (in_planes + 128) * plane * 4 + self.lib.os2d_packed_conv_bytes(1, PREC_ID[precision]))
-        if precision != "f32":
+            r["algorithmic_bytes"] = int(B * (in_planes + 128) * plane * 4 + self.lib.os2d_packed_conv_bytes(1, PREC_ID["f16x3" if precision == "fft" else precision]))
+        if precision not in ("f32", "fft"):
             # every algorithmic product costs three (f16x2: two, 7x7 layer only) half-precision MFMA products: the ceiling for
             # algorithmic FLOP/s on this instruction is peak/3 (peak/2); the executed rate also includes the tile /
             # channel-group padding (x1.118 for the 7x7 kernel)
@@ -431,7 +434,7 @@ def precision_deviation(w):
     out = {}
     with torch.no_grad():
         ref = [t.clone() for t in w.head(w.fm, precision="f32")]
-        for p in ("f16x3", "f16x2"):
+        for p in ("f16x3", "f16x2", "fft"):
             o = w.head(w.fm, precision=p)
             out[p] = {"cls": float((o[1] - ref[1]).abs().max()), "loc": float((o[0] - ref[0]).abs().max()),
                       "corners_px": float((o[3] - ref[3]).abs().max())}
@@ -515,7 +518,7 @@ def main():
     result["head_tflops_algorithmic"] = round(w.whole_head_flops_per_class() * value / 1e12, 3)
     if not args.no_other_precision:
         result["other_precisions"] = []
-        for other in ("f16x3", "f16x2", "f32"):
+        for other in ("f16x3", "fft", "f16x2", "f32"):
             if other == args.precision:
                 continue
             dt2, stage2 = w.run(other, max(2, min(args.steps, 10)), 1)

@@ -32,6 +32,11 @@ extern "C" {
                                /* its weights as fp16 roundings only (two MFMAs per product): box regression within   */
                                /* 5e-5, scores within 1e-6 of fp32 - inside the 1e-4 parity bound, 2/3 of the work     */
 
+#define OS2D_PRECISION_FFT 3   /* as F16X3, except that the 7x7 layer runs in the frequency domain in fp32: in-LDS real FFT of the  */
+                               /* normalised correlation, one complex 128 x 225 GEMM per bin on the fp32 matrix cores, inverse FFT  */
+                               /* (16.7x fewer multiply-adds; agrees with an fp64 convolution to 1e-7, closer than a direct fp32    */
+                               /* convolution).  Maps that do not fit the in-LDS transform are refused (-3): use F16X3 for them.   */
+
 /* ABI version of the loaded library (compare with OS2D_ABI_VERSION). */
 int os2d_abi_version(void);
 
@@ -70,6 +75,7 @@ int os2d_class_prepare_batch(const float* const* srcs, const int* sizes, int B, 
  * chunks; it must hold at least os2d_head_workspace_bytes(A,1,...) bytes.  C must be a multiple of 4 and W <= 209
  * (3344-px wide images at stride 16: the 7x7 kernels keep three halo rows in LDS); both are checked before any launch. */
 int os2d_head_workspace_bytes(int A, int B, int C, int H, int W, int P, size_t* bytes);
+int os2d_head_workspace_bytes_ex(int A, int B, int C, int H, int W, int P, int precision, size_t* bytes);  /* + spectra (FFT mode) */
 int os2d_head_forward(const float* fm, const float* qp, const float* w1, const float* b1, const float* w2,
                       const float* b2, const float* w3, const float* b3, int A, int B, int C, int H, int W, int P,
                       int inverse, int stride, int rec_field, float* loc, float* cls, float* corners,
@@ -108,13 +114,16 @@ int os2d_class_split(const float* qp, void* qs, int B, int C, void* stream);
  *   chunk_classes NULL, or receives the number of classes per chunk chosen for the given workspace;
  *   status        NULL, or a device-visible int (device memory or mapped pinned host memory) that receives sticky
  *                 status bits (plain system-scope stores, never cleared by the library): OS2D_STATUS_F16_RANGE when a split-fp16 activation left the
- *                 fp16 range (only possible with non-finite inputs) - the caller then re-runs in OS2D_PRECISION_F32.  */
+ *                 fp16 range (only possible with non-finite inputs) - the caller then re-runs in OS2D_PRECISION_F32;
+ *   wspec, twQ, twP  OS2D_PRECISION_FFT only (NULL otherwise): weight spectra of the 7x7 layer for THIS map size in the layout of
+ *                 os2d_spectral_gemm and the two twiddle tables of os2d_fft_forward (w1 / b1..b3 / w2 / w3 as for F16X3).      */
 #define OS2D_STATUS_F16_RANGE 1
 int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const float* b1, const void* w2,
                          const float* b2, const void* w3, const float* b3, int A, int B, int C, int H, int W, int P,
                          int inverse, int stride, int rec_field, float* loc, float* cls, float* corners,
                          void* workspace, size_t workspace_bytes, void* stream, int precision, const void* qs,
-                         void** stage_events, int* chunk_classes, int* status);
+                         void** stage_events, int* chunk_classes, int* status, const float* wspec, const float* twQ,
+                         const float* twP);
 int os2d_prof_event_create(void** ev);
 int os2d_prof_event_destroy(void* ev);
 int os2d_prof_event_elapsed_ms(void* begin, void* end, float* ms);   /* both events must have completed */
@@ -189,6 +198,29 @@ int os2d_detect_level_supported(int H, int W);
 int os2d_detect_level(const float* loc, const float* cls, int B, int H, int W, int stride, int rec_field, float img_w,
                       float img_h, float scale_x, float scale_y, float score_threshold, float iou_threshold,
                       float* out_boxes, float* out_scores, int* out_index, int* out_count, void* stream);
+
+/* ---- building block of the frequency-domain form of the 7x7 TransformNet layer (reference head.py:619-623; DESIGN.md
+ * section 8 "next"; not yet on the head's path): for every frequency bin the layer is one complex matrix product
+ *     Y[n][o][bin] = sum_c K[o][c][bin] * X[n][c][bin]      n = image x class, c < C input channels, o < Cout <= 128
+ * evaluated for all bins in one launch on the fp32 matrix cores (exact fp32 products, fp32 accumulation).
+ *   X [NB,C,nbins], Y [NB,Cout,nbins] interleaved complex64 (re, im), nbins a multiple of 8;
+ *   wspec: the weight spectra packed [nbins/8][2][C][8][64] complex64 - for bin group g, half h, channel c, bin j and
+ *   row r the entry is K[64*h + r][c][8*g + j] (zero for rows >= Cout); os2d_spectral_weight_bytes(C, Cout, nbins) bytes.  */
+size_t os2d_spectral_weight_bytes(int C, int Cout, int nbins);
+/* The transforms around it (in-LDS mixed-radix real FFT pair, one work-group per image):
+ *   os2d_fft_sizes    padded sizes P >= H+3, Q >= W+3 (products of 2s and 3s; the weight spectra carry the -3 shift of the
+ *                     centred kernel) and nbins = P*(Q/2+1) rounded up to a multiple of 8; -3 if the map does not fit
+ *   os2d_fft_forward  x = relu(corr [NB,C,H*W]) * inv_norm [NB,H*W] (head.py:650 folded into the load), zero-padded ->
+ *                     X [NB,C,nbins] complex64, bin = u*(Q/2+1) + v
+ *   os2d_fft_inverse  Y [NB,128,nbins] -> first H x W samples / (P*Q), + folded bias, ReLU, per-channel scale (packed_b of
+ *                     os2d_pack_conv_f16x3 for layer 1), fp16 hi|lo -> split-half blocked buffer (NB*os2d_shb_bytes(128,H,W))
+ *   twQ / twP         exp(-2 pi i m / Q), m < Q  and  exp(-2 pi i m / P), m < P  as complex64 device tables              */
+int os2d_fft_sizes(int H, int W, int* P, int* Q, int* nbins);
+int os2d_fft_forward(const float* corr, const float* inv_norm, float* X, const float* twQ, const float* twP, int NB, int C,
+                     int H, int W, void* stream);
+int os2d_fft_inverse(const float* Y, const float* packed_b, void* out, const float* twQ, const float* twP, int NB, int Cout,
+                     int H, int W, int* status, void* stream);
+int os2d_spectral_gemm(const float* wspec, const float* X, float* Y, int NB, int C, int Cout, int nbins, void* stream);
 
 /* ---- detection over a whole image pyramid: reference os2d/modeling/box_coder.py:448-536 per label for L levels, incl. the
  * reference's memory-bounded NMS (os2d/structures/bounding_box.py:343-374: lists longer than nms_max_batch are NMS-ed in

@@ -36,10 +36,16 @@ SIGNATURES = {
     "os2d_corr_normalize_f16x3": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "os2d_transform_conv_f16x3": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "os2d_alignment_grids": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "os2d_spectral_weight_bytes": (_sz, [_i, _i, _i]),
+    "os2d_spectral_gemm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "os2d_fft_sizes": (_i, [_i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "os2d_fft_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "os2d_fft_inverse": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "os2d_class_split": (_i, [_vp, _vp, _i, _i, _vp]),
     "os2d_class_split_bytes": (_sz, [_i, _i]),
     "os2d_head_forward_ex": (_i, [_vp] * 8 + [_i] * 9 + [_vp, _vp, _vp, _vp, _sz, _vp, _i, _vp,
-                                  ctypes.POINTER(_vp), ctypes.POINTER(_i), _vp]),
+                                  ctypes.POINTER(_vp), ctypes.POINTER(_i), _vp, _vp, _vp, _vp]),
+    "os2d_head_workspace_bytes_ex": (_i, [_i, _i, _i, _i, _i, _i, _i, ctypes.POINTER(_sz)]),
     "os2d_prof_event_create": (_i, [ctypes.POINTER(_vp)]),
     "os2d_prof_event_destroy": (_i, [_vp]),
     "os2d_prof_event_elapsed_ms": (_i, [_vp, _vp, ctypes.POINTER(_f)]),

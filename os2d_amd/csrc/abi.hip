@@ -28,9 +28,9 @@ int os2d_conv1_steps_padded() { return 25; }
 
 // workspace carve for a chunk of Bc classes
 struct Carve {
-  size_t sumsq, fs, corr, rpad, h1, h2, params, total;
+  size_t sumsq, fs, corr, rpad, h1, h2, params, invn, xspec, yspec, total;
 };
-Carve carve(int A, int Bc, int C, int H, int W, int P) {
+Carve carve(int A, int Bc, int C, int H, int W, int P, int fft_bins = 0) {
   const size_t HW = (size_t)H * W, PL = os2d_plane(H, W), NB = (size_t)A * Bc;
   Carve c;
   size_t off = 0;
@@ -46,6 +46,12 @@ Carve carve(int A, int Bc, int C, int H, int W, int P) {
   c.h1 = take(NB * 128 * PL);
   c.h2 = take(NB * 64 * PL);
   c.params = take(NB * P * HW);
+  c.invn = c.xspec = c.yspec = 0;
+  if (fft_bins > 0) {  // frequency-domain 7x7 layer: inverse norms, input / output spectra (complex64)
+    c.invn = take(NB * HW);
+    c.xspec = take(NB * OS2D_K * (size_t)fft_bins * 2);
+    c.yspec = take(NB * 128 * (size_t)fft_bins * 2);
+  }
   c.total = off;
   return c;
 }
@@ -148,6 +154,21 @@ int os2d_head_workspace_bytes(int A, int B, int C, int H, int W, int P, size_t* 
   return 0;
 }
 
+int os2d_head_workspace_bytes_ex(int A, int B, int C, int H, int W, int P, int precision, size_t* bytes) {
+  if (!bytes) {
+    os2d_set_error("os2d_head_workspace_bytes_ex: null output");
+    return -1;
+  }
+  if (!head_args_ok(A, B, C, H, W, P)) return -1;
+  int bins = 0;
+  if (precision == OS2D_PRECISION_FFT && !os2d_fft_plan(H, W, nullptr, nullptr, &bins)) {
+    os2d_set_error("os2d_head_workspace_bytes_ex: a %dx%d map does not fit the in-LDS transform of the FFT mode", H, W);
+    return -3;
+  }
+  *bytes = carve(A, B, C, H, W, P, bins).total;
+  return 0;
+}
+
 int os2d_fm_sumsq(const float* fm, float* sumsq, int A, int C, int H, int W, void* stream) {
   if (!fm || !sumsq || A < 1 || C < 1 || H < 1 || W < 1) {
     os2d_set_error("os2d_fm_sumsq: bad arguments");
@@ -189,7 +210,7 @@ int os2d_corr_f16x3(const float* fm, const void* qs, float* corr, void* rshb, in
   int rc = os2d_launch_fm_sumsq(fm, sumsq, A, C, H * W, S(stream));
   if (!rc) rc = os2d_launch_split_fm(fm, sumsq, fs, A, C, H * W, S(stream));
   if (!rc) rc = os2d_launch_border_zero_shb(rshb, A * B, H, W, S(stream));
-  if (!rc) rc = os2d_launch_corr_f16x3(fs, qs, corr, rshb, A, B, C, H, W, S(stream));
+  if (!rc) rc = os2d_launch_corr_f16x3(fs, qs, corr, rshb, nullptr, A, B, C, H, W, S(stream));
   return rc;
 }
 
@@ -273,14 +294,27 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
                          const float* b2, const void* w3, const float* b3, int A, int B, int C, int H, int W, int P,
                          int inverse, int stride, int rec_field, float* loc, float* cls, float* corners,
                          void* workspace, size_t workspace_bytes, void* stream, int precision, const void* qs,
-                         void** stage_events, int* chunk_classes, int* status) {
+                         void** stage_events, int* chunk_classes, int* status, const float* wspec, const float* twQ,
+                         const float* twP) {
   if (!fm || !qp || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !loc || !cls || !corners || !workspace) {
     os2d_set_error("os2d_head_forward: null pointer");
     return -1;
   }
-  if (precision != OS2D_PRECISION_F32 && precision != OS2D_PRECISION_F16X3 && precision != OS2D_PRECISION_F16X2) {
+  if (precision != OS2D_PRECISION_F32 && precision != OS2D_PRECISION_F16X3 && precision != OS2D_PRECISION_F16X2 &&
+      precision != OS2D_PRECISION_FFT) {
     os2d_set_error("os2d_head_forward: unknown precision %d", precision);
     return -1;
+  }
+  int fft_bins = 0;
+  if (precision == OS2D_PRECISION_FFT) {
+    if (!wspec || !twQ || !twP) {
+      os2d_set_error("os2d_head_forward: the FFT mode needs the weight spectra and the two twiddle tables");
+      return -1;
+    }
+    if (!os2d_fft_plan(H, W, nullptr, nullptr, &fft_bins)) {
+      os2d_set_error("os2d_head_forward: a %dx%d map does not fit the in-LDS transform of the FFT mode", H, W);
+      return -3;
+    }
   }
   if (precision != OS2D_PRECISION_F32 && !qs) {
     os2d_set_error("os2d_head_forward: precision f16x3 / f16x2 needs the split class operand (os2d_class_split)");
@@ -296,14 +330,14 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     return -1;
   }
   // largest class chunk that fits the workspace (footprint is affine in Bc)
-  const size_t one = carve(A, 1, C, H, W, P).total;
+  const size_t one = carve(A, 1, C, H, W, P, fft_bins).total;
   if (workspace_bytes < one) {
     os2d_set_error("os2d_head_forward: workspace too small (%zu B, need >= %zu B for one class)", workspace_bytes, one);
     return -2;
   }
   int Bc = B;
-  while (Bc > 1 && carve(A, Bc, C, H, W, P).total > workspace_bytes) {
-    const size_t two = carve(A, 2, C, H, W, P).total;
+  while (Bc > 1 && carve(A, Bc, C, H, W, P, fft_bins).total > workspace_bytes) {
+    const size_t two = carve(A, 2, C, H, W, P, fft_bins).total;
     const size_t per = two - one;
     int guess = per ? (int)((workspace_bytes - one) / per) + 1 : 1;
     if (guess >= Bc) guess = Bc - 1;
@@ -312,7 +346,10 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
   }
   hipStream_t st = S(stream);
   char* ws = static_cast<char*>(workspace);
-  const Carve c = carve(A, Bc, C, H, W, P);
+  const Carve c = carve(A, Bc, C, H, W, P, fft_bins);
+  float* invn = fft_bins ? reinterpret_cast<float*>(ws + c.invn) : nullptr;
+  float* xspec = fft_bins ? reinterpret_cast<float*>(ws + c.xspec) : nullptr;
+  float* yspec = fft_bins ? reinterpret_cast<float*>(ws + c.yspec) : nullptr;
   float* sumsq = reinterpret_cast<float*>(ws + c.sumsq);
   void* fsplit = ws + c.fs;
   float* corr = reinterpret_cast<float*>(ws + c.corr);
@@ -342,14 +379,21 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     }
     if (f16) {
       const char* qsb = static_cast<const char*>(qs) + (size_t)b0 * os2d_corr_groups(C) * 2 * 256 * 16;
-      if ((rc = os2d_launch_corr_f16x3(fsplit, qsb, corr, rpad, A, bc, C, H, W, st))) return rc;
+      if ((rc = os2d_launch_corr_f16x3(fsplit, qsb, corr, rpad, invn, A, bc, C, H, W, st))) return rc;
     } else {
       if ((rc = os2d_launch_corr(fm, qp + (size_t)b0 * C * OS2D_QROWS, sumsq, corr, rpad, A, bc, C, H, W, 0, st)))
         return rc;
     }
     mark(b0, 1);
     mark(b0, 2);
-    if (f16) {
+    if (fft_bins) {
+      // the 7x7 layer in the frequency domain (fft.hip, spectral.hip): fp32 FFT of relu(corr) / norm -> one complex GEMM
+      // per bin on the fp32 matrix cores -> inverse FFT + bias + ReLU + split into the activation buffer of the 5x5 layer
+      if ((rc = os2d_launch_fft_forward(corr, invn, xspec, twQ, twP, NB, OS2D_K, H, W, st))) return rc;
+      if ((rc = os2d_launch_spectral_gemm(wspec, xspec, yspec, NB, OS2D_K, 128, fft_bins, st))) return rc;
+      if ((rc = os2d_launch_border_zero_shb_planes(h1, NB * 16 * 2, H, W, st))) return rc;
+      if ((rc = os2d_launch_fft_inverse(yspec, b1, 128, h1, twQ, twP, NB, 128, H, W, status, st))) return rc;
+    } else if (f16) {
       if ((rc = os2d_launch_conv_f16x3(1, rpad, w1, b1, status, h1, NB, P, H, W, terms1, st))) return rc;
     } else {
       if ((rc = os2d_launch_conv(1, rpad, static_cast<const float*>(w1), b1, h1, NB, P, H, W, st))) return rc;
@@ -384,7 +428,7 @@ int os2d_head_forward(const float* fm, const float* qp, const float* w1, const f
                       size_t workspace_bytes, void* stream) {
   return os2d_head_forward_ex(fm, qp, w1, b1, w2, b2, w3, b3, A, B, C, H, W, P, inverse, stride, rec_field, loc, cls,
                               corners, workspace, workspace_bytes, stream, OS2D_PRECISION_F32, nullptr, nullptr, nullptr,
-                              nullptr);
+                              nullptr, nullptr, nullptr, nullptr);
 }
 
 size_t os2d_class_split_bytes(int B, int C) {
@@ -453,6 +497,56 @@ int os2d_transform_conv_f16x3(int layer, const void* in, const void* packed_w, c
     return -1;
   }
   return os2d_launch_conv_f16x3(layer, in, packed_w, packed_b, status, out, NB, P, H, W, terms, S(stream));
+}
+
+int os2d_fft_sizes(int H, int W, int* P, int* Q, int* nbins) {
+  if (!P || !Q || !nbins) {
+    os2d_set_error("os2d_fft_sizes: null output");
+    return -1;
+  }
+  if (!os2d_fft_plan(H, W, P, Q, nbins)) {
+    os2d_set_error("os2d_fft_sizes: a %dx%d map does not fit the in-LDS transform", H, W);
+    return -3;
+  }
+  return 0;
+}
+
+int os2d_fft_forward(const float* corr, const float* inv_norm, float* X, const float* twQ, const float* twP, int NB, int C,
+                     int H, int W, void* stream) {
+  if (!corr || !inv_norm || !X || !twQ || !twP || NB < 1 || C < 1 || H < 1 || W < 1) {
+    os2d_set_error("os2d_fft_forward: bad arguments");
+    return -1;
+  }
+  return os2d_launch_fft_forward(corr, inv_norm, X, twQ, twP, NB, C, H, W, S(stream));
+}
+
+int os2d_fft_inverse(const float* Y, const float* packed_b, void* out, const float* twQ, const float* twP, int NB, int Cout,
+                     int H, int W, int* status, void* stream) {
+  if (!Y || !packed_b || !out || !twQ || !twP || NB < 1 || Cout != 128 || H < 1 || W < 1) {
+    os2d_set_error("os2d_fft_inverse: bad arguments (Cout must be 128: the 7x7 layer)");
+    return -1;
+  }
+  int rc = os2d_launch_border_zero_shb_planes(out, NB * (Cout / 8) * 2, H, W, S(stream));
+  if (rc) return rc;
+  return os2d_launch_fft_inverse(Y, packed_b, 128, out, twQ, twP, NB, Cout, H, W, status, S(stream));
+}
+
+size_t os2d_spectral_weight_bytes(int C, int Cout, int nbins) {
+  if (C < 1 || Cout < 1 || Cout > 128 || nbins < 8 || (nbins & 7)) return 0;
+  return os2d_spectral_weight_floats(C, Cout, nbins) * sizeof(float);
+}
+
+int os2d_spectral_gemm(const float* wspec, const float* X, float* Y, int NB, int C, int Cout, int nbins, void* stream) {
+  if (!wspec || !X || !Y || NB < 1 || C < 1 || Cout < 1 || Cout > 128 || nbins < 8 || (nbins & 7)) {
+    os2d_set_error("os2d_spectral_gemm: bad arguments (NB=%d C=%d Cout=%d nbins=%d; nbins must be a multiple of 8)", NB, C,
+                   Cout, nbins);
+    return -1;
+  }
+  if ((reinterpret_cast<uintptr_t>(wspec) | reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) & 15) {
+    os2d_set_error("os2d_spectral_gemm: buffers must be 16-byte aligned");
+    return -1;
+  }
+  return os2d_launch_spectral_gemm(wspec, X, Y, NB, C, Cout, nbins, S(stream));
 }
 
 int os2d_alignment_grids(const float* params, int NB, int H, int W, int P, int inverse, float* theta, float* grids,

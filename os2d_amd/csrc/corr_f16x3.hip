@@ -33,7 +33,8 @@ constexpr int NPF = CH_UNITS / NTHR;     // 4 class units per thread
 template <int NI>
 __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  // [A][CGP][2][HW]  (no __restrict__, see
                                                              const u32x4* qs,  // [B][CGP][2][256]   conv_f16x3.hip)
-                                                             float* __restrict__ corr, char* __restrict__ rshb, int A,
+                                                             float* __restrict__ corr, char* __restrict__ rshb,
+                                                             float* __restrict__ invn /*[A*B][HW] 1/(norm+eps) or NULL*/, int A,
                                                              int B, int CGP /*channel groups, padded to a multiple of GC*/,
                                                              int H, int W, int PLANE, float unscale) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
@@ -258,6 +259,7 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
     // head.py:650,597 (eps 1e-6); the normalised values (<= 1) are stored scaled by 2^OS2D_RNORM_EXP so that their lo halves
     // stay normal fp16 numbers (the conv 7x7 epilogue undoes the scale exactly)
     const float inv_r = 1.0f / (sqrtf(red[0][col] + red[1][col]) + 1e-6f);
+    if (invn != nullptr && wm == 0 && hw == 0 && nin) invn[(size_t)nb * HW + n] = inv_r;   // for the frequency-domain 7x7 layer
     const float rscale = ldexpf(1.0f, OS2D_RNORM_EXP);
     const int nc = nin ? n : 0;
     const int h = nc / W, w = nc - h * W;
@@ -366,7 +368,7 @@ int os2d_launch_split_qp(const float* qp, void* qs, int B, int C, hipStream_t st
 namespace {
 
 template <int NI>
-int launch_corr(const void* fs, const void* qs, float* corr, void* rshb, int A, int B, int C, int H, int W,
+int launch_corr(const void* fs, const void* qs, float* corr, void* rshb, float* invn, int A, int B, int C, int H, int W,
                 hipStream_t stream) {
   constexpr int NT = 128 * NI;
   const int HW = H * W;
@@ -380,7 +382,7 @@ int launch_corr(const void* fs, const void* qs, float* corr, void* rshb, int A, 
   const long long groups = (long long)((HW + NT - 1) / NT) * B * A;
   dim3 grid((unsigned)((groups + 7) / 8 * 8));  // multiple of 8: every XCD gets the same number of logical slots
   hipLaunchKernelGGL(corr_f16x3_kernel<NI>, grid, dim3(NTHR), lds, stream, reinterpret_cast<const u32x4*>(fs),
-                     reinterpret_cast<const u32x4*>(qs), corr, reinterpret_cast<char*>(rshb), A, B,
+                     reinterpret_cast<const u32x4*>(qs), corr, reinterpret_cast<char*>(rshb), invn, A, B,
                      os2d_round_up((C + 7) / 8, GC), H, W,
                      os2d_plane(H, W), ldexpf(1.0f, -2 * SCALE_LOG2));
   return check("corr_f16x3");
@@ -388,9 +390,10 @@ int launch_corr(const void* fs, const void* qs, float* corr, void* rshb, int A, 
 
 }  // namespace
 
-int os2d_launch_corr_f16x3(const void* fs, const void* qs, float* corr, void* rshb, int A, int B, int C, int H, int W,
+int os2d_launch_corr_f16x3(const void* fs, const void* qs, float* corr, void* rshb, float* invn, int A, int B, int C, int H,
+                           int W,
                            hipStream_t stream) {
   // the 128-position shape as long as its work-groups still fit the chip in one round (see the kernel's comment)
-  if ((long long)((H * W + 127) / 128) * B * A <= 256) return launch_corr<1>(fs, qs, corr, rshb, A, B, C, H, W, stream);
-  return launch_corr<2>(fs, qs, corr, rshb, A, B, C, H, W, stream);
+  if ((long long)((H * W + 127) / 128) * B * A <= 256) return launch_corr<1>(fs, qs, corr, rshb, invn, A, B, C, H, W, stream);
+  return launch_corr<2>(fs, qs, corr, rshb, invn, A, B, C, H, W, stream);
 }

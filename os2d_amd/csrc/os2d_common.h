@@ -97,6 +97,7 @@ int os2d_launch_pack_conv(const float* w, const float* b, const float* bn_w, con
                           const float* bn_mean, const float* bn_var, float bn_eps, int Cout, int Cin, int KS,
                           int MT, float* wp, float* bp, hipStream_t stream);
 int os2d_launch_border_zero_shb(void* rnorm, int NB, int H, int W, hipStream_t stream);
+int os2d_launch_border_zero_shb_planes(void* buf, int planes, int H, int W, hipStream_t stream);
 int os2d_launch_pack_conv_f16(const float* w, const float* b, const float* bn_w, const float* bn_b, const float* bn_mean,
                               const float* bn_var, float bn_eps, int Cout, int Cin, int KS, int MT, int steps_padded,
                               const int* wexp, const int* in_exp, const int* out_exp, void* wp, float* bp,
@@ -130,9 +131,19 @@ size_t os2d_detect_level_lds_bytes(int H, int W);
 int os2d_launch_detect_level(const float* loc, const float* cls, int B, int H, int W, int stride, int rec_field,
                              float img_w, float img_h, float scale_x, float scale_y, float score_thr, float iou_thr,
                              float* out_boxes, float* out_scores, int* out_index, int* out_count, hipStream_t stream);
+// fft.hip
+int os2d_fft_plan(int H, int W, int* P, int* Q, int* nbins);
+int os2d_launch_fft_forward(const float* corr, const float* inv, float* X, const float* twQ, const float* twP, int NB, int C,
+                            int H, int W, hipStream_t stream);
+int os2d_launch_fft_inverse(const float* Y, const float* bp, int MTP, void* out, const float* twQ, const float* twP, int NB,
+                            int Cout, int H, int W, int* status, hipStream_t stream);
+// spectral.hip
+size_t os2d_spectral_weight_floats(int C, int Cout, int NBINS);
+int os2d_launch_spectral_gemm(const float* wspec, const float* X, float* Y, int NB, int C, int Cout, int NBINS,
+                              hipStream_t stream);
 // corr_f16x3.hip
 int os2d_corr_groups(int C);  // 8-channel groups of the split correlation operands, padded to whole K chunks
 int os2d_launch_split_fm(const float* fm, const float* sumsq, void* fs, int A, int C, int HW, hipStream_t stream);
 int os2d_launch_split_qp(const float* qp, void* qs, int B, int C, hipStream_t stream);
-int os2d_launch_corr_f16x3(const void* fs, const void* qs, float* corr, void* rshb, int A, int B, int C, int H, int W,
+int os2d_launch_corr_f16x3(const void* fs, const void* qs, float* corr, void* rshb, float* invn, int A, int B, int C, int H, int W,
                            hipStream_t stream);

@@ -375,6 +375,12 @@ int os2d_launch_border_zero_shb(void* rnorm, int NB, int H, int W, hipStream_t s
   return check_launch("border_zero_shb");
 }
 
+int os2d_launch_border_zero_shb_planes(void* buf, int planes, int H, int W, hipStream_t stream) {
+  hipLaunchKernelGGL(border_zero_shb_kernel, dim3(planes), dim3(256), 0, stream, reinterpret_cast<uint4*>(buf), H, W,
+                     os2d_plane(H, W));
+  return check_launch("border_zero_shb");
+}
+
 int os2d_launch_pack_conv_f16(const float* w, const float* b, const float* bn_w, const float* bn_b, const float* bn_mean,
                               const float* bn_var, float bn_eps, int Cout, int Cin, int KS, int MT, int steps_padded,
                               const int* wexp, const int* in_exp, const int* out_exp, void* wp, float* bp,

@@ -26,15 +26,18 @@ from .box_coder import BoxGridGenerator
 
 TEMPLATE = 15
 QROWS = 256
-PRECISIONS = {"f32": 0, "f16x3": 1, "f16x2": 2}     # OS2D_PRECISION_* of include/os2d_hip.h
+FFT_MIN_PAIRS = 12      # precision "fft": image x class pairs below which the direct 7x7 kernel is used instead
+PRECISIONS = {"f32": 0, "f16x3": 1, "f16x2": 2, "fft": 3}     # OS2D_PRECISION_* of include/os2d_hip.h
 
 
 def resolve_precision(precision=None):
     """Arithmetic of the two large TransformNet convolutions: "f32" (exact fp32 MFMA) or "f16x3" (fp16 hi/lo split on
     the half-precision matrix cores, fp32-equivalent results: same 2.4e-7 agreement with the reference on every
     parity case), or "f16x2" (as f16x3, but the 7x7 layer takes its weights as fp16 roundings only: 2/3 of the
-    matrix-core work, box regression within 5e-5 and scores within 1e-6 of fp32, inside the 1e-4 parity bound).
-    Default from $OS2D_PRECISION, else "f16x3"."""
+    matrix-core work, box regression within 5e-5 and scores within 1e-6 of fp32, inside the 1e-4 parity bound), or "fft"
+    (as f16x3, but the 7x7 layer runs in the frequency domain in fp32: real FFT -> one complex GEMM per bin on the fp32
+    matrix cores -> inverse FFT; fp32-equivalent, 16.7x fewer multiply-adds; maps that do not fit the in-LDS transform and
+    small class batches fall back to f16x3).  Default from $OS2D_PRECISION, else "f16x3"."""
     precision = precision or os.environ.get("OS2D_PRECISION", "f16x3")
     if precision not in PRECISIONS:
         raise ValueError("precision must be one of {}, got {!r}".format(sorted(PRECISIONS), precision))
@@ -228,8 +231,9 @@ class TransformationNet(nn.Module):
         of ``range_plan``.  Cached until a parameter changes; the cache entry carries an event so that other streams never
         read half-written buffers."""
         precision = resolve_precision(precision)
-        if precision == "f16x2":
-            precision = "f16x3"        # same packed weights and scales; the kernel just skips the lo halves of layer 1
+        if precision in ("f16x2", "fft"):
+            precision = "f16x3"        # same packed weights and scales (f16x2 skips the lo halves of layer 1; fft replaces
+                                       # layer 1 by ``spectra`` and keeps its bias / output scales)
         key = (precision,) + self._state_key()
         dev = self.linear.weight.device
         cached = self._packed_cache.get(precision)
@@ -275,6 +279,49 @@ class TransformationNet(nn.Module):
                 out += [pw, pb]
             result = tuple(out)
             self._packed_cache[precision] = _StreamOrdered(key, result, dev)
+        return result
+
+    def spectra(self, H, W):
+        """Frequency-domain form of the 7x7 layer for an H x W map (precision "fft"): (wspec, twQ, twP, nbins) or None when
+        the map does not fit the in-LDS transform.  The BatchNorm-folded 7x7 filters are centred on the origin of the
+        P x Q grid (tap (t, s) at ((3 - t) mod P, (3 - s) mod Q): the circular convolution then IS the zero-padded
+        correlation of head.py:619 for the first H x W samples), transformed once with torch.fft in float64 and packed for
+        os2d_spectral_gemm; the twiddle tables are exact float64 values rounded once.  Cached per map size until a
+        parameter changes (722 MB for 60 x 80; event-tracked like ``packed``)."""
+        lib = _lib.load()
+        cP, cQ, cN = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        if lib.os2d_fft_sizes(int(H), int(W), ctypes.byref(cP), ctypes.byref(cQ), ctypes.byref(cN)) != 0:
+            return None
+        P, Q, nbins = cP.value, cQ.value, cN.value
+        dev = self.linear.weight.device
+        key = ("fft", H, W) + self._state_key()
+        cached = self._packed_cache.get(("fft", H, W))
+        if cached is not None and cached.key == key:
+            return cached.get(dev)
+        with torch.cuda.device(dev), torch.no_grad():
+            (w1, _), _, _ = self._folded()                       # float64 [128,225,7,7]
+            V = Q // 2 + 1
+            packed = torch.zeros(nbins // 8, 2, 225, 8, 64, dtype=torch.complex64, device=dev)
+            ti = (3 - torch.arange(7, device=dev)) % P
+            si = (3 - torch.arange(7, device=dev)) % Q
+            for half in range(2):                               # 64 output channels at a time bounds the float64 transient
+                k = torch.zeros(64, 225, P, Q, dtype=torch.float64, device=dev)
+                k[:, :, ti.view(-1, 1), si.view(1, -1)] = w1[64 * half:64 * half + 64]
+                K = torch.fft.rfft2(k).reshape(64, 225, P * V).to(torch.complex64)
+                del k
+                Kp = torch.zeros(64, 225, nbins, dtype=torch.complex64, device=dev)
+                Kp[:, :, :P * V] = K
+                del K
+                packed[:, half] = Kp.view(64, 225, nbins // 8, 8).permute(2, 1, 3, 0)      # [g][c][j][r]
+                del Kp
+            wspec = torch.view_as_real(packed).contiguous()
+
+            def table(n):
+                m = torch.arange(n, dtype=torch.float64)
+                ang = -2.0 * torch.pi * m / n
+                return torch.stack([torch.cos(ang), torch.sin(ang)], 1).float().to(dev).contiguous()
+            result = (wspec, table(Q), table(P), nbins)
+            self._packed_cache[("fft", H, W)] = _StreamOrdered(key, result, dev)
         return result
 
     def forward(self, corr_maps, precision="f32"):
@@ -593,6 +640,13 @@ class Os2dHead(nn.Module):
             if precision is not None and resolve_precision(precision) != "f32":
                 precision = "f32"
         precision = resolve_precision(precision or self.precision)
+        spectra = None
+        if precision == "fft":
+            # the frequency-domain 7x7 layer pays off from a dozen classes on (it streams 0.7 GB of weight spectra per call)
+            # and needs the map to fit its in-LDS transform; otherwise the direct f16x3 kernel does the layer
+            spectra = regressor.spectra(H, W) if A * B >= FFT_MIN_PAIRS else None
+            if spectra is None:
+                precision = "f16x3"
         w1, b1, w2, b2, w3, b3 = regressor.packed(precision)
         if out is None:
             loc = torch.empty(A, B, 4, H, W, dtype=torch.float32, device=dev)
@@ -605,8 +659,8 @@ class Os2dHead(nn.Module):
                     raise RuntimeError("out tensors must be contiguous float32 [A,B,{},H,W] on {}".format(k, dev))
         full = ctypes.c_size_t()
         one = ctypes.c_size_t()
-        _lib.check(lib.os2d_head_workspace_bytes(A, B, C, H, W, P, ctypes.byref(full)), "os2d_head_workspace_bytes")
-        _lib.check(lib.os2d_head_workspace_bytes(A, 1, C, H, W, P, ctypes.byref(one)), "os2d_head_workspace_bytes")
+        _lib.check(lib.os2d_head_workspace_bytes_ex(A, B, C, H, W, P, PRECISIONS[precision], ctypes.byref(full)), "os2d_head_workspace_bytes_ex")
+        _lib.check(lib.os2d_head_workspace_bytes_ex(A, 1, C, H, W, P, PRECISIONS[precision], ctypes.byref(one)), "os2d_head_workspace_bytes_ex")
         with torch.cuda.device(dev):     # hipFuncSetAttribute / launches act on the CURRENT device
             ws = get_workspace(dev, full.value, one.value)
             status = self._status_word() if precision != "f32" else None
@@ -616,7 +670,8 @@ class Os2dHead(nn.Module):
                 self._stride, self._rec_field, _lib.ptr(loc), _lib.ptr(cls), _lib.ptr(corners),
                 _lib.ptr(ws), ws.numel(), _lib.current_stream(dev), PRECISIONS[precision],
                 _lib.ptr(self._split_class_operand()) if precision != "f32" else None, stage_events, None,
-                _lib.host_ptr(status)), "os2d_head_forward_ex")
+                _lib.host_ptr(status), *([_lib.ptr(t) for t in spectra[:3]] if spectra is not None else [None, None, None])),
+                "os2d_head_forward_ex")
         strict = self.strict_range if strict_range is None else strict_range
         if strict and precision != "f32":
             torch.cuda.current_stream(dev).synchronize()

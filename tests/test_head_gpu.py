@@ -16,7 +16,15 @@ pytestmark = pytest.mark.gpu
 TOL_CLS, TOL_LOC, TOL_CORNERS = util.TOL_CLS, util.TOL_LOC, util.TOL_CORNERS
 
 
-PRECISIONS = ["f32", "f16x3", "f16x2"]     # every arithmetic mode must meet the same tolerances
+PRECISIONS = ["f32", "f16x3", "f16x2", "fft"]     # every arithmetic mode must meet the same tolerances
+
+
+@pytest.fixture(autouse=True)
+def _fft_mode_for_any_batch(monkeypatch):
+    """precision="fft" hands small class batches to the direct kernel (FFT_MIN_PAIRS); the parity tests want the
+    frequency-domain path itself, whatever the batch."""
+    from os2d_amd.modeling import head as head_mod
+    monkeypatch.setattr(head_mod, "FFT_MIN_PAIRS", 1)
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -85,10 +93,10 @@ def test_image_batch_chunking_and_cat(precision, device, monkeypatch):
         two = ctypes.c_size_t()
         _lib.check(_lib.load().os2d_head_workspace_bytes(2, 2, 32, 9, 14, P, ctypes.byref(two)), "ws")
         head_mod.release_workspaces()
-        monkeypatch.setattr(head_mod, "workspace_cap_bytes", lambda: two.value)
-        out_chunked = head(fm.to(device))
+        with monkeypatch.context() as m:
+            m.setattr(head_mod, "workspace_cap_bytes", lambda: two.value)
+            out_chunked = head(fm.to(device))
         head_mod.release_workspaces()
-        monkeypatch.undo()
         singles = [creator.create_os2d_head([c.to(device)]) for c in class_fms]
         out_cat = head_mod.Os2dHead.cat(singles)(fm.to(device), precision=precision)
     for i, tol in ((0, TOL_LOC), (1, TOL_CLS), (3, TOL_CORNERS)):

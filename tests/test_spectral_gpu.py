@@ -1,0 +1,138 @@
+"""GPU: building blocks of the frequency-domain form of the 7x7 TransformNet layer (os2d_amd/csrc/spectral.hip)."""
+import numpy as np
+import pytest
+import torch
+
+from os2d_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def pack_weight_spectra(K, nbins_pad=None):
+    """K [Cout, C, nbins] complex64 -> the layout of include/os2d_hip.h: [nbins/8][2][C][8][64] complex."""
+    Cout, C, nbins = K.shape
+    assert nbins % 8 == 0 and Cout <= 128
+    Kp = torch.zeros(128, C, nbins, dtype=K.dtype, device=K.device)
+    Kp[:Cout] = K
+    # [h, r, c, g, j] -> [g, h, c, j, r]
+    return Kp.view(2, 64, C, nbins // 8, 8).permute(3, 0, 2, 4, 1).contiguous()
+
+
+def run_spectral_gemm(Wp, X, Cout):
+    lib = _lib.load()
+    NB, C, nbins = X.shape
+    assert Wp.numel() * 8 == lib.os2d_spectral_weight_bytes(C, Cout, nbins)
+    Y = torch.full((NB, Cout, nbins), float("nan"), dtype=torch.complex64, device=X.device)
+    _lib.check(lib.os2d_spectral_gemm(_lib.ptr(torch.view_as_real(Wp)), _lib.ptr(torch.view_as_real(X)), _lib.ptr(torch.view_as_real(Y)),
+                                      NB, C, Cout, nbins, _lib.current_stream(X.device)), "os2d_spectral_gemm")
+    return Y
+
+
+@pytest.mark.parametrize("NB,C,Cout,nbins", [(64, 225, 128, 64), (3, 225, 128, 40), (70, 20, 64, 16), (129, 9, 128, 8), (5, 31, 6, 24)])
+def test_spectral_gemm_matches_float64(NB, C, Cout, nbins, device):
+    g = torch.Generator().manual_seed(NB * 1000 + C)
+    K = torch.complex(torch.randn(Cout, C, nbins, generator=g), torch.randn(Cout, C, nbins, generator=g)).to(device)
+    X = torch.complex(torch.randn(NB, C, nbins, generator=g), torch.randn(NB, C, nbins, generator=g)).to(device)
+    Y = run_spectral_gemm(pack_weight_spectra(K), X.contiguous(), Cout)
+    ref = torch.einsum("ocf,ncf->nof", K.to(torch.complex128), X.to(torch.complex128))
+    err = float((Y.to(torch.complex128) - ref).abs().max())
+    scale = float(ref.abs().max())
+    assert err < 3e-6 * scale, (err, scale)          # fp32 accumulation of 2 * C products
+
+
+def test_spectral_gemm_full_size_timing(device):
+    """The real problem size (3,528 bins, 225 -> 128 channels, 64 classes): correctness on a sample of bins + time."""
+    import time
+    NB, C, Cout, nbins = 64, 225, 128, 72 * 49
+    g = torch.Generator().manual_seed(1)
+    K = torch.complex(torch.randn(Cout, C, nbins, generator=g), torch.randn(Cout, C, nbins, generator=g)).to(device)
+    X = torch.complex(torch.randn(NB, C, nbins, generator=g), torch.randn(NB, C, nbins, generator=g)).to(device)
+    Wp = pack_weight_spectra(K)
+    Y = run_spectral_gemm(Wp, X, Cout)
+    sel = torch.tensor([0, 7, 8, 1763, 3520, 3527], device=device)
+    ref = torch.einsum("ocf,ncf->nof", K[:, :, sel].to(torch.complex128), X[:, :, sel].to(torch.complex128))
+    assert float((Y[:, :, sel].to(torch.complex128) - ref).abs().max()) < 3e-6 * float(ref.abs().max())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        run_spectral_gemm(Wp, X, Cout)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    flops = 8.0 * Cout * C * NB * nbins
+    print("spectral GEMM {} bins x {}x{}x{}: {:.3f} ms = {:.1f} TFLOP/s".format(nbins, Cout, C, NB, ms, flops / ms / 1e9))
+    assert ms < 5.0
+
+
+# ------------------------------------------------------------------------------------------------ the transforms
+def twiddles(n, device):
+    m = torch.arange(n, dtype=torch.float64)
+    ang = -2.0 * np.pi * m / n
+    return torch.stack([torch.cos(ang), torch.sin(ang)], 1).float().to(device).contiguous()     # exp(-2 pi i m / n)
+
+
+def fft_sizes(H, W):
+    import ctypes
+    lib = _lib.load()
+    P, Q, nb = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _lib.check(lib.os2d_fft_sizes(H, W, ctypes.byref(P), ctypes.byref(Q), ctypes.byref(nb)), "os2d_fft_sizes")
+    return P.value, Q.value, nb.value
+
+
+@pytest.mark.parametrize("H,W,NB,C", [(60, 80, 2, 7), (30, 40, 1, 5), (11, 13, 3, 4), (48, 64, 1, 3), (9, 16, 2, 2), (1, 1, 1, 1)])
+def test_fft_forward_matches_torch_fft(H, W, NB, C, device):
+    lib = _lib.load()
+    P, Q, nbins = fft_sizes(H, W)
+    assert P >= H + 3 and Q >= W + 3 and nbins % 8 == 0 and nbins >= P * (Q // 2 + 1)
+    g = torch.Generator().manual_seed(H * 100 + W)
+    corr = (torch.rand(NB, C, H, W, generator=g) - 0.3).to(device)
+    inv = (0.5 + torch.rand(NB, H, W, generator=g)).to(device)
+    X = torch.full((NB, C, nbins, 2), float("nan"), device=device)
+    tq, tp = twiddles(Q, device), twiddles(P, device)          # keep them alive: the call only takes raw pointers
+    _lib.check(lib.os2d_fft_forward(_lib.ptr(corr), _lib.ptr(inv), _lib.ptr(X), _lib.ptr(tq), _lib.ptr(tp),
+                                    NB, C, H, W, _lib.current_stream(device)), "os2d_fft_forward")
+    x = (corr.clamp(min=0) * inv.unsqueeze(1)).double()
+    ref = torch.fft.rfft2(x, s=(P, Q)).reshape(NB, C, -1)                       # [NB,C,P*V], bin = u*V + v
+    got = torch.view_as_complex(X)[..., :P * (Q // 2 + 1)].to(torch.complex128)
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 2e-6 * scale
+    assert float(X[:, :, P * (Q // 2 + 1):].abs().max() if nbins > P * (Q // 2 + 1) else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("H,W,NB", [(60, 80, 2), (30, 40, 1), (11, 13, 2), (48, 64, 1)])
+def test_fft_inverse_matches_torch_fft_and_epilogue(H, W, NB, device):
+    """Inverse transform + the layer epilogue (bias, ReLU, per-channel power-of-two scale, fp16 hi|lo split into the
+    split-half blocked buffer with zero borders) against torch.fft.irfft2."""
+    lib = _lib.load()
+    P, Q, nbins = fft_sizes(H, W)
+    V = Q // 2 + 1
+    Cout = 128
+    g = torch.Generator().manual_seed(H + W)
+    y_true = torch.randn(NB, Cout, H, W, generator=g).double() * 0.3                 # what the inverse should give back
+    full = torch.zeros(NB, Cout, P, Q, dtype=torch.float64)
+    full[:, :, :H, :W] = y_true
+    full[:, :, H:, :] = torch.randn(NB, Cout, P - H, Q, generator=g).double()        # content outside the crop is arbitrary
+    Yc = torch.fft.rfft2(full)                                                       # [NB,Cout,P,V]
+    Y = torch.zeros(NB, Cout, nbins, 2)
+    Y[:, :, :P * V] = torch.view_as_real(Yc.reshape(NB, Cout, P * V).to(torch.complex64))
+    bias = torch.randn(Cout, generator=g) * 0.1
+    oexp = torch.randint(0, 6, (Cout,), generator=g)
+    bp = torch.zeros(3 * 128)
+    bp[:Cout] = bias
+    bp[256:256 + Cout] = torch.exp2(oexp.float())
+    shb_bytes = lib.os2d_shb_bytes(Cout, H, W)
+    out = torch.full((NB * shb_bytes,), 0x5A, dtype=torch.uint8, device=device)
+    status = torch.zeros(1, dtype=torch.int32, device=device)
+    tq, tp, Yd, bpd = twiddles(Q, device), twiddles(P, device), Y.to(device), bp.to(device)
+    _lib.check(lib.os2d_fft_inverse(_lib.ptr(Yd), _lib.ptr(bpd), _lib.ptr(out), _lib.ptr(tq), _lib.ptr(tp), NB, Cout, H, W,
+                                    _lib.ptr(status), _lib.current_stream(device)), "os2d_fft_inverse")
+    plane = lib.os2d_plane_floats(H, W)
+    Ws, base = W + 3, (3 * (W + 3) + 3 + 3) // 4 * 4
+    units = out.view(torch.float16).view(NB, Cout // 8, 2, plane, 8).float().cpu()
+    val = (units[:, :, 0] + units[:, :, 1]).permute(0, 1, 3, 2).reshape(NB, Cout, plane)          # [NB,Cout,PLANE] scaled values
+    got = val[:, :, base:base + H * Ws].reshape(NB, Cout, H, Ws)[..., :W] / torch.exp2(oexp.float()).view(1, -1, 1, 1)
+    ref = torch.relu(y_true + bias.double().view(1, -1, 1, 1))
+    assert float((got.double() - ref).abs().max()) < 2e-6 * float(full.abs().max())
+    border = val.clone()
+    border[:, :, base:base + H * Ws].view(NB, Cout, H, Ws)[..., :W] = 0
+    assert float(border.abs().max()) == 0.0
+    assert int(status.item()) == 0

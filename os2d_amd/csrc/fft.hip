@@ -22,15 +22,26 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 constexpr int FFT_THR = 512;
 constexpr int MAXPASS = 8;
+constexpr int FFT_EPT_MAX = 14;  // elements per thread the register prefetch can hold at most (bounds the map size, see
+                                 // make_plan); the kernels are instantiated for 6 / 10 / 14 so that the 60 x 80 map of the
+                                 // benchmark keeps 4 waves per SIMD (two work-groups per CU)
 
 struct FftPlan {
   int P, Q, V;               // padded sizes, V = Q/2 + 1
   int np_row, np_col;        // number of passes
   int rad_row[MAXPASS], rad_col[MAXPASS];
   int PS;                    // padded stride of a column in LDS (P + 1: keeps the transposed accesses off one bank)
+  int QS;                    // padded stride of a row pair in LDS (Q + 1: the row -> column transposition reads one
+                             // element of every row pair per lane; with stride Q = 96 complex they all sit in ONE bank)
   int AB;                    // complex numbers of the A | B region = max(2 * ceil(H/2) * Q, V * PS): the second column
                              // buffer D aliases it
 };
+
+// Work-group barrier for data exchanged through LDS only: waits for this wave's LDS operations, NOT for its global loads
+// and stores.  __syncthreads() carries a full fence (s_waitcnt vmcnt(0)): inside the per-image loop it would wait for the
+// prefetch of the next image and for the stores of the previous one at every one of the ~10 barriers of an image - the
+// whole HBM latency serialised per image (measured: 8 us of an image's 17 us).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ f32x2 cmul(f32x2 a, f32x2 b) { return f32x2{a[0] * b[0] - a[1] * b[1], a[0] * b[1] + a[1] * b[0]}; }
 __device__ __forceinline__ f32x2 cconj(f32x2 a) { return f32x2{a[0], -a[1]}; }
@@ -42,14 +53,24 @@ __device__ __forceinline__ void stockham_pass(const f32x2* __restrict__ in, f32x
                                               int stride, const f32x2* __restrict__ tw, int tid) {
   const int nb = N / R;          // butterflies per transform
   const int step = N / (Ns * R);
-  for (int i = tid; i < nfft * nb; i += FFT_THR) {
-    const int f = i / nb, j = i - f * nb;
-    const int k = j % Ns;
+  // thread -> (transform f, butterfly j) with shifts only: 2^lg >= nb threads per transform (no integer division in the
+  // loop; Ns is a power of two except in the last pass of a size with two factors 3)
+  const int lg = 32 - __builtin_clz(nb - 1 > 0 ? nb - 1 : 1) - (nb == 1 ? 1 : 0);
+  const int tpf = 1 << lg;
+  const bool pow2 = (Ns & (Ns - 1)) == 0;
+  for (int i = tid; i < (nfft << lg); i += FFT_THR) {
+    const int f = i >> lg, j = i & (tpf - 1);
+    if (j >= nb) continue;
+    const int k = pow2 ? (j & (Ns - 1)) : (j % Ns);
     f32x2 v[R];
 #pragma unroll
     for (int q = 0; q < R; ++q) {
       v[q] = in[f * stride + j + q * nb];
+#ifdef OS2D_DIAG_FFT_TW0
       if (q > 0) {
+#else
+      if (q > 0 && Ns > 1) {      // the first pass (Ns = 1) has k = 0: all twiddles are 1
+#endif
         f32x2 w = tw[q * k * step];
         if (INV) w = cconj(w);
         v[q] = cmul(v[q], w);
@@ -94,7 +115,7 @@ __device__ __forceinline__ f32x2* fft_batch(f32x2* a, f32x2* b, int N, int nfft,
     else if (R == 3) stockham_pass<3, INV>(a, b, N, Ns, nfft, stride, tw, tid);
     else stockham_pass<2, INV>(a, b, N, Ns, nfft, stride, tw, tid);
     Ns *= R;
-    __syncthreads();
+    lds_barrier();
     f32x2* t = a;
     a = b;
     b = t;
@@ -104,146 +125,204 @@ __device__ __forceinline__ f32x2* fft_batch(f32x2* a, f32x2* b, int N, int nfft,
 
 // LDS (in complex numbers): twiddles Q + P | rows A, B: 2 x (HP x Q), HP = ceil(H/2) row pairs | columns C: V x PS.
 // The second column buffer D aliases A|B (the row stage is finished by then).
-__global__ __launch_bounds__(FFT_THR) void fft_forward_kernel(const float* __restrict__ corr,   // [NB][C][H*W]
+template <int FFT_EPT>
+__global__ __launch_bounds__(FFT_THR, FFT_EPT <= 6 ? 4 : 2) void fft_forward_kernel(const float* __restrict__ corr,   // [NB][C][H*W]
                                                              const float* __restrict__ inv,    // [NB][H*W]
                                                              f32x2* __restrict__ X,            // [NB][C][NBINS]
                                                              const f32x2* __restrict__ twQ, const f32x2* __restrict__ twP,
                                                              FftPlan pl, int C, int H, int W, int NBINS, int images) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int P = pl.P, Q = pl.Q, V = pl.V, PS = pl.PS, HP = (H + 1) >> 1, HW = H * W;
+  const int P = pl.P, Q = pl.Q, V = pl.V, PS = pl.PS, QS = pl.QS, HP = (H + 1) >> 1, HW = H * W;
   f32x2* tQ = reinterpret_cast<f32x2*>(smem);
   f32x2* tP = tQ + Q;
   f32x2* A = tP + P;
-  f32x2* Bf = A + HP * Q;
+  f32x2* Bf = A + HP * QS;
   f32x2* Cc = A + pl.AB;
   f32x2* D = A;                     // aliases A | B (the row stage is over when the columns start)
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int NWV = FFT_THR / 64;
   for (int i = tid; i < Q; i += FFT_THR) tQ[i] = twQ[i];
   for (int i = tid; i < P; i += FFT_THR) tP[i] = twP[i];
+  // Every global load of an image is issued up front into registers (EPT elements per thread, their (row pair, column)
+  // computed once), and the loads of the NEXT image are in flight while this one is transformed: the serial chain of a
+  // work-group has no global-memory latency in it.
+  const int nelem = HP * Q;
+  int eoff[FFT_EPT];             // source offset of the element's even row (or -1: zero padding)
+  int edst[FFT_EPT];             // its place in A
+  bool eodd[FFT_EPT];            // the pair's odd row exists
+#pragma unroll
+  for (int k = 0; k < FFT_EPT; ++k) {
+    const int i = tid + k * FFT_THR;
+    const int p = i / Q, w = i - p * Q;
+    const bool in = i < nelem && w < W;
+    eoff[k] = in ? (2 * p) * W + w : -1;
+    eodd[k] = in && 2 * p + 1 < H;
+    edst[k] = p * QS + w;
+  }
+  // RAW values only are held (correlation + inverse norm of the even and the odd row): any arithmetic here would make the
+  // compiler wait for each load right where it is issued; addresses are clamped instead of predicated (no branches)
+  float pa0[FFT_EPT], pn0[FFT_EPT], pa1[FFT_EPT], pn1[FFT_EPT];
+#define FFT_PREFETCH(IMG)                                                                                         \
+  {                                                                                                               \
+    const float* src_ = corr + (size_t)(IMG)*HW;                                                                  \
+    const float* nv_ = inv + (size_t)((IMG) / C) * HW;                                                            \
+    _Pragma("unroll") for (int k = 0; k < FFT_EPT; ++k) {                                                         \
+      const int o0_ = max(eoff[k], 0), o1_ = eodd[k] ? o0_ + W : o0_;                                             \
+      pa0[k] = src_[o0_];                                                                                         \
+      pn0[k] = nv_[o0_];                                                                                          \
+      pa1[k] = src_[o1_];                                                                                         \
+      pn1[k] = nv_[o1_];                                                                                          \
+    }                                                                                                             \
+  }
+  if (blockIdx.x < images) FFT_PREFETCH(blockIdx.x)
   for (int img = blockIdx.x; img < images; img += gridDim.x) {
-    const int nb = img / C;
-    const float* src = corr + (size_t)img * HW;
-    const float* nv = inv + (size_t)nb * HW;
-    __syncthreads();
-    // ---- load: row pair p, column w -> A[p][w] = (x[2p][w], x[2p+1][w]); zero beyond the map
-    for (int i = tid; i < HP * Q; i += FFT_THR) {
-      const int p = i / Q, w = i - p * Q;
-      float re = 0.f, im = 0.f;
-      if (w < W) {
-        const int n0 = (2 * p) * W + w;
-        re = fmaxf(src[n0], 0.f) * nv[n0];
-        if (2 * p + 1 < H) im = fmaxf(src[n0 + W], 0.f) * nv[n0 + W];
-      }
-      A[i] = f32x2{re, im};
-    }
-    __syncthreads();
-    f32x2* R = fft_batch<false>(A, Bf, Q, HP, Q, pl.np_row, pl.rad_row, tQ, tid);
+    lds_barrier();
+    // ---- row pair p, column w -> A[p][w] = (x[2p][w], x[2p+1][w]) with x = relu(corr) * inv_norm; zero beyond the map
+#pragma unroll
+    for (int k = 0; k < FFT_EPT; ++k)
+      if (tid + k * FFT_THR < nelem)
+        A[edst[k]] = f32x2{eoff[k] >= 0 ? fmaxf(pa0[k], 0.f) * pn0[k] : 0.f, eodd[k] ? fmaxf(pa1[k], 0.f) * pn1[k] : 0.f};
+    lds_barrier();
+    if (img + (int)gridDim.x < images) FFT_PREFETCH(img + gridDim.x)
+#ifdef OS2D_DIAG_FFT_NOROW
+    f32x2* R = A;
+#else
+    f32x2* R = fft_batch<false>(A, Bf, Q, HP, QS, pl.np_row, pl.rad_row, tQ, tid);
+#endif
     // ---- untangle the two real rows of every pair and transpose into the column buffer C[v][u]; rows >= H are zero
     f32x2* Cb = (R == A) ? Cc : Cc;   // C is separate from A | B
-    for (int i = tid; i < V * P; i += FFT_THR) {
-      const int v = i / P, u = i - v * P;
-      f32x2 o = f32x2{0.f, 0.f};
-      if (u < H) {
-        const int p = u >> 1;
-        const f32x2 z = R[p * Q + v], zc = cconj(R[p * Q + (v == 0 ? 0 : Q - v)]);
-        if ((u & 1) == 0) o = 0.5f * (z + zc);
-        else {
-          const f32x2 d = z - zc;            // (Z - conj Z') / (2 i) = -i d / 2
-          o = f32x2{0.5f * d[1], -0.5f * d[0]};
+    for (int v = wv; v < V; v += NWV)
+      for (int u = lane; u < P; u += 64) {
+        f32x2 o = f32x2{0.f, 0.f};
+        if (u < H) {
+          const int p = u >> 1;
+          const f32x2 z = R[p * QS + v], zc = cconj(R[p * QS + (v == 0 ? 0 : Q - v)]);
+          if ((u & 1) == 0) o = 0.5f * (z + zc);
+          else {
+            const f32x2 d = z - zc;            // (Z - conj Z') / (2 i) = -i d / 2
+            o = f32x2{0.5f * d[1], -0.5f * d[0]};
+          }
         }
+        Cb[v * PS + u] = o;
       }
-      Cb[v * PS + u] = o;
-    }
-    __syncthreads();
+    lds_barrier();
+#ifdef OS2D_DIAG_FFT_NOCOL
+    f32x2* Rc = Cb;
+#else
     f32x2* Rc = fft_batch<false>(Cb, D, P, V, PS, pl.np_col, pl.rad_col, tP, tid);
+#endif
     // ---- store X[u * V + v] (v fastest) + zero padding bins
     f32x2* dst = X + (size_t)img * NBINS;
-    for (int i = tid; i < NBINS; i += FFT_THR) {
-      f32x2 o = f32x2{0.f, 0.f};
-      if (i < P * V) {
-        const int u = i / V, v = i - u * V;
-        o = Rc[v * PS + u];
-      }
-      dst[i] = o;
-    }
+    for (int u = wv; u < P; u += NWV)
+      for (int v = lane; v < V; v += 64) dst[u * V + v] = Rc[v * PS + u];
+    for (int i = P * V + tid; i < NBINS; i += FFT_THR) dst[i] = f32x2{0.f, 0.f};
   }
 }
 
 // Inverse: Y -> columns (inverse FFT of length P over u for every v) -> re-tangle row pairs -> inverse complex FFT of
 // length Q -> real rows; epilogue of the layer.
-__global__ __launch_bounds__(FFT_THR) void fft_inverse_kernel(const f32x2* __restrict__ Y,      // [NB][Cout][NBINS]
+template <int FFT_EPT>
+__global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_kernel(const f32x2* __restrict__ Y,      // [NB][Cout][NBINS]
                                                              const float* __restrict__ bp,     // [3][MTP]: bias | - | 2^out_exp
                                                              int MTP, char* __restrict__ out,  // SHB [NB][Cout/8][2][PLANE] x 16 B
                                                              const f32x2* __restrict__ twQ, const f32x2* __restrict__ twP,
                                                              FftPlan pl, int Cout, int H, int W, int NBINS, int PLANE,
                                                              int images, int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int P = pl.P, Q = pl.Q, V = pl.V, PS = pl.PS, HP = (H + 1) >> 1;
+  const int P = pl.P, Q = pl.Q, V = pl.V, PS = pl.PS, QS = pl.QS, HP = (H + 1) >> 1;
   f32x2* tQ = reinterpret_cast<f32x2*>(smem);
   f32x2* tP = tQ + Q;
   f32x2* A = tP + P;
-  f32x2* Bf = A + HP * Q;
+  f32x2* Bf = A + HP * QS;
   f32x2* Cc = A + pl.AB;
   f32x2* D = A;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int NWV = FFT_THR / 64;
   const int Ws = os2d_ws(W), BASE = os2d_base(W);
   const float norm = 1.0f / (float)(P * Q);
   for (int i = tid; i < Q; i += FFT_THR) tQ[i] = twQ[i];
   for (int i = tid; i < P; i += FFT_THR) tP[i] = twP[i];
   bool bad = false;
+  // register prefetch of the spectra (see fft_forward_kernel): element i of the image (v fastest) goes to Cc[v][u]
+  const int nelem = P * V;
+  int ldst[FFT_EPT];
+#pragma unroll
+  for (int k = 0; k < FFT_EPT; ++k) {
+    const int i = min(tid + k * FFT_THR, nelem - 1);
+    const int u = i / V, v = i - u * V;
+    ldst[k] = v * PS + u;
+  }
+  f32x2 pf[FFT_EPT];
+#define FFT_PREFETCH_Y(IMG)                                                                                       \
+  {                                                                                                               \
+    const f32x2* src_ = Y + (size_t)(IMG)*NBINS;                                                                  \
+    _Pragma("unroll") for (int k = 0; k < FFT_EPT; ++k)                                                           \
+      if (k * FFT_THR < nelem) pf[k] = src_[min(tid + k * FFT_THR, nelem - 1)];                                   \
+  }
+  if (blockIdx.x < images) FFT_PREFETCH_Y(blockIdx.x)
   for (int img = blockIdx.x; img < images; img += gridDim.x) {
     const int nb = img / Cout, o = img - nb * Cout;
-    const f32x2* src = Y + (size_t)img * NBINS;
-    __syncthreads();
-    for (int i = tid; i < V * P; i += FFT_THR) {
-      const int u = i / V, v = i - u * V;   // global order: v fastest
-      Cc[v * PS + u] = src[i];
-    }
-    __syncthreads();
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < FFT_EPT; ++k)
+      if (tid + k * FFT_THR < nelem) Cc[ldst[k]] = pf[k];
+    lds_barrier();
+    if (img + (int)gridDim.x < images) FFT_PREFETCH_Y(img + gridDim.x)
+#ifdef OS2D_DIAG_FFT_NOCOL
+    f32x2* Rc = Cc;
+#else
     f32x2* Rc = fft_batch<true>(Cc, D, P, V, PS, pl.np_col, pl.rad_col, tP, tid);
+#endif
     // ---- rows 2p, 2p+1 (only h < H are needed) as one complex spectrum Z[v] = X_2p[v] + i X_2p+1[v], v < Q, with the
     // Hermitian halves of the two real rows: X[Q - v] = conj X[v].  Rc may be D = A | B: stage through registers per element
     // into the row buffer that does not overlap what is still to be read - rows go to Bf (second half of A | B) only after
     // the column results were copied out, so copy the needed H x V block to Cc's region first when Rc aliases A | B.
     f32x2* S = Rc;
     if (Rc == D) {   // move the H x V block that is still needed out of A | B (Cc is free now)
-      for (int i = tid; i < V * H; i += FFT_THR) {
-        const int v = i / H, u = i - v * H;
-        Cc[v * PS + u] = Rc[v * PS + u];
-      }
-      __syncthreads();
+      for (int v = wv; v < V; v += NWV)
+        for (int u = lane; u < H; u += 64) Cc[v * PS + u] = Rc[v * PS + u];
+      lds_barrier();
       S = Cc;
     }
-    for (int i = tid; i < HP * Q; i += FFT_THR) {
-      const int p = i / Q, v = i - p * Q;
-      const int vv = v < V ? v : Q - v;                 // Hermitian mirror
-      f32x2 x0 = S[vv * PS + 2 * p];
-      f32x2 x1 = (2 * p + 1 < H) ? S[vv * PS + 2 * p + 1] : f32x2{0.f, 0.f};
-      if (v >= V) {
-        x0 = cconj(x0);
-        x1 = cconj(x1);
+    for (int p = wv; p < HP; p += NWV)
+      for (int v = lane; v < Q; v += 64) {
+        const int vv = v < V ? v : Q - v;                 // Hermitian mirror
+        f32x2 x0 = S[vv * PS + 2 * p];
+        f32x2 x1 = (2 * p + 1 < H) ? S[vv * PS + 2 * p + 1] : f32x2{0.f, 0.f};
+        if (v >= V) {
+          x0 = cconj(x0);
+          x1 = cconj(x1);
+        }
+        A[p * QS + v] = f32x2{x0[0] - x1[1], x0[1] + x1[0]};      // x0 + i x1
       }
-      A[i] = f32x2{x0[0] - x1[1], x0[1] + x1[0]};       // x0 + i x1
-    }
-    __syncthreads();
-    f32x2* R = fft_batch<true>(A, Bf, Q, HP, Q, pl.np_row, pl.rad_row, tQ, tid);
+    lds_barrier();
+#ifdef OS2D_DIAG_FFT_NOROW
+    f32x2* R = A;
+#else
+    f32x2* R = fft_batch<true>(A, Bf, Q, HP, QS, pl.np_row, pl.rad_row, tQ, tid);
+#endif
     // ---- epilogue: y = re / im of R (rows 2p / 2p+1), + bias, ReLU, channel scale, fp16 hi | lo into the SHB unit of
     // (nb, o / 8) at slot o % 8 (2-byte stores: the 8 channels of a unit come from 8 different images)
     const float bias = bp[o], osc = bp[2 * MTP + o];
     const int grp = o >> 3, slot = o & 7;
     _Float16* hi = reinterpret_cast<_Float16*>(out + (((size_t)nb * ((Cout + 7) >> 3) + grp) * 2 + 0) * (size_t)PLANE * 16) + slot;
     _Float16* lo = reinterpret_cast<_Float16*>(out + (((size_t)nb * ((Cout + 7) >> 3) + grp) * 2 + 1) * (size_t)PLANE * 16) + slot;
-    for (int i = tid; i < H * W; i += FFT_THR) {
-      const int h = i / W, w = i - h * W;
-      const f32x2 z = R[(h >> 1) * Q + w];
-      float t = ((h & 1) ? z[1] : z[0]) * norm + bias;
-      t = fmaxf(t, 0.f) * osc;
-      if (!(fabsf(t) <= 65504.f)) bad = true;
-      const _Float16 hv = (_Float16)t;
-      const size_t cell = (size_t)BASE + (size_t)h * Ws + w;
-      hi[cell * 8] = hv;
-      lo[cell * 8] = (_Float16)(t - (float)hv);
-    }
+    for (int h = wv; h < H; h += NWV)
+      for (int w = lane; w < W; w += 64) {
+        const f32x2 z = R[(h >> 1) * QS + w];
+        float t = ((h & 1) ? z[1] : z[0]) * norm + bias;
+        t = fmaxf(t, 0.f) * osc;
+        if (!(fabsf(t) <= 65504.f)) bad = true;
+        const _Float16 hv = (_Float16)t;
+        const size_t cell = (size_t)BASE + (size_t)h * Ws + w;
+#ifdef OS2D_DIAG_FFT_NOSTORE
+        if (t == 123.456f)
+#endif
+        {
+          hi[cell * 8] = hv;
+          lo[cell * 8] = (_Float16)(t - (float)hv);
+        }
+      }
   }
   if (status != nullptr && __builtin_amdgcn_ballot_w64(bad) != 0ull) {
     if ((tid & 63) == 0) __hip_atomic_store(status, OS2D_STATUS_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -283,14 +362,20 @@ bool make_plan(int H, int W, FftPlan* pl, size_t* lds) {
   pl->Q = next_size(W + 3);
   pl->V = pl->Q / 2 + 1;
   pl->PS = pl->P + 1;
+#ifdef OS2D_DIAG_FFT_QS0
+  pl->QS = pl->Q;
+#else
+  pl->QS = pl->Q + 1;
+#endif
   pl->np_row = factor(pl->Q, pl->rad_row);
   pl->np_col = factor(pl->P, pl->rad_col);
   if (!pl->np_row || !pl->np_col) return false;
   const int HP = (H + 1) / 2;
-  const size_t rows = (size_t)2 * HP * pl->Q, cc = (size_t)pl->V * pl->PS;
+  const size_t rows = (size_t)2 * HP * pl->QS, cc = (size_t)pl->V * pl->PS;
   const size_t ab = rows > cc ? rows : cc;
   pl->AB = (int)ab;
   *lds = (size_t)(pl->Q + pl->P + ab + cc) * 8;
+  if ((size_t)HP * pl->Q > (size_t)FFT_EPT_MAX * FFT_THR || (size_t)pl->P * pl->V > (size_t)FFT_EPT_MAX * FFT_THR) return false;
   return *lds <= 160 * 1024;
 }
 
@@ -324,7 +409,9 @@ int os2d_launch_fft_forward(const float* corr, const float* inv, float* X, const
     os2d_set_error("fft_forward: a %dx%d map does not fit the in-LDS transform", H, W);
     return -3;
   }
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fft_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int ept = (((H + 1) / 2) * pl.Q + FFT_THR - 1) / FFT_THR;
+  auto kern = ept <= 6 ? fft_forward_kernel<6> : ept <= 10 ? fft_forward_kernel<10> : fft_forward_kernel<14>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) {
     os2d_set_error("hipFuncSetAttribute(fft_forward): %s", hipGetErrorString(e));
     return -4;
@@ -332,7 +419,7 @@ int os2d_launch_fft_forward(const float* corr, const float* inv, float* X, const
   const int images = NB * C;
   const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
   const int grid = images < 256 * per_cu * 4 ? images : 256 * per_cu * 4;
-  hipLaunchKernelGGL(fft_forward_kernel, dim3(grid), dim3(FFT_THR), lds, stream, corr, inv, reinterpret_cast<f32x2*>(X),
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(FFT_THR), lds, stream, corr, inv, reinterpret_cast<f32x2*>(X),
                      reinterpret_cast<const f32x2*>(twQ), reinterpret_cast<const f32x2*>(twP), pl, C, H, W,
                      os2d_round_up(pl.P * pl.V, 8), images);
   return check("fft_forward");
@@ -346,7 +433,9 @@ int os2d_launch_fft_inverse(const float* Y, const float* bp, int MTP, void* out,
     os2d_set_error("fft_inverse: a %dx%d map does not fit the in-LDS transform", H, W);
     return -3;
   }
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fft_inverse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int ept = (pl.P * pl.V + FFT_THR - 1) / FFT_THR;
+  auto kern = ept <= 6 ? fft_inverse_kernel<6> : ept <= 10 ? fft_inverse_kernel<10> : fft_inverse_kernel<14>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) {
     os2d_set_error("hipFuncSetAttribute(fft_inverse): %s", hipGetErrorString(e));
     return -4;
@@ -354,7 +443,7 @@ int os2d_launch_fft_inverse(const float* Y, const float* bp, int MTP, void* out,
   const int images = NB * Cout;
   const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
   const int grid = images < 256 * per_cu * 4 ? images : 256 * per_cu * 4;
-  hipLaunchKernelGGL(fft_inverse_kernel, dim3(grid), dim3(FFT_THR), lds, stream, reinterpret_cast<const f32x2*>(Y), bp, MTP,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(FFT_THR), lds, stream, reinterpret_cast<const f32x2*>(Y), bp, MTP,
                      static_cast<char*>(out), reinterpret_cast<const f32x2*>(twQ), reinterpret_cast<const f32x2*>(twP), pl,
                      Cout, H, W, os2d_round_up(pl.P * pl.V, 8), os2d_plane(H, W), images, status);
   return check("fft_inverse");

@@ -30,10 +30,15 @@ constexpr int SG_WUNITS = SG_CC * SG_BINS * SG_OH / 2;   // 16-byte units of a w
 constexpr int SG_XUNITS = SG_CC * SG_NB * SG_BINS / 2;   // ... of a spectra chunk: 2304
 constexpr int SG_XPF = (SG_XUNITS + SG_THR - 1) / SG_THR;  // 5 units per thread
 
+// NBLK = 2: a work-group owns a whole unit (8 bins x 64 output channels x 64 classes).  NBLK = 1: it owns one 32 x 32
+// QUARTER of a unit (same staging, a quarter of the matrix instructions) - used for the units left over after the last
+// full round of 256 work-groups, so that the tail of the launch costs a quarter of a round instead of a whole one.
+template <int NBLK>
 __global__ __launch_bounds__(SG_THR, 2) void spectral_gemm_kernel(const f32x2* wspec,  // [G][2][C][8][64] complex
                                                                   const f32x2* __restrict__ X,  // [NB][C][NBINS]
                                                                   f32x2* __restrict__ Y,        // [NB][Cout][NBINS]
-                                                                  int NB, int C, int Cout, int NBINS, int G) {
+                                                                  int NB, int C, int Cout, int NBINS, int G, int unit0,
+                                                                  int nunits) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   f32x2* ldsW = reinterpret_cast<f32x2*>(smem);                                      // [2][CC][8][64]
   f32x2* ldsX = reinterpret_cast<f32x2*>(smem + 2 * SG_WUNITS * 16);                 // [2][CC][8][64]
@@ -43,18 +48,20 @@ __global__ __launch_bounds__(SG_THR, 2) void spectral_gemm_kernel(const f32x2* w
   // o half fastest, so the two halves of a bin group and neighbouring bin groups - which share the spectra's cache lines -
   // run on one XCD at about the same time
   const int per = gridDim.x >> 3;
-  const int logical = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  const int nbt = (NB + SG_NB - 1) / SG_NB;
-  if (logical >= 2 * G * nbt) return;
+  const int lidx = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  constexpr int SUB = NBLK == 2 ? 1 : 4;                 // work-groups per unit
+  if (lidx >= nunits * SUB) return;
+  const int logical = unit0 + lidx / SUB, sub = lidx % SUB;
+  const int oq = NBLK == 2 ? 0 : (sub & 1), bq = NBLK == 2 ? 0 : (sub >> 1);   // quarter: o block / class block
   const int half = logical & 1, g = (logical >> 1) % G, bt = (logical >> 1) / G;
   const int nb0 = bt * SG_NB, bin0 = g * SG_BINS;
   const int nchunks = (C + SG_CC - 1) / SG_CC;
 
-  f32x16 yr[2][2], yi[2][2];
+  f32x16 yr[NBLK][NBLK], yi[NBLK][NBLK];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < NBLK; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NBLK; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         yr[a][b][r] = 0.f;
@@ -119,27 +126,35 @@ __global__ __launch_bounds__(SG_THR, 2) void spectral_gemm_kernel(const f32x2* w
 #endif
     }
     __builtin_amdgcn_sched_barrier(0);
-    const f32x2* wB = ldsW + (t & 1) * (SG_WUNITS * 2) + wv * SG_OH + l31;      // [c][bin = wv][o]
-    const f32x2* xB = ldsX + (t & 1) * (SG_XUNITS * 2) + wv * SG_NB + l31;      // [c][bin = wv][class]
+    const f32x2* wB = ldsW + (t & 1) * (SG_WUNITS * 2) + wv * SG_OH + oq * 32 + l31;      // [c][bin = wv][o]
+    const f32x2* xB = ldsX + (t & 1) * (SG_XUNITS * 2) + wv * SG_NB + bq * 32 + l31;      // [c][bin = wv][class]
     const int cc = min(SG_CC, C - t * SG_CC);
-#ifdef OS2D_DIAG_SG_UNROLL
-#pragma unroll 3
-#endif
-    for (int c = 0; c < cc; ++c) {
-      f32x2 kf[2], xf[2];
+    // fragments of channel c+1 are read while the 8 matrix instructions of channel c issue (two register sets)
+    f32x2 kf[2][NBLK], xf[2][NBLK];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) kf[a] = wB[c * SG_BINS * SG_OH + a * 32];
+    for (int a = 0; a < NBLK; ++a) kf[0][a] = wB[a * 32];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) xf[b] = xB[c * SG_BINS * SG_NB + b * 32];
+    for (int b = 0; b < NBLK; ++b) xf[0][b] = xB[b * 32];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const float ar = hw ? -kf[a][1] : kf[a][0];   // row of [Kr | -Ki]
-        const float ai = hw ? kf[a][0] : kf[a][1];    // row of [Ki |  Kr]
+    for (int c = 0; c < SG_CC; ++c) {
+      if (c < cc) {
+        const int cur = c & 1, nxt = cur ^ 1;
+        if (c + 1 < cc) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const float xb = hw ? xf[b][1] : xf[b][0];  // column of [Xr ; Xi]
-          yr[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, xb, yr[a][b], 0, 0, 0);
-          yi[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, xb, yi[a][b], 0, 0, 0);
+          for (int a = 0; a < NBLK; ++a) kf[nxt][a] = wB[(c + 1) * SG_BINS * SG_OH + a * 32];
+#pragma unroll
+          for (int b = 0; b < NBLK; ++b) xf[nxt][b] = xB[(c + 1) * SG_BINS * SG_NB + b * 32];
+        }
+#pragma unroll
+        for (int a = 0; a < NBLK; ++a) {
+          const float ar = hw ? -kf[cur][a][1] : kf[cur][a][0];   // row of [Kr | -Ki]
+          const float ai = hw ? kf[cur][a][0] : kf[cur][a][1];    // row of [Ki |  Kr]
+#pragma unroll
+          for (int b = 0; b < NBLK; ++b) {
+            const float xb = hw ? xf[cur][b][1] : xf[cur][b][0];  // column of [Xr ; Xi]
+            yr[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, xb, yr[a][b], 0, 0, 0);
+            yi[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, xb, yi[a][b], 0, 0, 0);
+          }
         }
       }
     }
@@ -156,14 +171,14 @@ __global__ __launch_bounds__(SG_THR, 2) void spectral_gemm_kernel(const f32x2* w
   // ---- epilogue: Y[class][o][bin]: the 8 waves of the group write the 8 consecutive bins of every (class, o) pair
   const int bin = bin0 + wv;
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int nb = nb0 + b * 32 + l31;
+  for (int b = 0; b < NBLK; ++b) {
+    const int nb = nb0 + (bq + b) * 32 + l31;
     if (nb >= NB) continue;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NBLK; ++a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int o = half * SG_OH + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hw;
+        const int o = half * SG_OH + (oq + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hw;
 #ifdef OS2D_DIAG_SG_NOSTORE
         if (o < Cout && yr[a][b][r] == 123.456f) {
 #else
@@ -190,17 +205,32 @@ int os2d_launch_spectral_gemm(const float* wspec, const float* X, float* Y, int 
   }
   const int G = NBINS / SG_BINS, nbt = (NB + SG_NB - 1) / SG_NB;
   const size_t lds = (size_t)(2 * SG_WUNITS + 2 * SG_XUNITS) * 16;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spectral_gemm_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) {
-    os2d_set_error("hipFuncSetAttribute(spectral_gemm): %s", hipGetErrorString(e));
-    return -4;
+  for (const void* k : {reinterpret_cast<const void*>(spectral_gemm_kernel<2>), reinterpret_cast<const void*>(spectral_gemm_kernel<1>)}) {
+    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      os2d_set_error("hipFuncSetAttribute(spectral_gemm): %s", hipGetErrorString(e));
+      return -4;
+    }
   }
-  const long long groups = 2LL * G * nbt;
-  dim3 grid((unsigned)((groups + 7) / 8 * 8));
-  hipLaunchKernelGGL(spectral_gemm_kernel, grid, dim3(SG_THR), lds, stream, reinterpret_cast<const f32x2*>(wspec),
-                     reinterpret_cast<const f32x2*>(X), reinterpret_cast<f32x2*>(Y), NB, C, Cout, NBINS, G);
-  e = hipGetLastError();
+  // units = (class tile, bin group, o half); one unit fills a CU (144 KB of LDS).  Whole rounds of 256 units go to the
+  // full-tile kernel; what is left (16 of 784 units at 64 classes - a fourth round for 2 % of the work) is cut into
+  // 32 x 32 quarters so that the tail takes a quarter of a round.
+  const long long units = 2LL * G * nbt;
+  const long long main_units = units >= 256 ? units / 256 * 256 : 0;
+  const f32x2* w = reinterpret_cast<const f32x2*>(wspec);
+  const f32x2* x = reinterpret_cast<const f32x2*>(X);
+  f32x2* y = reinterpret_cast<f32x2*>(Y);
+  if (main_units > 0) {
+    dim3 grid((unsigned)((main_units + 7) / 8 * 8));
+    hipLaunchKernelGGL(spectral_gemm_kernel<2>, grid, dim3(SG_THR), lds, stream, w, x, y, NB, C, Cout, NBINS, G, 0, (int)main_units);
+  }
+  if (units > main_units) {
+    const long long tail = units - main_units;
+    dim3 grid((unsigned)((tail * 4 + 7) / 8 * 8));
+    hipLaunchKernelGGL(spectral_gemm_kernel<1>, grid, dim3(SG_THR), lds, stream, w, x, y, NB, C, Cout, NBINS, G, (int)main_units,
+                       (int)tail);
+  }
+  hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     os2d_set_error("spectral_gemm launch: %s", hipGetErrorString(e));
     return -4;

@@ -2,7 +2,7 @@
 """Benchmark of the MI355X OS2D head: query-image-pairs/s (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--classes B_per_gpu | --classes-total B] [--variant v2|v1]
-                    [--precision f16x3|f16x2|f32] [--pyramid] [--gather all|scores|detections]
+                    [--precision fft|f16x3|f16x2|f32] [--pyramid] [--gather all|scores|detections]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -26,7 +26,13 @@ Workloads
                    --classes B keeps B classes per GPU instead (weak scaling).
 
 Arithmetic (``--precision``):
-  f16x3 (default)  every fp32 operand of the four GEMM-shaped stages is split into fp16 hi + lo and each product is
+  fft (default)    as f16x3, except that the dominant 7x7 layer (225 -> 128 channels) runs in the frequency domain in fp32:
+                   in-LDS real FFT of the normalised correlation maps, one complex GEMM per frequency bin on
+                   v_mfma_f32_32x32x2_f32, inverse FFT with the bias / ReLU / fp16-split epilogue fused.  16.7x fewer
+                   multiply-adds than the direct layer, fp32 arithmetic throughout (closer to an fp64 evaluation than the
+                   direct fp32 kernel); class batches below 12 pairs and maps that do not fit the in-LDS transform take
+                   the f16x3 kernel;
+  f16x3            every fp32 operand of the four GEMM-shaped stages is split into fp16 hi + lo and each product is
                    evaluated with three v_mfma_f32_32x32x16_f16 (fp32 accumulation); per-channel power-of-two scales
                    derived from rigorous bounds make fp16 overflow impossible for finite inputs (a sticky status flag
                    reports anything else).  Outputs agree with the reference to the same 2.4e-7 as the fp32 mode
@@ -40,9 +46,12 @@ The primary line is measured in the selected mode; the other modes are timed rig
 "other_precisions" so all are always on record.
 
 Prints ONE JSON line on rank 0 with the driver's contract fields plus
-  roofline     - the dominant kernel (conv 7x7 225->128 MFMA implicit GEMM): ALGORITHMIC FLOPs per launch divided by its
-                 mean launch duration, measured LIVE with HIP events recorded on the launch stream inside the timed
-                 steps, against the dense MFMA peak of the instruction it runs on.  `traffic` / `hbm_gbps` /
+  roofline     - the dominant kernel: ALGORITHMIC FLOPs per launch divided by its mean launch duration, measured LIVE
+                 with HIP events recorded on the launch stream inside the timed steps, against the dense MFMA peak of
+                 the instruction it runs on.  fft mode: spectral_gemm_kernel (the per-bin complex GEMM [128 x 225] x
+                 [225 x pairs] over the P*(Q/2+1) bins of the transform, 8 real FLOPs per complex multiply-add; its
+                 operands are streamed once from HBM, so the HBM view of the same launch is given as well);
+                 direct modes: the conv 7x7 225->128 MFMA implicit GEMM.  `traffic` / `hbm_gbps` /
                  `mfma_pipe_busy` / `effective_clock_ghz` are REPLAYED from the committed rocprofv3 PMC passes
                  (profiles/conv1_traffic_<precision>.json, see `counters_source`), scaled to the class count of the run
   stages_ms    - mean duration of every stage of the step (same events)
@@ -85,7 +94,7 @@ def parse():
     ap.add_argument("--classes-total", type=int, default=None,
                     help="classes in total, block-sharded over the ranks (strong scaling); default 1024 at N>1")
     ap.add_argument("--variant", default="v2", choices=["v2", "v1"], help="v2: affine+inverse (P=6); v1: simplified (P=4)")
-    ap.add_argument("--precision", default=os.environ.get("OS2D_PRECISION", "f16x3"), choices=["f32", "f16x3", "f16x2", "fft"])
+    ap.add_argument("--precision", default=os.environ.get("OS2D_PRECISION", "fft"), choices=["f32", "f16x3", "f16x2", "fft"])
     ap.add_argument("--pyramid", action="store_true",
                     help="BASELINE configs[4]: 7-scale pyramid (0.5-1.6) of the 1280x960 image, one HIP stream per level; "
                          "a pair then means one (image, class) over all 7 levels")
@@ -281,8 +290,8 @@ class Workload(object):
         return w
 
     def _new_event_set(self):
-        arr = (ctypes.c_void_p * 10)()
-        for i in range(10):
+        arr = (ctypes.c_void_p * 13)()
+        for i in range(13):
             ev = ctypes.c_void_p()
             self._lib_mod.check(self.lib.os2d_prof_event_create(ctypes.byref(ev)), "os2d_prof_event_create")
             arr[i] = ev.value
@@ -302,7 +311,7 @@ class Workload(object):
         head, sharded, runner = self.head, self.sharded, self.runner
         head.precision = precision
         staged = sharded is None and runner is None
-        # one set of 10 stage events per timed step, so nothing has to be read back inside the timed region
+        # one set of 13 stage events per timed step, so nothing has to be read back inside the timed region
         event_sets = [self._new_event_set() for _ in range(steps)] if staged else []
         pending = []
 
@@ -358,10 +367,15 @@ class Workload(object):
                 for st in range(5):
                     self._lib_mod.check(self.lib.os2d_prof_event_elapsed_ms(evs[2 * st], evs[2 * st + 1], ctypes.byref(ms)), "elapsed")
                     row.append(ms.value)
+                if precision == "fft":       # sub-stages of the 7x7 layer: forward FFT | spectral GEMM | inverse FFT
+                    for a, b in ((10, 11), (11, 12), (12, 3)):
+                        if self.lib.os2d_prof_event_elapsed_ms(evs[a], evs[b], ctypes.byref(ms)) != 0:
+                            break                # not recorded: the head took its f16x3 fallback
+                        row.append(ms.value)
                 rows.append(row)
                 for ev in evs:
                     self.lib.os2d_prof_event_destroy(ev)
-            stage_ms = [sum(r[st] for r in rows) / len(rows) for st in range(5)]
+            stage_ms = [sum(r[st] for r in rows) / len(rows) for st in range(min(len(r) for r in rows))]
         return dt, stage_ms
 
     def whole_head_flops_per_class(self):
@@ -374,6 +388,8 @@ class Workload(object):
         time) - `kernel` says which."""
         peak = PEAK[precision]
         B = self.B_local
+        if stage_ms is not None and precision == "fft" and len(stage_ms) >= 8:
+            return self.roofline_fft(stage_ms)
         if stage_ms is not None:
             flops = FLOP_PER_LOC["conv1"] * H_FM * W_FM * B            # algorithmic FLOPs of ONE conv1 launch
             seconds = stage_ms[1] * 1e-3
@@ -382,6 +398,8 @@ class Workload(object):
                 else "frequency domain: fft_forward + spectral_gemm (v_mfma_f32_32x32x2_f32) + fft_inverse; the FLOPs are the "
                      "DIRECT layer's (the transform route executes 16.7x fewer), so frac may exceed 1" if precision == "fft"
                 else "conv_f16x3_kernel<7,...>, v_mfma_f32_32x32x16_f16 x{} per product".format(precision[-1]))
+        elif precision == "fft":
+            return self.roofline_fft_whole(seconds_per_step)
         else:
             flops = self.whole_head_flops_per_class() * B
             seconds = seconds_per_step
@@ -421,6 +439,59 @@ class Workload(object):
                 r["executed_frac_of_peak"] = round(terms * achieved * 1.118 / peak, 4)
         return r
 
+    def roofline_fft_whole(self, seconds):
+        """fft mode without stage events (several streams / ranks): all MFMA work of one rank's step against the blend of
+        the two instruction peaks it runs on - the correlation, the two 5x5 layers (and the 7x7 layer of maps that do not
+        fit the in-LDS transform) count their ALGORITHMIC FLOPs against the fp16 MFMA peak (each costs three MFMA products:
+        ceiling 1/3), the per-bin complex GEMMs their executed FLOPs against the fp32 MFMA peak."""
+        B = self.B_local
+        levels = LEVEL_HW if self.pyramid else [(H_FM, W_FM)]
+        f16 = f32 = 0
+        for h, w in levels:
+            pP, pQ, nb = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            per_loc = FLOP_PER_LOC["corr"] + FLOP_PER_LOC["conv2"] + 2 * self.P * 64 * 25
+            if self.lib.os2d_fft_sizes(h, w, ctypes.byref(pP), ctypes.byref(pQ), ctypes.byref(nb)) == 0:
+                f32 += 8 * 128 * 225 * B * pP.value * (pQ.value // 2 + 1)
+            else:
+                per_loc += FLOP_PER_LOC["conv1"]
+            f16 += per_loc * h * w * B
+        peak = (f16 + f32) / (f16 / PEAK["f16x3"] + f32 / PEAK["fft"])
+        achieved = (f16 + f32) / seconds
+        return {"kernel": "whole head of one rank: correlation + 5x5 layers on v_mfma_f32_32x32x16_f16 (algorithmic FLOPs, three "
+                          "MFMA products each) + per-bin complex GEMMs of the 7x7 layer on v_mfma_f32_32x32x2_f32 (executed FLOPs)"
+                          + (", 7 levels on 7 HIP streams" if self.pyramid else ""),
+                "bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": None, "flops_per_launch": f16 + f32,
+                "flops_fp16_mfma_algorithmic": f16, "flops_fp32_mfma_executed": f32,
+                "peak_is": "FLOP-weighted harmonic blend of the fp16 (2500) and fp32 (157.3) dense MFMA peaks for this mix",
+                "avg_launch_ms": round(seconds * 1e3, 4), "timing": "wall clock of the timed steps, this run"}
+
+    def roofline_fft(self, stage_ms):
+        """fft mode: the spectral GEMM (dominant kernel of the step).  Per bin Y[128 x pairs] = K[128 x 225] X[225 x pairs]
+        in complex fp32 = 8 real FLOPs per complex multiply-add, all of them issued as v_mfma_f32_32x32x2_f32 with
+        k = {re, im}; bins = P * (Q/2 + 1) of the P x Q transform of the map.  Algorithmic HBM bytes: the weight spectra,
+        the input spectra and the output spectra once each (8 B per complex value)."""
+        pP, pQ, nb = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        self.lib.os2d_fft_sizes(H_FM, W_FM, ctypes.byref(pP), ctypes.byref(pQ), ctypes.byref(nb))
+        bins, pairs = pP.value * (pQ.value // 2 + 1), self.B_local
+        fwd, gemm, inv = stage_ms[5] * 1e-3, stage_ms[6] * 1e-3, stage_ms[7] * 1e-3
+        flops = 8 * 128 * 225 * pairs * bins
+        nbytes = 8 * bins * (128 * 225 + 225 * pairs + 128 * pairs)
+        peak = PEAK["fft"]
+        direct = FLOP_PER_LOC["conv1"] * H_FM * W_FM * pairs
+        return {"kernel": "spectral_gemm_kernel (7x7 layer in the frequency domain: complex GEMM per bin, v_mfma_f32_32x32x2_f32)",
+                "bound": "mfma", "achieved": round(flops / gemm / 1e12, 3), "peak": peak / 1e12, "unit": "TFLOP/s",
+                "frac": round(flops / gemm / peak, 4), "traffic": None, "flops_per_launch": flops,
+                "avg_launch_ms": round(gemm * 1e3, 4), "timing": "HIP events on the launch stream, this run",
+                "transform": [pP.value, pQ.value], "bins": bins,
+                "algorithmic_bytes": nbytes, "hbm_view": {"achieved": round(nbytes / gemm / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                                          "frac": round(nbytes / gemm / 8e12, 4)},
+                "layer_ms": {"fft_forward": round(fwd * 1e3, 4), "spectral_gemm": round(gemm * 1e3, 4),
+                             "fft_inverse": round(inv * 1e3, 4)},
+                "layer_direct_equivalent_tflops": round(direct / (stage_ms[1] * 1e-3) / 1e12, 1),
+                "note": "layer_direct_equivalent_tflops = FLOPs of the DIRECT 7x7 layer / time of the whole frequency-domain "
+                        "layer (the transform route executes {:.1f}x fewer FLOPs); not a utilisation figure".format(direct / flops)}
+
     def describe(self):
         return ("OS2D head, ResNet50-C4 features of one 1280x960 image ({}), {} classes in total ({} on this GPU), {}, {} "
                 "(P={}, inverse={}), head only, features resident in HBM".format(
@@ -434,10 +505,16 @@ def precision_deviation(w):
     out = {}
     with torch.no_grad():
         ref = [t.clone() for t in w.head(w.fm, precision="f32")]
+        keep = {}
         for p in ("f16x3", "f16x2", "fft"):
             o = w.head(w.fm, precision=p)
             out[p] = {"cls": float((o[1] - ref[1]).abs().max()), "loc": float((o[0] - ref[0]).abs().max()),
                       "corners_px": float((o[3] - ref[3]).abs().max())}
+            if p != "f16x2":
+                keep[p] = o[0].clone()
+        # the two fp32-equivalent modes share every stage but the 7x7 layer: their outputs differ in the last bits only
+        out["fft_vs_f16x3_loc"] = float((keep["fft"] - keep["f16x3"]).abs().max())
+        out["fft_vs_f16x3_identical_fraction"] = float((keep["fft"] == keep["f16x3"]).float().mean())
         out["range_flag"] = w.head.range_status(synchronize=True)
     return out
 
@@ -449,7 +526,7 @@ def sweep_entry(dev, name, classes, variant, pyramid, precision, steps, warmup):
          "precision": precision, "steps": steps, "warmup": warmup, "value": round(classes * steps / dt, 2),
          "unit": "query-image-pairs/s", "ms_per_step": round(dt / steps * 1e3, 4)}
     if stage_ms:
-        e["stages_ms"] = {k: round(v, 4) for k, v in zip(STAGES, stage_ms)}
+        e["stages_ms"] = {k: round(v, 4) for k, v in zip(STAGES, stage_ms)}      # zip stops at the 5 stages
     e["roofline"] = w.roofline(precision, stage_ms, dt / steps)
     e["head_tflops_algorithmic"] = round(w.whole_head_flops_per_class() * classes * steps / dt / 1e12, 3)
     return e, w
@@ -457,6 +534,9 @@ def sweep_entry(dev, name, classes, variant, pyramid, precision, steps, warmup):
 
 def main():
     args = parse()
+    if os.environ.get("OS2D_BENCH_WATCHDOG"):      # debugging aid: dump the Python stacks every N seconds to stderr
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["OS2D_BENCH_WATCHDOG"]), repeat=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define OS2D_ABI_VERSION 4
+#define OS2D_ABI_VERSION 5
 
 /* arithmetic of the two large TransformNet convolutions (everything else is fp32 in both modes) */
 #define OS2D_PRECISION_F32 0   /* v_mfma_f32_32x32x2_f32: exact fp32 (k-ordered fmaf chain)                            */
@@ -108,9 +108,11 @@ int os2d_class_split(const float* qp, void* qs, int B, int C, void* stream);
 /* ---- extended head entry point: identical to os2d_head_forward, plus
  *   precision     OS2D_PRECISION_F32 (w1..w3 from os2d_pack_conv; qs ignored) or OS2D_PRECISION_F16X3 / _F16X2
  *                 (w1..w3 from os2d_pack_conv_f16x3, qs [B, C/8, 2, 256, 8] halves from os2d_class_split);
- *   stage_events  NULL, or an array of 10 hipEvent_t (from os2d_prof_event_create); events [2s] / [2s+1] are recorded
- *                 on `stream` right before / after stage s of the FIRST class chunk
- *                 (s = 0 correlation, 1 conv 7x7, 2 conv 5x5 128->64, 3 conv 5x5 64->P, 4 resample+encode);
+ *   stage_events  NULL, or an array of 13 hipEvent_t (from os2d_prof_event_create; NULL entries are skipped); events
+ *                 [2s] / [2s+1] are recorded on `stream` right before / after stage s of the FIRST class chunk
+ *                 (s = 0 correlation, 1 conv 7x7, 2 conv 5x5 128->64, 3 conv 5x5 64->P, 4 resample+encode); under
+ *                 OS2D_PRECISION_FFT events [10], [11], [12] additionally mark the start of the forward transform, its end
+ *                 (= start of the spectral GEMM) and the end of the GEMM (= start of the inverse transform) inside stage 1;
  *   chunk_classes NULL, or receives the number of classes per chunk chosen for the given workspace;
  *   status        NULL, or a device-visible int (device memory or mapped pinned host memory) that receives sticky
  *                 status bits (plain system-scope stores, never cleared by the library): OS2D_STATUS_F16_RANGE when a split-fp16 activation left the

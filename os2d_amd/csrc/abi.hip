@@ -389,9 +389,12 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     if (fft_bins) {
       // the 7x7 layer in the frequency domain (fft.hip, spectral.hip): fp32 FFT of relu(corr) / norm -> one complex GEMM
       // per bin on the fp32 matrix cores -> inverse FFT + bias + ReLU + split into the activation buffer of the 5x5 layer
-      if ((rc = os2d_launch_fft_forward(corr, invn, xspec, twQ, twP, NB, OS2D_K, H, W, st))) return rc;
-      if ((rc = os2d_launch_spectral_gemm(wspec, xspec, yspec, NB, OS2D_K, 128, fft_bins, st))) return rc;
       if ((rc = os2d_launch_border_zero_shb_planes(h1, NB * 16 * 2, H, W, st))) return rc;
+      mark(b0, 10);
+      if ((rc = os2d_launch_fft_forward(corr, invn, xspec, twQ, twP, NB, OS2D_K, H, W, st))) return rc;
+      mark(b0, 11);
+      if ((rc = os2d_launch_spectral_gemm(wspec, xspec, yspec, NB, OS2D_K, 128, fft_bins, st))) return rc;
+      mark(b0, 12);
       if ((rc = os2d_launch_fft_inverse(yspec, b1, 128, h1, twQ, twP, NB, 128, H, W, status, st))) return rc;
     } else if (f16) {
       if ((rc = os2d_launch_conv_f16x3(1, rpad, w1, b1, status, h1, NB, P, H, W, terms1, st))) return rc;

@@ -13,6 +13,7 @@ All arithmetic of the path runs in the hand-written gfx950 kernels (os2d_amd/csr
 memory, the stream and the parameter containers.  There is no CPU / eager fallback: CPU tensors raise.
 Training through the head (autograd) is out of scope and raises as well.
 """
+import collections
 import ctypes
 import logging
 import os
@@ -28,6 +29,7 @@ TEMPLATE = 15
 QROWS = 256
 FFT_MIN_PAIRS = 12      # precision "fft": image x class pairs below which the direct 7x7 kernel is used instead
 PRECISIONS = {"f32": 0, "f16x3": 1, "f16x2": 2, "fft": 3}     # OS2D_PRECISION_* of include/os2d_hip.h
+DEFAULT_PRECISION = "fft"
 
 
 def resolve_precision(precision=None):
@@ -37,8 +39,8 @@ def resolve_precision(precision=None):
     matrix-core work, box regression within 5e-5 and scores within 1e-6 of fp32, inside the 1e-4 parity bound), or "fft"
     (as f16x3, but the 7x7 layer runs in the frequency domain in fp32: real FFT -> one complex GEMM per bin on the fp32
     matrix cores -> inverse FFT; fp32-equivalent, 16.7x fewer multiply-adds; maps that do not fit the in-LDS transform and
-    small class batches fall back to f16x3).  Default from $OS2D_PRECISION, else "f16x3"."""
-    precision = precision or os.environ.get("OS2D_PRECISION", "f16x3")
+    small class batches fall back to f16x3).  Default from $OS2D_PRECISION, else "fft" (the fastest fp32-equivalent mode)."""
+    precision = precision or os.environ.get("OS2D_PRECISION", DEFAULT_PRECISION)
     if precision not in PRECISIONS:
         raise ValueError("precision must be one of {}, got {!r}".format(sorted(PRECISIONS), precision))
     return precision
@@ -106,7 +108,22 @@ class _StreamOrdered(object):
         stream = torch.cuda.current_stream(device)
         if stream.cuda_stream != self._stream:
             stream.wait_event(self._event)
+            for t in self._tensors():     # the cache may drop the operand while this stream's kernels still read it
+                t.record_stream(stream)
         return self.value
+
+    def _tensors(self):
+        values = self.value if isinstance(self.value, (tuple, list)) else (self.value,)
+        return [t for t in values if isinstance(t, torch.Tensor)]
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self._tensors())
+
+
+def spectra_cache_cap_bytes():
+    """Upper bound for the cached weight spectra of precision "fft" over all transform sizes (least recently used sizes
+    are dropped first; 722 MB for the 64 x 96 transform of a 60 x 80 map).  $OS2D_FFT_CACHE_BYTES, default 16 GiB."""
+    return int(os.environ.get("OS2D_FFT_CACHE_BYTES", 16 << 30))
 
 
 def _require_device_f32(t, name):
@@ -157,6 +174,7 @@ class TransformationNet(nn.Module):
                 self.linear.bias[2] = 1
         self.output_dim = output_dim
         self._packed_cache = {}
+        self._spectra_cache = collections.OrderedDict()     # (P, Q) -> _StreamOrdered, least recently used first
         if use_cuda:
             self.conv.cuda()
             self.linear.cuda()
@@ -286,18 +304,23 @@ class TransformationNet(nn.Module):
         the map does not fit the in-LDS transform.  The BatchNorm-folded 7x7 filters are centred on the origin of the
         P x Q grid (tap (t, s) at ((3 - t) mod P, (3 - s) mod Q): the circular convolution then IS the zero-padded
         correlation of head.py:619 for the first H x W samples), transformed once with torch.fft in float64 and packed for
-        os2d_spectral_gemm; the twiddle tables are exact float64 values rounded once.  Cached per map size until a
-        parameter changes (722 MB for 60 x 80; event-tracked like ``packed``)."""
+        os2d_spectral_gemm; the twiddle tables are exact float64 values rounded once.  Cached per TRANSFORM size (P, Q) -
+        sizes are products of 2s and 3s, so the many map sizes of a dataset share a few tens of them - until a parameter
+        changes, least recently used first out above ``spectra_cache_cap_bytes()`` (722 MB for 60 x 80; event-tracked like
+        ``packed``)."""
         lib = _lib.load()
         cP, cQ, cN = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         if lib.os2d_fft_sizes(int(H), int(W), ctypes.byref(cP), ctypes.byref(cQ), ctypes.byref(cN)) != 0:
             return None
         P, Q, nbins = cP.value, cQ.value, cN.value
         dev = self.linear.weight.device
-        key = ("fft", H, W) + self._state_key()
-        cached = self._packed_cache.get(("fft", H, W))
+        key = self._state_key()
+        cached = self._spectra_cache.get((P, Q))
         if cached is not None and cached.key == key:
+            self._spectra_cache.move_to_end((P, Q))
             return cached.get(dev)
+        for k in [k for k, c in self._spectra_cache.items() if c.key != key]:
+            del self._spectra_cache[k]                           # a parameter changed: every cached size is stale
         with torch.cuda.device(dev), torch.no_grad():
             (w1, _), _, _ = self._folded()                       # float64 [128,225,7,7]
             V = Q // 2 + 1
@@ -321,7 +344,13 @@ class TransformationNet(nn.Module):
                 ang = -2.0 * torch.pi * m / n
                 return torch.stack([torch.cos(ang), torch.sin(ang)], 1).float().to(dev).contiguous()
             result = (wspec, table(Q), table(P), nbins)
-            self._packed_cache[("fft", H, W)] = _StreamOrdered(key, result, dev)
+            entry = _StreamOrdered(key, result, dev)
+            cap, used = spectra_cache_cap_bytes(), entry.nbytes()
+            for k in list(self._spectra_cache):                  # oldest first
+                if used + sum(c.nbytes() for c in self._spectra_cache.values()) <= cap:
+                    break
+                del self._spectra_cache[k]
+            self._spectra_cache[(P, Q)] = entry
         return result
 
     def forward(self, corr_maps, precision="f32"):
@@ -540,7 +569,7 @@ class Os2dHead(nn.Module):
         mask[:, :, pool_border_width:TEMPLATE - pool_border_width, pool_border_width:TEMPLATE - pool_border_width] = 1
         self.class_pool_mask = mask / mask.sum(dim=(2, 3), keepdim=True)
         self.aligner = aligner
-        self.precision = None      # None: follow $OS2D_PRECISION (default "f16x3"); or "f32" / "f16x3" / "f16x2"
+        self.precision = None      # None: follow $OS2D_PRECISION (default "fft"); or "f32" / "f16x3" / "f16x2" / "fft"
         # sticky status word of the split-fp16 kernels in mapped pinned host memory: the kernels store to it only when an
         # activation leaves the fp16 range (impossible for finite inputs, see TransformationNet.range_plan), the host
         # reads it without synchronising
@@ -614,7 +643,7 @@ class Os2dHead(nn.Module):
 
         ``out``: optional preallocated (loc, cls, corners) device tensors of exactly those shapes (contiguous) - used
         by the class-sharded wrapper to let the kernels write straight into the all-gather buffer.
-        ``stage_events``: optional ctypes array of 10 event handles for os2d_head_forward_profiled (bench.py).
+        ``stage_events``: optional ctypes array of 13 event handles for os2d_head_forward_profiled (bench.py).
         ``strict_range`` (default $OS2D_STRICT_RANGE, off): synchronise after a split-fp16 call and, if the range flag
         was raised, re-run it in exact fp32 before returning.  Without it the flag is looked at when the next call
         starts (no synchronisation): the head then switches itself to "f32" for good."""

@@ -136,3 +136,29 @@ def test_fft_inverse_matches_torch_fft_and_epilogue(H, W, NB, device):
     border[:, :, base:base + H * Ws].view(NB, Cout, H, Ws)[..., :W] = 0
     assert float(border.abs().max()) == 0.0
     assert int(status.item()) == 0
+
+
+def test_weight_spectra_cache_is_keyed_by_transform_size_and_bounded(device, monkeypatch):
+    """Map sizes that share a transform size share ONE cached weight spectrum; the cache drops the least recently used
+    size above its byte cap and is invalidated when a parameter changes."""
+    from os2d_amd.modeling import head as head_mod
+    from os2d_amd.utils import synthetic
+    net = head_mod.TransformationNet(output_dim=6)
+    net.load_state_dict(synthetic.make_transform_net_state(6, seed=2))
+    net.to(device).eval()
+    a = net.spectra(12, 20)          # P = 16, Q = 24
+    b = net.spectra(13, 21)          # same transform size
+    assert a[0].data_ptr() == b[0].data_ptr() and len(net._spectra_cache) == 1
+    c = net.spectra(20, 30)          # P = 24, Q = 36
+    assert len(net._spectra_cache) == 2 and c[0].data_ptr() != a[0].data_ptr()
+    one = next(iter(net._spectra_cache.values())).nbytes()
+    monkeypatch.setenv("OS2D_FFT_CACHE_BYTES", str(one + 1))
+    d = net.spectra(30, 40)          # larger than the cap: everything else goes, the new entry stays
+    assert list(net._spectra_cache) == [(36, 48)] and d[3] == 36 * 25 + (-36 * 25) % 8
+    monkeypatch.delenv("OS2D_FFT_CACHE_BYTES")
+    net.spectra(12, 20)
+    with torch.no_grad():
+        net.conv[0].weight.mul_(1.5)
+    e = net.spectra(12, 20)
+    assert list(net._spectra_cache) == [(16, 24)]
+    assert not torch.equal(e[0], a[0])

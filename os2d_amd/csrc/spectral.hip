@@ -21,14 +21,23 @@ namespace {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int SG_THR = 512;
-constexpr int SG_BINS = 8;     // bins per work-group (= waves)
+constexpr int SG_BINS = 8;     // bins per group of the packed weight layout
 constexpr int SG_CC = 9;       // channels per K chunk (225 = 25 * 9)
 constexpr int SG_OH = 64;      // output channels per work-group (half of 128)
 constexpr int SG_NB = 64;      // classes per work-group
-constexpr int SG_WUNITS = SG_CC * SG_BINS * SG_OH / 2;   // 16-byte units of a weight chunk (2 complex each): 2304
-constexpr int SG_XUNITS = SG_CC * SG_NB * SG_BINS / 2;   // ... of a spectra chunk: 2304
+#ifndef OS2D_SG_WB
+#define OS2D_SG_WB 4
+#endif
+// WB = bins (= waves) per work-group.  8: one work-group of 512 threads per CU (144 KB of LDS).  4: two independent
+// work-groups of 256 threads per CU (72 KB each, the two halves of a bin group): while one waits at its chunk barrier for
+// the next operands, the other keeps the matrix pipes busy.
+constexpr int SG_WB = OS2D_SG_WB;
+constexpr int SG_THR = SG_WB * 64;
+constexpr int SG_NBH = SG_BINS / SG_WB;                  // work-groups per bin group
+constexpr int SG_WUNITS = SG_CC * SG_WB * SG_OH / 2;     // 16-byte units of a weight chunk (2 complex each)
+constexpr int SG_XUNITS = SG_CC * SG_NB * SG_WB / 2;     // ... of a spectra chunk
 constexpr int SG_XPF = (SG_XUNITS + SG_THR - 1) / SG_THR;  // 5 units per thread
+constexpr int SG_SLOTS = 256 * SG_NBH;                   // work-groups resident on the chip at a time
 
 // NBLK = 2: a work-group owns a whole unit (8 bins x 64 output channels x 64 classes).  NBLK = 1: it owns one 32 x 32
 // QUARTER of a unit (same staging, a quarter of the matrix instructions) - used for the units left over after the last
@@ -44,17 +53,20 @@ __global__ __launch_bounds__(SG_THR, 2) void spectral_gemm_kernel(const f32x2* w
   f32x2* ldsX = reinterpret_cast<f32x2*>(smem + 2 * SG_WUNITS * 16);                 // [2][CC][8][64]
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hw = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // XCD-aware order (work-group L runs on XCD L % 8): consecutive logical indices = (class tile, bin group, o half) with the
-  // o half fastest, so the two halves of a bin group and neighbouring bin groups - which share the spectra's cache lines -
-  // run on one XCD at about the same time
+  // XCD-aware order (work-group L runs on XCD L % 8; each XCD has its own L2): every XCD takes a contiguous range of
+  // logical indices = (bin group, class tile, o half, part of the bin group), last fastest.  The work-groups that share
+  // cache lines run on one XCD at about the same time: the parts / halves of a bin group share the input spectra, the
+  // class tiles of a bin group share the weight spectra (which therefore leave HBM once, not once per class tile)
   const int per = gridDim.x >> 3;
   const int lidx = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   constexpr int SUB = NBLK == 2 ? 1 : 4;                 // work-groups per unit
   if (lidx >= nunits * SUB) return;
   const int logical = unit0 + lidx / SUB, sub = lidx % SUB;
   const int oq = NBLK == 2 ? 0 : (sub & 1), bq = NBLK == 2 ? 0 : (sub >> 1);   // quarter: o block / class block
-  const int half = logical & 1, g = (logical >> 1) % G, bt = (logical >> 1) / G;
-  const int nb0 = bt * SG_NB, bin0 = g * SG_BINS;
+  const int bh = logical % SG_NBH, lg = logical / SG_NBH;                      // part of the bin group
+  const int nbt = (NB + SG_NB - 1) / SG_NB;
+  const int half = lg & 1, bt = (lg >> 1) % nbt, g = (lg >> 1) / nbt;
+  const int nb0 = bt * SG_NB, bin0 = g * SG_BINS + bh * SG_WB;
   const int nchunks = (C + SG_CC - 1) / SG_CC;
 
   f32x16 yr[NBLK][NBLK], yi[NBLK][NBLK];
@@ -70,19 +82,21 @@ __global__ __launch_bounds__(SG_THR, 2) void spectral_gemm_kernel(const f32x2* w
 
   typedef const void __attribute__((address_space(1))) * gptr_t;
   typedef void __attribute__((address_space(3))) * lptr_t;
-  const char* wbase = reinterpret_cast<const char*>(wspec) + ((size_t)(g * 2 + half) * C) * SG_BINS * SG_OH * 8;
+  const char* wbase = reinterpret_cast<const char*>(wspec) + (((size_t)(g * 2 + half) * C) * SG_BINS + bh * SG_WB) * SG_OH * 8;
   u32x4 pfx[SG_XPF];
 
-  // weights of chunk t: contiguous in global memory, 1 KB per wave instruction straight into LDS
+  // weights of chunk t: WB * 512 contiguous bytes per channel, 1 KB per wave instruction straight into LDS
 #define SG_DMA_W(T)                                                                                               \
   {                                                                                                               \
     const int c0_ = (T)*SG_CC;                                                                                    \
-    const int units_ = min(SG_CC, C - c0_) * SG_BINS * SG_OH / 2;                                                 \
+    const int units_ = min(SG_CC, C - c0_) * SG_WB * SG_OH / 2;                                                   \
     const char* src_ = wbase + (size_t)c0_ * SG_BINS * SG_OH * 8;                                                 \
-    for (int u_ = wv * 64; u_ < units_; u_ += SG_THR)                                                             \
-      __builtin_amdgcn_global_load_lds((gptr_t)(src_ + (size_t)(u_ + lane) * 16),                                 \
+    for (int u_ = wv * 64; u_ < units_; u_ += SG_THR) {                                                           \
+      const int cl_ = u_ / (SG_WB * 32), r_ = u_ % (SG_WB * 32);                                                  \
+      __builtin_amdgcn_global_load_lds((gptr_t)(src_ + ((size_t)cl_ * SG_BINS * 32 + r_ + lane) * 16),            \
                                        (lptr_t)(reinterpret_cast<char*>(ldsW) + (((T)&1) * SG_WUNITS + u_) * 16), \
                                        16, 0, 0);                                                                 \
+    }                                                                                                             \
   }
   // spectra of chunk t: unit u = (c, class, bin pair); out-of-range classes / channels read a valid address and are
   // zeroed when stored to LDS
@@ -90,8 +104,9 @@ __global__ __launch_bounds__(SG_THR, 2) void spectral_gemm_kernel(const f32x2* w
   {                                                                                                               \
     _Pragma("unroll") for (int k_ = 0; k_ < SG_XPF; ++k_) {                                                       \
       const int u_ = min(tid + k_ * SG_THR, SG_XUNITS - 1);                                                       \
-      const int c_ = min((T)*SG_CC + u_ / (SG_NB * 4), C - 1), b_ = min(nb0 + (u_ >> 2) % SG_NB, NB - 1);         \
-      pfx[k_] = *reinterpret_cast<const u32x4*>(X + ((size_t)b_ * C + c_) * NBINS + bin0 + 2 * (u_ & 3));         \
+      const int c_ = min((T)*SG_CC + u_ / (SG_NB * (SG_WB / 2)), C - 1);                                          \
+      const int b_ = min(nb0 + (u_ / (SG_WB / 2)) % SG_NB, NB - 1);                                               \
+      pfx[k_] = *reinterpret_cast<const u32x4*>(X + ((size_t)b_ * C + c_) * NBINS + bin0 + 2 * (u_ % (SG_WB / 2))); \
     }                                                                                                             \
   }
 #define SG_STORE_X(T)                                                                                             \
@@ -99,12 +114,12 @@ __global__ __launch_bounds__(SG_THR, 2) void spectral_gemm_kernel(const f32x2* w
     _Pragma("unroll") for (int k_ = 0; k_ < SG_XPF; ++k_) {                                                       \
       const int u_ = tid + k_ * SG_THR;                                                                           \
       if (u_ < SG_XUNITS) {                                                                                       \
-        const int cl_ = u_ / (SG_NB * 4), bl_ = (u_ >> 2) % SG_NB, q_ = u_ & 3;                                   \
+        const int cl_ = u_ / (SG_NB * (SG_WB / 2)), bl_ = (u_ / (SG_WB / 2)) % SG_NB, q_ = u_ % (SG_WB / 2);      \
         const bool ok_ = (T)*SG_CC + cl_ < C && nb0 + bl_ < NB;                                                   \
         f32x2 e0_ = {__uint_as_float(pfx[k_][0]), __uint_as_float(pfx[k_][1])};                                   \
         f32x2 e1_ = {__uint_as_float(pfx[k_][2]), __uint_as_float(pfx[k_][3])};                                   \
         if (!ok_) e0_ = e1_ = f32x2{0.f, 0.f};                                                                    \
-        f32x2* dst_ = ldsX + ((T)&1) * (SG_XUNITS * 2) + (cl_ * SG_BINS + 2 * q_) * SG_NB + bl_;                  \
+        f32x2* dst_ = ldsX + ((T)&1) * (SG_XUNITS * 2) + (cl_ * SG_WB + 2 * q_) * SG_NB + bl_;                    \
         dst_[0] = e0_;                                                                                            \
         dst_[SG_NB] = e1_;                                                                                        \
       }                                                                                                           \
@@ -141,9 +156,9 @@ __global__ __launch_bounds__(SG_THR, 2) void spectral_gemm_kernel(const f32x2* w
         const int cur = c & 1, nxt = cur ^ 1;
         if (c + 1 < cc) {
 #pragma unroll
-          for (int a = 0; a < NBLK; ++a) kf[nxt][a] = wB[(c + 1) * SG_BINS * SG_OH + a * 32];
+          for (int a = 0; a < NBLK; ++a) kf[nxt][a] = wB[(c + 1) * SG_WB * SG_OH + a * 32];
 #pragma unroll
-          for (int b = 0; b < NBLK; ++b) xf[nxt][b] = xB[(c + 1) * SG_BINS * SG_NB + b * 32];
+          for (int b = 0; b < NBLK; ++b) xf[nxt][b] = xB[(c + 1) * SG_WB * SG_NB + b * 32];
         }
 #pragma unroll
         for (int a = 0; a < NBLK; ++a) {
@@ -212,11 +227,11 @@ int os2d_launch_spectral_gemm(const float* wspec, const float* X, float* Y, int 
       return -4;
     }
   }
-  // units = (class tile, bin group, o half); one unit fills a CU (144 KB of LDS).  Whole rounds of 256 units go to the
-  // full-tile kernel; what is left (16 of 784 units at 64 classes - a fourth round for 2 % of the work) is cut into
-  // 32 x 32 quarters so that the tail takes a quarter of a round.
-  const long long units = 2LL * G * nbt;
-  const long long main_units = units >= 256 ? units / 256 * 256 : 0;
+  // units = (class tile, bin group, o half, part of the bin group); 8 / WB units fill a CU.  Whole rounds of the resident
+  // work-groups go to the full-tile kernel; what is left (2 % of the work at 64 classes, which would cost a whole extra
+  // round) is cut into 32 x 32 quarters so that the tail takes a quarter of a round.
+  const long long units = 2LL * G * nbt * SG_NBH;
+  const long long main_units = units >= SG_SLOTS ? units / SG_SLOTS * SG_SLOTS : 0;
   const f32x2* w = reinterpret_cast<const f32x2*>(wspec);
   const f32x2* x = reinterpret_cast<const f32x2*>(X);
   f32x2* y = reinterpret_cast<f32x2*>(Y);

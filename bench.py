@@ -147,7 +147,7 @@ def replayed_counters(precision):
     """The committed rocprofv3 PMC passes of the conv 7x7 kernel (profiles/conv1_traffic_<precision>.json, written by
     tools/summarize_prof.py --traffic: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, SQ / GRBM pass;
     separate passes).  These are NOT measured in this run."""
-    path = os.path.join(REPO, "profiles", "conv1_traffic_{}.json".format(precision))
+    path = os.path.join(REPO, "profiles", "spectral_traffic_fft.json" if precision == "fft" else "conv1_traffic_{}.json".format(precision))
     if not os.path.exists(path):
         return None
     with open(path) as f:
@@ -367,10 +367,9 @@ class Workload(object):
                 for st in range(5):
                     self._lib_mod.check(self.lib.os2d_prof_event_elapsed_ms(evs[2 * st], evs[2 * st + 1], ctypes.byref(ms)), "elapsed")
                     row.append(ms.value)
-                if precision == "fft":       # sub-stages of the 7x7 layer: forward FFT | spectral GEMM | inverse FFT
+                if head.last_precision == "fft":   # sub-stages of the 7x7 layer: forward FFT | spectral GEMM | inverse FFT
                     for a, b in ((10, 11), (11, 12), (12, 3)):
-                        if self.lib.os2d_prof_event_elapsed_ms(evs[a], evs[b], ctypes.byref(ms)) != 0:
-                            break                # not recorded: the head took its f16x3 fallback
+                        self._lib_mod.check(self.lib.os2d_prof_event_elapsed_ms(evs[a], evs[b], ctypes.byref(ms)), "elapsed")
                         row.append(ms.value)
                 rows.append(row)
                 for ev in evs:
@@ -386,10 +385,13 @@ class Workload(object):
         """Roofline object.  With stage events: the conv 7x7 kernel alone (algorithmic FLOPs of one launch / its mean
         duration).  Without (several streams / ranks): the whole head of this rank (algorithmic FLOPs of a step / step
         time) - `kernel` says which."""
-        peak = PEAK[precision]
         B = self.B_local
         if stage_ms is not None and precision == "fft" and len(stage_ms) >= 8:
             return self.roofline_fft(stage_ms)
+        fell_back = precision == "fft" and stage_ms is not None     # staged run without the sub-stage events: the class batch
+        if fell_back:                                               # is below FFT_MIN_PAIRS and the direct f16x3 kernel ran
+            precision = "f16x3"
+        peak = PEAK[precision]
         if stage_ms is not None:
             flops = FLOP_PER_LOC["conv1"] * H_FM * W_FM * B            # algorithmic FLOPs of ONE conv1 launch
             seconds = stage_ms[1] * 1e-3
@@ -437,6 +439,8 @@ class Workload(object):
             if stage_ms is not None:
                 r["executed_mfma_tflops"] = round(terms * achieved * 1.118 / 1e12, 1)
                 r["executed_frac_of_peak"] = round(terms * achieved * 1.118 / peak, 4)
+        if fell_back:
+            r["note"] = "precision fft requested; with fewer than 12 image-class pairs the head runs the direct f16x3 7x7 kernel"
         return r
 
     def roofline_fft_whole(self, seconds):
@@ -479,7 +483,7 @@ class Workload(object):
         nbytes = 8 * bins * (128 * 225 + 225 * pairs + 128 * pairs)
         peak = PEAK["fft"]
         direct = FLOP_PER_LOC["conv1"] * H_FM * W_FM * pairs
-        return {"kernel": "spectral_gemm_kernel (7x7 layer in the frequency domain: complex GEMM per bin, v_mfma_f32_32x32x2_f32)",
+        r = {"kernel": "spectral_gemm_kernel (7x7 layer in the frequency domain: complex GEMM per bin, v_mfma_f32_32x32x2_f32)",
                 "bound": "mfma", "achieved": round(flops / gemm / 1e12, 3), "peak": peak / 1e12, "unit": "TFLOP/s",
                 "frac": round(flops / gemm / peak, 4), "traffic": None, "flops_per_launch": flops,
                 "avg_launch_ms": round(gemm * 1e3, 4), "timing": "HIP events on the launch stream, this run",
@@ -491,6 +495,17 @@ class Workload(object):
                 "layer_direct_equivalent_tflops": round(direct / (stage_ms[1] * 1e-3) / 1e12, 1),
                 "note": "layer_direct_equivalent_tflops = FLOPs of the DIRECT 7x7 layer / time of the whole frequency-domain "
                         "layer (the transform route executes {:.1f}x fewer FLOPs); not a utilisation figure".format(direct / flops)}
+        c = replayed_counters("fft")
+        if c and c.get("classes_profiled") == pairs:      # the weight spectra are shared by all classes: no per-class scaling
+            r["traffic"] = int(c["bytes_per_launch"])
+            r["hbm_gbps"] = round(r["traffic"] / gemm / 1e9, 1)
+            r["mfma_pipe_busy"] = c.get("mfma_pipe_busy")
+            r["effective_clock_ghz"] = c.get("effective_clock_ghz")
+            if c.get("effective_clock_ghz"):
+                r["frac_clock_adjusted"] = round(flops / gemm / (peak * c["effective_clock_ghz"] / 2.4), 4)
+            r["counters_source"] = "REPLAYED from {} (rocprofv3 PMC passes recorded at {} classes, {}); not measured in this run".format(
+                c["path"], c.get("classes_profiled"), c.get("source"))
+        return r
 
     def describe(self):
         return ("OS2D head, ResNet50-C4 features of one 1280x960 image ({}), {} classes in total ({} on this GPU), {}, {} "
@@ -572,6 +587,9 @@ def main():
 
     dt, stage_ms = w.run(args.precision, args.steps, args.warmup)
     value = classes_total * args.steps / dt
+    effective = args.precision          # below 12 image-class pairs the fft mode runs the direct f16x3 kernel for the 7x7 layer
+    if not args.pyramid and getattr(w.head, "last_precision", None):
+        effective = w.head.last_precision
     gather_desc = {"all": "loc | cls | corners maps (every rank can decode every class)", "scores": "score maps only",
                    "detections": "local decode + per-class NMS, then the surviving detections"}
     result = {
@@ -581,7 +599,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-        "dtype": DTYPE[args.precision], "data": "synthetic",
+        "dtype": DTYPE[effective], "data": "synthetic",
         "config": {"workload": ("BASELINE.json configs[{}]: ".format(
                                     4 if args.pyramid else (2 if classes_total == 1024 and args.variant == "v2" else
                                                             (1 if classes_total == 64 and world == 1 and args.variant == "v2" else "-")))

@@ -569,6 +569,7 @@ class Os2dHead(nn.Module):
         mask[:, :, pool_border_width:TEMPLATE - pool_border_width, pool_border_width:TEMPLATE - pool_border_width] = 1
         self.class_pool_mask = mask / mask.sum(dim=(2, 3), keepdim=True)
         self.aligner = aligner
+        self.last_precision = None
         self.precision = None      # None: follow $OS2D_PRECISION (default "fft"); or "f32" / "f16x3" / "f16x2" / "fft"
         # sticky status word of the split-fp16 kernels in mapped pinned host memory: the kernels store to it only when an
         # activation leaves the fp16 range (impossible for finite inputs, see TransformationNet.range_plan), the host
@@ -676,6 +677,7 @@ class Os2dHead(nn.Module):
             spectra = regressor.spectra(H, W) if A * B >= FFT_MIN_PAIRS else None
             if spectra is None:
                 precision = "f16x3"
+        self.last_precision = precision          # the arithmetic that actually ran (bench.py / tests)
         w1, b1, w2, b2, w3, b3 = regressor.packed(precision)
         if out is None:
             loc = torch.empty(A, B, 4, H, W, dtype=torch.float32, device=dev)

@@ -14,6 +14,7 @@
 // (float64 on the host, rounded once).  The kernel is centred on the map (the weight spectra carry the -3 shift), so only
 // P >= H + 3 and Q >= W + 3 are needed and the result is cropped at the origin.
 #include "os2d_common.h"
+#include "fft_regs.h"
 
 namespace {
 
@@ -33,6 +34,11 @@ struct FftPlan {
   int PS;                    // padded stride of a column in LDS (P + 1: keeps the transposed accesses off one bank)
   int QS;                    // padded stride of a row pair in LDS (Q + 1: the row -> column transposition reads one
                              // element of every row pair per lane; with stride Q = 96 complex they all sit in ONE bank)
+  int row_r1, row_r2;        // two-stage register factorisation Q = r1 * r2 of fft_regs.h (0: Stockham passes)
+  int col_r1, col_r2;        // ... of P
+  int zs_row, zs_col;        // odd strides of a sequence in the exchange buffer of the two-stage form
+  unsigned inv_hp, inv_v;    // ceil(2^32 / HP), ceil(2^32 / V) (0 for a single sequence): item -> (index, sequence)
+  unsigned inv_q;            // ceil(2^32 / Q)
   int AB;                    // complex numbers of the A | B region = max(2 * ceil(H/2) * Q, V * PS): the second column
                              // buffer D aliases it
 };
@@ -123,6 +129,39 @@ __device__ __forceinline__ f32x2* fft_batch(f32x2* a, f32x2* b, int N, int nfft,
   return a;
 }
 
+// N = r1 * r2 in the two-stage register form (fft_regs.h): a -> Z (= b) -> a; falls back to the Stockham passes for
+// factorisations that are not instantiated.  Returns the buffer holding the result.
+template <int R1, int R2, bool INV>
+__device__ __forceinline__ f32x2* fft_two_stage(f32x2* a, f32x2* z, int nfft, int stride, int zstride, unsigned inv_nfft,
+                                                const f32x2* tw, int tid) {
+  os2d_fft::two_stage_first<R1, R2, INV, FFT_THR>(a, stride, z, zstride, nfft, inv_nfft, tw, tid);
+  lds_barrier();
+  os2d_fft::two_stage_second<R1, R2, INV, FFT_THR>(z, zstride, a, stride, nfft, inv_nfft, tid);
+  lds_barrier();
+  return a;
+}
+
+template <bool INV>
+__device__ __forceinline__ f32x2* fft_any(int r1, int r2, f32x2* a, f32x2* b, int N, int nfft, int stride, int zstride,
+                                          unsigned inv_nfft, int npass, const int* rad, const f32x2* tw, int tid) {
+  switch (r1 * 32 + r2) {
+#define OS2D_FFT_CASE(A_, B_) \
+  case A_ * 32 + B_:          \
+    return fft_two_stage<A_, B_, INV>(a, b, nfft, stride, zstride, inv_nfft, tw, tid);
+    OS2D_FFT_CASE(6, 6)     // 36
+    OS2D_FFT_CASE(8, 6)     // 48
+    OS2D_FFT_CASE(9, 6)     // 54
+    OS2D_FFT_CASE(8, 8)     // 64
+    OS2D_FFT_CASE(9, 8)     // 72
+    OS2D_FFT_CASE(12, 8)    // 96
+    OS2D_FFT_CASE(12, 9)    // 108
+    OS2D_FFT_CASE(16, 8)    // 128
+#undef OS2D_FFT_CASE
+    default:
+      return fft_batch<INV>(a, b, N, nfft, stride, npass, rad, tw, tid);
+  }
+}
+
 // LDS (in complex numbers): twiddles Q + P | rows A, B: 2 x (HP x Q), HP = ceil(H/2) row pairs | columns C: V x PS.
 // The second column buffer D aliases A|B (the row stage is finished by then).
 template <int FFT_EPT>
@@ -147,47 +186,51 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 6 ? 4 : 2) void fft_forward_ker
   // computed once), and the loads of the NEXT image are in flight while this one is transformed: the serial chain of a
   // work-group has no global-memory latency in it.
   const int nelem = HP * Q;
-  int eoff[FFT_EPT];             // source offset of the element's even row (or -1: zero padding)
-  int edst[FFT_EPT];             // its place in A
-  bool eodd[FFT_EPT];            // the pair's odd row exists
-#pragma unroll
-  for (int k = 0; k < FFT_EPT; ++k) {
-    const int i = tid + k * FFT_THR;
-    const int p = i / Q, w = i - p * Q;
-    const bool in = i < nelem && w < W;
-    eoff[k] = in ? (2 * p) * W + w : -1;
-    eodd[k] = in && 2 * p + 1 < H;
-    edst[k] = p * QS + w;
-  }
+  // element k of a thread: (row pair p, column w) = (i / Q, i % Q) of i = tid + k * 512 -> source offset of its even row
+  // (-1: zero padding), whether the odd row exists, its place in A.  Recomputed per image from an opaque copy of the thread
+  // index (a multiply-high each): held across the image loop they cost 3 registers per element and spill
+#define FFT_ELEM(TID, K)                                                                                          \
+  const int i_ = (TID) + (K)*FFT_THR;                                                                             \
+  const int p_ = (int)__umulhi((unsigned)i_, pl.inv_q), w_ = i_ - p_ * Q;                                         \
+  const bool in_ = i_ < nelem && w_ < W;                                                                          \
+  const int eoff_ = in_ ? (2 * p_) * W + w_ : -1;                                                                 \
+  const bool eodd_ = in_ && 2 * p_ + 1 < H;                                                                       \
+  const int edst_ = p_ * QS + w_;
   // RAW values only are held (correlation + inverse norm of the even and the odd row): any arithmetic here would make the
   // compiler wait for each load right where it is issued; addresses are clamped instead of predicated (no branches)
   float pa0[FFT_EPT], pn0[FFT_EPT], pa1[FFT_EPT], pn1[FFT_EPT];
-#define FFT_PREFETCH(IMG)                                                                                         \
+#define FFT_PREFETCH(IMG, TID)                                                                                    \
   {                                                                                                               \
     const float* src_ = corr + (size_t)(IMG)*HW;                                                                  \
     const float* nv_ = inv + (size_t)((IMG) / C) * HW;                                                            \
     _Pragma("unroll") for (int k = 0; k < FFT_EPT; ++k) {                                                         \
-      const int o0_ = max(eoff[k], 0), o1_ = eodd[k] ? o0_ + W : o0_;                                             \
+      FFT_ELEM(TID, k)                                                                                            \
+      (void)edst_;                                                                                                \
+      const int o0_ = max(eoff_, 0), o1_ = eodd_ ? o0_ + W : o0_;                                                 \
       pa0[k] = src_[o0_];                                                                                         \
       pn0[k] = nv_[o0_];                                                                                          \
       pa1[k] = src_[o1_];                                                                                         \
       pn1[k] = nv_[o1_];                                                                                          \
     }                                                                                                             \
   }
-  if (blockIdx.x < images) FFT_PREFETCH(blockIdx.x)
+  if (blockIdx.x < images) FFT_PREFETCH(blockIdx.x, tid)
   for (int img = blockIdx.x; img < images; img += gridDim.x) {
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
     lds_barrier();
     // ---- row pair p, column w -> A[p][w] = (x[2p][w], x[2p+1][w]) with x = relu(corr) * inv_norm; zero beyond the map
 #pragma unroll
-    for (int k = 0; k < FFT_EPT; ++k)
-      if (tid + k * FFT_THR < nelem)
-        A[edst[k]] = f32x2{eoff[k] >= 0 ? fmaxf(pa0[k], 0.f) * pn0[k] : 0.f, eodd[k] ? fmaxf(pa1[k], 0.f) * pn1[k] : 0.f};
+    for (int k = 0; k < FFT_EPT; ++k) {
+      FFT_ELEM(tl, k)
+      if (i_ < nelem)
+        A[edst_] = f32x2{eoff_ >= 0 ? fmaxf(pa0[k], 0.f) * pn0[k] : 0.f, eodd_ ? fmaxf(pa1[k], 0.f) * pn1[k] : 0.f};
+    }
     lds_barrier();
-    if (img + (int)gridDim.x < images) FFT_PREFETCH(img + gridDim.x)
+    if (img + (int)gridDim.x < images) FFT_PREFETCH(img + gridDim.x, tl)
 #ifdef OS2D_DIAG_FFT_NOROW
     f32x2* R = A;
 #else
-    f32x2* R = fft_batch<false>(A, Bf, Q, HP, QS, pl.np_row, pl.rad_row, tQ, tid);
+    f32x2* R = fft_any<false>(pl.row_r1, pl.row_r2, A, Bf, Q, HP, QS, pl.zs_row, pl.inv_hp, pl.np_row, pl.rad_row, tQ, tid);
 #endif
     // ---- untangle the two real rows of every pair and transpose into the column buffer C[v][u]; rows >= H are zero
     f32x2* Cb = (R == A) ? Cc : Cc;   // C is separate from A | B
@@ -209,7 +252,7 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 6 ? 4 : 2) void fft_forward_ker
 #ifdef OS2D_DIAG_FFT_NOCOL
     f32x2* Rc = Cb;
 #else
-    f32x2* Rc = fft_batch<false>(Cb, D, P, V, PS, pl.np_col, pl.rad_col, tP, tid);
+    f32x2* Rc = fft_any<false>(pl.col_r1, pl.col_r2, Cb, D, P, V, PS, pl.zs_col, pl.inv_v, pl.np_col, pl.rad_col, tP, tid);
 #endif
     // ---- store X[u * V + v] (v fastest) + zero padding bins
     f32x2* dst = X + (size_t)img * NBINS;
@@ -251,15 +294,16 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
   // register prefetch of the spectra (see fft_forward_kernel): element i of the image (v fastest) goes to Cc[v][u]
   const int nelem = P * V;
   f32x2 pf[FFT_EPT];
-#define FFT_PREFETCH_Y(IMG)                                                                                       \
+#define FFT_PREFETCH_Y(IMG, TID)                                                                                  \
   {                                                                                                               \
     const f32x2* src_ = Y + (size_t)(IMG)*NBINS;                                                                  \
     _Pragma("unroll") for (int k = 0; k < FFT_EPT; ++k)                                                           \
-      if (k * FFT_THR < nelem) pf[k] = src_[min(tid + k * FFT_THR, nelem - 1)];                                   \
+      if (k * FFT_THR < nelem) pf[k] = src_[min((TID) + k * FFT_THR, nelem - 1)];                                 \
   }
   constexpr int GRP = CPT > 0 ? GRPT : 1;                 // consecutive channels per work-group iteration (4 or 2)
   constexpr int NACC = CPT > 0 ? CPT : 1, NR = GRP == 4 ? 2 : 1;
-  unsigned hreg[NACC][NR] = {}, lreg[NACC][NR] = {};
+  // GRP == 2 keeps the first channel of a pair as ONE register per cell (hi | lo << 16) and recombines at the second
+  unsigned hreg[NACC][NR] = {}, lreg[GRP == 4 ? NACC : 1][NR] = {};
   const int ngroups = images / GRP, cells = H * W;
   // XCD-aware order (work-group L runs on XCD L % 8, one L2 per XCD): every XCD takes a contiguous range of channel
   // groups, so the 8 / GRP work-groups that fill the 16-byte units of one (class, 8-channel group) with their 4- / 8-byte
@@ -267,26 +311,30 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
   // left a different L2 as a masked 32-byte write: 632 MB written for 183 MB of activations)
   const int per_xcd = gridDim.x >> 3;                      // the launcher rounds the grid to a multiple of 8
   const int first = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (first < ngroups) FFT_PREFETCH_Y(first * GRP)
+  if (first < ngroups) FFT_PREFETCH_Y(first * GRP, tid)
   for (int it = first * GRP; it < images; it = ((it + 1) % GRP) ? it + 1 : (it / GRP + (int)gridDim.x) * GRP) {
     const int img = it;
     const int nxt = ((it + 1) % GRP) ? it + 1 : (it / GRP + (int)gridDim.x) * GRP;
     const int nb = img / Cout, o = img - nb * Cout;
+    // the per-thread addresses below are cheap to recompute per image; an opaque copy of the thread index keeps the
+    // compiler from hoisting ~50 registers of them out of the image loop (and spilling them at the 128-register budget)
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
     lds_barrier();
 #pragma unroll
     for (int k = 0; k < FFT_EPT; ++k) {
-      const int i = tid + k * FFT_THR;
+      const int i = tl + k * FFT_THR;
       if (i < nelem) {
         const int u = (int)__umulhi((unsigned)i, inv_v);     // i / V (inv_v = ceil(2^32 / V), V >= 2)
         Cc[(i - u * V) * PS + u] = pf[k];
       }
     }
     lds_barrier();
-    if (nxt < images) FFT_PREFETCH_Y(nxt)
+    if (nxt < images) FFT_PREFETCH_Y(nxt, tl)
 #ifdef OS2D_DIAG_FFT_NOCOL
     f32x2* Rc = Cc;
 #else
-    f32x2* Rc = fft_batch<true>(Cc, D, P, V, PS, pl.np_col, pl.rad_col, tP, tid);
+    f32x2* Rc = fft_any<true>(pl.col_r1, pl.col_r2, Cc, D, P, V, PS, pl.zs_col, pl.inv_v, pl.np_col, pl.rad_col, tP, tid);
 #endif
     // ---- rows 2p, 2p+1 (only h < H are needed) as one complex spectrum Z[v] = X_2p[v] + i X_2p+1[v], v < Q, with the
     // Hermitian halves of the two real rows: X[Q - v] = conj X[v].  Rc may be D = A | B: stage through registers per element
@@ -314,7 +362,7 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
 #ifdef OS2D_DIAG_FFT_NOROW
     f32x2* R = A;
 #else
-    f32x2* R = fft_batch<true>(A, Bf, Q, HP, QS, pl.np_row, pl.rad_row, tQ, tid);
+    f32x2* R = fft_any<true>(pl.row_r1, pl.row_r2, A, Bf, Q, HP, QS, pl.zs_row, pl.inv_hp, pl.np_row, pl.rad_row, tQ, tid);
 #endif
     // ---- epilogue: y = re / im of R (rows 2p / 2p+1), + bias, ReLU, channel scale, fp16 hi | lo into the SHB unit of
     // (nb, o / 8) at slot o % 8 (2-byte stores: the 8 channels of a unit come from 8 different images)
@@ -326,7 +374,7 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
 #pragma unroll
       for (int k = 0; k < CPT; ++k) {
         __builtin_amdgcn_sched_barrier(0);                 // keep the unrolled iterations apart: register pressure
-        const int i = tid + k * FFT_THR;
+        const int i = tl + k * FFT_THR;
         if (i < cells) {
           const int h = inv_w ? (int)__umulhi((unsigned)i, inv_w) : i;    // i / W (inv_w = ceil(2^32 / W); 0 for W == 1)
           const int w = i - h * W;
@@ -343,8 +391,7 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
             lreg[k][0] = (lreg[k][0] >> 16) | (lreg[k][1] << 16);
             lreg[k][1] = (lreg[k][1] >> 16) | (lb << 16);
           } else {
-            hreg[k][0] = (hreg[k][0] >> 16) | (hb << 16);
-            lreg[k][0] = (lreg[k][0] >> 16) | (lb << 16);
+            if ((slot & 1) == 0) hreg[k][0] = hb | (lb << 16);
           }
           if ((slot & (GRP - 1)) == GRP - 1) {
             const size_t off = ((size_t)BASE + (size_t)h * Ws + w) * 16 + (slot & (8 - GRP)) * 2;
@@ -356,8 +403,8 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
                 *reinterpret_cast<uint2*>(hi_unit + off) = uint2{hreg[k][0], hreg[k][NR - 1]};
                 *reinterpret_cast<uint2*>(lo_unit + off) = uint2{lreg[k][0], lreg[k][NR - 1]};
               } else {
-                *reinterpret_cast<unsigned*>(hi_unit + off) = hreg[k][0];
-                *reinterpret_cast<unsigned*>(lo_unit + off) = lreg[k][0];
+                *reinterpret_cast<unsigned*>(hi_unit + off) = (hreg[k][0] & 0xffffu) | (hb << 16);
+                *reinterpret_cast<unsigned*>(lo_unit + off) = (hreg[k][0] >> 16) | (lb << 16);
               }
             }
           }
@@ -431,8 +478,29 @@ bool make_plan(int H, int W, FftPlan* pl, size_t* lds) {
   pl->np_col = factor(pl->P, pl->rad_col);
   if (!pl->np_row || !pl->np_col) return false;
   const int HP = (H + 1) / 2;
-  const size_t rows = (size_t)2 * HP * pl->QS, cc = (size_t)pl->V * pl->PS;
-  const size_t ab = rows > cc ? rows : cc;
+  // two-stage register form for the sizes of the benchmark configurations (fft_any instantiates exactly these)
+  auto split = [](int N, int* r1, int* r2) {
+    static const int table[][3] = {{36, 6, 6}, {48, 8, 6}, {54, 9, 6}, {64, 8, 8}, {72, 9, 8}, {96, 12, 8}, {108, 12, 9}, {128, 16, 8}};
+    *r1 = *r2 = 0;
+#ifndef OS2D_DIAG_FFT_STOCKHAM
+    for (const auto& e : table)
+      if (e[0] == N) {
+        *r1 = e[1];
+        *r2 = e[2];
+      }
+#endif
+  };
+  split(pl->Q, &pl->row_r1, &pl->row_r2);
+  split(pl->P, &pl->col_r1, &pl->col_r2);
+  pl->zs_row = pl->row_r1 ? ((pl->row_r1 * (pl->row_r2 | 1)) | 1) : 0;
+  pl->zs_col = pl->col_r1 ? ((pl->col_r1 * (pl->col_r2 | 1)) | 1) : 0;
+  pl->inv_hp = HP > 1 ? (unsigned)(((1ull << 32) + HP - 1) / HP) : 0u;
+  pl->inv_v = (unsigned)(((1ull << 32) + pl->V - 1) / pl->V);
+  pl->inv_q = (unsigned)(((1ull << 32) + pl->Q - 1) / pl->Q);
+  size_t rows = (size_t)2 * HP * pl->QS, cc = (size_t)pl->V * pl->PS;
+  if ((size_t)HP * (pl->QS + pl->zs_row) > rows) rows = (size_t)HP * (pl->QS + pl->zs_row);   // A | exchange buffer
+  const size_t dd = (size_t)pl->V * pl->zs_col > cc ? (size_t)pl->V * pl->zs_col : cc;         // exchange buffer in D = A | B
+  const size_t ab = rows > dd ? rows : dd;
   pl->AB = (int)ab;
   *lds = (size_t)(pl->Q + pl->P + ab + cc) * 8;
   if ((size_t)HP * pl->Q > (size_t)FFT_EPT_MAX * FFT_THR || (size_t)pl->P * pl->V > (size_t)FFT_EPT_MAX * FFT_THR) return false;

@@ -149,10 +149,12 @@ __device__ __forceinline__ f32x2* fft_any(int r1, int r2, f32x2* a, f32x2* b, in
   case A_ * 32 + B_:          \
     return fft_two_stage<A_, B_, INV>(a, b, nfft, stride, zstride, inv_nfft, tw, tid);
     OS2D_FFT_CASE(6, 6)     // 36
+    OS2D_FFT_CASE(6, 7)     // 42
     OS2D_FFT_CASE(8, 6)     // 48
     OS2D_FFT_CASE(9, 6)     // 54
     OS2D_FFT_CASE(8, 8)     // 64
     OS2D_FFT_CASE(9, 8)     // 72
+    OS2D_FFT_CASE(12, 7)    // 84
     OS2D_FFT_CASE(12, 8)    // 96
     OS2D_FFT_CASE(12, 9)    // 108
     OS2D_FFT_CASE(16, 8)    // 128
@@ -454,10 +456,28 @@ int factor(int N, int* rad) {
   return m == 1 ? n : 0;
 }
 
-int next_size(int n) {  // smallest 2^a 3^b >= n (a >= 1: the row length must be even)
+// N = r1 * r2 in the two-stage register form, for the transform sizes of the benchmark configurations (fft_any
+// instantiates exactly these); sizes with a factor 7 exist in this form only
+bool split_size(int N, int* r1, int* r2) {
+  static const int table[][3] = {{36, 6, 6}, {42, 6, 7}, {48, 8, 6}, {54, 9, 6}, {64, 8, 8},  {72, 9, 8},
+                                 {84, 12, 7}, {96, 12, 8}, {108, 12, 9}, {128, 16, 8}};
+  *r1 = *r2 = 0;
+#ifndef OS2D_DIAG_FFT_STOCKHAM
+  for (const auto& e : table)
+    if (e[0] == N) {
+      *r1 = e[1];
+      *r2 = e[2];
+      return true;
+    }
+#endif
+  return false;
+}
+
+int next_size(int n) {  // smallest even transform size >= n: 2^a 3^b (Stockham passes), or one with a two-stage form (42, 84)
   for (int s = n;; ++s) {
-    int m = s;
+    int m = s, r1, r2;
     if (m & 1) continue;
+    if (split_size(s, &r1, &r2)) return s;
     while (m % 2 == 0) m /= 2;
     while (m % 3 == 0) m /= 3;
     if (m == 1) return s;
@@ -476,22 +496,9 @@ bool make_plan(int H, int W, FftPlan* pl, size_t* lds) {
 #endif
   pl->np_row = factor(pl->Q, pl->rad_row);
   pl->np_col = factor(pl->P, pl->rad_col);
-  if (!pl->np_row || !pl->np_col) return false;
   const int HP = (H + 1) / 2;
-  // two-stage register form for the sizes of the benchmark configurations (fft_any instantiates exactly these)
-  auto split = [](int N, int* r1, int* r2) {
-    static const int table[][3] = {{36, 6, 6}, {48, 8, 6}, {54, 9, 6}, {64, 8, 8}, {72, 9, 8}, {96, 12, 8}, {108, 12, 9}, {128, 16, 8}};
-    *r1 = *r2 = 0;
-#ifndef OS2D_DIAG_FFT_STOCKHAM
-    for (const auto& e : table)
-      if (e[0] == N) {
-        *r1 = e[1];
-        *r2 = e[2];
-      }
-#endif
-  };
-  split(pl->Q, &pl->row_r1, &pl->row_r2);
-  split(pl->P, &pl->col_r1, &pl->col_r2);
+  const bool row_fast = split_size(pl->Q, &pl->row_r1, &pl->row_r2), col_fast = split_size(pl->P, &pl->col_r1, &pl->col_r2);
+  if ((!pl->np_row && !row_fast) || (!pl->np_col && !col_fast)) return false;
   pl->zs_row = pl->row_r1 ? ((pl->row_r1 * (pl->row_r2 | 1)) | 1) : 0;
   pl->zs_col = pl->col_r1 ? ((pl->col_r1 * (pl->col_r2 | 1)) | 1) : 0;
   pl->inv_hp = HP > 1 ? (unsigned)(((1ull << 32) + HP - 1) / HP) : 0u;

@@ -132,11 +132,36 @@ struct Dft<4, INV> {
     v[3] = b - d;
   }
 };
+// 7 points, directly: with a_n = x_n + x_(7-n), b_n = x_n - x_(7-n) (n = 1..3)
+//   X_k, X_(7-k) = x_0 + sum_n a_n cos(2 pi n k / 7)  -+ i sum_n b_n sin(2 pi n k / 7)        (signs swapped for INV)
+template <bool INV>
+struct Dft<7, INV> {
+  static OS2D_FFT_HD void run(cf32 (&v)[7]) {
+    cf32 a[3], b[3];
+    static_for<0, 3>([&](auto n) {
+      a[n.value] = v[n.value + 1] + v[6 - n.value];
+      b[n.value] = v[n.value + 1] - v[6 - n.value];
+    });
+    const cf32 x0 = v[0];
+    v[0] = x0 + a[0] + a[1] + a[2];
+    static_for<1, 4>([&](auto k) {
+      cf32 re = x0, im = cf32{0.f, 0.f};
+      static_for<0, 3>([&](auto n) {
+        constexpr float c = (float)unit_cos((n.value + 1) * k.value, 7), s = (float)unit_sin((n.value + 1) * k.value, 7);
+        re += c * a[n.value];
+        im += s * b[n.value];
+      });
+      const cf32 rot = INV ? cf32{-im[1], im[0]} : cf32{im[1], -im[0]};     // -+ i im
+      v[k.value] = re + rot;
+      v[7 - k.value] = re - rot;
+    });
+  }
+};
 template <int R, bool INV>
 struct Dft {
   static constexpr int RA = R % 4 == 0 ? 4 : R % 3 == 0 ? 3 : 2;
   static constexpr int RB = R / RA;
-  static_assert(R > 4 && RA * RB == R, "sizes are products of 2s and 3s");
+  static_assert(R > 4 && RA * RB == R, "composite sizes are products of 2s and 3s");
   static OS2D_FFT_HD void run(cf32 (&v)[R]) {
     cf32 sub[RA][RB];
     static_for<0, RA>([&](auto s) {

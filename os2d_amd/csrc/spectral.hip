@@ -231,7 +231,10 @@ int os2d_launch_spectral_gemm(const float* wspec, const float* X, float* Y, int 
   // work-groups go to the full-tile kernel; what is left (2 % of the work at 64 classes, which would cost a whole extra
   // round) is cut into 32 x 32 quarters so that the tail takes a quarter of a round.
   const long long units = 2LL * G * nbt * SG_NBH;
-  const long long main_units = units >= SG_SLOTS ? units / SG_SLOTS * SG_SLOTS : 0;
+  // a small remainder (up to an eighth of a round) goes to the quarter-tile kernel; a larger one is cheaper as one more
+  // partly filled round of full tiles (quarter tiles load the operands of a whole unit for a quarter of its arithmetic)
+  long long main_units = units >= SG_SLOTS ? units / SG_SLOTS * SG_SLOTS : 0;
+  if (units - main_units > SG_SLOTS / 8) main_units = units;
   const f32x2* w = reinterpret_cast<const f32x2*>(wspec);
   const f32x2* x = reinterpret_cast<const f32x2*>(X);
   f32x2* y = reinterpret_cast<f32x2*>(Y);

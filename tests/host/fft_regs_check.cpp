@@ -78,12 +78,12 @@ static void both(int nfft) {
 
 int main() {
   check_dft<2, false>(); check_dft<3, false>(); check_dft<4, false>(); check_dft<6, false>(); check_dft<8, false>();
-  check_dft<9, false>(); check_dft<12, false>(); check_dft<16, false>();
+  check_dft<9, false>(); check_dft<12, false>(); check_dft<16, false>(); check_dft<7, false>(); check_dft<7, true>();
   check_dft<2, true>(); check_dft<3, true>(); check_dft<4, true>(); check_dft<6, true>(); check_dft<8, true>();
   check_dft<9, true>(); check_dft<12, true>(); check_dft<16, true>();
   for (int nfft : {1, 3, 30, 49}) {
     both<4, 4>(nfft); both<6, 4>(nfft); both<8, 4>(nfft); both<6, 6>(nfft); both<8, 6>(nfft); both<9, 6>(nfft); both<8, 8>(nfft);
-    both<9, 8>(nfft); both<12, 8>(nfft); both<12, 9>(nfft); both<16, 8>(nfft); both<12, 12>(nfft);
+    both<9, 8>(nfft); both<12, 8>(nfft); both<12, 7>(nfft); both<6, 7>(nfft); both<12, 9>(nfft); both<16, 8>(nfft); both<12, 12>(nfft);
   }
   std::printf("ok worst abs error %.3g\n", worst);
   return 0;

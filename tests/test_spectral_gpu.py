@@ -78,17 +78,20 @@ def fft_sizes(H, W):
     return P.value, Q.value, nb.value
 
 
-# the pyramid levels of BASELINE.json configs[4] exercise every two-stage register factorisation of fft.hip (36 = 6x6,
-# 48 = 8x6, 54 = 9x6, 64 = 8x8, 72 = 9x8, 96 = 12x8, 108 = 12x9, 128 = 16x8); the small / odd maps take the Stockham passes
+# the pyramid levels of BASELINE.json configs[4] (+ two more maps) exercise every two-stage register factorisation of
+# fft.hip: 36 = 6x6, 42 = 6x7, 48 = 8x6, 54 = 9x6, 64 = 8x8, 72 = 9x8, 84 = 12x7, 96 = 12x8, 108 = 12x9, 128 = 16x8; the
+# small / odd maps take the Stockham passes
 PYRAMID_LEVELS = [(30, 40), (38, 50), (48, 64), (60, 80), (72, 96), (84, 112)]
+MORE_LEVELS = [(44, 90), (90, 60)]
 
 
 def test_two_stage_factorisations_are_the_pyramid_sizes():
-    assert [fft_sizes(h, w)[:2] for h, w in PYRAMID_LEVELS] == [(36, 48), (48, 54), (54, 72), (64, 96), (96, 108), (96, 128)]
+    assert [fft_sizes(h, w)[:2] for h, w in PYRAMID_LEVELS] == [(36, 48), (42, 54), (54, 72), (64, 84), (84, 108), (96, 128)]
+    assert [fft_sizes(h, w)[:2] for h, w in MORE_LEVELS] == [(48, 96), (96, 64)]
 
 
 @pytest.mark.parametrize("H,W,NB,C", [(60, 80, 2, 7), (30, 40, 1, 5), (38, 50, 1, 3), (48, 64, 1, 3), (72, 96, 1, 2), (84, 112, 1, 2),
-                                      (11, 13, 3, 4), (9, 16, 2, 2), (2, 5, 1, 2), (1, 1, 1, 1)])
+                                      (44, 90, 1, 2), (90, 60, 1, 2), (11, 13, 3, 4), (9, 16, 2, 2), (2, 5, 1, 2), (1, 1, 1, 1)])
 def test_fft_forward_matches_torch_fft(H, W, NB, C, device):
     lib = _lib.load()
     P, Q, nbins = fft_sizes(H, W)
@@ -108,7 +111,8 @@ def test_fft_forward_matches_torch_fft(H, W, NB, C, device):
     assert float(X[:, :, P * (Q // 2 + 1):].abs().max() if nbins > P * (Q // 2 + 1) else 0.0) == 0.0
 
 
-@pytest.mark.parametrize("H,W,NB", [(60, 80, 2), (30, 40, 1), (38, 50, 1), (48, 64, 1), (72, 96, 1), (84, 112, 1), (11, 13, 2), (2, 5, 1)])
+@pytest.mark.parametrize("H,W,NB", [(60, 80, 2), (30, 40, 1), (38, 50, 1), (48, 64, 1), (72, 96, 1), (84, 112, 1), (44, 90, 1), (90, 60, 1),
+                                    (11, 13, 2), (2, 5, 1)])
 def test_fft_inverse_matches_torch_fft_and_epilogue(H, W, NB, device):
     """Inverse transform + the layer epilogue (bias, ReLU, per-channel power-of-two scale, fp16 hi|lo split into the
     split-half blocked buffer with zero borders) against torch.fft.irfft2."""

@@ -42,7 +42,8 @@ Carve carve(int A, int Bc, int C, int H, int W, int P, int fft_bins = 0) {
   c.sumsq = take((size_t)A * HW);
   c.fs = take((size_t)A * os2d_corr_groups(C) * 2 * HW * 4);  // f16x3: split image features, 16 B per (group, part, cell)
   c.corr = take(NB * OS2D_K * HW);
-  c.rpad = take(NB * (OS2D_G * 2 * 4) * PL);  // fp32: 226 planes; f16x3: 29 groups x (hi|lo) x 16 B = 232 floats
+  // fp32: 226 planes; f16x3: 29 groups x (hi|lo) x 16 B = 232 floats; not needed by the frequency-domain 7x7 layer
+  c.rpad = take(fft_bins > 0 ? 0 : NB * (OS2D_G * 2 * 4) * PL);
   c.h1 = take(NB * 128 * PL);
   c.h2 = take(NB * 64 * PL);
   c.params = take(NB * P * HW);
@@ -373,13 +374,14 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     const int terms1 = precision == OS2D_PRECISION_F16X2 ? 2 : 3;  // 7x7 layer: weights as fp16 roundings only under f16x2
     mark(b0, 0);
     if (f16) {
-      if ((rc = os2d_launch_border_zero_shb(rpad, NB, H, W, st))) return rc;
+      // the frequency-domain 7x7 layer takes corr + invn; the split / blocked copy of the normalised maps is not written
+      if (!fft_bins && (rc = os2d_launch_border_zero_shb(rpad, NB, H, W, st))) return rc;
     } else {
       if ((rc = os2d_launch_border_zero(rpad, NB * OS2D_KP, H, W, st))) return rc;
     }
     if (f16) {
       const char* qsb = static_cast<const char*>(qs) + (size_t)b0 * os2d_corr_groups(C) * 2 * 256 * 16;
-      if ((rc = os2d_launch_corr_f16x3(fsplit, qsb, corr, rpad, invn, A, bc, C, H, W, st))) return rc;
+      if ((rc = os2d_launch_corr_f16x3(fsplit, qsb, corr, fft_bins ? nullptr : rpad, invn, A, bc, C, H, W, st))) return rc;
     } else {
       if ((rc = os2d_launch_corr(fm, qp + (size_t)b0 * C * OS2D_QROWS, sumsq, corr, rpad, A, bc, C, H, W, 0, st)))
         return rc;

@@ -264,6 +264,7 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
     const int nc = nin ? n : 0;
     const int h = nc / W, w = nc - h * W;
     const size_t cell = (size_t)BASE + (size_t)h * Ws + w;
+    if (rshb == nullptr) continue;   // frequency-domain 7x7 layer: it reads corr + invn, the split activations are not needed
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll

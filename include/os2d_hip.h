@@ -201,17 +201,18 @@ int os2d_detect_level(const float* loc, const float* cls, int B, int H, int W, i
                       float img_h, float scale_x, float scale_y, float score_threshold, float iou_threshold,
                       float* out_boxes, float* out_scores, int* out_index, int* out_count, void* stream);
 
-/* ---- building block of the frequency-domain form of the 7x7 TransformNet layer (reference head.py:619-623; DESIGN.md
- * section 8 "next"; not yet on the head's path): for every frequency bin the layer is one complex matrix product
+/* ---- the frequency-domain form of the 7x7 TransformNet layer (reference head.py:619-623; DESIGN.md section 4, "fft"):
+ * what os2d_head_forward_ex chains under OS2D_PRECISION_FFT, exported for callers and tests.  For every frequency bin the
+ * layer is one complex matrix product
  *     Y[n][o][bin] = sum_c K[o][c][bin] * X[n][c][bin]      n = image x class, c < C input channels, o < Cout <= 128
  * evaluated for all bins in one launch on the fp32 matrix cores (exact fp32 products, fp32 accumulation).
  *   X [NB,C,nbins], Y [NB,Cout,nbins] interleaved complex64 (re, im), nbins a multiple of 8;
  *   wspec: the weight spectra packed [nbins/8][2][C][8][64] complex64 - for bin group g, half h, channel c, bin j and
  *   row r the entry is K[64*h + r][c][8*g + j] (zero for rows >= Cout); os2d_spectral_weight_bytes(C, Cout, nbins) bytes.  */
 size_t os2d_spectral_weight_bytes(int C, int Cout, int nbins);
-/* The transforms around it (in-LDS mixed-radix real FFT pair, one work-group per image):
- *   os2d_fft_sizes    padded sizes P >= H+3, Q >= W+3 (products of 2s and 3s; the weight spectra carry the -3 shift of the
- *                     centred kernel) and nbins = P*(Q/2+1) rounded up to a multiple of 8; -3 if the map does not fit
+/* The transforms around it (in-LDS real FFT pair, one work-group per image at a time):
+ *   os2d_fft_sizes    padded sizes P >= H+3, Q >= W+3 (even; 2^a 3^b, or 42 / 84; the weight spectra carry the -3 shift of
+ *                     the centred kernel) and nbins = P*(Q/2+1) rounded up to a multiple of 8; -3 if the map does not fit
  *   os2d_fft_forward  x = relu(corr [NB,C,H*W]) * inv_norm [NB,H*W] (head.py:650 folded into the load), zero-padded ->
  *                     X [NB,C,nbins] complex64, bin = u*(Q/2+1) + v
  *   os2d_fft_inverse  Y [NB,128,nbins] -> first H x W samples / (P*Q), + folded bias, ReLU, per-channel scale (packed_b of

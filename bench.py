@@ -75,13 +75,15 @@ sys.path.insert(0, REPO)
 C_FEAT, H_FM, W_FM = 1024, 60, 80          # ResNet50-C4 features of a 1280x960 input
 LEVEL_HW = [(30, 40), (38, 50), (48, 64), (60, 80), (72, 96), (84, 112), (96, 128)]   # 7 scales 0.5-1.6
 FLOP_PER_LOC = {"corr": 2 * 225 * 1024, "conv1": 2 * 128 * 225 * 49, "conv2": 2 * 64 * 128 * 25}
-PEAK = {"f32": 157.3e12, "f16x3": 2.5e15, "f16x2": 2.5e15, "fft": 157.3e12}  # dense MFMA peaks (MI355X_MICROARCH.md): fp32-input MFMA; fp16/bf16 MFMA
+PEAK = {"f32": 157.3e12, "f16x3": 2.5e15, "f16x2": 2.5e15, "fft": 157.3e12, "fftx3": 2.5e15}  # dense MFMA peaks (MI355X_MICROARCH.md): fp32-input MFMA; fp16/bf16 MFMA
 STAGES = ("corr", "conv1", "conv2", "conv3", "sample")
-PREC_ID = {"f32": 0, "f16x3": 1, "f16x2": 2, "fft": 3}
+FFT_MODES = ("fft", "fftx3")
+PREC_ID = {"f32": 0, "f16x3": 1, "f16x2": 2, "fft": 3, "fftx3": 4}
 DTYPE = {"f32": "f32",
          "f16x3": "f16x3 (fp32 operands split into fp16 hi+lo, 3 half MFMAs per product, fp32 accumulate)",
          "f16x2": "f16x2 (as f16x3; the 7x7 layer's weights enter as fp16 roundings only, 2 half MFMAs per product)",
-         "fft": "fft (as f16x3; the 7x7 layer in the frequency domain in fp32: real FFT, complex GEMM per bin on the fp32 MFMA, inverse FFT)"}
+         "fft": "fft (as f16x3; the 7x7 layer in the frequency domain in fp32: real FFT, complex GEMM per bin on the fp32 MFMA, inverse FFT)",
+         "fftx3": "fftx3 (as fft; the per-bin complex GEMM on the fp16 MFMA with spectra split into fp16 hi+lo, 3 MFMAs per product, fp32 accumulate)"}
 DISTINCT_CLASS_MAPS = 64     # synthetic class maps are generated for 64 seeds and repeated (separate device copies)
 
 
@@ -94,7 +96,7 @@ def parse():
     ap.add_argument("--classes-total", type=int, default=None,
                     help="classes in total, block-sharded over the ranks (strong scaling); default 1024 at N>1")
     ap.add_argument("--variant", default="v2", choices=["v2", "v1"], help="v2: affine+inverse (P=6); v1: simplified (P=4)")
-    ap.add_argument("--precision", default=os.environ.get("OS2D_PRECISION", "fft"), choices=["f32", "f16x3", "f16x2", "fft"])
+    ap.add_argument("--precision", default=os.environ.get("OS2D_PRECISION", "fftx3"), choices=["f32", "f16x3", "f16x2", "fft", "fftx3"])
     ap.add_argument("--pyramid", action="store_true",
                     help="BASELINE configs[4]: 7-scale pyramid (0.5-1.6) of the 1280x960 image, one HIP stream per level; "
                          "a pair then means one (image, class) over all 7 levels")
@@ -147,7 +149,7 @@ def replayed_counters(precision):
     """The committed rocprofv3 PMC passes of the conv 7x7 kernel (profiles/conv1_traffic_<precision>.json, written by
     tools/summarize_prof.py --traffic: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, SQ / GRBM pass;
     separate passes).  These are NOT measured in this run."""
-    path = os.path.join(REPO, "profiles", "spectral_traffic_fft.json" if precision == "fft" else "conv1_traffic_{}.json".format(precision))
+    path = os.path.join(REPO, "profiles", ("spectral_traffic_{}.json" if precision in FFT_MODES else "conv1_traffic_{}.json").format(precision))
     if not os.path.exists(path):
         return None
     with open(path) as f:
@@ -367,7 +369,7 @@ class Workload(object):
                 for st in range(5):
                     self._lib_mod.check(self.lib.os2d_prof_event_elapsed_ms(evs[2 * st], evs[2 * st + 1], ctypes.byref(ms)), "elapsed")
                     row.append(ms.value)
-                if head.last_precision == "fft":   # sub-stages of the 7x7 layer: forward FFT | spectral GEMM | inverse FFT
+                if head.last_precision in FFT_MODES:   # sub-stages of the 7x7 layer: forward FFT | spectral GEMM | inverse FFT
                     for a, b in ((10, 11), (11, 12), (12, 3)):
                         self._lib_mod.check(self.lib.os2d_prof_event_elapsed_ms(evs[a], evs[b], ctypes.byref(ms)), "elapsed")
                         row.append(ms.value)
@@ -386,9 +388,9 @@ class Workload(object):
         duration).  Without (several streams / ranks): the whole head of this rank (algorithmic FLOPs of a step / step
         time) - `kernel` says which."""
         B = self.B_local
-        if stage_ms is not None and precision == "fft" and len(stage_ms) >= 8:
-            return self.roofline_fft(stage_ms)
-        fell_back = precision == "fft" and stage_ms is not None     # staged run without the sub-stage events: the class batch
+        if stage_ms is not None and precision in FFT_MODES and len(stage_ms) >= 8:
+            return self.roofline_fft(stage_ms, precision)
+        fell_back = precision in FFT_MODES and stage_ms is not None     # staged run without the sub-stage events: the class batch
         if fell_back:                                               # is below FFT_MIN_PAIRS and the direct f16x3 kernel ran
             precision = "f16x3"
         peak = PEAK[precision]
@@ -400,8 +402,8 @@ class Workload(object):
                 else "frequency domain: fft_forward + spectral_gemm (v_mfma_f32_32x32x2_f32) + fft_inverse; the FLOPs are the "
                      "DIRECT layer's (the transform route executes 16.7x fewer), so frac may exceed 1" if precision == "fft"
                 else "conv_f16x3_kernel<7,...>, v_mfma_f32_32x32x16_f16 x{} per product".format(precision[-1]))
-        elif precision == "fft":
-            return self.roofline_fft_whole(seconds_per_step)
+        elif precision in FFT_MODES:
+            return self.roofline_fft_whole(seconds_per_step, precision)
         else:
             flops = self.whole_head_flops_per_class() * B
             seconds = seconds_per_step
@@ -443,7 +445,7 @@ class Workload(object):
             r["note"] = "precision fft requested; with fewer than 12 image-class pairs the head runs the direct f16x3 7x7 kernel"
         return r
 
-    def roofline_fft_whole(self, seconds):
+    def roofline_fft_whole(self, seconds, precision="fft"):
         """fft mode without stage events (several streams / ranks): all MFMA work of one rank's step against the blend of
         the two instruction peaks it runs on - the correlation, the two 5x5 layers (and the 7x7 layer of maps that do not
         fit the in-LDS transform) count their ALGORITHMIC FLOPs against the fp16 MFMA peak (each costs three MFMA products:
@@ -459,6 +461,8 @@ class Workload(object):
             else:
                 per_loc += FLOP_PER_LOC["conv1"]
             f16 += per_loc * h * w * B
+        if precision == "fftx3":       # the per-bin GEMMs run on the fp16 MFMA too: three matrix products per complex product term
+            f16, f32 = f16 + f32, 0
         peak = (f16 + f32) / (f16 / PEAK["f16x3"] + f32 / PEAK["fft"])
         achieved = (f16 + f32) / seconds
         return {"kernel": "whole head of one rank: correlation + 5x5 layers on v_mfma_f32_32x32x16_f16 (algorithmic FLOPs, three "
@@ -470,7 +474,7 @@ class Workload(object):
                 "peak_is": "FLOP-weighted harmonic blend of the fp16 (2500) and fp32 (157.3) dense MFMA peaks for this mix",
                 "avg_launch_ms": round(seconds * 1e3, 4), "timing": "wall clock of the timed steps, this run"}
 
-    def roofline_fft(self, stage_ms):
+    def roofline_fft(self, stage_ms, precision="fft"):
         """fft mode: the spectral GEMM (dominant kernel of the step).  Per bin Y[128 x pairs] = K[128 x 225] X[225 x pairs]
         in complex fp32 = 8 real FLOPs per complex multiply-add, all of them issued as v_mfma_f32_32x32x2_f32 with
         k = {re, im}; bins = P * (Q/2 + 1) of the P x Q transform of the map.  Algorithmic HBM bytes: the weight spectra,
@@ -495,14 +499,23 @@ class Workload(object):
                 "layer_direct_equivalent_tflops": round(direct / (stage_ms[1] * 1e-3) / 1e12, 1),
                 "note": "layer_direct_equivalent_tflops = FLOPs of the DIRECT 7x7 layer / time of the whole frequency-domain "
                         "layer (the transform route executes {:.1f}x fewer FLOPs); not a utilisation figure".format(direct / flops)}
-        c = replayed_counters("fft")
+        if precision == "fftx3":
+            # split-half GEMM: 16x the matrix rate for 3x the matrix work - the launch is a stream of its operands
+            r["kernel"] = ("spectral_gemm_f16_kernel (7x7 layer in the frequency domain: complex GEMM per bin on v_mfma_f32_32x32x16_f16, "
+                           "spectra split into fp16 hi + lo)")
+            r["mfma_view"] = {"achieved": r["achieved"], "executed_tflops": round(3 * flops / gemm / 1e12 * 232 / 225, 1), "peak": PEAK["fftx3"] / 1e12,
+                              "unit": "TFLOP/s", "frac_executed": round(3 * flops / gemm / PEAK["fftx3"] * 232 / 225, 4)}
+            hv = r.pop("hbm_view")
+            r.update({"bound": "hbm", "achieved": hv["achieved"], "peak": 8000.0, "unit": "GB/s", "frac": hv["frac"]})
+        c = replayed_counters(precision)
         if c and c.get("classes_profiled") == pairs:      # the weight spectra are shared by all classes: no per-class scaling
             r["traffic"] = int(c["bytes_per_launch"])
             r["hbm_gbps"] = round(r["traffic"] / gemm / 1e9, 1)
             r["mfma_pipe_busy"] = c.get("mfma_pipe_busy")
             r["effective_clock_ghz"] = c.get("effective_clock_ghz")
             if c.get("effective_clock_ghz"):
-                r["frac_clock_adjusted"] = round(flops / gemm / (peak * c["effective_clock_ghz"] / 2.4), 4)
+                if precision == "fft":
+                    r["frac_clock_adjusted"] = round(flops / gemm / (peak * c["effective_clock_ghz"] / 2.4), 4)
             r["counters_source"] = "REPLAYED from {} (rocprofv3 PMC passes recorded at {} classes, {}); not measured in this run".format(
                 c["path"], c.get("classes_profiled"), c.get("source"))
         return r
@@ -521,11 +534,11 @@ def precision_deviation(w):
     with torch.no_grad():
         ref = [t.clone() for t in w.head(w.fm, precision="f32")]
         keep = {}
-        for p in ("f16x3", "f16x2", "fft"):
+        for p in ("f16x3", "f16x2", "fft", "fftx3"):
             o = w.head(w.fm, precision=p)
             out[p] = {"cls": float((o[1] - ref[1]).abs().max()), "loc": float((o[0] - ref[0]).abs().max()),
                       "corners_px": float((o[3] - ref[3]).abs().max())}
-            if p != "f16x2":
+            if p in ("fft", "f16x3"):
                 keep[p] = o[0].clone()
         # the two fp32-equivalent modes share every stage but the 7x7 layer: their outputs differ in the last bits only
         out["fft_vs_f16x3_loc"] = float((keep["fft"] - keep["f16x3"]).abs().max())
@@ -616,7 +629,7 @@ def main():
     result["head_tflops_algorithmic"] = round(w.whole_head_flops_per_class() * value / 1e12, 3)
     if not args.no_other_precision:
         result["other_precisions"] = []
-        for other in ("f16x3", "fft", "f16x2", "f32"):
+        for other in ("fft", "fftx3", "f16x3", "f16x2", "f32"):
             if other == args.precision:
                 continue
             dt2, stage2 = w.run(other, max(2, min(args.steps, 10)), 1)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define OS2D_ABI_VERSION 5
+#define OS2D_ABI_VERSION 6
 
 /* arithmetic of the two large TransformNet convolutions (everything else is fp32 in both modes) */
 #define OS2D_PRECISION_F32 0   /* v_mfma_f32_32x32x2_f32: exact fp32 (k-ordered fmaf chain)                            */
@@ -36,6 +36,11 @@ extern "C" {
                                /* normalised correlation, one complex 128 x 225 GEMM per bin on the fp32 matrix cores, inverse FFT  */
                                /* (16.7x fewer multiply-adds; agrees with an fp64 convolution to 1e-7, closer than a direct fp32    */
                                /* convolution).  Maps that do not fit the in-LDS transform are refused (-3): use F16X3 for them.   */
+
+#define OS2D_PRECISION_FFTX3 4 /* as FFT, with the per-bin complex GEMM on the half-precision matrix cores: spectra split into fp16   */
+                               /* hi + lo (three v_mfma_f32_32x32x16_f16 per product, the arithmetic of F16X3; scales chosen so that  */
+                               /* no spectrum value can leave the fp16 range: |X| <= H*W by construction, the weight spectra are     */
+                               /* host data); wspec = the split weight spectra of os2d_spectral_weight16_bytes                     */
 
 /* ABI version of the loaded library (compare with OS2D_ABI_VERSION). */
 int os2d_abi_version(void);
@@ -206,7 +211,8 @@ int os2d_detect_level(const float* loc, const float* cls, int B, int H, int W, i
  * layer is one complex matrix product
  *     Y[n][o][bin] = sum_c K[o][c][bin] * X[n][c][bin]      n = image x class, c < C input channels, o < Cout <= 128
  * evaluated for all bins in one launch on the fp32 matrix cores (exact fp32 products, fp32 accumulation).
- *   X [NB,C,nbins], Y [NB,Cout,nbins] interleaved complex64 (re, im), nbins a multiple of 8;
+ *   X [C,NB,nbins] (channel-major: the pairs of one channel are neighbours), Y [NB,Cout,nbins] interleaved complex64 (re, im),
+ *   nbins a multiple of 8;
  *   wspec: the weight spectra packed [nbins/8][2][C][8][64] complex64 - for bin group g, half h, channel c, bin j and
  *   row r the entry is K[64*h + r][c][8*g + j] (zero for rows >= Cout); os2d_spectral_weight_bytes(C, Cout, nbins) bytes.  */
 size_t os2d_spectral_weight_bytes(int C, int Cout, int nbins);
@@ -214,7 +220,7 @@ size_t os2d_spectral_weight_bytes(int C, int Cout, int nbins);
  *   os2d_fft_sizes    padded sizes P >= H+3, Q >= W+3 (even; 2^a 3^b, or 42 / 84; the weight spectra carry the -3 shift of
  *                     the centred kernel) and nbins = P*(Q/2+1) rounded up to a multiple of 8; -3 if the map does not fit
  *   os2d_fft_forward  x = relu(corr [NB,C,H*W]) * inv_norm [NB,H*W] (head.py:650 folded into the load), zero-padded ->
- *                     X [NB,C,nbins] complex64, bin = u*(Q/2+1) + v
+ *                     X [C,NB,nbins] complex64, bin = u*(Q/2+1) + v
  *   os2d_fft_inverse  Y [NB,128,nbins] -> first H x W samples / (P*Q), + folded bias, ReLU, per-channel scale (packed_b of
  *                     os2d_pack_conv_f16x3 for layer 1), fp16 hi|lo -> split-half blocked buffer (NB*os2d_shb_bytes(128,H,W))
  *   twQ / twP         exp(-2 pi i m / Q), m < Q  and  exp(-2 pi i m / P), m < P  as complex64 device tables              */
@@ -224,6 +230,16 @@ int os2d_fft_forward(const float* corr, const float* inv_norm, float* X, const f
 int os2d_fft_inverse(const float* Y, const float* packed_b, void* out, const float* twQ, const float* twP, int NB, int Cout,
                      int H, int W, int* status, void* stream);
 int os2d_spectral_gemm(const float* wspec, const float* X, float* Y, int NB, int C, int Cout, int nbins, void* stream);
+/* The same product on the half-precision matrix cores (OS2D_PRECISION_FFTX3).  w16: the weight spectra pre-split on the host,
+ * [nbins/8][2][KS = ceil(C/8)][8 bins][2 channel groups][hi|lo][64 rows] units of 8 halves = (Kr, Ki) of 4 channels, row o
+ * scaled by 2^wexp[o] (largest |Kr|, |Ki| of the row <= 32768), followed by 128 floats 2^-wexp[o]:
+ * os2d_spectral_weight16_bytes(C, nbins) bytes.  The input spectra are scaled by os2d_spectral_xscale(H, W) (largest power of
+ * two with xscale * H * W <= 65504: |X| <= H * W because every sample of the normalised maps is <= 1) and split on the fly;
+ * Y is returned unscaled, exactly as os2d_spectral_gemm returns it (up to the 2^-22 relative error of a split product).   */
+size_t os2d_spectral_weight16_bytes(int C, int nbins);
+float os2d_spectral_xscale(int H, int W);
+int os2d_spectral_gemm_f16(const void* w16, const float* X, float* Y, int NB, int C, int Cout, int nbins, float xscale,
+                           void* stream);
 
 /* ---- detection over a whole image pyramid: reference os2d/modeling/box_coder.py:448-536 per label for L levels, incl. the
  * reference's memory-bounded NMS (os2d/structures/bounding_box.py:343-374: lists longer than nms_max_batch are NMS-ed in

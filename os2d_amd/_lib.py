@@ -9,7 +9,7 @@ import os
 
 from .build import LIB_PATH
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _c_float_p = ctypes.c_void_p   # device pointers travel as raw addresses (tensor.data_ptr())
 _vp = ctypes.c_void_p
@@ -38,6 +38,9 @@ SIGNATURES = {
     "os2d_alignment_grids": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "os2d_spectral_weight_bytes": (_sz, [_i, _i, _i]),
     "os2d_spectral_gemm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "os2d_spectral_weight16_bytes": (_sz, [_i, _i]),
+    "os2d_spectral_xscale": (_f, [_i, _i]),
+    "os2d_spectral_gemm_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "os2d_fft_sizes": (_i, [_i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "os2d_fft_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "os2d_fft_inverse": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -162,7 +162,7 @@ int os2d_head_workspace_bytes_ex(int A, int B, int C, int H, int W, int P, int p
   }
   if (!head_args_ok(A, B, C, H, W, P)) return -1;
   int bins = 0;
-  if (precision == OS2D_PRECISION_FFT && !os2d_fft_plan(H, W, nullptr, nullptr, &bins)) {
+  if ((precision == OS2D_PRECISION_FFT || precision == OS2D_PRECISION_FFTX3) && !os2d_fft_plan(H, W, nullptr, nullptr, &bins)) {
     os2d_set_error("os2d_head_workspace_bytes_ex: a %dx%d map does not fit the in-LDS transform of the FFT mode", H, W);
     return -3;
   }
@@ -302,12 +302,12 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     return -1;
   }
   if (precision != OS2D_PRECISION_F32 && precision != OS2D_PRECISION_F16X3 && precision != OS2D_PRECISION_F16X2 &&
-      precision != OS2D_PRECISION_FFT) {
+      precision != OS2D_PRECISION_FFT && precision != OS2D_PRECISION_FFTX3) {
     os2d_set_error("os2d_head_forward: unknown precision %d", precision);
     return -1;
   }
   int fft_bins = 0;
-  if (precision == OS2D_PRECISION_FFT) {
+  if (precision == OS2D_PRECISION_FFT || precision == OS2D_PRECISION_FFTX3) {
     if (!wspec || !twQ || !twP) {
       os2d_set_error("os2d_head_forward: the FFT mode needs the weight spectra and the two twiddle tables");
       return -1;
@@ -395,7 +395,12 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
       mark(b0, 10);
       if ((rc = os2d_launch_fft_forward(corr, invn, xspec, twQ, twP, NB, OS2D_K, H, W, st))) return rc;
       mark(b0, 11);
-      if ((rc = os2d_launch_spectral_gemm(wspec, xspec, yspec, NB, OS2D_K, 128, fft_bins, st))) return rc;
+      if (precision == OS2D_PRECISION_FFTX3) {
+        if ((rc = os2d_launch_spectral_gemm_f16(wspec, xspec, yspec, NB, OS2D_K, 128, fft_bins, os2d_spectral_xscale_for(H, W), st)))
+          return rc;
+      } else if ((rc = os2d_launch_spectral_gemm(wspec, xspec, yspec, NB, OS2D_K, 128, fft_bins, st))) {
+        return rc;
+      }
       mark(b0, 12);
       if ((rc = os2d_launch_fft_inverse(yspec, b1, 128, h1, twQ, twP, NB, 128, H, W, status, st))) return rc;
     } else if (f16) {
@@ -552,6 +557,27 @@ int os2d_spectral_gemm(const float* wspec, const float* X, float* Y, int NB, int
     return -1;
   }
   return os2d_launch_spectral_gemm(wspec, X, Y, NB, C, Cout, nbins, S(stream));
+}
+
+size_t os2d_spectral_weight16_bytes(int C, int nbins) {
+  if (C < 1 || nbins < 8 || (nbins & 7)) return 0;
+  return os2d_spectral_weight16_size(C, nbins);
+}
+
+float os2d_spectral_xscale(int H, int W) { return (H < 1 || W < 1) ? 0.f : os2d_spectral_xscale_for(H, W); }
+
+int os2d_spectral_gemm_f16(const void* w16, const float* X, float* Y, int NB, int C, int Cout, int nbins, float xscale,
+                           void* stream) {
+  if (!w16 || !X || !Y || NB < 1 || C < 1 || Cout < 1 || Cout > 128 || nbins < 8 || (nbins & 7) || !(xscale > 0.f)) {
+    os2d_set_error("os2d_spectral_gemm_f16: bad arguments (NB=%d C=%d Cout=%d nbins=%d; nbins must be a multiple of 8)", NB, C,
+                   Cout, nbins);
+    return -1;
+  }
+  if ((reinterpret_cast<uintptr_t>(w16) | reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) & 15) {
+    os2d_set_error("os2d_spectral_gemm_f16: buffers must be 16-byte aligned");
+    return -1;
+  }
+  return os2d_launch_spectral_gemm_f16(w16, X, Y, NB, C, Cout, nbins, xscale, S(stream));
 }
 
 int os2d_alignment_grids(const float* params, int NB, int H, int W, int P, int inverse, float* theta, float* grids,

@@ -2,7 +2,7 @@
 // see spectral.hip.  Everything of one image lives in LDS; one work-group per image at a time.
 //
 //   fft_forward   x[h][w] = relu(corr[nb][c][h][w]) * inv_norm[nb][h][w]  (the TransformNet input normalisation of
-//                 reference head.py:650 folded into the load), zero-padded to P x Q  ->  X[nb][c][u * V + v], V = Q/2 + 1
+//                 reference head.py:650 folded into the load), zero-padded to P x Q  ->  X[c][nb][u * V + v], V = Q/2 + 1
 //   fft_inverse   Y[nb][o][u * V + v]  ->  y[h][w] = the first H x W samples of the inverse transform / (P * Q), then the
 //                 layer's epilogue: + bias, ReLU, per-channel power-of-two scale, fp16 hi|lo split into the split-half
 //                 blocked activation buffer of conv_f16x3.hip (BatchNorm is folded into the weight spectra and the bias)
@@ -169,7 +169,7 @@ __device__ __forceinline__ f32x2* fft_any(int r1, int r2, f32x2* a, f32x2* b, in
 template <int FFT_EPT>
 __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 6 ? 4 : 2) void fft_forward_kernel(const float* __restrict__ corr,   // [NB][C][H*W]
                                                              const float* __restrict__ inv,    // [NB][H*W]
-                                                             f32x2* __restrict__ X,            // [NB][C][NBINS]
+                                                             f32x2* __restrict__ X,            // [C][NB][NBINS]
                                                              const f32x2* __restrict__ twQ, const f32x2* __restrict__ twP,
                                                              FftPlan pl, int C, int H, int W, int NBINS, int images) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -257,7 +257,9 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 6 ? 4 : 2) void fft_forward_ker
     f32x2* Rc = fft_any<false>(pl.col_r1, pl.col_r2, Cb, D, P, V, PS, pl.zs_col, pl.inv_v, pl.np_col, pl.rad_col, tP, tid);
 #endif
     // ---- store X[u * V + v] (v fastest) + zero padding bins
-    f32x2* dst = X + (size_t)img * NBINS;
+    // X[c][pair][bin]: the 64 pairs a GEMM work-group reads for one channel lie in ONE 1.4 MB stretch (22 KB apart), not 5 MB
+    // apart - its load instructions then need one address translation instead of one per pair
+    f32x2* dst = X + ((size_t)(img % C) * (images / C) + img / C) * NBINS;
     for (int u = wv; u < P; u += NWV)
       for (int v = lane; v < V; v += 64) dst[u * V + v] = Rc[v * PS + u];
     for (int i = P * V + tid; i < NBINS; i += FFT_THR) dst[i] = f32x2{0.f, 0.f};

@@ -141,6 +141,11 @@ int os2d_launch_fft_inverse(const float* Y, const float* bp, int MTP, void* out,
 size_t os2d_spectral_weight_floats(int C, int Cout, int NBINS);
 int os2d_launch_spectral_gemm(const float* wspec, const float* X, float* Y, int NB, int C, int Cout, int NBINS,
                               hipStream_t stream);
+// spectral_f16.hip
+size_t os2d_spectral_weight16_size(int C, int NBINS);
+float os2d_spectral_xscale_for(int H, int W);
+int os2d_launch_spectral_gemm_f16(const void* w16, const float* X, float* Y, int NB, int C, int Cout, int NBINS, float xscale,
+                                  hipStream_t stream);
 // corr_f16x3.hip
 int os2d_corr_groups(int C);  // 8-channel groups of the split correlation operands, padded to whole K chunks
 int os2d_launch_split_fm(const float* fm, const float* sumsq, void* fs, int A, int C, int HW, hipStream_t stream);

@@ -44,7 +44,7 @@ constexpr int SG_SLOTS = 256 * SG_NBH;                   // work-groups resident
 // full round of 256 work-groups, so that the tail of the launch costs a quarter of a round instead of a whole one.
 template <int NBLK>
 __global__ __launch_bounds__(SG_THR, 2) void spectral_gemm_kernel(const f32x2* wspec,  // [G][2][C][8][64] complex
-                                                                  const f32x2* __restrict__ X,  // [NB][C][NBINS]
+                                                                  const f32x2* __restrict__ X,  // [C][NB][NBINS]
                                                                   f32x2* __restrict__ Y,        // [NB][Cout][NBINS]
                                                                   int NB, int C, int Cout, int NBINS, int G, int unit0,
                                                                   int nunits) {
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(SG_THR, 2) void spectral_gemm_kernel(const f32x2* w
       const int u_ = min(tid + k_ * SG_THR, SG_XUNITS - 1);                                                       \
       const int c_ = min((T)*SG_CC + u_ / (SG_NB * (SG_WB / 2)), C - 1);                                          \
       const int b_ = min(nb0 + (u_ / (SG_WB / 2)) % SG_NB, NB - 1);                                               \
-      pfx[k_] = *reinterpret_cast<const u32x4*>(X + ((size_t)b_ * C + c_) * NBINS + bin0 + 2 * (u_ % (SG_WB / 2))); \
+      pfx[k_] = *reinterpret_cast<const u32x4*>(X + ((size_t)c_ * NB + b_) * NBINS + bin0 + 2 * (u_ % (SG_WB / 2))); \
     }                                                                                                             \
   }
 #define SG_STORE_X(T)                                                                                             \
@@ -167,8 +167,10 @@ __global__ __launch_bounds__(SG_THR, 2) void spectral_gemm_kernel(const f32x2* w
 #pragma unroll
           for (int b = 0; b < NBLK; ++b) {
             const float xb = hw ? xf[cur][b][1] : xf[cur][b][0];  // column of [Xr ; Xi]
-            yr[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, xb, yr[a][b], 0, 0, 0);
-            yi[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, xb, yi[a][b], 0, 0, 0);
+            // the spectra are the ROW operand: accumulator registers run over the pairs, lanes over the output channels, so a
+            // store instruction stays inside one pair's rows (22 KB apart) instead of touching 32 pairs (3 MB apart)
+            yr[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xb, ar, yr[a][b], 0, 0, 0);
+            yi[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xb, ai, yi[a][b], 0, 0, 0);
           }
         }
       }
@@ -183,21 +185,21 @@ __global__ __launch_bounds__(SG_THR, 2) void spectral_gemm_kernel(const f32x2* w
 #undef SG_LOAD_X
 #undef SG_STORE_X
 
-  // ---- epilogue: Y[class][o][bin]: the 8 waves of the group write the 8 consecutive bins of every (class, o) pair
+  // ---- epilogue: Y[pair][o][bin]
   const int bin = bin0 + wv;
 #pragma unroll
-  for (int b = 0; b < NBLK; ++b) {
-    const int nb = nb0 + (bq + b) * 32 + l31;
-    if (nb >= NB) continue;
+  for (int a = 0; a < NBLK; ++a) {
+    const int o = half * SG_OH + (oq + a) * 32 + l31;
+    if (o >= Cout) continue;
 #pragma unroll
-    for (int a = 0; a < NBLK; ++a)
+    for (int b = 0; b < NBLK; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int o = half * SG_OH + (oq + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hw;
+        const int nb = nb0 + (bq + b) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hw;
 #ifdef OS2D_DIAG_SG_NOSTORE
-        if (o < Cout && yr[a][b][r] == 123.456f) {
+        if (nb < NB && yr[a][b][r] == 123.456f) {
 #else
-        if (o < Cout) {
+        if (nb < NB) {
 #endif
           const float vr = yr[a][b][r], vi = yi[a][b][r];   // (copies: see the ext-vector element note in corr_f16x3.hip)
           Y[((size_t)nb * Cout + o) * NBINS + bin] = f32x2{vr, vi};

@@ -1,0 +1,254 @@
+// The per-bin complex GEMM of the frequency-domain 7x7 layer (see spectral.hip) on the HALF-PRECISION matrix cores with
+// split operands - precision "fftx3".  The fp32-MFMA version sits at the ridge of its two roofs (0.27 ms of matrix time,
+// ~0.28 ms of HBM time at 64 classes, measured 0.57 ms); v_mfma_f32_32x32x16_f16 is 16x faster, three of them per product
+// (hi*hi + hi*lo + lo*hi, fp32 accumulation: the arithmetic of the f16x3 mode) leave ~0.06 ms of matrix time and the kernel
+// becomes a stream of its 1.1 GB of operands.
+//
+// As a real GEMM per bin:  [Yr; Yi] = [[Kr, -Ki], [Ki, Kr]] . [Xr; Xi]  with k = (channel, re | im) - the interleaved storage
+// of a complex number IS the k order.  One k-step of the instruction = 16 k = 8 channels; lanes 0-31 take channels 0-3,
+// lanes 32-63 channels 4-7 (one 16-byte unit of 8 halves = 4 complex numbers each).
+//   B operand (spectra of the correlation maps): staged global -> registers -> LDS; the fp32 complex values are scaled by
+//     2^xexp (|X| <= H*W by construction - every sample is <= 1 after the per-location normalisation - so 2^xexp * H * W
+//     <= 65504: no overflow), split into fp16 hi + lo on the way and laid out [bin][channel group][hi|lo][pair] units;
+//   A operand (weight spectra, host data): stored ONCE as [Kr, Ki] units, pre-split, row o scaled by 2^wexp[o] (its largest
+//     |Kr|, |Ki| -> <= 32768); the two row types are derived in registers: [Kr, -Ki] = sign flip of the odd halves,
+//     [Ki, Kr] = half swap within each dword (8 VALU operations per fragment pair against 6 matrix instructions);
+//   the accumulators are multiplied by 2^-(wexp[o] + xexp) before the store, so Y is what the fp32 kernel produces (up to
+//     the 2^-22 relative error of a split product) and the inverse transform is unchanged.
+// Work decomposition, XCD-aware order and the Y layout are those of spectral_gemm_kernel: 4 waves = 4 bins x 64 output
+// channels x 64 pairs per work-group, two work-groups per CU (64 KB of LDS each), K loop in double-buffered k-steps.
+#include "os2d_common.h"
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+constexpr int SH_THR = 256;
+constexpr int SH_WB = 4;        // bins (= waves) per work-group
+constexpr int SH_BINS = 8;      // bins per group of the packed weight layout
+constexpr int SH_OH = 64, SH_NB = 64;
+constexpr int SH_KC = 8;        // channels per k-step
+constexpr int SH_STAGE = SH_WB * 2 * 2 * 64;   // 16-byte units of one operand stage: [bin][group][hi|lo][row]: 1024 = 16 KB
+#ifndef OS2D_SH_WRING
+#define OS2D_SH_WRING 3
+#endif
+constexpr int SH_WRING = OS2D_SH_WRING;        // weight stages in LDS (ring): the DMA of k-step s + WRING - 1 is in flight
+                                               // while k-step s is multiplied; the spectra are two k-steps ahead in registers
+
+// barrier for data exchanged through LDS that leaves the wave's global loads in flight (see fft.hip)
+__device__ __forceinline__ void sh_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(SH_THR, 2) void spectral_gemm_f16_kernel(const u32x4* w16,            // [G][2][KS][8][2][2][64] units
+                                                                      const float* __restrict__ wscale,  // [128] 2^-wexp[o]
+                                                                      const f32x2* __restrict__ X,       // [C][NB][NBINS]
+                                                                      f32x2* __restrict__ Y,             // [NB][Cout][NBINS]
+                                                                      int NB, int C, int Cout, int NBINS, int G, float xscale,
+                                                                      int nunits) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* ldsW = reinterpret_cast<u32x4*>(smem);                 // [SH_WRING][SH_STAGE]
+  u32x4* ldsX = ldsW + SH_WRING * SH_STAGE;                     // [2][SH_STAGE]
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hw = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int per = gridDim.x >> 3;
+  const int lidx = (blockIdx.x & 7) * per + (blockIdx.x >> 3);   // XCD-aware order, see spectral_gemm_kernel
+  if (lidx >= nunits) return;
+  constexpr int NBH = SH_BINS / SH_WB;
+  const int bh = lidx % NBH, lg = lidx / NBH;
+  const int nbt = (NB + SH_NB - 1) / SH_NB;
+  const int half = lg & 1, bt = (lg >> 1) % nbt, g = (lg >> 1) / nbt;
+  const int nb0 = bt * SH_NB, bin0 = g * SH_BINS + bh * SH_WB;
+  const int KS = (C + SH_KC - 1) / SH_KC;
+
+  f32x16 yr[2][2], yi[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        yr[a][b][r] = 0.f;
+        yi[a][b][r] = 0.f;
+      }
+
+  typedef const void __attribute__((address_space(1))) * gptr_t;
+  typedef void __attribute__((address_space(3))) * lptr_t;
+  // weights of k-step s for this work-group's 4 bins: 1024 contiguous units
+  const u32x4* wbase = w16 + ((size_t)(g * 2 + half) * KS) * (SH_BINS * 256) + bh * SH_STAGE;
+#define SH_DMA_W(S)                                                                                                 \
+  {                                                                                                                 \
+    const u32x4* src_ = wbase + (size_t)(S) * (SH_BINS * 256);                                                      \
+    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) {                                                              \
+      const int u_ = (wv * 4 + k_) * 64;                                                                            \
+      __builtin_amdgcn_global_load_lds((gptr_t)(src_ + u_ + lane), (lptr_t)(ldsW + ((S) % SH_WRING) * SH_STAGE + u_), 16, 0, 0); \
+    }                                                                                                               \
+  }
+  // spectra of k-step s: this thread owns pair xn, bins 2 xj / 2 xj + 1 and the 4 channels of group xg.  A wave covers 16
+  // pairs x (2 bin pairs x 2 channel groups): the rows of different pairs lie 5 MB apart, and a load instruction that touches
+  // 64 of them (one pair per lane) spends its time in address translation, not in the memory system
+  const int xn = wv * 16 + (lane & 15), xj = (lane >> 4) & 1, xg = lane >> 5;
+  const bool xn_ok = nb0 + xn < NB;
+  const f32x2* xrow = X + (size_t)min(nb0 + xn, NB - 1) * NBINS + bin0 + 2 * xj;
+  u32x4 pfa[4], pfb[4];     // two k-steps of spectra in flight (even / odd k-steps)
+#define SH_LOAD_X(S, pfx)                                                                                           \
+  {                                                                                                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                              \
+      const int c_ = min((S)*SH_KC + xg * 4 + i_, C - 1);                                                           \
+      pfx[i_] = *reinterpret_cast<const u32x4*>(xrow + (size_t)c_ * NB * NBINS);                                    \
+    }                                                                                                               \
+  }
+#define SH_STORE_X(S, pfx)                                                                                          \
+  {                                                                                                                 \
+    _Pragma("unroll") for (int b2_ = 0; b2_ < 2; ++b2_) {                                                           \
+      half8 h_, l_;                                                                                                 \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                            \
+        const bool ok_ = xn_ok && (S)*SH_KC + xg * 4 + i_ < C;                                                      \
+        _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_) {                                                          \
+          const unsigned raw_ = pfx[i_][2 * b2_ + p_];   /* (scalar copy first: see the ext-vector note in corr_f16x3.hip) */ \
+          const float v_ = ok_ ? __uint_as_float(raw_) * xscale : 0.f;                                              \
+          const _Float16 hv_ = (_Float16)v_;                                                                        \
+          h_[2 * i_ + p_] = hv_;                                                                                    \
+          l_[2 * i_ + p_] = (_Float16)(v_ - (float)hv_);                                                            \
+        }                                                                                                           \
+      }                                                                                                             \
+      u32x4* dst_ = ldsX + ((S)&1) * SH_STAGE + (((2 * xj + b2_) * 2 + xg) * 2) * 64 + xn;                          \
+      *reinterpret_cast<half8*>(dst_) = h_;                                                                         \
+      *reinterpret_cast<half8*>(dst_ + 64) = l_;                                                                    \
+    }                                                                                                               \
+  }
+
+#define SH_COMPUTE(S)                                                                                               \
+  {                                                                                                                 \
+    const u32x4* aB = ldsW + ((S) % SH_WRING) * SH_STAGE + ((wv * 2 + hw) * 2) * 64 + l31; /* [bin = wv][group = hw][hi|lo][o] */ \
+    const u32x4* bB = ldsX + ((S)&1) * SH_STAGE + ((wv * 2 + hw) * 2) * 64 + l31;          /* ... [pair] */                    \
+    half8 bhf[2], blf[2];                                                                                           \
+    _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                                 \
+      bhf[b] = *reinterpret_cast<const half8*>(bB + b * 32);                                                        \
+      blf[b] = *reinterpret_cast<const half8*>(bB + 64 + b * 32);                                                   \
+    }                                                                                                               \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                                 \
+      const u32x4 kh = aB[a * 32], kl = aB[64 + a * 32]; /* [Kr, Ki] x 4 channels, hi and lo */                     \
+      u32x4 rh, rl, ih, il;                                                                                         \
+      _Pragma("unroll") for (int d = 0; d < 4; ++d) {                                                               \
+        rh[d] = kh[d] ^ 0x80000000u; /* [Kr, -Ki] */                                                                \
+        rl[d] = kl[d] ^ 0x80000000u;                                                                                \
+        ih[d] = __builtin_amdgcn_alignbit(kh[d], kh[d], 16); /* [Ki, Kr] */                                         \
+        il[d] = __builtin_amdgcn_alignbit(kl[d], kl[d], 16);                                                        \
+      }                                                                                                             \
+      const half8 arh = __builtin_bit_cast(half8, rh), arl = __builtin_bit_cast(half8, rl);                         \
+      const half8 aih = __builtin_bit_cast(half8, ih), ail = __builtin_bit_cast(half8, il);                         \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                               \
+        /* the spectra are the ROW operand: the accumulator registers run over the pairs, the lanes over the output channels - a \
+           store instruction then stays inside one pair's rows (22 KB apart) instead of touching 32 pairs (3 MB apart) */    \
+        yr[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhf[b], arl, yr[a][b], 0, 0, 0);                          \
+        yr[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(blf[b], arh, yr[a][b], 0, 0, 0);                          \
+        yr[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhf[b], arh, yr[a][b], 0, 0, 0);                          \
+        yi[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhf[b], ail, yi[a][b], 0, 0, 0);                          \
+        yi[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(blf[b], aih, yi[a][b], 0, 0, 0);                          \
+        yi[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhf[b], aih, yi[a][b], 0, 0, 0);                          \
+      }                                                                                                             \
+    }                                                                                                               \
+  }
+  // one k-step: spectra of step S+2 -> registers PN (the registers PC hold step S+1, loaded one step ago), weights of step
+  // S + WRING - 1 -> LDS ring; multiply step S; split + store step S+1 into the other spectra buffer; barrier.  Per wave the
+  // memory operations complete in issue order and the weights of a step are issued BEFORE its spectra: when the spectra of
+  // step S+1 have arrived (the split below waits for them) its weights are in LDS as well; the barrier itself waits for LDS
+  // traffic only.
+#define SH_STEP(S, PC, PN)                                                                                          \
+  {                                                                                                                 \
+    if ((S) + SH_WRING - 1 < KS) SH_DMA_W((S) + SH_WRING - 1)                                                       \
+    if ((S) + 2 < KS) SH_LOAD_X((S) + 2, PN)                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    SH_COMPUTE(S)                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    if ((S) + 1 < KS) SH_STORE_X((S) + 1, PC)                                                                       \
+    sh_lds_barrier();                                                                                               \
+  }
+
+  static_assert(SH_WRING >= 3, "the spectra run two k-steps ahead: the weight ring must reach at least as far");
+  SH_DMA_W(0)
+  SH_LOAD_X(0, pfb)
+  if (1 < KS) {
+    SH_DMA_W(1)
+    SH_LOAD_X(1, pfa)
+  }
+#pragma unroll
+  for (int s = 2; s < SH_WRING - 1; ++s)
+    if (s < KS) SH_DMA_W(s)
+  SH_STORE_X(0, pfb)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // prologue only: weights of step 0 (.. WRING - 2) are in LDS
+  sh_lds_barrier();
+  for (int s = 0; s < KS; s += 2) {
+    SH_STEP(s, pfa, pfb)
+    if (s + 1 < KS) SH_STEP(s + 1, pfb, pfa)
+  }
+#undef SH_STEP
+#undef SH_COMPUTE
+#undef SH_DMA_W
+#undef SH_LOAD_X
+#undef SH_STORE_X
+
+  // ---- epilogue: undo the operand scales, Y[pair][o][bin] (as spectral_gemm_kernel)
+  const int bin = bin0 + wv;
+  const float inv_x = 1.0f / xscale;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int o = half * SH_OH + a * 32 + l31;
+    if (o >= Cout) continue;
+    const float sc = wscale[o] * inv_x;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int nb = nb0 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hw;
+        if (nb < NB) {
+          const float vr = yr[a][b][r], vi = yi[a][b][r];
+          Y[((size_t)nb * Cout + o) * NBINS + bin] = f32x2{vr * sc, vi * sc};
+        }
+      }
+  }
+}
+
+}  // namespace
+
+// bytes of the split weight spectra: [NBINS/8][2][KS][8][2][2][64] units of 16 B, followed by the 128 row scales (floats)
+size_t os2d_spectral_weight16_size(int C, int NBINS) {
+  const size_t KS = (size_t)(C + SH_KC - 1) / SH_KC;
+  return (size_t)(NBINS / SH_BINS) * 2 * KS * SH_BINS * 256 * 16 + 128 * sizeof(float);
+}
+
+// largest power-of-two scale of the input spectra that cannot overflow fp16: |X| <= H * W
+float os2d_spectral_xscale_for(int H, int W) {
+  float s = 1.0f;
+  while (s * 2.0f * (float)H * (float)W <= 65504.0f) s *= 2.0f;
+  return s;
+}
+
+int os2d_launch_spectral_gemm_f16(const void* w16, const float* X, float* Y, int NB, int C, int Cout, int NBINS, float xscale,
+                                  hipStream_t stream) {
+  if (NBINS % SH_BINS || Cout > 2 * SH_OH) {
+    os2d_set_error("spectral_gemm_f16: NBINS %d must be a multiple of %d and Cout %d <= %d", NBINS, SH_BINS, Cout, 2 * SH_OH);
+    return -3;
+  }
+  const int G = NBINS / SH_BINS, nbt = (NB + SH_NB - 1) / SH_NB;
+  const size_t lds = (size_t)(SH_WRING + 2) * SH_STAGE * 16;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spectral_gemm_f16_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) {
+    os2d_set_error("hipFuncSetAttribute(spectral_gemm_f16): %s", hipGetErrorString(e));
+    return -4;
+  }
+  const long long units = 2LL * G * nbt * (SH_BINS / SH_WB);
+  const size_t KS = (size_t)(C + SH_KC - 1) / SH_KC;
+  const float* wscale = reinterpret_cast<const float*>(static_cast<const char*>(w16) + (size_t)G * 2 * KS * SH_BINS * 256 * 16);
+  dim3 grid((unsigned)((units + 7) / 8 * 8));
+  hipLaunchKernelGGL(spectral_gemm_f16_kernel, grid, dim3(SH_THR), lds, stream, static_cast<const u32x4*>(w16), wscale,
+                     reinterpret_cast<const f32x2*>(X), reinterpret_cast<f32x2*>(Y), NB, C, Cout, NBINS, G, xscale, (int)units);
+  e = hipGetLastError();
+  if (e != hipSuccess) {
+    os2d_set_error("spectral_gemm_f16 launch: %s", hipGetErrorString(e));
+    return -4;
+  }
+  return 0;
+}

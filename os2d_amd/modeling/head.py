@@ -28,8 +28,9 @@ from .box_coder import BoxGridGenerator
 TEMPLATE = 15
 QROWS = 256
 FFT_MIN_PAIRS = 12      # precision "fft": image x class pairs below which the direct 7x7 kernel is used instead
-PRECISIONS = {"f32": 0, "f16x3": 1, "f16x2": 2, "fft": 3}     # OS2D_PRECISION_* of include/os2d_hip.h
-DEFAULT_PRECISION = "fft"
+PRECISIONS = {"f32": 0, "f16x3": 1, "f16x2": 2, "fft": 3, "fftx3": 4}     # OS2D_PRECISION_* of include/os2d_hip.h
+FFT_MODES = ("fft", "fftx3")
+DEFAULT_PRECISION = "fftx3"
 
 
 def resolve_precision(precision=None):
@@ -39,7 +40,8 @@ def resolve_precision(precision=None):
     matrix-core work, box regression within 5e-5 and scores within 1e-6 of fp32, inside the 1e-4 parity bound), or "fft"
     (as f16x3, but the 7x7 layer runs in the frequency domain in fp32: real FFT -> one complex GEMM per bin on the fp32
     matrix cores -> inverse FFT; fp32-equivalent, 16.7x fewer multiply-adds; maps that do not fit the in-LDS transform and
-    small class batches fall back to f16x3).  Default from $OS2D_PRECISION, else "fft" (the fastest fp32-equivalent mode)."""
+    small class batches fall back to f16x3), or "fftx3" (as fft, with the per-bin GEMM on the half-precision matrix cores:
+    spectra split into fp16 hi + lo, the arithmetic of f16x3).  Default from $OS2D_PRECISION, else DEFAULT_PRECISION."""
     precision = precision or os.environ.get("OS2D_PRECISION", DEFAULT_PRECISION)
     if precision not in PRECISIONS:
         raise ValueError("precision must be one of {}, got {!r}".format(sorted(PRECISIONS), precision))
@@ -249,7 +251,7 @@ class TransformationNet(nn.Module):
         of ``range_plan``.  Cached until a parameter changes; the cache entry carries an event so that other streams never
         read half-written buffers."""
         precision = resolve_precision(precision)
-        if precision in ("f16x2", "fft"):
+        if precision in ("f16x2", "fft", "fftx3"):
             precision = "f16x3"        # same packed weights and scales (f16x2 skips the lo halves of layer 1; fft replaces
                                        # layer 1 by ``spectra`` and keeps its bias / output scales)
         key = (precision,) + self._state_key()
@@ -299,8 +301,9 @@ class TransformationNet(nn.Module):
             self._packed_cache[precision] = _StreamOrdered(key, result, dev)
         return result
 
-    def spectra(self, H, W):
-        """Frequency-domain form of the 7x7 layer for an H x W map (precision "fft"): (wspec, twQ, twP, nbins) or None when
+    def spectra(self, H, W, split=False):
+        """Frequency-domain form of the 7x7 layer for an H x W map (precision "fft"; ``split``: "fftx3", the weight spectra
+        pre-split into fp16 hi + lo with per-row power-of-two scales for os2d_spectral_gemm_f16): (wspec, twQ, twP, nbins) or None when
         the map does not fit the in-LDS transform.  The BatchNorm-folded 7x7 filters are centred on the origin of the
         P x Q grid (tap (t, s) at ((3 - t) mod P, (3 - s) mod Q): the circular convolution then IS the zero-padded
         correlation of head.py:619 for the first H x W samples), transformed once with torch.fft in float64 and packed for
@@ -315,29 +318,56 @@ class TransformationNet(nn.Module):
         P, Q, nbins = cP.value, cQ.value, cN.value
         dev = self.linear.weight.device
         key = self._state_key()
-        cached = self._spectra_cache.get((P, Q))
+        slot = (P, Q, bool(split))
+        cached = self._spectra_cache.get(slot)
         if cached is not None and cached.key == key:
-            self._spectra_cache.move_to_end((P, Q))
+            self._spectra_cache.move_to_end(slot)
             return cached.get(dev)
         for k in [k for k, c in self._spectra_cache.items() if c.key != key]:
             del self._spectra_cache[k]                           # a parameter changed: every cached size is stale
         with torch.cuda.device(dev), torch.no_grad():
             (w1, _), _, _ = self._folded()                       # float64 [128,225,7,7]
             V = Q // 2 + 1
-            packed = torch.zeros(nbins // 8, 2, 225, 8, 64, dtype=torch.complex64, device=dev)
+            G, KS = nbins // 8, (225 + 7) // 8
+            if split:
+                nunits = G * 2 * KS * 8 * 2 * 2 * 64
+                wbuf = torch.zeros(nunits * 16 + 128 * 4, dtype=torch.uint8, device=dev)
+                packed16 = wbuf[:nunits * 16].view(torch.float16).view(G, 2, KS, 8, 2, 2, 64, 8)
+                wscale = wbuf[nunits * 16:].view(torch.float32)
+            else:
+                packed = torch.zeros(G, 2, 225, 8, 64, dtype=torch.complex64, device=dev)
             ti = (3 - torch.arange(7, device=dev)) % P
             si = (3 - torch.arange(7, device=dev)) % Q
             for half in range(2):                               # 64 output channels at a time bounds the float64 transient
                 k = torch.zeros(64, 225, P, Q, dtype=torch.float64, device=dev)
                 k[:, :, ti.view(-1, 1), si.view(1, -1)] = w1[64 * half:64 * half + 64]
-                K = torch.fft.rfft2(k).reshape(64, 225, P * V).to(torch.complex64)
+                K = torch.fft.rfft2(k).reshape(64, 225, P * V)
                 del k
-                Kp = torch.zeros(64, 225, nbins, dtype=torch.complex64, device=dev)
-                Kp[:, :, :P * V] = K
-                del K
-                packed[:, half] = Kp.view(64, 225, nbins // 8, 8).permute(2, 1, 3, 0)      # [g][c][j][r]
-                del Kp
-            wspec = torch.view_as_real(packed).contiguous()
+                if split:
+                    # row o scaled by the power of two that puts its largest |Kr|, |Ki| in (16384, 32768]; fp16 hi + lo of
+                    # (Kr, Ki); units of 4 channels x (re, im): [g][half][k-step][bin][channel group][hi|lo][o][8 halves]
+                    T = torch.zeros(64, KS * 8, nbins, 2, dtype=torch.float64, device=dev)
+                    T[:, :225, :P * V] = torch.view_as_real(K)
+                    del K
+                    amax = T.abs().amax(dim=(1, 2, 3)).clamp_min(1e-300)
+                    wexp = torch.floor(torch.log2(32768.0 / amax)).clamp(-100, 100)
+                    T *= torch.exp2(wexp).view(-1, 1, 1, 1)
+                    wscale[64 * half:64 * half + 64] = torch.exp2(-wexp).float()
+                    hi = T.to(torch.float16)
+                    T -= hi.double()
+                    lo = T.to(torch.float16)
+                    del T
+                    for part, t in enumerate((hi, lo)):
+                        # [o][ks][grp][c4][g][bin][ri] -> [g][ks][bin][grp][o][c4][ri]
+                        packed16[:, half, :, :, :, part] = t.view(64, KS, 2, 4, G, 8, 2).permute(4, 1, 5, 2, 0, 3, 6).reshape(G, KS, 8, 2, 64, 8)
+                    del hi, lo
+                else:
+                    Kp = torch.zeros(64, 225, nbins, dtype=torch.complex64, device=dev)
+                    Kp[:, :, :P * V] = K.to(torch.complex64)
+                    del K
+                    packed[:, half] = Kp.view(64, 225, G, 8).permute(2, 1, 3, 0)      # [g][c][j][r]
+                    del Kp
+            wspec = wbuf if split else torch.view_as_real(packed).contiguous()
 
             def table(n):
                 m = torch.arange(n, dtype=torch.float64)
@@ -350,7 +380,7 @@ class TransformationNet(nn.Module):
                 if used + sum(c.nbytes() for c in self._spectra_cache.values()) <= cap:
                     break
                 del self._spectra_cache[k]
-            self._spectra_cache[(P, Q)] = entry
+            self._spectra_cache[slot] = entry
         return result
 
     def forward(self, corr_maps, precision="f32"):
@@ -671,10 +701,10 @@ class Os2dHead(nn.Module):
                 precision = "f32"
         precision = resolve_precision(precision or self.precision)
         spectra = None
-        if precision == "fft":
+        if precision in FFT_MODES:
             # the frequency-domain 7x7 layer pays off from a dozen classes on (it streams 0.7 GB of weight spectra per call)
             # and needs the map to fit its in-LDS transform; otherwise the direct f16x3 kernel does the layer
-            spectra = regressor.spectra(H, W) if A * B >= FFT_MIN_PAIRS else None
+            spectra = regressor.spectra(H, W, split=precision == "fftx3") if A * B >= FFT_MIN_PAIRS else None
             if spectra is None:
                 precision = "f16x3"
         self.last_precision = precision          # the arithmetic that actually ran (bench.py / tests)

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 TOL_CLS, TOL_LOC, TOL_CORNERS = util.TOL_CLS, util.TOL_LOC, util.TOL_CORNERS
 
 
-PRECISIONS = ["f32", "f16x3", "f16x2", "fft"]     # every arithmetic mode must meet the same tolerances
+PRECISIONS = ["f32", "f16x3", "f16x2", "fft", "fftx3"]     # every arithmetic mode must meet the same tolerances
 
 
 @pytest.fixture(autouse=True)

@@ -19,11 +19,13 @@ def pack_weight_spectra(K, nbins_pad=None):
 
 
 def run_spectral_gemm(Wp, X, Cout):
+    """X [NB,C,nbins] (test order) -> the kernel's channel-major [C,NB,nbins]."""
     lib = _lib.load()
     NB, C, nbins = X.shape
     assert Wp.numel() * 8 == lib.os2d_spectral_weight_bytes(C, Cout, nbins)
     Y = torch.full((NB, Cout, nbins), float("nan"), dtype=torch.complex64, device=X.device)
-    _lib.check(lib.os2d_spectral_gemm(_lib.ptr(torch.view_as_real(Wp)), _lib.ptr(torch.view_as_real(X)), _lib.ptr(torch.view_as_real(Y)),
+    Xk = X.permute(1, 0, 2).contiguous()
+    _lib.check(lib.os2d_spectral_gemm(_lib.ptr(torch.view_as_real(Wp)), _lib.ptr(torch.view_as_real(Xk)), _lib.ptr(torch.view_as_real(Y)),
                                       NB, C, Cout, nbins, _lib.current_stream(X.device)), "os2d_spectral_gemm")
     return Y
 
@@ -99,13 +101,13 @@ def test_fft_forward_matches_torch_fft(H, W, NB, C, device):
     g = torch.Generator().manual_seed(H * 100 + W)
     corr = (torch.rand(NB, C, H, W, generator=g) - 0.3).to(device)
     inv = (0.5 + torch.rand(NB, H, W, generator=g)).to(device)
-    X = torch.full((NB, C, nbins, 2), float("nan"), device=device)
+    X = torch.full((C, NB, nbins, 2), float("nan"), device=device)               # channel-major (what the GEMM kernels read)
     tq, tp = twiddles(Q, device), twiddles(P, device)          # keep them alive: the call only takes raw pointers
     _lib.check(lib.os2d_fft_forward(_lib.ptr(corr), _lib.ptr(inv), _lib.ptr(X), _lib.ptr(tq), _lib.ptr(tp),
                                     NB, C, H, W, _lib.current_stream(device)), "os2d_fft_forward")
     x = (corr.clamp(min=0) * inv.unsqueeze(1)).double()
     ref = torch.fft.rfft2(x, s=(P, Q)).reshape(NB, C, -1)                       # [NB,C,P*V], bin = u*V + v
-    got = torch.view_as_complex(X)[..., :P * (Q // 2 + 1)].to(torch.complex128)
+    got = torch.view_as_complex(X)[..., :P * (Q // 2 + 1)].to(torch.complex128).permute(1, 0, 2)
     scale = float(ref.abs().max())
     assert float((got - ref).abs().max()) <= 2e-6 * scale
     assert float(X[:, :, P * (Q // 2 + 1):].abs().max() if nbins > P * (Q // 2 + 1) else 0.0) == 0.0
@@ -168,11 +170,57 @@ def test_weight_spectra_cache_is_keyed_by_transform_size_and_bounded(device, mon
     one = next(iter(net._spectra_cache.values())).nbytes()
     monkeypatch.setenv("OS2D_FFT_CACHE_BYTES", str(one + 1))
     d = net.spectra(30, 40)          # larger than the cap: everything else goes, the new entry stays
-    assert list(net._spectra_cache) == [(36, 48)] and d[3] == 36 * 25 + (-36 * 25) % 8
+    assert list(net._spectra_cache) == [(36, 48, False)] and d[3] == 36 * 25 + (-36 * 25) % 8
     monkeypatch.delenv("OS2D_FFT_CACHE_BYTES")
     net.spectra(12, 20)
     with torch.no_grad():
         net.conv[0].weight.mul_(1.5)
     e = net.spectra(12, 20)
-    assert list(net._spectra_cache) == [(16, 24)]
+    assert list(net._spectra_cache) == [(16, 24, False)]
     assert not torch.equal(e[0], a[0])
+
+
+@pytest.mark.parametrize("H,W,NB", [(11, 13, 5), (30, 40, 70)])
+def test_split_half_spectral_gemm_matches_float64(H, W, NB, device):
+    """os2d_spectral_gemm_f16 (spectra split into fp16 hi + lo on the half-precision matrix cores) and os2d_spectral_gemm (fp32
+    matrix cores) against a float64 product, with the weight spectra as TransformationNet.spectra packs them."""
+    from os2d_amd.modeling import head as head_mod
+    from os2d_amd.utils import synthetic
+    lib = _lib.load()
+    net = head_mod.TransformationNet(output_dim=6)
+    net.load_state_dict(synthetic.make_transform_net_state(6, seed=3))
+    net.to(device).eval()
+    P, Q, nbins = fft_sizes(H, W)
+    V = Q // 2 + 1
+    w32 = net.spectra(H, W)[0]
+    w16 = net.spectra(H, W, split=True)[0]
+    assert w16.numel() == lib.os2d_spectral_weight16_bytes(225, nbins)
+    # input spectra of maps with samples in [0, 1] (what the layer sees), a few channels forced to the extremes of the range
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.rand(NB, 225, H, W, generator=g, dtype=torch.float64)
+    x[:, 0] = 1.0                       # DC bin = H * W: the largest value the scale must hold
+    x[:, 1] *= 1e-6                     # tiny channel: its lo halves are subnormal
+    Xc = torch.fft.rfft2(x, s=(P, Q)).reshape(NB, 225, P * V)
+    X = torch.zeros(NB, 225, nbins, 2)
+    X[:, :, :P * V] = torch.view_as_real(Xc.to(torch.complex64))
+    Xd = X.permute(1, 0, 2, 3).contiguous().to(device)              # channel-major
+    # reference from the fp32 spectra actually uploaded (isolates the kernels' arithmetic from the packing)
+    (w1, _), _, _ = net._folded()
+    k = torch.zeros(128, 225, P, Q, dtype=torch.float64)
+    k[:, :, ((3 - torch.arange(7)) % P).view(-1, 1), ((3 - torch.arange(7)) % Q).view(1, -1)] = w1.cpu()
+    K = torch.fft.rfft2(k).reshape(128, 225, P * V)
+    ref = torch.einsum("ocb,ncb->nob", K, torch.view_as_complex(X[:, :, :P * V].double().contiguous()))
+    scale = float(ref.abs().max())
+    st = _lib.current_stream(device)
+    for name in ("f32", "f16"):
+        Y = torch.full((NB, 128, nbins, 2), float("nan"), device=device)
+        if name == "f32":
+            _lib.check(lib.os2d_spectral_gemm(_lib.ptr(w32), _lib.ptr(Xd), _lib.ptr(Y), NB, 225, 128, nbins, st), "gemm")
+        else:
+            xs = lib.os2d_spectral_xscale(H, W)
+            assert xs * H * W <= 65504 < 2 * xs * H * W
+            _lib.check(lib.os2d_spectral_gemm_f16(_lib.ptr(w16), _lib.ptr(Xd), _lib.ptr(Y), NB, 225, 128, nbins, xs, st), "gemm16")
+        got = torch.view_as_complex(Y.cpu()[:, :, :P * V].contiguous()).to(torch.complex128)
+        err = float((got - ref).abs().max())
+        print("spectral GEMM {} {}x{} NB={}: max err {:.3g} of {:.3g}".format(name, H, W, NB, err, scale))
+        assert err <= 2e-6 * scale, name

@@ -12,7 +12,7 @@ H, W, C, Cout = 60, 80, 225, 128
 P, Q, nbins = fft_sizes(H, W)
 tq, tp = twiddles(Q, dev), twiddles(P, dev)
 corr = torch.randn(NB, C, H * W, device=dev); inv = torch.rand(NB, H * W, device=dev)
-X = torch.empty(NB, C, nbins, 2, device=dev); Y = torch.randn(NB, Cout, nbins, 2, device=dev)
+X = torch.empty(C, NB, nbins, 2, device=dev); Y = torch.randn(NB, Cout, nbins, 2, device=dev)
 Wsp = torch.randn(lib.os2d_spectral_weight_bytes(C, Cout, nbins) // 4, device=dev)
 bp = torch.ones(3 * 128, device=dev)
 out = torch.empty(NB * lib.os2d_shb_bytes(Cout, H, W), dtype=torch.uint8, device=dev)
@@ -25,4 +25,10 @@ def t(f, n=10):
 fwd = lambda: _lib.check(lib.os2d_fft_forward(_lib.ptr(corr), _lib.ptr(inv), _lib.ptr(X), _lib.ptr(tq), _lib.ptr(tp), NB, C, H, W, st), "f")
 gem = lambda: _lib.check(lib.os2d_spectral_gemm(_lib.ptr(Wsp), _lib.ptr(X), _lib.ptr(Y), NB, C, Cout, nbins, st), "g")
 inv_ = lambda: _lib.check(lib.os2d_fft_inverse(_lib.ptr(Y), _lib.ptr(bp), _lib.ptr(out), _lib.ptr(tq), _lib.ptr(tp), NB, Cout, H, W, _lib.ptr(status), st), "i")
-print("NB={} P={} Q={} bins={}: forward {:.3f} ms, spectral GEMM {:.3f} ms, inverse {:.3f} ms".format(NB, P, Q, nbins, t(fwd), t(gem), t(inv_)))
+W16 = torch.randn(lib.os2d_spectral_weight16_bytes(C, nbins) // 2, device=dev).to(torch.float16).view(torch.uint8)
+W16.view(torch.float32)[-128:] = 1.0
+xs = lib.os2d_spectral_xscale(H, W)
+gem16 = lambda: _lib.check(lib.os2d_spectral_gemm_f16(_lib.ptr(W16), _lib.ptr(X), _lib.ptr(Y), NB, C, Cout, nbins, xs, st), "g16")
+X.normal_()
+print("NB={} P={} Q={} bins={}: forward {:.3f} ms, spectral GEMM {:.3f} ms (split-half: {:.3f} ms), inverse {:.3f} ms".format(
+    NB, P, Q, nbins, t(fwd), t(gem), t(gem16), t(inv_)))

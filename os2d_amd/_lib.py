@@ -41,6 +41,7 @@ SIGNATURES = {
     "os2d_spectral_weight16_bytes": (_sz, [_i, _i]),
     "os2d_spectral_xscale": (_f, [_i, _i]),
     "os2d_spectral_gemm_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "os2d_debug_set_dump": (None, [_vp, _i, _vp, _sz]),
     "os2d_fft_sizes": (_i, [_i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "os2d_fft_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "os2d_fft_inverse": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -4,6 +4,7 @@
 
 #include "../../include/os2d_hip.h"
 #include "os2d_common.h"
+#include <vector>
 
 namespace {
 thread_local char g_err[512] = {0};
@@ -57,6 +58,20 @@ Carve carve(int A, int Bc, int C, int H, int W, int P, int fft_bins = 0) {
   return c;
 }
 
+// ---- debugging aid (tools/diag_*.py): copies of intermediate buffers of os2d_head_forward_ex, per stream
+struct DumpEntry {
+  void* stream;
+  int slot;
+  void* dst;
+  size_t bytes;
+};
+std::vector<DumpEntry> g_dumps;
+void dump_slot(void* stream, int slot, const void* src, size_t bytes) {
+  for (const DumpEntry& e : g_dumps)
+    if (e.stream == stream && e.slot == slot)
+      (void)hipMemcpyAsync(e.dst, src, bytes < e.bytes ? bytes : e.bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream));
+}
+
 bool head_args_ok(int A, int B, int C, int H, int W, int P) {
   if (A < 1 || B < 1 || C < 4 || (C & 3) || H < 1 || W < 1 || (P != 6 && P != 4)) {
     os2d_set_error("bad head shape A=%d B=%d C=%d H=%d W=%d P=%d (need A,B,H,W>=1, C%%4==0, P in {6,4})", A, B, C, H,
@@ -71,6 +86,16 @@ bool head_args_ok(int A, int B, int C, int H, int W, int P) {
   return true;
 }
 }  // namespace
+
+void os2d_debug_set_dump(void* stream, int slot, void* dst, size_t bytes) {
+  for (DumpEntry& e : g_dumps)
+    if (e.stream == stream && e.slot == slot) {
+      e.dst = dst;
+      e.bytes = bytes;
+      return;
+    }
+  g_dumps.push_back(DumpEntry{stream, slot, dst, bytes});
+}
 
 void os2d_set_error(const char* fmt, ...) {
   va_list ap;
@@ -410,6 +435,16 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     }
     mark(b0, 3);
     mark(b0, 4);
+    if (!g_dumps.empty() && b0 == 0) {   // slots: 0 corr, 1 inverse norms, 2 input spectra, 3 output spectra, 4 h1, 5 h2, 6 params
+      const size_t PLb = os2d_plane(H, W);
+      dump_slot(stream, 0, corr, (size_t)NB * OS2D_K * H * W * 4);
+      if (fft_bins) {
+        dump_slot(stream, 1, invn, (size_t)NB * H * W * 4);
+        dump_slot(stream, 2, xspec, (size_t)NB * OS2D_K * fft_bins * 8);
+        dump_slot(stream, 3, yspec, (size_t)NB * 128 * fft_bins * 8);
+      }
+      dump_slot(stream, 4, h1, (size_t)NB * 128 * PLb * 4);
+    }
     if (f16) {
       if ((rc = os2d_launch_conv_f16x3(2, h1, w2, b2, status, h2, NB, P, H, W, 3, st))) return rc;
     } else {
@@ -417,6 +452,7 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     }
     mark(b0, 5);
     mark(b0, 6);
+    if (!g_dumps.empty() && b0 == 0) dump_slot(stream, 5, h2, (size_t)NB * 64 * os2d_plane(H, W) * 4);
     if (f16) {
       if ((rc = os2d_launch_conv_f16x3(3, h2, w3, b3, status, params, NB, P, H, W, 3, st))) return rc;
     } else {
@@ -424,6 +460,7 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     }
     mark(b0, 7);
     mark(b0, 8);
+    if (!g_dumps.empty() && b0 == 0) dump_slot(stream, 6, params, (size_t)NB * P * H * W * 4);
     if ((rc = os2d_launch_sample_decode(corr, params, NB, H, W, P, inverse, stride, rec_field, bc, B, b0, loc, cls,
                                         corners, st)))
       return rc;

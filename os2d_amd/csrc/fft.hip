@@ -47,7 +47,11 @@ struct FftPlan {
 // and stores.  __syncthreads() carries a full fence (s_waitcnt vmcnt(0)): inside the per-image loop it would wait for the
 // prefetch of the next image and for the stores of the previous one at every one of the ~10 barriers of an image - the
 // whole HBM latency serialised per image (measured: 8 us of an image's 17 us).
+#ifdef OS2D_DIAG_FFT_FULLBARRIER
+__device__ __forceinline__ void lds_barrier() { __syncthreads(); }
+#else
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 
 __device__ __forceinline__ f32x2 cmul(f32x2 a, f32x2 b) { return f32x2{a[0] * b[0] - a[1] * b[1], a[0] * b[1] + a[1] * b[0]}; }
 __device__ __forceinline__ f32x2 cconj(f32x2 a) { return f32x2{a[0], -a[1]}; }
@@ -546,6 +550,9 @@ int os2d_launch_fft_forward(const float* corr, const float* inv, float* X, const
     os2d_set_error("fft_forward: a %dx%d map does not fit the in-LDS transform", H, W);
     return -3;
   }
+#ifdef OS2D_DIAG_FFT_LDS_MIN
+  if (lds < (size_t)OS2D_DIAG_FFT_LDS_MIN) lds = OS2D_DIAG_FFT_LDS_MIN;
+#endif
   const int ept = (((H + 1) / 2) * pl.Q + FFT_THR - 1) / FFT_THR;
   auto kern = ept <= 6 ? fft_forward_kernel<6> : ept <= 10 ? fft_forward_kernel<10> : fft_forward_kernel<14>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -2,7 +2,7 @@
 """Benchmark of the MI355X OS2D head: query-image-pairs/s (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--classes B_per_gpu | --classes-total B] [--variant v2|v1]
-                    [--precision fft|f16x3|f16x2|f32] [--pyramid] [--gather all|scores|detections]
+                    [--precision fftx3|fft|f16x3|f16x2|f32] [--pyramid] [--gather all|scores|detections]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -26,7 +26,11 @@ Workloads
                    --classes B keeps B classes per GPU instead (weak scaling).
 
 Arithmetic (``--precision``):
-  fft (default)    as f16x3, except that the dominant 7x7 layer (225 -> 128 channels) runs in the frequency domain in fp32:
+  fftx3 (default)  as fft, with the per-bin complex GEMM on v_mfma_f32_32x32x16_f16: spectra split into fp16 hi + lo (three
+                   MFMAs per product, fp32 accumulation; the weight spectra pre-split on the host with per-row scales, the
+                   input spectra - bounded by H*W - split on the fly): the launch is bound by the HBM stream of its operands,
+                   so the roofline object of this mode is an HBM one (algorithmic bytes / live launch time against 8 TB/s);
+  fft              as f16x3, except that the dominant 7x7 layer (225 -> 128 channels) runs in the frequency domain in fp32:
                    in-LDS real FFT of the normalised correlation maps, one complex GEMM per frequency bin on
                    v_mfma_f32_32x32x2_f32, inverse FFT with the bias / ReLU / fp16-split epilogue fused.  16.7x fewer
                    multiply-adds than the direct layer, fp32 arithmetic throughout (closer to an fp64 evaluation than the

@@ -446,7 +446,7 @@ class Workload(object):
                 r["executed_mfma_tflops"] = round(terms * achieved * 1.118 / 1e12, 1)
                 r["executed_frac_of_peak"] = round(terms * achieved * 1.118 / peak, 4)
         if fell_back:
-            r["note"] = "precision fft requested; with fewer than 12 image-class pairs the head runs the direct f16x3 7x7 kernel"
+            r["note"] = "a frequency-domain mode was requested; with fewer than 12 image-class pairs the head runs the direct f16x3 7x7 kernel"
         return r
 
     def roofline_fft_whole(self, seconds, precision="fft"):

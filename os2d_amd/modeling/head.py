@@ -27,7 +27,7 @@ from .box_coder import BoxGridGenerator
 
 TEMPLATE = 15
 QROWS = 256
-FFT_MIN_PAIRS = 12      # precision "fft": image x class pairs below which the direct 7x7 kernel is used instead
+FFT_MIN_PAIRS = 12      # precision "fft" / "fftx3": image x class pairs below which the direct 7x7 kernel is used instead
 PRECISIONS = {"f32": 0, "f16x3": 1, "f16x2": 2, "fft": 3, "fftx3": 4}     # OS2D_PRECISION_* of include/os2d_hip.h
 FFT_MODES = ("fft", "fftx3")
 DEFAULT_PRECISION = "fftx3"
@@ -600,7 +600,7 @@ class Os2dHead(nn.Module):
         self.class_pool_mask = mask / mask.sum(dim=(2, 3), keepdim=True)
         self.aligner = aligner
         self.last_precision = None
-        self.precision = None      # None: follow $OS2D_PRECISION (default "fft"); or "f32" / "f16x3" / "f16x2" / "fft"
+        self.precision = None      # None: follow $OS2D_PRECISION (default "fftx3"); or one of PRECISIONS
         # sticky status word of the split-fp16 kernels in mapped pinned host memory: the kernels store to it only when an
         # activation leaves the fp16 range (impossible for finite inputs, see TransformationNet.range_plan), the host
         # reads it without synchronising

@@ -34,7 +34,7 @@ Arithmetic (``--precision``):
                    in-LDS real FFT of the normalised correlation maps, one complex GEMM per frequency bin on
                    v_mfma_f32_32x32x2_f32, inverse FFT with the bias / ReLU / fp16-split epilogue fused.  16.7x fewer
                    multiply-adds than the direct layer, fp32 arithmetic throughout (closer to an fp64 evaluation than the
-                   direct fp32 kernel); class batches below 12 pairs and maps that do not fit the in-LDS transform take
+                   direct fp32 kernel); class batches below 7 pairs and maps that do not fit the in-LDS transform take
                    the f16x3 kernel;
   f16x3            every fp32 operand of the four GEMM-shaped stages is split into fp16 hi + lo and each product is
                    evaluated with three v_mfma_f32_32x32x16_f16 (fp32 accumulation); per-channel power-of-two scales
@@ -446,7 +446,7 @@ class Workload(object):
                 r["executed_mfma_tflops"] = round(terms * achieved * 1.118 / 1e12, 1)
                 r["executed_frac_of_peak"] = round(terms * achieved * 1.118 / peak, 4)
         if fell_back:
-            r["note"] = "a frequency-domain mode was requested; with fewer than 12 image-class pairs the head runs the direct f16x3 7x7 kernel"
+            r["note"] = "a frequency-domain mode was requested; with fewer than 7 image-class pairs the head runs the direct f16x3 7x7 kernel"
         return r
 
     def roofline_fft_whole(self, seconds, precision="fft"):
@@ -604,7 +604,7 @@ def main():
 
     dt, stage_ms = w.run(args.precision, args.steps, args.warmup)
     value = classes_total * args.steps / dt
-    effective = args.precision          # below 12 image-class pairs the fft mode runs the direct f16x3 kernel for the 7x7 layer
+    effective = args.precision          # below 7 image-class pairs the fft modes run the direct f16x3 kernel for the 7x7 layer
     if not args.pyramid and getattr(w.head, "last_precision", None):
         effective = w.head.last_precision
     gather_desc = {"all": "loc | cls | corners maps (every rank can decode every class)", "scores": "score maps only",

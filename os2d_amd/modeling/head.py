@@ -27,7 +27,8 @@ from .box_coder import BoxGridGenerator
 
 TEMPLATE = 15
 QROWS = 256
-FFT_MIN_PAIRS = 12      # precision "fft" / "fftx3": image x class pairs below which the direct 7x7 kernel is used instead
+FFT_MIN_PAIRS = 7       # precision "fft" / "fftx3": image x class pairs below which the direct 7x7 kernel is used instead
+                        # (measured crossover at 60 x 80, tools/time_small_batches.py: 6 pairs 0.413 vs 0.416 ms, 8 pairs 0.46 vs 0.53)
 PRECISIONS = {"f32": 0, "f16x3": 1, "f16x2": 2, "fft": 3, "fftx3": 4}     # OS2D_PRECISION_* of include/os2d_hip.h
 FFT_MODES = ("fft", "fftx3")
 DEFAULT_PRECISION = "fftx3"
@@ -702,7 +703,7 @@ class Os2dHead(nn.Module):
         precision = resolve_precision(precision or self.precision)
         spectra = None
         if precision in FFT_MODES:
-            # the frequency-domain 7x7 layer pays off from a dozen classes on (it streams 0.7 GB of weight spectra per call)
+            # the frequency-domain 7x7 layer pays off from 7 pairs on (it streams 0.65 GB of weight spectra per call)
             # and needs the map to fit its in-LDS transform; otherwise the direct f16x3 kernel does the layer
             spectra = regressor.spectra(H, W, split=precision == "fftx3") if A * B >= FFT_MIN_PAIRS else None
             if spectra is None:

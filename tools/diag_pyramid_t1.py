@@ -18,7 +18,7 @@ base = [c.to(dev) for c in synthetic.make_class_feature_maps(8, 1024, seed=7000)
 creator = util.make_head_creator(6, True, state, dev)
 with torch.no_grad():
     head = creator.create_os2d_head([base[b % 8] for b in range(128)])
-    head.precision = "fft"
+    head.precision = sys.argv[2] if len(sys.argv) > 2 else "fft"
     ser = [head(l)[1].clone() for l in levels]
     torch.cuda.synchronize()
     bad = 0

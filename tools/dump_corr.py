@@ -5,7 +5,6 @@ import torch
 REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 import util
-from oracle import head_oracle as O
 from os2d_amd.modeling import head as head_mod
 dev = torch.device("cuda:0")
 fx = util.load_head_fixture(sys.argv[1] if len(sys.argv) > 1 else "affine_noinv")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the building blocks of the frequency-domain 7x7 layer at the benchmark size (64 classes, 60x80)."""
-import os, sys, time, ctypes
+import os, sys, time
 import torch
 REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))

@@ -129,6 +129,22 @@ def spectra_cache_cap_bytes():
     return int(os.environ.get("OS2D_FFT_CACHE_BYTES", 16 << 30))
 
 
+def split_rows_f16(T):
+    """fp16 hi + lo split of a float64 tensor whose leading dimension indexes rows that get their own power-of-two scale
+    (precision "fftx3": the weight spectra; one row per output channel): row r is multiplied by 2^wexp[r], the largest
+    power of two that keeps its largest |entry| <= 32768 (< 65504: no overflow, also not through rounding), then
+    hi = rn16(v), lo = rn16(v - hi): hi + lo carries 22 bits of v wherever |v| >= 2^-3 and an absolute 2^-25 below (fp16
+    subnormal spacing).  Returns (hi, lo, wexp); works in place on T (which holds the residual afterwards)."""
+    dims = tuple(range(1, T.dim()))
+    amax = T.abs().amax(dim=dims).clamp_min(1e-300)
+    wexp = torch.floor(torch.log2(32768.0 / amax)).clamp(-100, 100)
+    T *= torch.exp2(wexp).view(-1, *([1] * (T.dim() - 1)))
+    hi = T.to(torch.float16)
+    T -= hi.double()
+    lo = T.to(torch.float16)
+    return hi, lo, wexp
+
+
 def _require_device_f32(t, name):
     if not isinstance(t, torch.Tensor):
         raise TypeError("{} must be a torch.Tensor".format(name))
@@ -350,14 +366,9 @@ class TransformationNet(nn.Module):
                     T = torch.zeros(64, KS * 8, nbins, 2, dtype=torch.float64, device=dev)
                     T[:, :225, :P * V] = torch.view_as_real(K)
                     del K
-                    amax = T.abs().amax(dim=(1, 2, 3)).clamp_min(1e-300)
-                    wexp = torch.floor(torch.log2(32768.0 / amax)).clamp(-100, 100)
-                    T *= torch.exp2(wexp).view(-1, 1, 1, 1)
-                    wscale[64 * half:64 * half + 64] = torch.exp2(-wexp).float()
-                    hi = T.to(torch.float16)
-                    T -= hi.double()
-                    lo = T.to(torch.float16)
+                    hi, lo, wexp = split_rows_f16(T)
                     del T
+                    wscale[64 * half:64 * half + 64] = torch.exp2(-wexp).float()
                     for part, t in enumerate((hi, lo)):
                         # [o][ks][grp][c4][g][bin][ri] -> [g][ks][bin][grp][o][c4][ri]
                         packed16[:, half, :, :, :, part] = t.view(64, KS, 2, 4, G, 8, 2).permute(4, 1, 5, 2, 0, 3, 6).reshape(G, KS, 8, 2, 64, 8)

@@ -97,3 +97,25 @@ def test_degenerate_weights_give_a_valid_plan():
             if e is not None:
                 assert e.dtype == torch.int32 and int(e.abs().max()) <= 60
     assert int(plan["out_exp"][0][3]) == 0 and int(plan["weight_exp"][0][3]) == 0
+
+
+def test_split_rows_f16_scales_and_reconstructs():
+    """Host logic of precision "fftx3": per-row power-of-two scales keep the largest entry of every row in (16384, 32768]
+    (no fp16 overflow, also not through rounding), and hi + lo reproduces the scaled value to 2^-22 relative / 2^-25 absolute -
+    for rows whose magnitudes differ by twelve decades."""
+    import torch
+    from os2d_amd.modeling.head import split_rows_f16
+    g = torch.Generator().manual_seed(5)
+    T = torch.randn(6, 40, 30, 2, generator=g, dtype=torch.float64)
+    T *= torch.tensor([1e-6, 1e-3, 1.0, 37.5, 1e3, 1e6], dtype=torch.float64).view(-1, 1, 1, 1)
+    T[2, 0, 0, 0] = 0.0
+    T[3, 1] *= 1e-7                                   # entries far below the row maximum: lo halves subnormal
+    ref = T.clone()
+    hi, lo, wexp = split_rows_f16(T)
+    scaled = ref * torch.exp2(wexp).view(-1, 1, 1, 1)
+    amax = scaled.abs().amax(dim=(1, 2, 3))
+    assert bool((amax <= 32768).all()) and bool((amax > 16384).all())
+    assert bool(torch.isfinite(hi.float()).all()) and bool(torch.isfinite(lo.float()).all())
+    err = (hi.double() + lo.double() - scaled).abs()
+    assert bool((err <= torch.maximum(scaled.abs() * 2.0 ** -21, torch.full_like(err, 2.0 ** -24))).all())
+    assert float(err.max()) <= 32768 * 2.0 ** -21

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libos2d_hip.so")
 BUILD_DIR = os.path.join(HERE, "csrc", "build")
-SOURCES = ["abi.hip", "prep.hip", "corr_mfma.hip", "conv_mfma.hip", "conv_f16x3.hip", "corr_f16x3.hip", "sample_decode.hip", "nms.hip", "detect.hip", "detect_pyramid.hip", "spectral.hip", "spectral_f16.hip", "fft.hip"]
+SOURCES = ["abi.hip", "prep.hip", "corr_mfma.hip", "conv_mfma.hip", "conv_f16x3.hip", "conv3_f16x3.hip", "corr_f16x3.hip", "sample_decode.hip", "nms.hip", "detect.hip", "detect_pyramid.hip", "spectral.hip", "spectral_f16.hip", "fft.hip"]
 HEADERS = [os.path.join(CSRC, "os2d_common.h"), os.path.join(HERE, "..", "include", "os2d_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]

@@ -402,6 +402,10 @@ int launch(const void* in, const void* wp, const float* bp, int* status, void* o
 // same order in both shapes, so results do not depend on which one ran (tests: small batch == slice of a large batch).
 int os2d_launch_conv_f16x3(int layer, const void* in, const void* wp, const float* bp, int* status, void* out, int NB,
                            int P, int H, int W, int terms, hipStream_t stream) {
+#ifndef OS2D_DIAG_CONV3_GENERIC
+  // the last layer has its own kernel (16-row MFMA, conv3_f16x3.hip), one shape for every batch size
+  if (layer == 3) return os2d_launch_conv3_f16x3(in, wp, bp, out, NB, P, H, W, stream);
+#endif
   const long long std_groups = (long long)((H * os2d_ws(W) + 255) / 256) * NB;
   if (std_groups * (layer == 1 ? 2 : 1) < 384) {  // measured crossover at 60x80: finer shapes win up to 9 classes
     if (layer == 1 && terms == 2)

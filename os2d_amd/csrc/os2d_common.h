@@ -110,6 +110,8 @@ int os2d_launch_corr_normalize_shb(const float* corr, void* rshb, int NB, int H,
 int os2d_launch_corr(const float* fm, const float* qp, const float* sumsq, float* corr, void* rnorm,
                      int A, int B, int C, int H, int W, int shb, hipStream_t stream);
 // conv_f16x3.hip
+int os2d_launch_conv3_f16x3(const void* in, const void* wp, const float* bp, void* out, int NB, int P, int H, int W,
+                            hipStream_t stream);   // conv3_f16x3.hip: layer 3 on the 16-row MFMA
 int os2d_launch_conv_f16x3(int layer, const void* in, const void* wp, const float* bp, int* status, void* out, int NB,
                            int P, int H, int W, int terms, hipStream_t stream);
 // conv_mfma.hip

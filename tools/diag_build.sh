@@ -5,7 +5,7 @@
 TAG=$1; shift
 OUT=gpurun_out/diag/$TAG
 mkdir -p $OUT/obj
-for f in abi prep corr_mfma conv_mfma conv_f16x3 corr_f16x3 sample_decode nms detect detect_pyramid spectral spectral_f16 fft; do
+for f in abi prep corr_mfma conv_mfma conv_f16x3 conv3_f16x3 corr_f16x3 sample_decode nms detect detect_pyramid spectral spectral_f16 fft; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-function -Xclang -target-feature -Xclang -packed-fp32-ops "$@" -c os2d_amd/csrc/$f.hip -o $OUT/obj/$f.o &
 done
 wait

@@ -71,6 +71,9 @@ def build(force=False, verbose=True):
     os.makedirs(LIB_DIR, exist_ok=True)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     objs = []
+    # object files carry no record of the flags they were compiled with: when the stamp (sources + headers + FLAGS) does not
+    # match, everything is recompiled - a flag change must not leave objects of the old flavour in the library
+    force = force or not up_to_date()
     for s in srcs:
         src = os.path.join(CSRC, s)
         obj = os.path.join(BUILD_DIR, s.replace(".hip", ".o"))

@@ -143,16 +143,16 @@ __global__ __launch_bounds__(NTHR) void detect_level_kernel(const float* __restr
     const int idx = base + lane;
     const bool valid = idx < n;
     const float4 me = valid ? sbox[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float my_area = (me.z - me.x) * (me.w - me.y);
+    const float my_area = os2d_box_area(me);
     unsigned int v = 0u;
     const int nk_lds = min(nk, kcap);
     for (int j = wv; j < nk_lds; j += NWAVE) {
       const float4 kb = kbox[j];
-      v |= os2d_iou_gt(kb, (kb.z - kb.x) * (kb.w - kb.y), me, my_area, iou_thr) ? 1u : 0u;
+      v |= os2d_iou_gt(kb, os2d_box_area(kb), me, my_area, iou_thr) ? 1u : 0u;
     }
     for (int j = kcap + wv; j < nk; j += NWAVE) {
       const float4 kb = sbox[kpos[j]];
-      v |= os2d_iou_gt(kb, (kb.z - kb.x) * (kb.w - kb.y), me, my_area, iou_thr) ? 1u : 0u;
+      v |= os2d_iou_gt(kb, os2d_box_area(kb), me, my_area, iou_thr) ? 1u : 0u;
     }
     vote[wv][lane] = v;
     __syncthreads();
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(NTHR) void detect_level_kernel(const float* __restr
         kb.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, me.y), i));
         kb.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, me.z), i));
         kb.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, me.w), i));
-        const bool hit = os2d_iou_gt(kb, (kb.z - kb.x) * (kb.w - kb.y), me, my_area, iou_thr);
+        const bool hit = os2d_iou_gt(kb, os2d_box_area(kb), me, my_area, iou_thr);
         alive &= ~(__ballot(hit) | ((2ull << i) - 1ull));  // drop lanes 0..i and everything the new box suppresses
       }
       if ((kbits >> lane) & 1ull) {

@@ -246,16 +246,16 @@ __global__ __launch_bounds__(NTHR) void pyr_chunk_nms_kernel(int pass, int N, in
       const int idx = w0 + base + lane;
       const bool valid = base + lane < wn;
       const float4 me = valid ? wbox[base + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float my_area = (me.z - me.x) * (me.w - me.y);
+      const float my_area = os2d_box_area(me);
       unsigned int v = 0u;
       const int nk_lds = min(nk, KCAP);
       for (int j = wv; j < nk_lds; j += NWAVE) {
         const float4 kbx = kbox[j];
-        v |= os2d_iou_gt(kbx, (kbx.z - kbx.x) * (kbx.w - kbx.y), me, my_area, iou_thr) ? 1u : 0u;
+        v |= os2d_iou_gt(kbx, os2d_box_area(kbx), me, my_area, iou_thr) ? 1u : 0u;
       }
       for (int j = KCAP + wv; j < nk; j += NWAVE) {
         const float4 kbx = bx[srt[kpos[j]]];
-        v |= os2d_iou_gt(kbx, (kbx.z - kbx.x) * (kbx.w - kbx.y), me, my_area, iou_thr) ? 1u : 0u;
+        v |= os2d_iou_gt(kbx, os2d_box_area(kbx), me, my_area, iou_thr) ? 1u : 0u;
       }
       vote[wv][lane] = v;
       __syncthreads();
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(NTHR) void pyr_chunk_nms_kernel(int pass, int N, in
           kbx.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, me.y), i));
           kbx.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, me.z), i));
           kbx.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, me.w), i));
-          const bool hit = os2d_iou_gt(kbx, (kbx.z - kbx.x) * (kbx.w - kbx.y), me, my_area, iou_thr);
+          const bool hit = os2d_iou_gt(kbx, os2d_box_area(kbx), me, my_area, iou_thr);
           alive &= ~(__ballot(hit) | ((2ull << i) - 1ull));
         }
         if ((kbits >> lane) & 1ull) {

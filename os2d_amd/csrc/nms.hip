@@ -41,13 +41,13 @@ __global__ __launch_bounds__(256) void nms_kernel(const float4* __restrict__ box
     const bool valid = idx < n;
     const float4 me = nxt;
     if (base + 64 + lane < n) nxt = bx[base + 64 + lane];  // in flight while this chunk is resolved
-    const float my_area = (me.z - me.x) * (me.w - me.y);
+    const float my_area = os2d_box_area(me);
     // ---- phase 1: against the kept list, 4 waves take interleaved kept boxes
     int d = 0;
     const int nk_lds = min(nk, KEPT_LDS);
     for (int j = wv; j < nk_lds; j += 4) {  // no early exit: a wave-uniform trip count keeps the loop pipelined
       const float4 k = kept_lds[j];
-      d |= os2d_iou_gt(k, (k.z - k.x) * (k.w - k.y), me, my_area, thr) ? 1 : 0;
+      d |= os2d_iou_gt(k, os2d_box_area(k), me, my_area, thr) ? 1 : 0;
     }
     for (int j = KEPT_LDS + wv; j < nk; j += 4) {
       const volatile float4* kv = kept;  // written by wave 0 in earlier steps: read past this CU's L1
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const float4* __restrict__ box
       k.y = kv[j].y;
       k.z = kv[j].z;
       k.w = kv[j].w;
-      d |= os2d_iou_gt(k, (k.z - k.x) * (k.w - k.y), me, my_area, thr) ? 1 : 0;
+      d |= os2d_iou_gt(k, os2d_box_area(k), me, my_area, thr) ? 1 : 0;
     }
     dead[wv][lane] = d;
     __syncthreads();
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const float4* __restrict__ box
         kb.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, me.y), i));
         kb.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, me.z), i));
         kb.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, me.w), i));
-        const bool hit = os2d_iou_gt(kb, (kb.z - kb.x) * (kb.w - kb.y), me, my_area, thr);
+        const bool hit = os2d_iou_gt(kb, os2d_box_area(kb), me, my_area, thr);
         alive &= ~(__ballot(hit) | ((2ull << i) - 1ull));  // drop lanes 0..i and everything the new box suppresses
       }
       const bool k = (kbits >> lane) & 1ull;

@@ -70,11 +70,24 @@ __device__ __forceinline__ float4 os2d_decode_box(const float* __restrict__ l, i
 // executed when some lane of the wave is within 1e-5 (relative) of the threshold - everywhere else comparing inter with
 // thr * union gives the same answer as the rounded quotient.  The vote makes the branch wave-uniform, so it is a real
 // branch and not an if-converted select.
+// Every product and sum below is rounded on its own, like the reference's tensor expressions: the compiler must NOT contract
+// them into fused multiply-adds (hipcc's default for device code is -ffp-contract=fast, and HIP's __fmul_rn / __fadd_rn are
+// plain operators that it fuses just the same: area_a + area_b - w * h became two v_fma_f32).  Whether it did depended on
+// unrelated code generation choices - the decisions at the threshold flipped when the library was first built without
+// packed-FP32 instructions (tests/test_decode_gpu.py::test_nms_decisions_at_the_iou_threshold).
+__device__ __forceinline__ float os2d_box_area(float4 b) {
+#pragma clang fp contract(off)
+  const float bw = b.z - b.x, bh = b.w - b.y;
+  return bw * bh;
+}
+
 __device__ __forceinline__ bool os2d_iou_gt(float4 a, float area_a, float4 b, float area_b, float thr) {
+#pragma clang fp contract(off)
   const float w = fmaxf(fminf(a.z, b.z) - fmaxf(a.x, b.x), 0.f);
   const float h = fmaxf(fminf(a.w, b.w) - fmaxf(a.y, b.y), 0.f);
   const float inter = w * h;
-  const float uni = area_a + area_b - inter;
+  const float sum = area_a + area_b;
+  const float uni = sum - inter;
   const float tu = thr * uni;
   bool res = inter > tu;
   const bool near = !(uni > 0.f && fabsf(inter - tu) > 1e-5f * fabsf(tu));

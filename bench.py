@@ -449,6 +449,22 @@ class Workload(object):
             r["note"] = "a frequency-domain mode was requested; with fewer than 7 image-class pairs the head runs the direct f16x3 7x7 kernel"
         return r
 
+    def roofline_corr(self, stage_ms, precision):
+        """The correlation kernel (as long as the spectral GEMM in the default mode): algorithmic FLOPs of one launch
+        (2 x 225 x 1024 per class-location) / its mean duration from the same stage events, against the MFMA peak of the
+        instruction it runs on; the split-fp16 kernel executes three MFMAs per product on 256 padded rows."""
+        flops = FLOP_PER_LOC["corr"] * H_FM * W_FM * self.B_local
+        seconds = stage_ms[0] * 1e-3
+        f16 = precision != "f32"
+        peak = PEAK["f16x3"] if f16 else PEAK["f32"]
+        r = {"kernel": "corr_f16x3_kernel (v_mfma_f32_32x32x16_f16 x3 per product)" if f16 else "corr_mfma_kernel (v_mfma_f32_32x32x2_f32)",
+             "bound": "mfma", "achieved": round(flops / seconds / 1e12, 3), "peak": peak / 1e12, "unit": "TFLOP/s",
+             "frac": round(flops / seconds / peak, 4), "flops_per_launch": flops, "avg_launch_ms": round(seconds * 1e3, 4),
+             "timing": "HIP events on the launch stream, this run"}
+        if f16:
+            r["executed_frac_of_peak"] = round(3 * (256.0 / 225.0) * flops / seconds / peak, 4)
+        return r
+
     def roofline_fft_whole(self, seconds, precision="fft"):
         """fft mode without stage events (several streams / ranks): all MFMA work of one rank's step against the blend of
         the two instruction peaks it runs on - the correlation, the two 5x5 layers (and the 7x7 layer of maps that do not
@@ -630,6 +646,8 @@ def main():
     if stage_ms:
         result["stages_ms"] = {k: round(v, 4) for k, v in zip(STAGES, stage_ms)}
     result["roofline"] = w.roofline(args.precision, stage_ms, dt / args.steps)
+    if stage_ms:
+        result["roofline_corr"] = w.roofline_corr(stage_ms, effective)       # the second-longest (or longest) kernel of the step
     result["head_tflops_algorithmic"] = round(w.whole_head_flops_per_class() * value / 1e12, 3)
     if not args.no_other_precision:
         result["other_precisions"] = []

@@ -21,8 +21,8 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
 # No packed-FP32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32).  Measured on MI355X (round 2, DESIGN.md
 # section 8): the FFT kernels - 19k of these instructions for their complex arithmetic - return wrong values in 16-lane
 # groups of single registers, a few images in 30,000, whenever MFMA-heavy kernels of OTHER streams run at the same time
-# (never alone, never on one stream; with the feature off: 0 of 32 runs against 16 of 32).  Scalar v_fma_f32 code is
-# 3 % slower in those kernels and not at all elsewhere.
+# (never alone, never on one stream; with the feature off: 0 of 32 runs against 16 of 32).  Scalar v_fma_f32 code costs
+# nothing measurable in those kernels (LDS / latency bound); the resampler pays 0.017 ms per 64 classes.
 FLAGS += ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 FLAGS += os.environ.get("OS2D_EXTRA_HIPCC_FLAGS", "").split()      # kernel experiments (-DOS2D_DIAG_...); part of the source hash
 

@@ -68,3 +68,12 @@ def test_library_is_built_without_packed_fp32_instructions():
     """v_pk_*_f32 results were wrong in 16-lane groups next to MFMA-heavy kernels of other streams."""
     from os2d_amd import build
     assert "-packed-fp32-ops" in build.FLAGS
+
+
+def test_compiler_flags_are_part_of_the_build_stamp(monkeypatch):
+    """Object files carry no record of their flags: a flag change must invalidate the stamp (and with it every object) -
+    the first -packed-fp32-ops build left the untouched sources compiled the old way."""
+    from os2d_amd import build
+    h0 = build.source_hash()
+    monkeypatch.setattr(build, "FLAGS", build.FLAGS + ["-DOS2D_SOME_EXPERIMENT"])
+    assert build.source_hash() != h0

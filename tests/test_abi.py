@@ -77,3 +77,36 @@ def test_compiler_flags_are_part_of_the_build_stamp(monkeypatch):
     h0 = build.source_hash()
     monkeypatch.setattr(build, "FLAGS", build.FLAGS + ["-DOS2D_SOME_EXPERIMENT"])
     assert build.source_hash() != h0
+
+
+def test_fft_plan_host_logic():
+    """os2d_fft_sizes is host code: transform sizes of the frequency-domain 7x7 layer for the pyramid levels of
+    BASELINE.json configs[4], the invariants every size must satisfy, and the refusal of maps that do not fit the LDS."""
+    import ctypes
+    from os2d_amd import _lib
+    lib = _lib.load()
+
+    def sizes(h, w):
+        P, Q, nb = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        rc = lib.os2d_fft_sizes(h, w, ctypes.byref(P), ctypes.byref(Q), ctypes.byref(nb))
+        return (rc, P.value, Q.value, nb.value)
+
+    expected = {(30, 40): (36, 48), (38, 50): (42, 54), (48, 64): (54, 72), (60, 80): (64, 84), (72, 96): (84, 108), (84, 112): (96, 128)}
+    for (h, w), (p, q) in expected.items():
+        rc, P, Q, nb = sizes(h, w)
+        assert rc == 0 and (P, Q) == (p, q) and nb == (p * (q // 2 + 1) + 7) // 8 * 8
+    for h in range(1, 100, 7):
+        for w in range(1, 130, 9):
+            rc, P, Q, nb = sizes(h, w)
+            if rc != 0:
+                continue
+            assert P >= h + 3 and Q >= w + 3 and P % 2 == 0 and Q % 2 == 0 and nb % 8 == 0 and nb >= P * (Q // 2 + 1)
+            for n in (P, Q):            # 2^a 3^b, or one of the sizes with a factor 7 that have a two-stage form
+                m = n
+                while m % 2 == 0:
+                    m //= 2
+                while m % 3 == 0:
+                    m //= 3
+                assert m == 1 or n in (42, 84)
+    assert sizes(96, 128)[0] != 0          # 108 x 144 needs 177 KB of LDS: the head uses the direct kernel there
+    assert lib.os2d_spectral_xscale(60, 80) == 8.0 and lib.os2d_spectral_xscale(96, 128) == 4.0

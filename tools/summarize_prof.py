@@ -23,7 +23,7 @@ def kernel_stats(db):
         "from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id group by s.kernel_name order by 3 desc").fetchall()
     total = sum(r[2] for r in rows) or 1
     out = []
-    for name, n, tot, avg, mn, mx, vg, ag, sg, lds, grid, wg in rows[:16]:
+    for name, n, tot, avg, mn, mx, vg, ag, sg, lds, grid, wg in rows[:30]:
         out.append("  {:<84s} calls {:>4d}  avg_us {:>10.2f}  min_us {:>10.2f}  max_us {:>10.2f}  pct {:>5.1f}  vgpr {:>3} agpr {:>3} sgpr {:>3} lds {:>6} grid_threads {:>8} wg {}".format(
             short(name), n, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * tot / total, vg, ag, sg, lds, grid, wg))
     return out

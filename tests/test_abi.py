@@ -64,10 +64,17 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         _lib.load()
 
 
-def test_library_is_built_without_packed_fp32_instructions():
-    """v_pk_*_f32 results were wrong in 16-lane groups next to MFMA-heavy kernels of other streams."""
+def test_packed_fp32_setting_is_per_translation_unit():
+    """v_pk_*_f32 results were wrong in 16-lane groups next to MFMA-heavy kernels of other streams.
+    The switch is per translation unit (build.NO_PACKED_FP32); the transforms - the kernels it was found in - are always in."""
     from os2d_amd import build
-    assert "-packed-fp32-ops" in build.FLAGS
+    assert "fft.hip" in build.NO_PACKED_FP32
+    assert "-packed-fp32-ops" in build.flags_for("fft.hip")
+    for s in build.SOURCES:
+        assert ("-packed-fp32-ops" in build.flags_for(s)) == (s in build.NO_PACKED_FP32)
+    assert "-packed-fp32-ops" not in build.flags_for("fft.hip", packed="on")
+    assert "-packed-fp32-ops" in build.flags_for("nms.hip", packed="off")
+    assert "-packed-fp32-ops" not in build.flags_for("nms.hip", packed="fft")
 
 
 def test_compiler_flags_are_part_of_the_build_stamp(monkeypatch):
@@ -76,6 +83,28 @@ def test_compiler_flags_are_part_of_the_build_stamp(monkeypatch):
     from os2d_amd import build
     h0 = build.source_hash()
     monkeypatch.setattr(build, "FLAGS", build.FLAGS + ["-DOS2D_SOME_EXPERIMENT"])
+    h1 = build.source_hash()
+    assert h1 != h0
+    monkeypatch.setattr(build, "NO_PACKED_FP32", set(build.NO_PACKED_FP32) - {"nms.hip"})      # a per-unit flag counts too
+    assert build.source_hash() != h1
+
+
+def test_every_included_header_is_part_of_the_build_stamp(tmp_path, monkeypatch):
+    """fft_regs.h (all the register DFTs) was in neither the hash nor the object dependencies, so editing it left a
+    stale library in use.  Headers are globbed now; every quoted #include of every source must resolve to one of them, and a
+    header that appears later changes the hash."""
+    import os
+    from os2d_amd import build
+    names = {os.path.basename(h) for h in build.headers()}
+    assert "fft_regs.h" in names and "os2d_common.h" in names and "os2d_hip.h" in names
+    for path in [os.path.join(build.CSRC, s) for s in build.SOURCES] + build.headers():
+        for inc in build.local_includes(path):
+            assert os.path.basename(inc) in names, (path, inc)
+    h0 = build.source_hash()
+    extra = tmp_path / "new_header.h"
+    extra.write_text("// new\n")
+    real = build.headers
+    monkeypatch.setattr(build, "headers", lambda: real() + [str(extra)])
     assert build.source_hash() != h0
 
 

@@ -226,57 +226,16 @@ def test_split_half_spectral_gemm_matches_float64(H, W, NB, device):
         assert err <= 2e-6 * scale, name
 
 
-def test_fft_kernels_are_stable_next_to_mfma_kernels(device):
-    """Regression test of the packed-FP32 finding: the transforms on four streams while the direct
-    7x7 kernel (half-precision MFMA at full rate) runs on three others must return exactly what they return alone.  With
-    v_pk_*_f32 instructions in the FFT kernels 8 of 16 such runs differed in 16-lane groups of single registers."""
-    import ctypes
-    from os2d_amd.modeling import head as head_mod
-    from os2d_amd.utils import synthetic
-    lib = _lib.load()
-    H, W, NB, C, Cout = 48, 64, 64, 225, 128
-    P, Q, nbins = fft_sizes(H, W)
-    tq, tp = twiddles(Q, device), twiddles(P, device)
-    g = torch.Generator().manual_seed(0)
-    NF, NA = 4, 3
-    fstreams = [torch.cuda.Stream(device=device) for _ in range(NF)]
-    astreams = [torch.cuda.Stream(device=device) for _ in range(NA)]
-    corr = [torch.randn(NB, C, H * W, generator=g).to(device) for _ in range(NF)]
-    inv = [torch.rand(NB, H * W, generator=g).to(device) + 0.5 for _ in range(NF)]
-    Yin = [torch.randn(NB, Cout, nbins, 2, generator=g).to(device) for _ in range(NF)]
-    bp = torch.ones(3 * 128, device=device)
-    status = torch.zeros(1, dtype=torch.int32, device=device)
-    shb = lib.os2d_shb_bytes(Cout, H, W)
-
-    def run_fft(i, X, out, st):
-        s = ctypes.c_void_p(st.cuda_stream)
-        _lib.check(lib.os2d_fft_forward(_lib.ptr(corr[i]), _lib.ptr(inv[i]), _lib.ptr(X), _lib.ptr(tq), _lib.ptr(tp), NB, C, H, W, s), "fwd")
-        _lib.check(lib.os2d_fft_inverse(_lib.ptr(Yin[i]), _lib.ptr(bp), _lib.ptr(out), _lib.ptr(tq), _lib.ptr(tp), NB, Cout, H, W,
-                                        _lib.ptr(status), s), "inv")
-
-    refX = [torch.zeros(C, NB, nbins, 2, device=device) for _ in range(NF)]
-    refO = [torch.zeros(NB * shb, dtype=torch.uint8, device=device) for _ in range(NF)]
-    main = torch.cuda.current_stream(device)
-    for i in range(NF):
-        run_fft(i, refX[i], refO[i], main)
-    torch.cuda.synchronize()
-    net = head_mod.TransformationNet(output_dim=6)
-    net.load_state_dict(synthetic.make_transform_net_state(6, seed=3))
-    net.to(device).eval()
-    w1, b1 = net.packed("f16x3")[:2]
-    rshb = [torch.zeros(2 * NB * lib.os2d_shb_bytes(225, H, W), dtype=torch.uint8, device=device) for _ in range(NA)]
-    h1 = [torch.zeros(2 * NB * shb, dtype=torch.uint8, device=device) for _ in range(NA)]
-    for it in range(3):
-        X = [torch.zeros_like(t) for t in refX]
-        O = [torch.zeros_like(t) for t in refO]
-        torch.cuda.synchronize()
-        for rep in range(3):
-            for j in range(NA):
-                _lib.check(lib.os2d_transform_conv_f16x3(1, _lib.ptr(rshb[j]), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(h1[j]), 2 * NB, 6, H, W, 3,
-                                                         _lib.ptr(status), ctypes.c_void_p(astreams[j].cuda_stream)), "conv1")
-            for i in range(NF):
-                run_fft(i, X[i], O[i], fstreams[i])
-        torch.cuda.synchronize()
-        for i in range(NF):
-            assert torch.equal(X[i], refX[i]), ("forward transform", it, i)
-            assert torch.equal(O[i], refO[i]), ("inverse transform", it, i)
+@pytest.mark.parametrize("kind", ["fft", "gemm16", "corr"])
+def test_kernels_are_stable_next_to_mfma_kernels(kind, device):
+    """Regression test of the packed-FP32 finding: a victim kernel on four streams while the direct
+    7x7 kernel (half-precision MFMA at full rate) runs on three others must return exactly the bytes it returns alone.
+    Victims: the transforms (with v_pk_*_f32 instructions 8 of 16 such runs differed in 16-lane groups of single registers)
+    and the two other kernels with hand-made LDS-only barriers and LDS-DMA pipelines - the split-half spectral GEMM and the
+    correlation.  tools/diag_aggressor.py runs the same harness for hundreds of rounds."""
+    from concurrency_victims import Harness
+    h = Harness(device, NB=64)
+    ref = h.reference(kind)
+    for it in range(8):
+        bad, _ = h.contend(kind, ref, aggressor=True)
+        assert not bad, (kind, "round", it, "(victim stream, output) that differ:", bad)

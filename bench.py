@@ -257,7 +257,7 @@ class Workload(object):
         self.sharded = None
         if use_dist:
             self.sharded = ClassShardedHead(self.creator, group=None, gather="scores" if gather == "scores" else "all",
-                                            num_classes=classes_total, local_head=self.head)
+                                            num_classes=classes_total, local_head=self.head, reuse_buffers=3)
         self.runner, self.level_fms = None, None
         if pyramid:
             from os2d_amd.engine.pyramid import PyramidHeadRunner
@@ -281,7 +281,7 @@ class Workload(object):
         w.gather = gather
         from os2d_amd.parallel import ClassShardedHead
         w.sharded = ClassShardedHead(self.creator, group=None, gather="scores" if gather == "scores" else "all",
-                                     num_classes=self.classes_total, local_head=self.head)
+                                     num_classes=self.classes_total, local_head=self.head, reuse_buffers=3)
         w.coder = None
         if self.pyramid:
             from os2d_amd.engine.pyramid import PyramidHeadRunner

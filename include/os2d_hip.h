@@ -131,8 +131,10 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
                          void* workspace, size_t workspace_bytes, void* stream, int precision, const void* qs,
                          void** stage_events, int* chunk_classes, int* status, const float* wspec, const float* twQ,
                          const float* twP);
-/* debugging aid: from now on os2d_head_forward_ex on `stream` copies an intermediate buffer of its first class chunk to dst
- * (slot 0 corr, 1 inverse norms, 2 input spectra, 3 output spectra, 4 h1, 5 h2, 6 params; at most `bytes`) on that stream. */
+/* debugging aid, DIAGNOSTIC builds only (-DOS2D_DIAG_DUMP; the product library ignores the call and sets os2d_last_error):
+ * from now on os2d_head_forward_ex on `stream` copies an intermediate buffer of its first class chunk to dst (slot 0 corr,
+ * 1 inverse norms, 2 input spectra, 3 output spectra, 4 h1, 5 h2, 6 params; at most `bytes`) on that stream; dst == NULL
+ * unregisters the slot (do that before freeing the destination).                                                         */
 void os2d_debug_set_dump(void* stream, int slot, void* dst, size_t bytes);
 int os2d_prof_event_create(void** ev);
 int os2d_prof_event_destroy(void* ev);

@@ -4,6 +4,7 @@
 
 #include "../../include/os2d_hip.h"
 #include "os2d_common.h"
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -58,7 +59,11 @@ Carve carve(int A, int Bc, int C, int H, int W, int P, int fft_bins = 0) {
   return c;
 }
 
-// ---- debugging aid (tools/diag_*.py): copies of intermediate buffers of os2d_head_forward_ex, per stream
+// ---- debugging aid (tools/diag_pyramid_dump.py): copies of intermediate buffers of os2d_head_forward_ex, per stream.
+// Compiled only into DIAGNOSTIC builds (python -m os2d_amd.build --variant dump -DOS2D_DIAG_DUMP): a registered destination
+// is a raw pointer nobody can unregister safely once its tensor is freed, and the table would be consulted by every
+// production call.  In the product library os2d_debug_set_dump only reports that it does nothing.
+#ifdef OS2D_DIAG_DUMP
 struct DumpEntry {
   void* stream;
   int slot;
@@ -66,11 +71,21 @@ struct DumpEntry {
   size_t bytes;
 };
 std::vector<DumpEntry> g_dumps;
+std::mutex g_dumps_mutex;               // ctypes releases the GIL: callers may race on the table
+bool dumps_active() {
+  std::lock_guard<std::mutex> lock(g_dumps_mutex);
+  return dumps_active();
+}
 void dump_slot(void* stream, int slot, const void* src, size_t bytes) {
+  std::lock_guard<std::mutex> lock(g_dumps_mutex);
   for (const DumpEntry& e : g_dumps)
-    if (e.stream == stream && e.slot == slot)
+    if (e.stream == stream && e.slot == slot && e.dst)
       (void)hipMemcpyAsync(e.dst, src, bytes < e.bytes ? bytes : e.bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream));
 }
+#else
+inline bool dumps_active() { return false; }
+inline void dump_slot(void*, int, const void*, size_t) {}
+#endif
 
 bool head_args_ok(int A, int B, int C, int H, int W, int P) {
   if (A < 1 || B < 1 || C < 4 || (C & 3) || H < 1 || W < 1 || (P != 6 && P != 4)) {
@@ -88,13 +103,23 @@ bool head_args_ok(int A, int B, int C, int H, int W, int P) {
 }  // namespace
 
 void os2d_debug_set_dump(void* stream, int slot, void* dst, size_t bytes) {
-  for (DumpEntry& e : g_dumps)
-    if (e.stream == stream && e.slot == slot) {
-      e.dst = dst;
-      e.bytes = bytes;
+#ifdef OS2D_DIAG_DUMP
+  std::lock_guard<std::mutex> lock(g_dumps_mutex);
+  for (size_t i = 0; i < g_dumps.size(); ++i)
+    if (g_dumps[i].stream == stream && g_dumps[i].slot == slot) {
+      if (dst) {
+        g_dumps[i].dst = dst;
+        g_dumps[i].bytes = bytes;
+      } else {
+        g_dumps.erase(g_dumps.begin() + i);          // dst == NULL unregisters the slot
+      }
       return;
     }
-  g_dumps.push_back(DumpEntry{stream, slot, dst, bytes});
+  if (dst) g_dumps.push_back(DumpEntry{stream, slot, dst, bytes});
+#else
+  (void)stream, (void)slot, (void)dst, (void)bytes;
+  os2d_set_error("os2d_debug_set_dump: this library was built without -DOS2D_DIAG_DUMP (diagnostic builds only)");
+#endif
 }
 
 void os2d_set_error(const char* fmt, ...) {
@@ -435,7 +460,7 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     }
     mark(b0, 3);
     mark(b0, 4);
-    if (!g_dumps.empty() && b0 == 0) {   // slots: 0 corr, 1 inverse norms, 2 input spectra, 3 output spectra, 4 h1, 5 h2, 6 params
+    if (dumps_active() && b0 == 0) {   // slots: 0 corr, 1 inverse norms, 2 input spectra, 3 output spectra, 4 h1, 5 h2, 6 params
       const size_t PLb = os2d_plane(H, W);
       dump_slot(stream, 0, corr, (size_t)NB * OS2D_K * H * W * 4);
       if (fft_bins) {
@@ -452,7 +477,7 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     }
     mark(b0, 5);
     mark(b0, 6);
-    if (!g_dumps.empty() && b0 == 0) dump_slot(stream, 5, h2, (size_t)NB * 64 * os2d_plane(H, W) * 4);
+    if (dumps_active() && b0 == 0) dump_slot(stream, 5, h2, (size_t)NB * 64 * os2d_plane(H, W) * 4);
     if (f16) {
       if ((rc = os2d_launch_conv_f16x3(3, h2, w3, b3, status, params, NB, P, H, W, 3, st))) return rc;
     } else {
@@ -460,7 +485,7 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     }
     mark(b0, 7);
     mark(b0, 8);
-    if (!g_dumps.empty() && b0 == 0) dump_slot(stream, 6, params, (size_t)NB * P * H * W * 4);
+    if (dumps_active() && b0 == 0) dump_slot(stream, 6, params, (size_t)NB * P * H * W * 4);
     if ((rc = os2d_launch_sample_decode(corr, params, NB, H, W, P, inverse, stride, rec_field, bc, B, b0, loc, cls,
                                         corners, st)))
       return rc;

@@ -386,6 +386,11 @@ class Os2dBoxCoder(object):
             return None
         if ts[0] is not None and len({(t.target_size.w, t.target_size.h) for t in ts}) != 1:
             return None
+        if ts[0] is None and len({(s_.w, s_.h) for s_ in size_pyr}) != 1:
+            # levels of different image sizes and nothing that maps them to a common frame: the reference's cat_boxlist
+            # refuses to concatenate them (reference structures/bounding_box.py:390-437) - the generic chain raises the same
+            # assertion; labelling the result with the first level's size here would hide it
+            return None
         lib = _lib.load()
         L = len(loc_pyr)
         fms = [self.get_feature_map_size(s) for s in size_pyr]

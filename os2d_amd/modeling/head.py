@@ -43,10 +43,21 @@ def resolve_precision(precision=None):
     matrix cores -> inverse FFT; fp32-equivalent, 16.7x fewer multiply-adds; maps that do not fit the in-LDS transform and
     small class batches fall back to f16x3), or "fftx3" (as fft, with the per-bin GEMM on the half-precision matrix cores:
     spectra split into fp16 hi + lo, the arithmetic of f16x3).  Default from $OS2D_PRECISION, else DEFAULT_PRECISION."""
+    return _resolve(precision)[0]
+
+
+def _resolve(precision=None):
+    """-> (name, pinned).  A trailing "!" on a frequency-domain mode ("fftx3!", "fft!") pins the ROUTE: the 7x7 layer runs in
+    the frequency domain whatever the number of (image, class) pairs of the call (``FFT_MIN_PAIRS`` is a speed heuristic;
+    the two routes differ in the last bits, so a caller that needs results independent of how classes are batched - a
+    class-sharded run with a ragged tail rank - pins it or passes ``route_pairs`` to ``Os2dHead.forward``)."""
     precision = precision or os.environ.get("OS2D_PRECISION", DEFAULT_PRECISION)
-    if precision not in PRECISIONS:
-        raise ValueError("precision must be one of {}, got {!r}".format(sorted(PRECISIONS), precision))
-    return precision
+    pinned = isinstance(precision, str) and precision.endswith("!")
+    name = precision[:-1] if pinned else precision
+    if name not in PRECISIONS or (pinned and name not in FFT_MODES):
+        raise ValueError("precision must be one of {} (\"fft!\" / \"fftx3!\" pin the frequency-domain route), got {!r}".format(
+            sorted(PRECISIONS), precision))
+    return name, pinned
 
 
 def build_os2d_head_creator(do_simple_affine, is_cuda, use_inverse_geom_model, feature_map_stride,
@@ -93,6 +104,22 @@ def get_workspace(device, wanted, minimum):
 
 def release_workspaces():
     _WORKSPACES.clear()
+
+
+_STATUS_WORDS = {}
+
+
+def device_status_word(device):
+    """The sticky range-status word of the split-fp16 kernels: ONE int32 in mapped pinned host memory per device, allocated
+    once and kept for the life of the process.  Kernels in flight store to it through a raw pointer (only when an activation
+    leaves the fp16 range), so it must never go back to the host allocator while any kernel of any head may still run -
+    a per-head tensor (round 2) could be garbage-collected with its head while that head's kernels were still queued
+    (ADVICE r2).  Every head of the device shares the word: whichever call starts next sees a raised flag."""
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    word = _STATUS_WORDS.get(index)
+    if word is None:
+        word = _STATUS_WORDS[index] = torch.zeros(1, dtype=torch.int32).pin_memory()
+    return word
 
 
 class _StreamOrdered(object):
@@ -203,6 +230,18 @@ class TransformationNet(nn.Module):
             if isinstance(layer, nn.BatchNorm2d):
                 layer.eval()
 
+    def check_ready(self):
+        """The HIP kernels need the parameters on a HIP device and eval-mode BatchNorm; said here, before ``packed`` /
+        ``spectra`` run torch operators on them (CPU-resident parameters used to surface as torch errors)."""
+        dev = self.linear.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("TransformationNet parameters are on {}: move the model to the HIP device "
+                               "(no CPU fallback)".format(dev))
+        if self.training and any(isinstance(m, nn.BatchNorm2d) and m.training for m in self.modules()):
+            raise RuntimeError("TransformationNet is in training mode: the HIP path implements eval-mode "
+                               "BatchNorm (running statistics) only; call .eval()")
+        return dev
+
     def _state_key(self):
         ts = list(self.parameters()) + list(self.buffers())
         return tuple((t.data_ptr(), t._version, str(t.device)) for t in ts)
@@ -277,12 +316,7 @@ class TransformationNet(nn.Module):
         if cached is not None and cached.key == key:
             return cached.get(dev)
         lib = _lib.load()
-        if dev.type != "cuda":
-            raise RuntimeError("TransformationNet parameters are on {}: move the model to the HIP device "
-                               "(no CPU fallback)".format(dev))
-        if self.training and any(isinstance(m, nn.BatchNorm2d) and m.training for m in self.modules()):
-            raise RuntimeError("TransformationNet is in training mode: the HIP path implements eval-mode "
-                               "BatchNorm (running statistics) only; call .eval()")
+        self.check_ready()
         with torch.cuda.device(dev):
             stream = _lib.current_stream(dev)
             cur = torch.cuda.current_stream(dev)
@@ -329,6 +363,7 @@ class TransformationNet(nn.Module):
         changes, least recently used first out above ``spectra_cache_cap_bytes()`` (722 MB for 60 x 80; event-tracked like
         ``packed``)."""
         lib = _lib.load()
+        self.check_ready()
         cP, cQ, cN = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         if lib.os2d_fft_sizes(int(H), int(W), ctypes.byref(cP), ctypes.byref(cQ), ctypes.byref(cN)) != 0:
             return None
@@ -613,9 +648,9 @@ class Os2dHead(nn.Module):
         self.aligner = aligner
         self.last_precision = None
         self.precision = None      # None: follow $OS2D_PRECISION (default "fftx3"); or one of PRECISIONS
-        # sticky status word of the split-fp16 kernels in mapped pinned host memory: the kernels store to it only when an
-        # activation leaves the fp16 range (impossible for finite inputs, see TransformationNet.range_plan), the host
-        # reads it without synchronising
+        # sticky status word of the split-fp16 kernels in mapped pinned host memory (one per device, process lifetime:
+        # ``device_status_word``): the kernels store to it only when an activation leaves the fp16 range (impossible for
+        # finite inputs, see TransformationNet.range_plan), the host reads it without synchronising
         self._status = None
         self.strict_range = os.environ.get("OS2D_STRICT_RANGE", "0") not in ("0", "", "false")
         box = box_grid_generator_image_level
@@ -651,26 +686,24 @@ class Os2dHead(nn.Module):
 
     def _status_word(self):
         if self._status is None:
-            self._status = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._status = device_status_word(self._qp.device)
         return self._status
 
     def range_status(self, synchronize=False):
         """Sticky status bits raised by the split-fp16 kernels (OS2D_STATUS_F16_RANGE = 1: an activation left the fp16
         range).  Without ``synchronize`` this reads the mapped host word as it is (kernels in flight may still set it)."""
-        if self._status is None:
-            return 0
         if synchronize:
             torch.cuda.synchronize(self._qp.device)
-        return int(self._status[0])
+        return int(self._status_word()[0])
 
     def _handle_range_flag(self):
-        """A previous split-fp16 call overflowed (non-finite inputs): from now on this head computes in exact fp32."""
+        """A previous split-fp16 call on this device overflowed (non-finite input: nothing else gets past the range plan).
+        The flag is cleared and the call that noticed it runs in exact fp32; later calls return to the configured arithmetic
+        (round 2 switched the head to fp32 for good: one NaN image made every later image 5.7x slower)."""
         self._status[0] = 0
-        if resolve_precision(self.precision) != "f32":
-            logging.getLogger("OS2D").warning(
-                "OS2D head: a split-fp16 activation left the fp16 range (non-finite or out-of-bound input); switching "
-                "this head to precision='f32'")
-            self.precision = "f32"
+        logging.getLogger("OS2D").warning(
+            "OS2D head: a split-fp16 activation left the fp16 range in an earlier call on this device (non-finite input); "
+            "this call runs in precision='f32'")
 
     @classmethod
     def cat(cls, heads):
@@ -681,7 +714,7 @@ class Os2dHead(nn.Module):
         return cls(q15, h0.aligner, h0.box_grid_generator_image_level, h0.box_grid_generator_feature_map_level,
                    _prepared=qp)
 
-    def forward(self, feature_maps, out=None, stage_events=None, precision=None, strict_range=None):
+    def forward(self, feature_maps, out=None, stage_events=None, precision=None, strict_range=None, route_pairs=None):
         """feature_maps [A,C,H,W] -> (loc [A,B,4,H,W], cls [A,B,1,H,W], cls_detached (same), corners [A,B,8,H,W]).
 
         ``out``: optional preallocated (loc, cls, corners) device tensors of exactly those shapes (contiguous) - used
@@ -689,7 +722,12 @@ class Os2dHead(nn.Module):
         ``stage_events``: optional ctypes array of 13 event handles for os2d_head_forward_profiled (bench.py).
         ``strict_range`` (default $OS2D_STRICT_RANGE, off): synchronise after a split-fp16 call and, if the range flag
         was raised, re-run it in exact fp32 before returning.  Without it the flag is looked at when the next call
-        starts (no synchronisation): the head then switches itself to "f32" for good."""
+        starts (no synchronisation): that call then runs in "f32".
+        ``route_pairs``: the number of (image, class) pairs the ROUTE decision of the frequency-domain modes is made for
+        (default: this call's own A * B).  A class-sharded caller passes the GLOBAL pair count, so that a ragged tail rank
+        holding fewer than ``FFT_MIN_PAIRS`` classes takes the same arithmetic route as the others and the sharded result
+        stays bit-equal to the unsharded one (os2d_amd/parallel.py); ``precision="fftx3!"`` / ``"fft!"`` pins the
+        frequency-domain route regardless of the pair count."""
         feature_maps = _require_device_f32(feature_maps, "feature_maps")
         if feature_maps.dim() != 4:
             raise RuntimeError("feature_maps must be [A,C,H,W], got {}".format(tuple(feature_maps.shape)))
@@ -707,16 +745,18 @@ class Os2dHead(nn.Module):
         dev = feature_maps.device
         regressor = self.aligner.parameter_regressor
         P = regressor.output_dim
-        if self._status is not None and int(self._status[0]) != 0:
+        precision, pinned = _resolve(precision or self.precision)
+        if precision != "f32" and int(self._status_word()[0]) != 0:
             self._handle_range_flag()
-            if precision is not None and resolve_precision(precision) != "f32":
-                precision = "f32"
-        precision = resolve_precision(precision or self.precision)
+            precision = "f32"
+        regressor.check_ready()                  # device / eval-mode errors before any torch op can trip over them
         spectra = None
         if precision in FFT_MODES:
-            # the frequency-domain 7x7 layer pays off from 7 pairs on (it streams 0.65 GB of weight spectra per call)
-            # and needs the map to fit its in-LDS transform; otherwise the direct f16x3 kernel does the layer
-            spectra = regressor.spectra(H, W, split=precision == "fftx3") if A * B >= FFT_MIN_PAIRS else None
+            # the frequency-domain 7x7 layer pays off from 7 pairs on (it streams 0.65 GB of weight spectra per call);
+            # below that the direct f16x3 kernel does the layer.  The decision is made on ``route_pairs`` when given
+            # (class-sharded callers: the global count), and not at all when the route is pinned
+            pairs = A * B if route_pairs is None else int(route_pairs)
+            spectra = regressor.spectra(H, W, split=precision == "fftx3") if (pinned or pairs >= FFT_MIN_PAIRS) else None
             if spectra is None:
                 precision = "f16x3"
         self.last_precision = precision          # the arithmetic that actually ran (bench.py / tests)

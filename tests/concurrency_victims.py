@@ -2,8 +2,9 @@
 
 A *victim* is one kernel (or kernel pair) of the head launched through the C ABI with fixed inputs; its output must be the
 same bytes whether it runs alone or on four streams while the direct 7x7 kernel (half-precision MFMA at full rate) runs on
-three others.  Victims: the transforms (`fft`: the kernels the finding was made in), and the two other kernels with
-hand-made barriers and LDS-DMA pipelines - the split-half spectral GEMM (`gemm16`) and the correlation (`corr`).
+three others.  Victims: the transforms (`fft`: the kernels the finding was made in), the two other kernels with
+hand-made barriers and LDS-DMA pipelines - the split-half spectral GEMM (`gemm16`) and the correlation (`corr`) - and the
+resampler (`sample`: 528 packed instructions when they are enabled).
 Used by tests/test_spectral_gpu.py and tools/diag_aggressor.py.
 """
 import ctypes
@@ -107,6 +108,19 @@ class Harness:
             def outputs(i):
                 return [torch.zeros(NB, 225, H * W, device=dev), torch.zeros(rshb_bytes, dtype=torch.uint8, device=dev)]
             keep = (fm, qp, qs, ws)
+        elif kind == "sample":          # the resampler: the other kernel with hundreds of packed-FP32 instructions when they are on
+            corr = [torch.randn(NB, 225, H * W, generator=g).to(dev) for _ in range(NF)]
+            par = torch.zeros(NB, 6, H * W)
+            par[:, 0], par[:, 4] = 1.0, 1.0
+            par = (par + 0.1 * torch.randn(NB, 6, H * W, generator=g)).to(dev)
+
+            def run(i, out, st):
+                _lib.check(lib.os2d_sample_decode(_lib.ptr(corr[i]), _lib.ptr(par), NB, H, W, 6, 1, 16, 16, _lib.ptr(out[0]), _lib.ptr(out[1]),
+                                                  _lib.ptr(out[2]), ctypes.c_void_p(st.cuda_stream)), "sample_decode")
+
+            def outputs(i):
+                return [torch.zeros(NB, k, H * W, device=dev) for k in (4, 1, 8)]
+            keep = (corr, par)
         else:
             raise ValueError(kind)
         self._victims[kind] = (run, outputs, keep)

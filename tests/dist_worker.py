@@ -38,7 +38,7 @@ def main():
             full_head = creator.create_os2d_head(class_fms)
             full = full_head(fm)
             for gather in ("all", "scores"):
-                sharded = ClassShardedHead(creator, class_fms, gather=gather)
+                sharded = ClassShardedHead(creator, class_fms, gather=gather, reuse_buffers=4 if gather == "all" else 0)
                 assert sharded.counts == [e - s for s, e in shard_bounds(n_classes, world)]
                 loc, cls, cls_det, corners = sharded(fm)
                 assert cls_det is cls and torch.equal(cls, full[1]), "scores differ ({})".format(gather)
@@ -69,7 +69,7 @@ def main():
             img_size = FeatureMapSize(w=16 * W, h=16 * H)
             ids = list(range(n_classes))
             s, e = shard_bounds(n_classes, world)[rank]
-            local = creator.create_os2d_head(class_fms[s:e])(fm)
+            local = creator.create_os2d_head(class_fms[s:e])(fm, route_pairs=fm.size(0) * n_classes)   # same arithmetic route as the full head
             mine = coder.decode_pyramid([local[0][0].flatten(2)], [local[1][0].flatten(1)], [img_size], ids[s:e],
                                         nms_score_threshold=0.3, transform_corners_pyramid=[local[3][0].flatten(2)])
             union = all_gather_detections(mine)

@@ -29,8 +29,9 @@ class _OracleHead(object):
         self.q, self.state, self.inverse = q_hat, state, inverse
         self.class_batch_size = q_hat.size(0)
 
-    def __call__(self, fm, out=None, stage_events=None):
+    def __call__(self, fm, out=None, stage_events=None, route_pairs=None):
         from oracle import head_oracle as O
+        self.route_pairs_seen = route_pairs
         with torch.no_grad():
             loc, cls, _, corners = O.head_forward(fm, self.q, self.state, self.inverse)
         if out is not None:
@@ -145,3 +146,90 @@ def test_all_gather_detections_world3():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in results)
+
+
+class _TableHead(object):
+    """Stand-in head whose outputs are a closed-form function of (global class id, image, channel, location): lets the
+    distributed logic be checked at BASELINE.json's class counts without computing anything."""
+
+    def __init__(self, first_class, n_local):
+        self.first, self.class_batch_size = first_class, n_local
+        self.route_pairs_seen = None
+
+    @staticmethod
+    def expected(class_ids, A, k, H, W):
+        c = torch.tensor(list(class_ids), dtype=torch.float32).view(1, -1, 1, 1, 1)
+        a = torch.arange(A, dtype=torch.float32).view(A, 1, 1, 1, 1)
+        ch = torch.arange(k, dtype=torch.float32).view(1, 1, k, 1, 1)
+        hw = torch.arange(H * W, dtype=torch.float32).view(1, 1, 1, H, W)
+        return c * 1000.0 + a * 100.0 + ch * 10.0 + hw / 64.0
+
+    def __call__(self, fm, out=None, stage_events=None, route_pairs=None):
+        self.route_pairs_seen = route_pairs
+        A, _, H, W = fm.shape
+        ids = range(self.first, self.first + self.class_batch_size)
+        for t, k in zip(out, (4, 1, 8)):
+            assert tuple(t.shape) == (A, self.class_batch_size, k, H, W) and t.is_contiguous()
+            t.copy_(self.expected(ids, A, k, H, W))
+        return out[0], out[1], out[1], out[2]
+
+
+def _table_worker(rank, world, port, n_classes, A, reuse, result_queue):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        from os2d_amd.modeling.head import FFT_MIN_PAIRS
+        from os2d_amd.parallel import ClassShardedHead
+        H, W = 3, 4
+        s, e = shard_bounds(n_classes, world)[rank]
+        head = _TableHead(s, e - s)
+        sharded = ClassShardedHead(None, gather="all", num_classes=n_classes, local_head=head, reuse_buffers=reuse)
+        fm = torch.zeros(A, 8, H, W)
+        ok = True
+        held = []
+        for it in range(3):
+            loc, cls, _, corners = sharded(fm)
+            held.append(cls)
+            for t, k in ((loc, 4), (cls, 1), (corners, 8)):
+                ok = ok and torch.equal(t, _TableHead.expected(range(n_classes), A, k, H, W))
+        pending = [sharded(fm, async_gather=True) for _ in range(2)]
+        for h in reversed(pending):
+            r = h()
+            ok = ok and torch.equal(r[0], _TableHead.expected(range(n_classes), A, 4, H, W))
+        equal = len({b - a for a, b in shard_bounds(n_classes, world)}) == 1
+        # one image per call and equal class counts: the collectives write the final layout, nothing is copied afterwards
+        copies_ok = sharded.copies_last_call == (0 if (A == 1 and equal) else 3)
+        # every rank - also a tail rank below the frequency-domain threshold - decides its arithmetic route on the GLOBAL count
+        route_ok = head.route_pairs_seen == A * n_classes
+        tail_below = (e - s) * A < FFT_MIN_PAIRS
+        if reuse:       # ring of `reuse` buffer sets: the result of the call `reuse` calls ago has been overwritten in place
+            ok = ok and held[0].data_ptr() == held[reuse].data_ptr() if len(held) > reuse else ok
+        result_queue.put((rank, bool(ok), bool(copies_ok), bool(route_ok), bool(tail_below), e - s))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_classes,A,reuse", [(8, 1024, 1, 0), (8, 1024, 1, 2), (3, 16, 1, 0), (3, 16, 2, 0), (2, 9, 1, 0)])
+def test_class_sharded_head_layout_route_and_buffers(world, n_classes, A, reuse):
+    """BASELINE.json configs[2] over 8 ranks (1024 classes -> 128 per rank: the gather lands in the final
+    layout, zero copies afterwards, also with a ring of reused buffers), ragged splits over 3 and 2 ranks (16 -> 6 + 5 + 5,
+    9 -> 5 + 4: trimmed correctly; the tail rank holds fewer classes than FFT_MIN_PAIRS and still routes on the global count)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_table_worker, args=(r, world, port, n_classes, A, reuse, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[5] for r in results] == [e - s for s, e in shard_bounds(n_classes, world)]
+    for rank, ok, copies_ok, route_ok, _, _ in results:
+        assert ok, "rank {} assembled a wrong result".format(rank)
+        assert copies_ok, "rank {}: unexpected number of post-gather copies".format(rank)
+        assert route_ok, "rank {} decided its route on a local pair count".format(rank)
+    if (world, n_classes, A) in ((3, 16, 1), (2, 9, 1)):
+        assert any(r[4] for r in results), "the case is meant to have a tail rank below FFT_MIN_PAIRS"

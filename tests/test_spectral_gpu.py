@@ -226,7 +226,7 @@ def test_split_half_spectral_gemm_matches_float64(H, W, NB, device):
         assert err <= 2e-6 * scale, name
 
 
-@pytest.mark.parametrize("kind", ["fft", "gemm16", "corr"])
+@pytest.mark.parametrize("kind", ["fft", "gemm16", "corr", "sample"])
 def test_kernels_are_stable_next_to_mfma_kernels(kind, device):
     """Regression test of the packed-FP32 finding: a victim kernel on four streams while the direct
     7x7 kernel (half-precision MFMA at full rate) runs on three others must return exactly the bytes it returns alone.

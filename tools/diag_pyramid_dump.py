@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Diagnostic: 7 identical levels on 7 streams, intermediate buffers dumped per stream; which stage differs first?"""
+"""NEEDS A DIAGNOSTIC BUILD: python -m os2d_amd.build --variant dump -DOS2D_DIAG_DUMP, then run with
+OS2D_HIP_LIB=tools/diag_libs/dump/libos2d_hip.so (the product library compiles the dump hook out).
+Diagnostic: 7 identical levels on 7 streams, intermediate buffers dumped per stream; which stage differs first?"""
 import os, sys, ctypes
 import torch
 REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))

@@ -9,8 +9,9 @@
 // Build (tools/diag_packed_fp32.sh does this):
 //   hipcc --offload-arch=gfx950 -O3 tools/repro_packed_fp32.hip -o tools/bin/repro_pk_on
 //   hipcc --offload-arch=gfx950 -O3 -Xclang -target-feature -Xclang -packed-fp32-ops tools/repro_packed_fp32.hip -o tools/bin/repro_pk_off
-// Run: repro_pk_on [rounds=200] [victim_iters=2000] [exclusive=0|1]   (exclusive: the victim asks for 160 KB of LDS per group,
-// so that no aggressor group can share its CU)
+// Run: repro_pk_on [rounds=200] [victim_iters=2000] [exclusive=0|1] [aggressor=0|1|2]
+//   exclusive: the victim asks for 160 KB of LDS per group and the aggressor for 1 KB, so that no aggressor group can share
+//              a CU with a victim group;  aggressor: 0 = fp16 MFMA (default), 1 = fp32 MFMA, 2 = scalar-FMA VALU loop (no MFMA)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -43,8 +44,47 @@ __global__ __launch_bounds__(512) void victim(f32x2* __restrict__ out, int iters
   for (int k = 0; k < NV; ++k) out[(size_t)t * NV + k] = a[k];
 }
 
-__global__ __launch_bounds__(256) void aggressor(float* __restrict__ out, int iters) {
+typedef float f32x16b __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void aggressor_f32(float* __restrict__ out, int iters) {     // v_mfma_f32_32x32x2_f32
+  __shared__ float pad[256];
   const int t = threadIdx.x;
+  pad[t] = 0.f;
+  const float a = 0.001f * (float)(t % 13), b = 0.002f * (float)(t % 7);
+  f32x16b acc[4] = {};
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+  }
+  float s = pad[t];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += acc[j][k];
+  out[blockIdx.x * 256 + t] = s;
+}
+
+__global__ __launch_bounds__(256) void aggressor_valu(float* __restrict__ out, int iters) {    // no matrix instructions
+  __shared__ float pad[256];
+  const int t = threadIdx.x;
+  pad[t] = 0.f;
+  float x[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = 0.001f * (float)((t + k) % 13);
+  const float m = 0.99999f, c = 1e-6f;
+  for (int i = 0; i < iters * 8; ++i) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = __builtin_fmaf(x[k], m, c);
+  }
+  float s = pad[t];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += x[k];
+  out[blockIdx.x * 256 + t] = s;
+}
+
+__global__ __launch_bounds__(256) void aggressor(float* __restrict__ out, int iters) {
+  __shared__ float pad[256];                            // 1 KB of LDS: cannot share a CU with a 160 KB victim group
+  const int t = threadIdx.x;
+  pad[t] = 0.f;
   half8 a, b;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -56,7 +96,7 @@ __global__ __launch_bounds__(256) void aggressor(float* __restrict__ out, int it
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[j], 0, 0, 0);
   }
-  float s = 0.f;
+  float s = pad[t];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -74,7 +114,7 @@ __global__ __launch_bounds__(256) void aggressor(float* __restrict__ out, int it
   } while (0)
 
 int main(int argc, char** argv) {
-  const int rounds = argc > 1 ? atoi(argv[1]) : 200, viters = argc > 2 ? atoi(argv[2]) : 2000, excl = argc > 3 ? atoi(argv[3]) : 0;
+  const int rounds = argc > 1 ? atoi(argv[1]) : 200, viters = argc > 2 ? atoi(argv[2]) : 2000, excl = argc > 3 ? atoi(argv[3]) : 0, akind = argc > 4 ? atoi(argv[4]) : 0;
   const int vgrid = 1024, agrid = 512, NA = 3, NF = 4;
   const size_t nout = (size_t)vgrid * 512 * NV, lds = excl ? 160 * 1024 : 0;
   hipDeviceProp_t prop;
@@ -100,7 +140,11 @@ int main(int argc, char** argv) {
       CK(hipDeviceSynchronize());
       for (int rep = 0; rep < 3; ++rep) {
         if (mode)
-          for (int j = 0; j < NA; ++j) hipLaunchKernelGGL(aggressor, dim3(agrid), dim3(256), 0, as[j], aout[j], 20000);
+          for (int j = 0; j < NA; ++j) {
+            if (akind == 0) hipLaunchKernelGGL(aggressor, dim3(agrid), dim3(256), 0, as[j], aout[j], 20000);
+            else if (akind == 1) hipLaunchKernelGGL(aggressor_f32, dim3(agrid), dim3(256), 0, as[j], aout[j], 10000);
+            else hipLaunchKernelGGL(aggressor_valu, dim3(agrid), dim3(256), 0, as[j], aout[j], 20000);
+          }
         for (int i = 0; i < NF; ++i) hipLaunchKernelGGL(victim, dim3(vgrid), dim3(512), lds, fs[i], got[i], viters);
       }
       CK(hipDeviceSynchronize());
@@ -124,9 +168,10 @@ int main(int argc, char** argv) {
         }
       }
     }
-    printf("%s: victim %s: %d of %d runs differ (device %s, %d CUs, victim iters %d, %s)\n", argv[0],
-           mode ? "next to MFMA aggressors" : "alone on four streams", bad_mode, rounds * NF, prop.name, prop.multiProcessorCount, viters,
-           excl ? "CU-exclusive victim" : "shared CUs");
+    static const char* anames[] = {"fp16-MFMA", "fp32-MFMA", "scalar-FMA VALU (no MFMA)"};
+    printf("%s: victim %s%s: %d of %d runs differ (device %s, %d CUs, victim iters %d, %s)\n", argv[0],
+           mode ? "next to aggressors: " : "alone on four streams", mode ? anames[akind] : "", bad_mode, rounds * NF, prop.gcnArchName,
+           prop.multiProcessorCount, viters, excl ? "CU-exclusive victim" : "shared CUs");
     bad_runs += bad_mode;
   }
   return bad_runs ? 1 : 0;

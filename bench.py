@@ -477,7 +477,9 @@ class Workload(object):
             pP, pQ, nb = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
             per_loc = FLOP_PER_LOC["corr"] + FLOP_PER_LOC["conv2"] + 2 * self.P * 64 * 25
             if self.lib.os2d_fft_sizes(h, w, ctypes.byref(pP), ctypes.byref(pQ), ctypes.byref(nb)) == 0:
-                f32 += 8 * 128 * 225 * B * pP.value * (pQ.value // 2 + 1)
+                t4 = [ctypes.c_int() for _ in range(4)]       # maps beyond one in-LDS transform: TY x TX overlap-save tiles
+                self.lib.os2d_fft_tiles(h, w, *[ctypes.byref(t) for t in t4])
+                f32 += 8 * 128 * 225 * B * t4[0].value * t4[1].value * pP.value * (pQ.value // 2 + 1)
             else:
                 per_loc += FLOP_PER_LOC["conv1"]
             f16 += per_loc * h * w * B

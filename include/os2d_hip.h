@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define OS2D_ABI_VERSION 6
+#define OS2D_ABI_VERSION 7
 
 /* arithmetic of the two large TransformNet convolutions (everything else is fp32 in both modes) */
 #define OS2D_PRECISION_F32 0   /* v_mfma_f32_32x32x2_f32: exact fp32 (k-ordered fmaf chain)                            */
@@ -35,7 +35,7 @@ extern "C" {
 #define OS2D_PRECISION_FFT 3   /* as F16X3, except that the 7x7 layer runs in the frequency domain in fp32: in-LDS real FFT of the  */
                                /* normalised correlation, one complex 128 x 225 GEMM per bin on the fp32 matrix cores, inverse FFT  */
                                /* (16.7x fewer multiply-adds; agrees with an fp64 convolution to 1e-7, closer than a direct fp32    */
-                               /* convolution).  Maps that do not fit the in-LDS transform are refused (-3): use F16X3 for them.   */
+                               /* convolution).  Maps larger than the in-LDS transform are cut into overlap-save tiles (os2d_fft_tiles) */
 
 #define OS2D_PRECISION_FFTX3 4 /* as FFT, with the per-bin complex GEMM on the half-precision matrix cores: spectra split into fp16   */
                                /* hi + lo (three v_mfma_f32_32x32x16_f16 per product, the arithmetic of F16X3; scales chosen so that  */
@@ -222,14 +222,21 @@ int os2d_detect_level(const float* loc, const float* cls, int B, int H, int W, i
  *   row r the entry is K[64*h + r][c][8*g + j] (zero for rows >= Cout); os2d_spectral_weight_bytes(C, Cout, nbins) bytes.  */
 size_t os2d_spectral_weight_bytes(int C, int Cout, int nbins);
 /* The transforms around it (in-LDS real FFT pair, one work-group per image at a time):
- *   os2d_fft_sizes    padded sizes P >= H+3, Q >= W+3 (even; 2^a 3^b, or 42 / 84; the weight spectra carry the -3 shift of
- *                     the centred kernel) and nbins = P*(Q/2+1) rounded up to a multiple of 8; -3 if the map does not fit
+ *   os2d_fft_sizes    transform sizes P, Q (even; 2^a 3^b, or 42 / 84; the weight spectra carry the -3 shift of the centred
+ *                     kernel) and nbins = P*(Q/2+1) rounded up to a multiple of 8.  A map that fits the in-LDS transform is
+ *                     ONE transform with P >= H+3, Q >= W+3 (the zero padding is the halo); a larger one (beyond ~96 x 128:
+ *                     the 96 x 128 level of the 7-scale pyramid, reference os2d/config.py:194, os2d/data/dataloader.py:326) is
+ *                     cut into TY x TX overlap-save tiles of tile_h x tile_w outputs, each transformed at P >= tile_h + 6,
+ *                     Q >= tile_w + 6 along a tiled axis: T = TY*TX transforms per (map, channel), sizes are those of a tile
+ *   os2d_fft_tiles    that tiling (1 x 1 and tile = map for an untiled one); a tile is one more "pair" for the kernels below:
+ *                     NBT = NB * T, pair' = nb * T + ty * TX + tx
  *   os2d_fft_forward  x = relu(corr [NB,C,H*W]) * inv_norm [NB,H*W] (head.py:650 folded into the load), zero-padded ->
- *                     X [C,NB,nbins] complex64, bin = u*(Q/2+1) + v
- *   os2d_fft_inverse  Y [NB,128,nbins] -> first H x W samples / (P*Q), + folded bias, ReLU, per-channel scale (packed_b of
+ *                     X [C,NBT,nbins] complex64, bin = u*(Q/2+1) + v
+ *   os2d_fft_inverse  Y [NBT,128,nbins] -> the tile's H x W samples / (P*Q), + folded bias, ReLU, per-channel scale (packed_b of
  *                     os2d_pack_conv_f16x3 for layer 1), fp16 hi|lo -> split-half blocked buffer (NB*os2d_shb_bytes(128,H,W))
  *   twQ / twP         exp(-2 pi i m / Q), m < Q  and  exp(-2 pi i m / P), m < P  as complex64 device tables              */
 int os2d_fft_sizes(int H, int W, int* P, int* Q, int* nbins);
+int os2d_fft_tiles(int H, int W, int* tiles_y, int* tiles_x, int* tile_h, int* tile_w);
 int os2d_fft_forward(const float* corr, const float* inv_norm, float* X, const float* twQ, const float* twP, int NB, int C,
                      int H, int W, void* stream);
 int os2d_fft_inverse(const float* Y, const float* packed_b, void* out, const float* twQ, const float* twP, int NB, int Cout,

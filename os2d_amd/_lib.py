@@ -9,7 +9,7 @@ import os
 
 from .build import LIB_PATH
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _c_float_p = ctypes.c_void_p   # device pointers travel as raw addresses (tensor.data_ptr())
 _vp = ctypes.c_void_p
@@ -43,6 +43,7 @@ SIGNATURES = {
     "os2d_spectral_gemm_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "os2d_debug_set_dump": (None, [_vp, _i, _vp, _sz]),
     "os2d_fft_sizes": (_i, [_i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "os2d_fft_tiles": (_i, [_i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "os2d_fft_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "os2d_fft_inverse": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "os2d_class_split": (_i, [_vp, _vp, _i, _i, _vp]),

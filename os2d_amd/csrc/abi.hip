@@ -32,7 +32,7 @@ int os2d_conv1_steps_padded() { return 25; }
 struct Carve {
   size_t sumsq, fs, corr, rpad, h1, h2, params, invn, xspec, yspec, total;
 };
-Carve carve(int A, int Bc, int C, int H, int W, int P, int fft_bins = 0) {
+Carve carve(int A, int Bc, int C, int H, int W, int P, int fft_bins = 0, int fft_tiles = 1) {
   const size_t HW = (size_t)H * W, PL = os2d_plane(H, W), NB = (size_t)A * Bc;
   Carve c;
   size_t off = 0;
@@ -52,8 +52,8 @@ Carve carve(int A, int Bc, int C, int H, int W, int P, int fft_bins = 0) {
   c.invn = c.xspec = c.yspec = 0;
   if (fft_bins > 0) {  // frequency-domain 7x7 layer: inverse norms, input / output spectra (complex64)
     c.invn = take(NB * HW);
-    c.xspec = take(NB * OS2D_K * (size_t)fft_bins * 2);
-    c.yspec = take(NB * 128 * (size_t)fft_bins * 2);
+    c.xspec = take(NB * fft_tiles * OS2D_K * (size_t)fft_bins * 2);     // a tile of a tiled map is one more "pair" (fft.hip)
+    c.yspec = take(NB * fft_tiles * 128 * (size_t)fft_bins * 2);
   }
   c.total = off;
   return c;
@@ -211,12 +211,12 @@ int os2d_head_workspace_bytes_ex(int A, int B, int C, int H, int W, int P, int p
     return -1;
   }
   if (!head_args_ok(A, B, C, H, W, P)) return -1;
-  int bins = 0;
-  if ((precision == OS2D_PRECISION_FFT || precision == OS2D_PRECISION_FFTX3) && !os2d_fft_plan(H, W, nullptr, nullptr, &bins)) {
-    os2d_set_error("os2d_head_workspace_bytes_ex: a %dx%d map does not fit the in-LDS transform of the FFT mode", H, W);
+  int bins = 0, tiles[6] = {1, 1, 0, 0, 0, 0};
+  if ((precision == OS2D_PRECISION_FFT || precision == OS2D_PRECISION_FFTX3) && !os2d_fft_plan(H, W, nullptr, nullptr, &bins, tiles)) {
+    os2d_set_error("os2d_head_workspace_bytes_ex: no transform plan for a %dx%d map", H, W);
     return -3;
   }
-  *bytes = carve(A, B, C, H, W, P, bins).total;
+  *bytes = carve(A, B, C, H, W, P, bins, tiles[0] * tiles[1]).total;
   return 0;
 }
 
@@ -356,17 +356,18 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     os2d_set_error("os2d_head_forward: unknown precision %d", precision);
     return -1;
   }
-  int fft_bins = 0;
+  int fft_bins = 0, tiles[6] = {1, 1, 0, 0, 0, 0};
   if (precision == OS2D_PRECISION_FFT || precision == OS2D_PRECISION_FFTX3) {
     if (!wspec || !twQ || !twP) {
       os2d_set_error("os2d_head_forward: the FFT mode needs the weight spectra and the two twiddle tables");
       return -1;
     }
-    if (!os2d_fft_plan(H, W, nullptr, nullptr, &fft_bins)) {
-      os2d_set_error("os2d_head_forward: a %dx%d map does not fit the in-LDS transform of the FFT mode", H, W);
+    if (!os2d_fft_plan(H, W, nullptr, nullptr, &fft_bins, tiles)) {
+      os2d_set_error("os2d_head_forward: no transform plan for a %dx%d map", H, W);
       return -3;
     }
   }
+  const int fft_T = tiles[0] * tiles[1];
   if (precision != OS2D_PRECISION_F32 && !qs) {
     os2d_set_error("os2d_head_forward: precision f16x3 / f16x2 needs the split class operand (os2d_class_split)");
     return -1;
@@ -381,14 +382,14 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     return -1;
   }
   // largest class chunk that fits the workspace (footprint is affine in Bc)
-  const size_t one = carve(A, 1, C, H, W, P, fft_bins).total;
+  const size_t one = carve(A, 1, C, H, W, P, fft_bins, fft_T).total;
   if (workspace_bytes < one) {
     os2d_set_error("os2d_head_forward: workspace too small (%zu B, need >= %zu B for one class)", workspace_bytes, one);
     return -2;
   }
   int Bc = B;
-  while (Bc > 1 && carve(A, Bc, C, H, W, P, fft_bins).total > workspace_bytes) {
-    const size_t two = carve(A, 2, C, H, W, P, fft_bins).total;
+  while (Bc > 1 && carve(A, Bc, C, H, W, P, fft_bins, fft_T).total > workspace_bytes) {
+    const size_t two = carve(A, 2, C, H, W, P, fft_bins, fft_T).total;
     const size_t per = two - one;
     int guess = per ? (int)((workspace_bytes - one) / per) + 1 : 1;
     if (guess >= Bc) guess = Bc - 1;
@@ -397,7 +398,7 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
   }
   hipStream_t st = S(stream);
   char* ws = static_cast<char*>(workspace);
-  const Carve c = carve(A, Bc, C, H, W, P, fft_bins);
+  const Carve c = carve(A, Bc, C, H, W, P, fft_bins, fft_T);
   float* invn = fft_bins ? reinterpret_cast<float*>(ws + c.invn) : nullptr;
   float* xspec = fft_bins ? reinterpret_cast<float*>(ws + c.xspec) : nullptr;
   float* yspec = fft_bins ? reinterpret_cast<float*>(ws + c.yspec) : nullptr;
@@ -446,9 +447,11 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
       if ((rc = os2d_launch_fft_forward(corr, invn, xspec, twQ, twP, NB, OS2D_K, H, W, st))) return rc;
       mark(b0, 11);
       if (precision == OS2D_PRECISION_FFTX3) {
-        if ((rc = os2d_launch_spectral_gemm_f16(wspec, xspec, yspec, NB, OS2D_K, 128, fft_bins, os2d_spectral_xscale_for(H, W), st)))
+        // |X| <= number of samples of a window (every sample of the normalised maps is <= 1): tiles[4] x tiles[5]
+        if ((rc = os2d_launch_spectral_gemm_f16(wspec, xspec, yspec, NB * fft_T, OS2D_K, 128, fft_bins,
+                                                os2d_spectral_xscale_for(tiles[4], tiles[5]), st)))
           return rc;
-      } else if ((rc = os2d_launch_spectral_gemm(wspec, xspec, yspec, NB, OS2D_K, 128, fft_bins, st))) {
+      } else if ((rc = os2d_launch_spectral_gemm(wspec, xspec, yspec, NB * fft_T, OS2D_K, 128, fft_bins, st))) {
         return rc;
       }
       mark(b0, 12);
@@ -465,8 +468,8 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
       dump_slot(stream, 0, corr, (size_t)NB * OS2D_K * H * W * 4);
       if (fft_bins) {
         dump_slot(stream, 1, invn, (size_t)NB * H * W * 4);
-        dump_slot(stream, 2, xspec, (size_t)NB * OS2D_K * fft_bins * 8);
-        dump_slot(stream, 3, yspec, (size_t)NB * 128 * fft_bins * 8);
+        dump_slot(stream, 2, xspec, (size_t)NB * fft_T * OS2D_K * fft_bins * 8);
+        dump_slot(stream, 3, yspec, (size_t)NB * fft_T * 128 * fft_bins * 8);
       }
       dump_slot(stream, 4, h1, (size_t)NB * 128 * PLb * 4);
     }
@@ -576,10 +579,27 @@ int os2d_fft_sizes(int H, int W, int* P, int* Q, int* nbins) {
     os2d_set_error("os2d_fft_sizes: null output");
     return -1;
   }
-  if (!os2d_fft_plan(H, W, P, Q, nbins)) {
-    os2d_set_error("os2d_fft_sizes: a %dx%d map does not fit the in-LDS transform", H, W);
+  if (!os2d_fft_plan(H, W, P, Q, nbins, nullptr)) {
+    os2d_set_error("os2d_fft_sizes: no transform plan for a %dx%d map", H, W);
     return -3;
   }
+  return 0;
+}
+
+int os2d_fft_tiles(int H, int W, int* tiles_y, int* tiles_x, int* tile_h, int* tile_w) {
+  int t[6];
+  if (!tiles_y || !tiles_x || !tile_h || !tile_w) {
+    os2d_set_error("os2d_fft_tiles: null output");
+    return -1;
+  }
+  if (!os2d_fft_plan(H, W, nullptr, nullptr, nullptr, t)) {
+    os2d_set_error("os2d_fft_tiles: no transform plan for a %dx%d map", H, W);
+    return -3;
+  }
+  *tiles_y = t[0];
+  *tiles_x = t[1];
+  *tile_h = t[2];
+  *tile_w = t[3];
   return 0;
 }
 
@@ -626,7 +646,11 @@ size_t os2d_spectral_weight16_bytes(int C, int nbins) {
   return os2d_spectral_weight16_size(C, nbins);
 }
 
-float os2d_spectral_xscale(int H, int W) { return (H < 1 || W < 1) ? 0.f : os2d_spectral_xscale_for(H, W); }
+float os2d_spectral_xscale(int H, int W) {
+  int t[6];
+  if (H < 1 || W < 1 || !os2d_fft_plan(H, W, nullptr, nullptr, nullptr, t)) return 0.f;
+  return os2d_spectral_xscale_for(t[4], t[5]);      // samples of one transform window (the whole map, or a tile + its halo)
+}
 
 int os2d_spectral_gemm_f16(const void* w16, const float* X, float* Y, int NB, int C, int Cout, int nbins, float xscale,
                            void* stream) {

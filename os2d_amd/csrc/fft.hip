@@ -13,6 +13,14 @@
 // (P and Q are products of 2s and 3s: 64 x 96 for a 60 x 80 map with its 3-cell halo); twiddles come from exact tables
 // (float64 on the host, rounded once).  The kernel is centred on the map (the weight spectra carry the -3 shift), so only
 // P >= H + 3 and Q >= W + 3 are needed and the result is cropped at the origin.
+//
+// Maps that do not fit the in-LDS transform (P x Q beyond ~96 x 128: the 96 x 128 level of BASELINE.json configs[4], anything up
+// to the 209-column limit of the other kernels) are cut into TY x TX TILES (overlap-save): tile (ty, tx) produces the outputs
+// of rows ty*TH .. ty*TH+TH-1 / columns tx*TW .. from an input window that starts 3 cells earlier and is 6 cells longer along
+// every tiled axis (cells outside the map are zero), transformed at P >= TH + 6, Q >= TW + 6; the wanted outputs then sit at
+// offset (3, 3) of the inverse transform and no wrap-around reaches them.  A tile is just one more "image" for all three
+// kernels: X is [C][NB * T][NBINS], Y is [NB * T][Cout][NBINS], pair' = nb * T + tile; the weight spectra depend on (P, Q)
+// only, so every map that tiles to the same transform size shares them.
 #include "os2d_common.h"
 #include "fft_regs.h"
 
@@ -41,7 +49,18 @@ struct FftPlan {
   unsigned inv_q;            // ceil(2^32 / Q)
   int AB;                    // complex numbers of the A | B region = max(2 * ceil(H/2) * Q, V * PS): the second column
                              // buffer D aliases it
+  // tiling (T = TY * TX = 1: the whole map in one transform, offsets 0)
+  int T, TY, TX;             // tiles per map
+  int TH, TW;                // output rows / columns of a tile (the last tile of an axis may reach beyond the map)
+  int oy, ox;                // 3 along a tiled axis (input window starts oy rows above the tile, outputs sit at row oy), else 0
+  int LH, LW;                // rows / columns of the input window a tile loads (TH + 6 | H, TW + 6 | W)
+  int RH;                    // rows of the inverse transform that are needed (oy + TH | H)
+  unsigned inv_t, inv_tx, inv_tw;   // ceil(2^32 / T), ceil(2^32 / TX), ceil(2^32 / TW) (0 where the divisor is 1)
+  unsigned inv_hpr;          // ceil(2^32 / ceil(RH / 2)): the inverse kernel transforms only the row pairs it needs
 };
+
+__host__ __device__ __forceinline__ unsigned magic_div(unsigned d) { return d > 1 ? (unsigned)(((1ull << 32) + d - 1) / d) : 0u; }
+__device__ __forceinline__ int div_magic(int x, unsigned magic) { return magic ? (int)__umulhi((unsigned)x, magic) : x; }
 
 // Work-group barrier for data exchanged through LDS only: waits for this wave's LDS operations, NOT for its global loads
 // and stores.  __syncthreads() carries a full fence (s_waitcnt vmcnt(0)): inside the per-image loop it would wait for the
@@ -176,8 +195,9 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 6 ? 4 : 2) void fft_forward_ker
                                                              f32x2* __restrict__ X,            // [C][NB][NBINS]
                                                              const f32x2* __restrict__ twQ, const f32x2* __restrict__ twP,
                                                              FftPlan pl, int C, int H, int W, int NBINS, int images) {
+  // images = NB * C * T: iteration `it` -> map it / T (= nb * C + c), tile it % T
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int P = pl.P, Q = pl.Q, V = pl.V, PS = pl.PS, QS = pl.QS, HP = (H + 1) >> 1, HW = H * W;
+  const int P = pl.P, Q = pl.Q, V = pl.V, PS = pl.PS, QS = pl.QS, HP = (pl.LH + 1) >> 1, HW = H * W, LH = pl.LH, LW = pl.LW;
   f32x2* tQ = reinterpret_cast<f32x2*>(smem);
   f32x2* tP = tQ + Q;
   f32x2* A = tP + P;
@@ -195,24 +215,31 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 6 ? 4 : 2) void fft_forward_ker
   // element k of a thread: (row pair p, column w) = (i / Q, i % Q) of i = tid + k * 512 -> source offset of its even row
   // (-1: zero padding), whether the odd row exists, its place in A.  Recomputed per image from an opaque copy of the thread
   // index (a multiply-high each): held across the image loop they cost 3 registers per element and spill
+  // the tile's window starts at map row Y0 / column X0 (negative along a tiled axis: the halo above / left of the map is zero)
+#define FFT_TILE(IT)                                                                                              \
+  const int m_ = div_magic((IT), pl.inv_t), t_ = (IT)-m_ * pl.T;                                                  \
+  const int ty_ = div_magic(t_, pl.inv_tx), tx_ = t_ - ty_ * pl.TX;                                               \
+  const int Y0 = ty_ * pl.TH - pl.oy, X0 = tx_ * pl.TW - pl.ox;
 #define FFT_ELEM(TID, K)                                                                                          \
   const int i_ = (TID) + (K)*FFT_THR;                                                                             \
   const int p_ = (int)__umulhi((unsigned)i_, pl.inv_q), w_ = i_ - p_ * Q;                                         \
-  const bool in_ = i_ < nelem && w_ < W;                                                                          \
-  const int eoff_ = in_ ? (2 * p_) * W + w_ : -1;                                                                 \
-  const bool eodd_ = in_ && 2 * p_ + 1 < H;                                                                       \
+  const int r_ = Y0 + 2 * p_, c_ = X0 + w_;                                                                       \
+  const bool in_ = i_ < nelem && w_ < LW && c_ >= 0 && c_ < W;                                                    \
+  const bool e0_ = in_ && r_ >= 0 && r_ < H && 2 * p_ < LH;                                                       \
+  const bool e1_ = in_ && r_ + 1 >= 0 && r_ + 1 < H && 2 * p_ + 1 < LH;                                           \
   const int edst_ = p_ * QS + w_;
   // RAW values only are held (correlation + inverse norm of the even and the odd row): any arithmetic here would make the
   // compiler wait for each load right where it is issued; addresses are clamped instead of predicated (no branches)
   float pa0[FFT_EPT], pn0[FFT_EPT], pa1[FFT_EPT], pn1[FFT_EPT];
-#define FFT_PREFETCH(IMG, TID)                                                                                    \
+#define FFT_PREFETCH(IT, TID)                                                                                     \
   {                                                                                                               \
-    const float* src_ = corr + (size_t)(IMG)*HW;                                                                  \
-    const float* nv_ = inv + (size_t)((IMG) / C) * HW;                                                            \
+    FFT_TILE(IT)                                                                                                  \
+    const float* src_ = corr + (size_t)m_ * HW;                                                                   \
+    const float* nv_ = inv + (size_t)(m_ / C) * HW;                                                               \
     _Pragma("unroll") for (int k = 0; k < FFT_EPT; ++k) {                                                         \
       FFT_ELEM(TID, k)                                                                                            \
       (void)edst_;                                                                                                \
-      const int o0_ = max(eoff_, 0), o1_ = eodd_ ? o0_ + W : o0_;                                                 \
+      const int o0_ = e0_ ? r_ * W + c_ : 0, o1_ = e1_ ? (r_ + 1) * W + c_ : o0_;                                 \
       pa0[k] = src_[o0_];                                                                                         \
       pn0[k] = nv_[o0_];                                                                                          \
       pa1[k] = src_[o1_];                                                                                         \
@@ -225,11 +252,12 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 6 ? 4 : 2) void fft_forward_ker
     asm volatile("" : "+v"(tl));
     lds_barrier();
     // ---- row pair p, column w -> A[p][w] = (x[2p][w], x[2p+1][w]) with x = relu(corr) * inv_norm; zero beyond the map
+    FFT_TILE(img)
 #pragma unroll
     for (int k = 0; k < FFT_EPT; ++k) {
       FFT_ELEM(tl, k)
       if (i_ < nelem)
-        A[edst_] = f32x2{eoff_ >= 0 ? fmaxf(pa0[k], 0.f) * pn0[k] : 0.f, eodd_ ? fmaxf(pa1[k], 0.f) * pn1[k] : 0.f};
+        A[edst_] = f32x2{e0_ ? fmaxf(pa0[k], 0.f) * pn0[k] : 0.f, e1_ ? fmaxf(pa1[k], 0.f) * pn1[k] : 0.f};
     }
     lds_barrier();
     if (img + (int)gridDim.x < images) FFT_PREFETCH(img + gridDim.x, tl)
@@ -243,7 +271,7 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 6 ? 4 : 2) void fft_forward_ker
     for (int v = wv; v < V; v += NWV)
       for (int u = lane; u < P; u += 64) {
         f32x2 o = f32x2{0.f, 0.f};
-        if (u < H) {
+        if (u < LH) {
           const int p = u >> 1;
           const f32x2 z = R[p * QS + v], zc = cconj(R[p * QS + (v == 0 ? 0 : Q - v)]);
           if ((u & 1) == 0) o = 0.5f * (z + zc);
@@ -263,7 +291,8 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 6 ? 4 : 2) void fft_forward_ker
     // ---- store X[u * V + v] (v fastest) + zero padding bins
     // X[c][pair][bin]: the 64 pairs a GEMM work-group reads for one channel lie in ONE 1.4 MB stretch (22 KB apart), not 5 MB
     // apart - its load instructions then need one address translation instead of one per pair
-    f32x2* dst = X + ((size_t)(img % C) * (images / C) + img / C) * NBINS;
+    const int nb_ = m_ / C;
+    f32x2* dst = X + ((size_t)(m_ - nb_ * C) * (images / C) + (size_t)nb_ * pl.T + t_) * NBINS;
     for (int u = wv; u < P; u += NWV)
       for (int v = lane; v < V; v += 64) dst[u * V + v] = Rc[v * PS + u];
     for (int i = P * V + tid; i < NBINS; i += FFT_THR) dst[i] = f32x2{0.f, 0.f};
@@ -283,13 +312,14 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
                                                              int MTP, char* __restrict__ out,  // SHB [NB][Cout/8][2][PLANE] x 16 B
                                                              const f32x2* __restrict__ twQ, const f32x2* __restrict__ twP,
                                                              FftPlan pl, int Cout, int H, int W, int NBINS, int PLANE,
-                                                             int images, unsigned inv_w, unsigned inv_v, int* __restrict__ status) {
+                                                             int images, unsigned inv_v, int* __restrict__ status) {
+  // images = NB * T * Cout: image -> (pair' = nb * T + tile, output channel); RH = rows of the inverse that are needed
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int P = pl.P, Q = pl.Q, V = pl.V, PS = pl.PS, QS = pl.QS, HP = (H + 1) >> 1;
+  const int P = pl.P, Q = pl.Q, V = pl.V, PS = pl.PS, QS = pl.QS, RH = pl.RH, HP = (RH + 1) >> 1;
   f32x2* tQ = reinterpret_cast<f32x2*>(smem);
   f32x2* tP = tQ + Q;
   f32x2* A = tP + P;
-  f32x2* Bf = A + HP * QS;
+  f32x2* Bf = A + ((pl.LH + 1) >> 1) * QS;          // the plan sizes A | B for the forward kernel's row pairs (>= HP)
   f32x2* Cc = A + pl.AB;
   f32x2* D = A;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -312,7 +342,7 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
   constexpr int NACC = CPT > 0 ? CPT : 1, NR = GRP == 4 ? 2 : 1;
   // GRP == 2 keeps the first channel of a pair as ONE register per cell (hi | lo << 16) and recombines at the second
   unsigned hreg[NACC][NR] = {}, lreg[GRP == 4 ? NACC : 1][NR] = {};
-  const int ngroups = images / GRP, cells = H * W;
+  const int ngroups = images / GRP, cells = pl.TH * pl.TW;
   // XCD-aware order (work-group L runs on XCD L % 8, one L2 per XCD): every XCD takes a contiguous range of channel
   // groups, so the 8 / GRP work-groups that fill the 16-byte units of one (class, 8-channel group) with their 4- / 8-byte
   // pieces run on ONE XCD at about the same time and the pieces merge in its L2 (with the round-robin order each piece
@@ -323,7 +353,10 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
   for (int it = first * GRP; it < images; it = ((it + 1) % GRP) ? it + 1 : (it / GRP + (int)gridDim.x) * GRP) {
     const int img = it;
     const int nxt = ((it + 1) % GRP) ? it + 1 : (it / GRP + (int)gridDim.x) * GRP;
-    const int nb = img / Cout, o = img - nb * Cout;
+    const int pr = img / Cout, o = img - pr * Cout;               // pair' = nb * T + tile
+    const int nb = div_magic(pr, pl.inv_t), tile = pr - nb * pl.T;
+    const int ty = div_magic(tile, pl.inv_tx), tx = tile - ty * pl.TX;
+    const int y0 = ty * pl.TH, x0 = tx * pl.TW, oy = pl.oy, ox = pl.ox;
     // the per-thread addresses below are cheap to recompute per image; an opaque copy of the thread index keeps the
     // compiler from hoisting ~50 registers of them out of the image loop (and spilling them at the 128-register budget)
     int tl = tid;
@@ -351,7 +384,7 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
     f32x2* S = Rc;
     if (Rc == D) {   // move the H x V block that is still needed out of A | B (Cc is free now)
       for (int v = wv; v < V; v += NWV)
-        for (int u = lane; u < H; u += 64) Cc[v * PS + u] = Rc[v * PS + u];
+        for (int u = lane; u < RH; u += 64) Cc[v * PS + u] = Rc[v * PS + u];
       lds_barrier();
       S = Cc;
     }
@@ -359,7 +392,7 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
       for (int v = lane; v < Q; v += 64) {
         const int vv = v < V ? v : Q - v;                 // Hermitian mirror
         f32x2 x0 = S[vv * PS + 2 * p];
-        f32x2 x1 = (2 * p + 1 < H) ? S[vv * PS + 2 * p + 1] : f32x2{0.f, 0.f};
+        f32x2 x1 = (2 * p + 1 < RH) ? S[vv * PS + 2 * p + 1] : f32x2{0.f, 0.f};
         if (v >= V) {
           x0 = cconj(x0);
           x1 = cconj(x1);
@@ -370,7 +403,7 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
 #ifdef OS2D_DIAG_FFT_NOROW
     f32x2* R = A;
 #else
-    f32x2* R = fft_any<true>(pl.row_r1, pl.row_r2, A, Bf, Q, HP, QS, pl.zs_row, pl.inv_hp, pl.np_row, pl.rad_row, tQ, tid);
+    f32x2* R = fft_any<true>(pl.row_r1, pl.row_r2, A, Bf, Q, HP, QS, pl.zs_row, pl.inv_hpr, pl.np_row, pl.rad_row, tQ, tid);
 #endif
     // ---- epilogue: y = re / im of R (rows 2p / 2p+1), + bias, ReLU, channel scale, fp16 hi | lo into the SHB unit of
     // (nb, o / 8) at slot o % 8 (2-byte stores: the 8 channels of a unit come from 8 different images)
@@ -383,11 +416,11 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
       for (int k = 0; k < CPT; ++k) {
         __builtin_amdgcn_sched_barrier(0);                 // keep the unrolled iterations apart: register pressure
         const int i = tl + k * FFT_THR;
-        if (i < cells) {
-          const int h = inv_w ? (int)__umulhi((unsigned)i, inv_w) : i;    // i / W (inv_w = ceil(2^32 / W); 0 for W == 1)
-          const int w = i - h * W;
-          const f32x2 z = R[(h >> 1) * QS + w];
-          float t = ((h & 1) ? z[1] : z[0]) * norm + bias;
+        const int th = div_magic(i, pl.inv_tw), tw = i - th * pl.TW;      // cell of the tile: i / TW, i % TW
+        const int h = y0 + th, w = x0 + tw;                               // ... of the map
+        if (i < cells && h < H && w < W) {
+          const f32x2 z = R[((th + oy) >> 1) * QS + tw + ox];
+          float t = (((th + oy) & 1) ? z[1] : z[0]) * norm + bias;
           t = fmaxf(t, 0.f) * osc;
           if (!(fabsf(t) <= 65504.f)) bad = true;
           const _Float16 hv = (_Float16)t;
@@ -421,10 +454,11 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
     } else {
       _Float16* hi = reinterpret_cast<_Float16*>(hi_unit) + slot;
       _Float16* lo = reinterpret_cast<_Float16*>(lo_unit) + slot;
-      for (int h = wv; h < H; h += NWV)
-        for (int w = lane; w < W; w += 64) {
-          const f32x2 z = R[(h >> 1) * QS + w];
-          float t = ((h & 1) ? z[1] : z[0]) * norm + bias;
+      for (int th = wv; th < pl.TH && y0 + th < H; th += NWV)
+        for (int tw = lane; tw < pl.TW && x0 + tw < W; tw += 64) {
+          const int h = y0 + th, w = x0 + tw;
+          const f32x2 z = R[((th + oy) >> 1) * QS + tw + ox];
+          float t = (((th + oy) & 1) ? z[1] : z[0]) * norm + bias;
           t = fmaxf(t, 0.f) * osc;
           if (!(fabsf(t) <= 65504.f)) bad = true;
           const _Float16 hv = (_Float16)t;
@@ -490,9 +524,10 @@ int next_size(int n) {  // smallest even transform size >= n: 2^a 3^b (Stockham 
   }
 }
 
-bool make_plan(int H, int W, FftPlan* pl, size_t* lds) {
-  pl->P = next_size(H + 3);
-  pl->Q = next_size(W + 3);
+// plan of ONE transform whose forward kernel loads an LH x LW window and whose inverse needs RH rows; P >= minP, Q >= minQ
+bool plan_transform(int LH, int LW, int RH, int minP, int minQ, FftPlan* pl, size_t* lds) {
+  pl->P = next_size(minP);
+  pl->Q = next_size(minQ);
   pl->V = pl->Q / 2 + 1;
   pl->PS = pl->P + 1;
 #ifdef OS2D_DIAG_FFT_QS0
@@ -502,12 +537,13 @@ bool make_plan(int H, int W, FftPlan* pl, size_t* lds) {
 #endif
   pl->np_row = factor(pl->Q, pl->rad_row);
   pl->np_col = factor(pl->P, pl->rad_col);
-  const int HP = (H + 1) / 2;
+  const int HP = (LH + 1) / 2, HPR = (RH + 1) / 2;
   const bool row_fast = split_size(pl->Q, &pl->row_r1, &pl->row_r2), col_fast = split_size(pl->P, &pl->col_r1, &pl->col_r2);
   if ((!pl->np_row && !row_fast) || (!pl->np_col && !col_fast)) return false;
   pl->zs_row = pl->row_r1 ? ((pl->row_r1 * (pl->row_r2 | 1)) | 1) : 0;
   pl->zs_col = pl->col_r1 ? ((pl->col_r1 * (pl->col_r2 | 1)) | 1) : 0;
-  pl->inv_hp = HP > 1 ? (unsigned)(((1ull << 32) + HP - 1) / HP) : 0u;
+  pl->inv_hp = magic_div((unsigned)HP);
+  pl->inv_hpr = magic_div((unsigned)HPR);
   pl->inv_v = (unsigned)(((1ull << 32) + pl->V - 1) / pl->V);
   pl->inv_q = (unsigned)(((1ull << 32) + pl->Q - 1) / pl->Q);
   size_t rows = (size_t)2 * HP * pl->QS, cc = (size_t)pl->V * pl->PS;
@@ -515,9 +551,67 @@ bool make_plan(int H, int W, FftPlan* pl, size_t* lds) {
   const size_t dd = (size_t)pl->V * pl->zs_col > cc ? (size_t)pl->V * pl->zs_col : cc;         // exchange buffer in D = A | B
   const size_t ab = rows > dd ? rows : dd;
   pl->AB = (int)ab;
+  pl->LH = LH;
+  pl->LW = LW;
+  pl->RH = RH;
   *lds = (size_t)(pl->Q + pl->P + ab + cc) * 8;
   if ((size_t)HP * pl->Q > (size_t)FFT_EPT_MAX * FFT_THR || (size_t)pl->P * pl->V > (size_t)FFT_EPT_MAX * FFT_THR) return false;
   return *lds <= 160 * 1024;
+}
+
+void set_tiles(FftPlan* pl, int TY, int TX, int TH, int TW) {
+  pl->TY = TY;
+  pl->TX = TX;
+  pl->T = TY * TX;
+  pl->TH = TH;
+  pl->TW = TW;
+  pl->oy = TY > 1 ? 3 : 0;
+  pl->ox = TX > 1 ? 3 : 0;
+  pl->inv_t = magic_div((unsigned)pl->T);
+  pl->inv_tx = magic_div((unsigned)TX);
+  pl->inv_tw = magic_div((unsigned)TW);
+}
+
+// The whole map in one transform when it fits the LDS and the register prefetch (P >= H + 3, Q >= W + 3: the zero padding is
+// the halo); otherwise the cheapest tiling.  An axis is either untiled (window = the whole axis, size >= n + 3) or cut into
+// >= 2 tiles of ceil(n / k) outputs whose window is 6 longer (size >= tile + 6).  Cost = bins in total, x 1.5 per axis whose
+// size has no two-stage register form (Stockham passes: ~2x the LDS traffic), x 1.15 when only one work-group fits a CU (no
+// second group to hide the barriers behind): 96 x 128 -> 2 x 2 tiles at 54 x 72 (7992 bins, 48 KB, the transform the 48 x 64
+// level uses - one set of weight spectra for both) rather than 2 x 1 at 54 x 144 (7888 bins, 96 KB, Stockham rows).
+bool make_plan(int H, int W, FftPlan* pl, size_t* lds) {
+  if (plan_transform(H, W, H, H + 3, W + 3, pl, lds)) {
+    set_tiles(pl, 1, 1, H, W);
+    return true;
+  }
+  bool found = false;
+  double best_cost = 0.0;
+  size_t best_lds = 0;
+  FftPlan best;
+  for (int TY = 1; TY <= 8; ++TY)
+    for (int TX = 1; TX <= 8; ++TX) {
+      if (TY * TX == 1) continue;
+      const int TH = (H + TY - 1) / TY, TW = (W + TX - 1) / TX;
+      if ((TY > 1 && (TY - 1) * TH >= H) || (TX > 1 && (TX - 1) * TW >= W)) continue;     // an empty last tile
+      const int LH = TY > 1 ? TH + 6 : H, LW = TX > 1 ? TW + 6 : W;
+      FftPlan c;
+      size_t l;
+      if (!plan_transform(LH, LW, TY > 1 ? TH + 3 : H, TY > 1 ? TH + 6 : H + 3, TX > 1 ? TW + 6 : W + 3, &c, &l)) continue;
+      set_tiles(&c, TY, TX, TH, TW);
+      double cost = (double)c.T * os2d_round_up(c.P * c.V, 8);
+      if (!c.row_r1) cost *= 1.5;
+      if (!c.col_r1) cost *= 1.5;
+      if (2 * l > 160 * 1024) cost *= 1.15;
+      if (!found || cost < best_cost || (cost == best_cost && l < best_lds)) {
+        found = true;
+        best = c;
+        best_cost = cost;
+        best_lds = l;
+      }
+    }
+  if (!found) return false;
+  *pl = best;
+  *lds = best_lds;
+  return true;
 }
 
 int check(const char* what) {
@@ -531,14 +625,23 @@ int check(const char* what) {
 
 }  // namespace
 
-// P, Q and the padded number of bins (multiple of 8) of the transform of an H x W map; 0 if the map does not fit the LDS plan
-int os2d_fft_plan(int H, int W, int* P, int* Q, int* nbins) {
+// P, Q and the padded number of bins (multiple of 8) of the transform of an H x W map (of ONE tile of it when the map is
+// tiled); tiles[6] (optional) = TY, TX, TH, TW, window rows, window columns.  0 if no plan exists.
+int os2d_fft_plan(int H, int W, int* P, int* Q, int* nbins, int* tiles) {
   FftPlan pl;
   size_t lds;
   if (H < 1 || W < 1 || !make_plan(H, W, &pl, &lds)) return 0;
   if (P) *P = pl.P;
   if (Q) *Q = pl.Q;
   if (nbins) *nbins = os2d_round_up(pl.P * pl.V, 8);
+  if (tiles) {
+    tiles[0] = pl.TY;
+    tiles[1] = pl.TX;
+    tiles[2] = pl.TH;
+    tiles[3] = pl.TW;
+    tiles[4] = pl.LH;
+    tiles[5] = pl.LW;
+  }
   return 1;
 }
 
@@ -553,14 +656,14 @@ int os2d_launch_fft_forward(const float* corr, const float* inv, float* X, const
 #ifdef OS2D_DIAG_FFT_LDS_MIN
   if (lds < (size_t)OS2D_DIAG_FFT_LDS_MIN) lds = OS2D_DIAG_FFT_LDS_MIN;
 #endif
-  const int ept = (((H + 1) / 2) * pl.Q + FFT_THR - 1) / FFT_THR;
+  const int ept = (((pl.LH + 1) / 2) * pl.Q + FFT_THR - 1) / FFT_THR;
   auto kern = ept <= 6 ? fft_forward_kernel<6> : ept <= 10 ? fft_forward_kernel<10> : fft_forward_kernel<14>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) {
     os2d_set_error("hipFuncSetAttribute(fft_forward): %s", hipGetErrorString(e));
     return -4;
   }
-  const int images = NB * C;
+  const int images = NB * C * pl.T;
   const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
   const int grid = images < 256 * per_cu * 4 ? images : 256 * per_cu * 4;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(FFT_THR), lds, stream, corr, inv, reinterpret_cast<f32x2*>(X),
@@ -582,7 +685,7 @@ int os2d_launch_fft_inverse(const float* Y, const float* bp, int MTP, void* out,
 #define OS2D_FFT_GRP 2
 #endif
   constexpr int CPT = 10, GRP = OS2D_FFT_GRP;
-  const bool grouped = Cout % GRP == 0 && H * W <= CPT * FFT_THR && ept <= 10;
+  const bool grouped = Cout % GRP == 0 && pl.TH * pl.TW <= CPT * FFT_THR && ept <= 10;
   auto kern = grouped ? (ept <= 6   ? fft_inverse_kernel<6, CPT, GRP>
                          : ept <= 8 ? fft_inverse_kernel<8, CPT, GRP>
                                     : fft_inverse_kernel<10, CPT, GRP>)
@@ -594,13 +697,12 @@ int os2d_launch_fft_inverse(const float* Y, const float* bp, int MTP, void* out,
     os2d_set_error("hipFuncSetAttribute(fft_inverse): %s", hipGetErrorString(e));
     return -4;
   }
-  const int images = NB * Cout, groups = grouped ? images / GRP : images;
+  const int images = NB * pl.T * Cout, groups = grouped ? images / GRP : images;
   const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
   const int grid = ((groups < 256 * per_cu * 4 ? groups : 256 * per_cu * 4) + 7) / 8 * 8;   // multiple of 8 (XCD-aware order)
-  const unsigned inv_w = W > 1 ? (unsigned)(((1ull << 32) + W - 1) / W) : 0u;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(FFT_THR), lds, stream, reinterpret_cast<const f32x2*>(Y), bp, MTP,
                      static_cast<char*>(out), reinterpret_cast<const f32x2*>(twQ), reinterpret_cast<const f32x2*>(twP), pl,
-                     Cout, H, W, os2d_round_up(pl.P * pl.V, 8), os2d_plane(H, W), images, inv_w,
+                     Cout, H, W, os2d_round_up(pl.P * pl.V, 8), os2d_plane(H, W), images,
                      (unsigned)(((1ull << 32) + pl.V - 1) / pl.V), status);
   return check("fft_inverse");
 }

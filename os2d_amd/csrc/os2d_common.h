@@ -147,7 +147,7 @@ int os2d_launch_detect_level(const float* loc, const float* cls, int B, int H, i
                              float img_w, float img_h, float scale_x, float scale_y, float score_thr, float iou_thr,
                              float* out_boxes, float* out_scores, int* out_index, int* out_count, hipStream_t stream);
 // fft.hip
-int os2d_fft_plan(int H, int W, int* P, int* Q, int* nbins);
+int os2d_fft_plan(int H, int W, int* P, int* Q, int* nbins, int* tiles /* [6]: TY, TX, TH, TW, window rows, window columns */);
 int os2d_launch_fft_forward(const float* corr, const float* inv, float* X, const float* twQ, const float* twP, int NB, int C,
                             int H, int W, hipStream_t stream);
 int os2d_launch_fft_inverse(const float* Y, const float* bp, int MTP, void* out, const float* twQ, const float* twP, int NB,

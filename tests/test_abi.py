@@ -109,27 +109,36 @@ def test_every_included_header_is_part_of_the_build_stamp(tmp_path, monkeypatch)
 
 
 def test_fft_plan_host_logic():
-    """os2d_fft_sizes is host code: transform sizes of the frequency-domain 7x7 layer for the pyramid levels of
-    BASELINE.json configs[4], the invariants every size must satisfy, and the refusal of maps that do not fit the LDS."""
+    """os2d_fft_sizes / os2d_fft_tiles are host code: transform sizes of the frequency-domain 7x7 layer for the pyramid
+    levels of BASELINE.json configs[4] (the 96 x 128 level is cut into overlap-save tiles), the invariants every plan must
+    satisfy for every map the head accepts (width <= 209), and the fp16 scale of the input spectra."""
     import ctypes
     from os2d_amd import _lib
     lib = _lib.load()
 
-    def sizes(h, w):
+    def plan(h, w):
         P, Q, nb = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        ty, tx, th, tw = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         rc = lib.os2d_fft_sizes(h, w, ctypes.byref(P), ctypes.byref(Q), ctypes.byref(nb))
-        return (rc, P.value, Q.value, nb.value)
+        rc2 = lib.os2d_fft_tiles(h, w, ctypes.byref(ty), ctypes.byref(tx), ctypes.byref(th), ctypes.byref(tw))
+        assert rc == rc2
+        return (rc, P.value, Q.value, nb.value, ty.value, tx.value, th.value, tw.value)
 
     expected = {(30, 40): (36, 48), (38, 50): (42, 54), (48, 64): (54, 72), (60, 80): (64, 84), (72, 96): (84, 108), (84, 112): (96, 128)}
     for (h, w), (p, q) in expected.items():
-        rc, P, Q, nb = sizes(h, w)
+        rc, P, Q, nb, ty, tx, th, tw = plan(h, w)
         assert rc == 0 and (P, Q) == (p, q) and nb == (p * (q // 2 + 1) + 7) // 8 * 8
-    for h in range(1, 100, 7):
-        for w in range(1, 130, 9):
-            rc, P, Q, nb = sizes(h, w)
-            if rc != 0:
-                continue
-            assert P >= h + 3 and Q >= w + 3 and P % 2 == 0 and Q % 2 == 0 and nb % 8 == 0 and nb >= P * (Q // 2 + 1)
+        assert (ty, tx, th, tw) == (1, 1, h, w)              # these fit one in-LDS transform
+    # the largest level of the 7-scale pyramid (reference os2d/config.py:194): 108 x 144 would need 177 KB of LDS -> four
+    # tiles of 48 x 64 outputs, each a 54 x 72 transform (the size the 48 x 64 level uses: one set of weight spectra)
+    assert plan(96, 128) == (0, 54, 72, 2000, 2, 2, 48, 64)
+    for h in list(range(1, 100, 7)) + [120, 157, 300]:
+        for w in list(range(1, 130, 9)) + [150, 209]:
+            rc, P, Q, nb, ty, tx, th, tw = plan(h, w)
+            assert rc == 0, (h, w)                           # every map the head accepts has a plan
+            assert ty >= 1 and tx >= 1 and ty * th >= h and tx * tw >= w and (ty - 1) * th < h and (tx - 1) * tw < w
+            assert P >= (th + 6 if ty > 1 else h + 3) and Q >= (tw + 6 if tx > 1 else w + 3)
+            assert P % 2 == 0 and Q % 2 == 0 and nb % 8 == 0 and nb >= P * (Q // 2 + 1)
             for n in (P, Q):            # 2^a 3^b, or one of the sizes with a factor 7 that have a two-stage form
                 m = n
                 while m % 2 == 0:
@@ -137,5 +146,5 @@ def test_fft_plan_host_logic():
                 while m % 3 == 0:
                     m //= 3
                 assert m == 1 or n in (42, 84)
-    assert sizes(96, 128)[0] != 0          # 108 x 144 needs 177 KB of LDS: the head uses the direct kernel there
-    assert lib.os2d_spectral_xscale(60, 80) == 8.0 and lib.os2d_spectral_xscale(96, 128) == 4.0
+    # |X| <= samples of one window: 60 x 80 -> 2^3 * 4800 <= 65504; a 96 x 128 map's window is a 54 x 70 tile + halo -> 2^4
+    assert lib.os2d_spectral_xscale(60, 80) == 8.0 and lib.os2d_spectral_xscale(96, 128) == 16.0

@@ -414,7 +414,7 @@ def test_range_flag_is_raised_not_clamped(device):
     """Non-finite input is the only way past the range plan: the split-fp16 kernels then raise the sticky status word
     (mapped host memory, no synchronisation needed to poll it) instead of clamping silently; ``strict_range`` re-runs
     the call in exact fp32 (whose result is what the reference would give: non-finite where the input was), and without it
-    the head switches itself to fp32 at the next call."""
+    the next call on the device runs in fp32 (one call, not for good)."""
     from os2d_amd.utils import synthetic
     P, inverse = 6, True
     state = synthetic.make_transform_net_state(P, seed=3)
@@ -429,8 +429,11 @@ def test_range_flag_is_raised_not_clamped(device):
         head.precision = "f16x3"
         head(fm)
         assert head.range_status(synchronize=True) == 1
-        head(fm)                                   # the flag is seen when the next call starts ...
-        assert head.precision == "f32"             # ... and the head computes in fp32 from then on
+        head(fm)                                   # the flag is seen when the next call starts: THAT call runs in fp32,
+        assert head.last_precision == "f32" and head.precision == "f16x3"      # the configured arithmetic stays
+        assert head.range_status(synchronize=True) == 0                       # fp32 kernels do not raise it; it was cleared
+        other = creator.create_os2d_head(class_fms)                           # the word is per DEVICE (process lifetime), shared by
+        assert other._status_word().data_ptr() == head._status_word().data_ptr()   # every head: no head owns memory kernels write to
         head2 = creator.create_os2d_head(class_fms)
         strict = head2(fm, precision="f16x3", strict_range=True)
         plain = head2(fm, precision="f32")
@@ -490,8 +493,39 @@ def test_baseline_config_pyramid_level_sizes_match_oracle(H, W, device):
         head = creator.create_os2d_head([c.to(device) for c in class_fms])
         for precision in PRECISIONS:
             loc, cls, _, corners = head(fm.to(device), precision=precision)
+            # every level runs the arithmetic it was asked for: the 96 x 128 level takes the frequency-domain route too
+            # (overlap-save tiles) - no silent fallback to the direct kernel
+            assert head.last_precision == precision
             util.assert_head_outputs_close("{}x{} {}".format(H, W, precision), loc, cls, corners, ref[0], ref[1], ref[3],
                                            scale=2.5 if precision != "f16x2" else 4.0)    # coordinates up to ~2000 px
+
+
+@pytest.mark.parametrize("H,W,C,B", [(100, 140, 64, 7), (157, 209, 32, 3), (64, 209, 32, 4), (200, 100, 32, 8)])
+def test_tiled_frequency_domain_route_matches_oracle_and_direct_kernel(H, W, C, B, device):
+    """Maps beyond one in-LDS transform (up to the 209-column limit of the other kernels): the frequency-domain modes cut
+    them into overlap-save tiles (os2d_fft_tiles).  Ragged tilings (tile sizes that do not divide the map), a one-axis
+    tiling and the widest supported map, against the oracle and against the direct f16x3 kernel on the same inputs."""
+    from os2d_amd.utils import synthetic
+    import ctypes
+    from os2d_amd import _lib
+    lib = _lib.load()
+    t4 = [ctypes.c_int() for _ in range(4)]
+    _lib.check(lib.os2d_fft_tiles(H, W, *[ctypes.byref(t) for t in t4]), "os2d_fft_tiles")
+    assert t4[0].value * t4[1].value > 1, "the case is meant to be tiled"
+    P, inverse = 6, True
+    state = synthetic.make_transform_net_state(P, seed=4)
+    fm = synthetic.make_feature_map(C, H, W, seed=H + W)
+    class_fms = synthetic.make_class_feature_maps(B, C, sizes=[(15, 15), (12, 18)], seed=77)
+    creator = util.make_head_creator(P, inverse, state, device)
+    ref = _oracle(fm, class_fms, state, inverse)
+    with torch.no_grad():
+        head = creator.create_os2d_head([c.to(device) for c in class_fms])
+        direct = [t.clone() for t in head(fm.to(device), precision="f16x3")]
+        for precision in ("fft", "fftx3"):
+            loc, cls, _, corners = head(fm.to(device), precision=precision)
+            assert head.last_precision == precision
+            util.assert_head_outputs_close("{}x{} {}".format(H, W, precision), loc, cls, corners, ref[0], ref[1], ref[3], scale=2.5)
+            util.assert_head_outputs_close("{}x{} {} vs direct".format(H, W, precision), loc, cls, corners, direct[0], direct[1], direct[3], scale=2.5)
 
 
 def test_baseline_config_pyramid_streams_128_classes(device):

@@ -80,6 +80,24 @@ def fft_sizes(H, W):
     return P.value, Q.value, nb.value
 
 
+def fft_tiles(H, W):
+    """(TY, TX, TH, TW): the overlap-save tiling of maps beyond the in-LDS transform (1, 1, H, W for the others)."""
+    import ctypes
+    lib = _lib.load()
+    v = [ctypes.c_int() for _ in range(4)]
+    _lib.check(lib.os2d_fft_tiles(H, W, *[ctypes.byref(x) for x in v]), "os2d_fft_tiles")
+    return tuple(x.value for x in v)
+
+
+def tile_windows(H, W):
+    """Per tile (row-major): (y0, x0, oy, ox, LH, LW) - the input window starts at map cell (y0 - oy, x0 - ox) and spans
+    LH x LW cells; the tile's outputs are map rows y0 .. y0 + TH - 1 found at offset (oy, ox) of the inverse transform."""
+    TY, TX, TH, TW = fft_tiles(H, W)
+    oy, ox = (3 if TY > 1 else 0), (3 if TX > 1 else 0)
+    LH, LW = (TH + 6 if TY > 1 else H), (TW + 6 if TX > 1 else W)
+    return [(ty * TH, tx * TW, oy, ox, LH, LW) for ty in range(TY) for tx in range(TX)], (TY, TX, TH, TW)
+
+
 # the pyramid levels of BASELINE.json configs[4] (+ two more maps) exercise every two-stage register factorisation of
 # fft.hip: 36 = 6x6, 42 = 6x7, 48 = 8x6, 54 = 9x6, 64 = 8x8, 72 = 9x8, 84 = 12x7, 96 = 12x8, 108 = 12x9, 128 = 16x8; the
 # small / odd maps take the Stockham passes
@@ -90,46 +108,69 @@ MORE_LEVELS = [(44, 90), (90, 60)]
 def test_two_stage_factorisations_are_the_pyramid_sizes():
     assert [fft_sizes(h, w)[:2] for h, w in PYRAMID_LEVELS] == [(36, 48), (42, 54), (54, 72), (64, 84), (84, 108), (96, 128)]
     assert [fft_sizes(h, w)[:2] for h, w in MORE_LEVELS] == [(48, 96), (96, 64)]
+    # the 96 x 128 level: 2 x 2 overlap-save tiles on the transform of the 48 x 64 level (shared weight spectra)
+    assert fft_sizes(96, 128)[:2] == (54, 72) and fft_tiles(96, 128) == (2, 2, 48, 64)
+
+
+TILED_MAPS = [(96, 128), (100, 132), (157, 209), (64, 209), (200, 100), (97, 129)]   # beyond one in-LDS transform: overlap-save tiles
+LARGE_UNTILED = [(120, 50), (50, 150), (3, 209), (150, 60)]      # long thin maps that still fit one transform (Stockham passes: 144, 162, 216)
 
 
 @pytest.mark.parametrize("H,W,NB,C", [(60, 80, 2, 7), (30, 40, 1, 5), (38, 50, 1, 3), (48, 64, 1, 3), (72, 96, 1, 2), (84, 112, 1, 2),
-                                      (44, 90, 1, 2), (90, 60, 1, 2), (11, 13, 3, 4), (9, 16, 2, 2), (2, 5, 1, 2), (1, 1, 1, 1)])
+                                      (44, 90, 1, 2), (90, 60, 1, 2), (11, 13, 3, 4), (9, 16, 2, 2), (2, 5, 1, 2), (1, 1, 1, 1)] +
+                         [(h, w, 2, 3) for h, w in TILED_MAPS + LARGE_UNTILED])
 def test_fft_forward_matches_torch_fft(H, W, NB, C, device):
     lib = _lib.load()
     P, Q, nbins = fft_sizes(H, W)
-    assert P >= H + 3 and Q >= W + 3 and nbins % 8 == 0 and nbins >= P * (Q // 2 + 1)
+    wins, (TY, TX, TH, TW) = tile_windows(H, W)
+    T = TY * TX
+    assert nbins % 8 == 0 and nbins >= P * (Q // 2 + 1)
+    assert P >= (TH + 6 if TY > 1 else H + 3) and Q >= (TW + 6 if TX > 1 else W + 3)
+    if (H, W) in TILED_MAPS:
+        assert T > 1
     g = torch.Generator().manual_seed(H * 100 + W)
     corr = (torch.rand(NB, C, H, W, generator=g) - 0.3).to(device)
     inv = (0.5 + torch.rand(NB, H, W, generator=g)).to(device)
-    X = torch.full((C, NB, nbins, 2), float("nan"), device=device)               # channel-major (what the GEMM kernels read)
+    X = torch.full((C, NB * T, nbins, 2), float("nan"), device=device)           # channel-major (what the GEMM kernels read)
     tq, tp = twiddles(Q, device), twiddles(P, device)          # keep them alive: the call only takes raw pointers
     _lib.check(lib.os2d_fft_forward(_lib.ptr(corr), _lib.ptr(inv), _lib.ptr(X), _lib.ptr(tq), _lib.ptr(tp),
                                     NB, C, H, W, _lib.current_stream(device)), "os2d_fft_forward")
     x = (corr.clamp(min=0) * inv.unsqueeze(1)).double()
-    ref = torch.fft.rfft2(x, s=(P, Q)).reshape(NB, C, -1)                       # [NB,C,P*V], bin = u*V + v
-    got = torch.view_as_complex(X)[..., :P * (Q // 2 + 1)].to(torch.complex128).permute(1, 0, 2)
-    scale = float(ref.abs().max())
-    assert float((got - ref).abs().max()) <= 2e-6 * scale
+    got = torch.view_as_complex(X)[..., :P * (Q // 2 + 1)].to(torch.complex128).view(C, NB, T, -1)
+    for t, (y0, x0, oy, ox, LH, LW) in enumerate(wins):
+        # the tile's window of the zero-extended map, then the plain zero-padded transform
+        big = torch.zeros(NB, C, H + 2 * LH + 6, W + 2 * LW + 6, dtype=torch.float64, device=device)
+        big[:, :, LH:LH + H, LW:LW + W] = x
+        win = big[:, :, LH + y0 - oy:LH + y0 - oy + LH, LW + x0 - ox:LW + x0 - ox + LW]
+        ref = torch.fft.rfft2(win, s=(P, Q)).reshape(NB, C, -1)                   # [NB,C,P*V], bin = u*V + v
+        scale = float(ref.abs().max())
+        assert float((got[:, :, t].permute(1, 0, 2) - ref).abs().max()) <= 2e-6 * max(scale, 1e-30), ("tile", t)
     assert float(X[:, :, P * (Q // 2 + 1):].abs().max() if nbins > P * (Q // 2 + 1) else 0.0) == 0.0
 
 
 @pytest.mark.parametrize("H,W,NB", [(60, 80, 2), (30, 40, 1), (38, 50, 1), (48, 64, 1), (72, 96, 1), (84, 112, 1), (44, 90, 1), (90, 60, 1),
-                                    (11, 13, 2), (2, 5, 1)])
+                                    (11, 13, 2), (2, 5, 1)] + [(h, w, 2) for h, w in TILED_MAPS + LARGE_UNTILED])
 def test_fft_inverse_matches_torch_fft_and_epilogue(H, W, NB, device):
     """Inverse transform + the layer epilogue (bias, ReLU, per-channel power-of-two scale, fp16 hi|lo split into the
-    split-half blocked buffer with zero borders) against torch.fft.irfft2."""
+    split-half blocked buffer with zero borders) against torch.fft.irfft2; for tiled maps every tile's spectrum holds its
+    part of the map at offset (3, 3) along the tiled axes and arbitrary content elsewhere."""
     lib = _lib.load()
     P, Q, nbins = fft_sizes(H, W)
+    wins, (TY, TX, TH, TW) = tile_windows(H, W)
+    T = TY * TX
     V = Q // 2 + 1
     Cout = 128
     g = torch.Generator().manual_seed(H + W)
     y_true = torch.randn(NB, Cout, H, W, generator=g).double() * 0.3                 # what the inverse should give back
-    full = torch.zeros(NB, Cout, P, Q, dtype=torch.float64)
-    full[:, :, :H, :W] = y_true
-    full[:, :, H:, :] = torch.randn(NB, Cout, P - H, Q, generator=g).double()        # content outside the crop is arbitrary
-    Yc = torch.fft.rfft2(full)                                                       # [NB,Cout,P,V]
-    Y = torch.zeros(NB, Cout, nbins, 2)
-    Y[:, :, :P * V] = torch.view_as_real(Yc.reshape(NB, Cout, P * V).to(torch.complex64))
+    Y = torch.zeros(NB, T, Cout, nbins, 2)
+    fmax = 0.0
+    for t, (y0, x0, oy, ox, LH, LW) in enumerate(wins):
+        full = torch.randn(NB, Cout, P, Q, generator=g).double()                     # content outside the crop is arbitrary
+        th, tw = min(TH, H - y0), min(TW, W - x0)
+        full[:, :, oy:oy + th, ox:ox + tw] = y_true[:, :, y0:y0 + th, x0:x0 + tw]
+        fmax = max(fmax, float(full.abs().max()))
+        Yc = torch.fft.rfft2(full)                                                   # [NB,Cout,P,V]
+        Y[:, t, :, :P * V] = torch.view_as_real(Yc.reshape(NB, Cout, P * V).to(torch.complex64))
     bias = torch.randn(Cout, generator=g) * 0.1
     oexp = torch.randint(0, 6, (Cout,), generator=g)
     bp = torch.zeros(3 * 128)
@@ -147,7 +188,7 @@ def test_fft_inverse_matches_torch_fft_and_epilogue(H, W, NB, device):
     val = (units[:, :, 0] + units[:, :, 1]).permute(0, 1, 3, 2).reshape(NB, Cout, plane)          # [NB,Cout,PLANE] scaled values
     got = val[:, :, base:base + H * Ws].reshape(NB, Cout, H, Ws)[..., :W] / torch.exp2(oexp.float()).view(1, -1, 1, 1)
     ref = torch.relu(y_true + bias.double().view(1, -1, 1, 1))
-    assert float((got.double() - ref).abs().max()) < 2e-6 * float(full.abs().max())
+    assert float((got.double() - ref).abs().max()) < 2e-6 * fmax
     border = val.clone()
     border[:, :, base:base + H * Ws].view(NB, Cout, H, Ws)[..., :W] = 0
     assert float(border.abs().max()) == 0.0

@@ -377,8 +377,11 @@ def make_model_fixture():
     arrays["image"] = image.numpy()
     for i, c in enumerate(class_images):
         arrays["class_image_{}".format(i)] = c.numpy()
+    # v1_r101 = BASELINE.json configs[3]: ResNet101 backbone (reference feature_extractor.py:120-129), V1-style simplified
+    # affine head, separate branches
     for name, merge, simplify, inverse, arch in (("v2_merged", True, False, True, "resnet50"),
-                                                 ("v1_split", False, True, False, "resnet50")):
+                                                 ("v1_split", False, True, False, "resnet50"),
+                                                 ("v1_r101", False, True, False, "resnet101")):
         net = Os2dModel(logger=logging.getLogger("golden"), is_cuda=False, merge_branch_parameters=merge,
                         backbone_arch=arch, use_inverse_geom_model=inverse, simplify_affine=simplify)
         sd = net.state_dict()

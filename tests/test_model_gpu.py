@@ -157,8 +157,9 @@ def test_detect_images_prefetching_iterator_equals_per_image_detect(device):
         assert util.maxdiff(det.bbox_xyxy, ref.bbox_xyxy) < 1e-2
 
 
-@pytest.mark.parametrize("name,merge,simplify,inverse", [("v2_merged", True, False, True), ("v1_split", False, True, False)])
-def test_model_forward_matches_the_reference_model(name, merge, simplify, inverse, device):
+@pytest.mark.parametrize("name,merge,simplify,inverse,arch", [("v2_merged", True, False, True, "resnet50"), ("v1_split", False, True, False, "resnet50"),
+                                                              ("v1_r101", False, True, False, "resnet101")])
+def test_model_forward_matches_the_reference_model(name, merge, simplify, inverse, arch, device):
     """``Os2dModel.forward(images, class_images)`` end to end against the REFERENCE model's CPU outputs
     (tests/golden/model_forward.npz): same weights (regenerated from key names and shapes, checksum-verified), backbone
     on MIOpen, class heads built from two class images of different sizes, HIP head.  The backbone runs through a
@@ -168,7 +169,7 @@ def test_model_forward_matches_the_reference_model(name, merge, simplify, invers
     from os2d_amd.modeling.model import Os2dModel
     from os2d_amd.utils import synthetic
     d = np.load(os.path.join(util.GOLDEN, "model_forward.npz"))
-    net = Os2dModel(is_cuda=False, merge_branch_parameters=merge, backbone_arch="resnet50",
+    net = Os2dModel(is_cuda=False, merge_branch_parameters=merge, backbone_arch=arch,
                     use_inverse_geom_model=inverse, simplify_affine=simplify)
     filled = synthetic.fill_model_state(net.state_dict(), seed=500, P=4 if simplify else 6)
     assert abs(synthetic.state_checksum(filled) - float(d["checksum_" + name])) < 1e-6 * float(d["checksum_" + name])

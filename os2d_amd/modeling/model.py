@@ -35,54 +35,67 @@ class LabelFeatureExtractor(nn.Module):
 
 
 class Os2dModel(nn.Module):
-    """reference model.py:123-288."""
+    """The detector as a module (reference model.py:123-288): two ResNet-C4 branches (image / class images; one shared
+    module when ``merge_branch_parameters``) and the head creator that owns the TransformNet.  Constructor arguments,
+    attribute names and the state-dict layout are the reference's - they are the interface; the bodies are ours."""
     default_normalization = {"mean": (0.485, 0.456, 0.406), "std": (0.229, 0.224, 0.225)}
 
     def __init__(self, logger=None, is_cuda=False, merge_branch_parameters=False, use_group_norm=False,
                  backbone_arch="resnet50", use_inverse_geom_model=True, simplify_affine=False, img_normalization=None):
         super(Os2dModel, self).__init__()
-        self.logger = logger or logging.getLogger("OS2D")
+        self.logger = logger if logger is not None else logging.getLogger("OS2D")
+        # plain settings first ...
+        self.is_cuda = bool(is_cuda)
         self.use_group_norm = use_group_norm
-        self.img_normalization = img_normalization if img_normalization else self.default_normalization
-        self.net_feature_maps = build_feature_extractor(backbone_arch, use_group_norm)
         self.merge_branch_parameters = merge_branch_parameters
-        extractor = self.net_feature_maps if merge_branch_parameters else build_feature_extractor(backbone_arch, use_group_norm)
         self.simplify_affine = simplify_affine
         self.use_inverse_geom_model = use_inverse_geom_model
-        self.os2d_head_creator = build_os2d_head_creator(self.simplify_affine, is_cuda, self.use_inverse_geom_model,
-                                                         self.net_feature_maps.feature_map_stride,
-                                                         self.net_feature_maps.feature_map_receptive_field)
-        self.net_label_features = LabelFeatureExtractor(feature_extractor=extractor)
-        self.eval()
-        self.is_cuda = is_cuda
+        self.img_normalization = img_normalization or dict(self.default_normalization)
+        # ... then the sub-modules, registered in the reference's order (it fixes the order of state_dict() keys, which
+        # tests/test_checkpoints.py pins against the reference model): image branch, head creator, class-image branch
+        image_branch = build_feature_extractor(backbone_arch, use_group_norm)
+        class_branch = image_branch if merge_branch_parameters else build_feature_extractor(backbone_arch, use_group_norm)
+        self.net_feature_maps = image_branch
+        self.os2d_head_creator = build_os2d_head_creator(simplify_affine, self.is_cuda, use_inverse_geom_model,
+                                                         image_branch.feature_map_stride,
+                                                         image_branch.feature_map_receptive_field)
+        self.net_label_features = LabelFeatureExtractor(feature_extractor=class_branch)
+        self.eval()                         # inference is the only mode the HIP head implements
         if self.is_cuda:
-            self.logger.info("Creating model on one GPU")
             self.cuda()
-        else:
-            self.logger.info("Creating model on CPU (parameters only: the head itself needs a HIP device)")
+        self.logger.info("OS2D model ({}, {} branches, {} transform{}) created on {}".format(
+            backbone_arch, "shared" if merge_branch_parameters else "separate", "simplified affine" if simplify_affine else "affine",
+            ", inverse geometric model" if use_inverse_geom_model else "",
+            "the HIP device" if self.is_cuda else "the CPU (parameters only - the head itself needs a HIP device)"))
+
+    # ---- training-time switches of the reference API (model.py:168-195); training itself is out of scope here
+    def _transform_net(self):
+        return self.os2d_head_creator.aligner.parameter_regressor
+
+    def _branches(self):
+        return (self.net_feature_maps, self.net_label_features)
 
     def train(self, mode=True, freeze_bn_in_extractor=False, freeze_transform_params=False, freeze_bn_transform=False):
         super(Os2dModel, self).train(mode)
-        if freeze_bn_in_extractor:
-            self.freeze_bn()
-        if freeze_transform_params:
-            self.freeze_transform_params()
-        if freeze_bn_transform:
-            self.os2d_head_creator.aligner.parameter_regressor.freeze_bn()
+        requested = ((freeze_bn_in_extractor, self.freeze_bn), (freeze_transform_params, self.freeze_transform_params),
+                     (freeze_bn_transform, self._transform_net().freeze_bn))
+        for wanted, action in requested:
+            if wanted:
+                action()
         return self
 
     def freeze_bn(self):
-        self.net_feature_maps.freeze_bn()
-        self.net_label_features.freeze_bn()
+        for branch in self._branches():
+            branch.freeze_bn()
 
     def freeze_transform_params(self):
-        self.os2d_head_creator.aligner.parameter_regressor.eval()
-        for p in self.os2d_head_creator.aligner.parameter_regressor.parameters():
-            p.requires_grad = False
+        net = self._transform_net()
+        net.eval()
+        net.requires_grad_(False)
 
     def freeze_extractor_blocks(self, num_blocks=0):
-        self.net_feature_maps.freeze_blocks(num_blocks)
-        self.net_label_features.freeze_blocks(num_blocks)
+        for branch in self._branches():
+            branch.freeze_blocks(num_blocks)
 
     def get_num_blocks_in_feature_extractor(self):
         return self.net_feature_maps.get_num_blocks_in_feature_extractor()
@@ -108,14 +121,15 @@ class Os2dModel(nn.Module):
         Returns (loc [A,B,4,HW], cls [A,B,HW], cls_detached [A,B,HW], FeatureMapSize, corners [A,B,8,HW])."""
         if train_mode:
             raise RuntimeError("train_mode=True: training through the HIP head is out of scope (inference only)")
+        # what is missing is computed from what was given; the messages are the reference's (callers match on them)
+        need_features, need_head = feature_maps is None, class_head is None
+        assert not need_features or images is not None, "If feature_maps is None than images cannot be None"
+        assert not need_head or class_images is not None, "If class_conv_layer is None than class_images cannot be None"
         with torch.no_grad():
-            if feature_maps is None:
-                assert images is not None, "If feature_maps is None than images cannot be None"
+            if need_features:
                 feature_maps = self.net_feature_maps(images)
-            if class_head is None:
-                assert class_images is not None, "If class_conv_layer is None than class_images cannot be None"
-                class_feature_maps = self.net_label_features(class_images)
-                class_head = self.os2d_head_creator.create_os2d_head(class_feature_maps)
+            if need_head:
+                class_head = self.os2d_head_creator.create_os2d_head(self.net_label_features(class_images))
             loc, cls, cls_det, corners = self.apply_class_heads_to_feature_maps(feature_maps, class_head)
         return loc, cls, cls_det, FeatureMapSize(img=feature_maps), corners
 
@@ -130,48 +144,55 @@ class Os2dModel(nn.Module):
                             do_nms_across_classes=do_nms_across_classes)
 
     def init_model_from_file(self, path, init_affine_transform_path=""):
-        """reference model.py:290-345: full ``{"net":..., "optimizer":...}`` checkpoint first; if ANYTHING about that
-        fails (no 'net' key, keys that do not fit the whole model - e.g. a checkpoint whose 'net' holds only a feature
-        extractor) fall through to the backbone-only chain of ``_load_network`` like the reference does; optionally a
-        weakalign TransformNet afterwards, whose failure is logged and ignored (reference model.py:331-345).
-        Returns the optimizer state (or None)."""
-        optimizer = None
-        checkpoint = None
+        """reference model.py:290-345, same outcomes for the same files: a whole-model ``{"net": ..., "optimizer": ...}``
+        checkpoint is tried first; if ANYTHING about that fails (unreadable file, no "net", keys that do not fit the whole
+        model - e.g. a "net" that holds only a feature extractor) the backbone-only chain of ``_load_network`` runs instead;
+        afterwards an optional weakalign TransformNet, whose failure is reported and ignored.  Returns the optimizer state
+        found in the checkpoint (or None)."""
+        checkpoint, optimizer = None, None
         try:
-            if path:
-                self.logger.info("Reading model file {}".format(path))
-                checkpoint = torch.load(path, map_location="cpu")
-            if checkpoint and "net" in checkpoint:
-                self.load_state_dict(checkpoint["net"])
-                self.logger.info("Loaded complete model from checkpoint")
-            else:
-                self.logger.info("Cannot find 'net' in the checkpoint file")
-                raise RuntimeError()
-            if "optimizer" in checkpoint:
-                optimizer = checkpoint["optimizer"]
-                self.logger.info("Loaded optimizer from checkpoint")
-            else:
-                self.logger.info("Cannot find 'optimizer' in the checkpoint file. Initializing optimizer from scratch.")
+            checkpoint = self._read_checkpoint(path)
+            optimizer = self._load_whole_model(checkpoint)
         except (KeyboardInterrupt, SystemExit):
             raise
-        except Exception:   # noqa: BLE001 - the reference's permissive loader (bare except, model.py:321)
-            self.logger.info("Failed to load the full model, trying to init feature extractors")
+        except Exception as e:   # noqa: BLE001 - the reference's loader is this permissive (bare except, model.py:321)
+            self.logger.info("whole-model load did not work ({}); initialising the feature extractors only".format(
+                type(e).__name__))
             if checkpoint is not None:
-                self._load_network(self.net_label_features.net_class_features, checkpoint)
-                if not self.merge_branch_parameters:
-                    self._load_network(self.net_feature_maps, self.net_label_features.net_class_features.state_dict())
+                class_branch = self.net_label_features.net_class_features
+                self._load_network(class_branch, checkpoint)
+                if not self.merge_branch_parameters:            # separate branches start from the same weights
+                    self._load_network(self.net_feature_maps, class_branch.state_dict())
         if init_affine_transform_path:
-            try:
-                self.logger.info("Trying to init affine transform from {}".format(init_affine_transform_path))
-                data = torch.load(init_affine_transform_path, map_location="cpu")
-                init_from_weakalign_model(data["state_dict"], None,
-                                          affine_regressor=self.os2d_head_creator.aligner.parameter_regressor)
-                self.logger.info("Successfully initialized the affine transform from the provided weakalign model.")
-            except (KeyboardInterrupt, SystemExit):
-                raise
-            except Exception:   # noqa: BLE001 - reference model.py:344
-                self.logger.info("Could not init affine transform from {0}.".format(init_affine_transform_path))
+            self._load_weakalign_transform(init_affine_transform_path)
         return optimizer
+
+    def _read_checkpoint(self, path):
+        if not path:
+            return None
+        self.logger.info("reading checkpoint {}".format(path))
+        return torch.load(path, map_location="cpu")
+
+    def _load_whole_model(self, checkpoint):
+        """checkpoint["net"] into the whole model (strict); -> checkpoint.get("optimizer").  Raises when it does not fit."""
+        if not checkpoint or "net" not in checkpoint:
+            raise KeyError("no 'net' entry in the checkpoint")
+        self.load_state_dict(checkpoint["net"])
+        has_optimizer = "optimizer" in checkpoint
+        self.logger.info("whole model restored from the checkpoint{}".format(
+            "; optimizer state found" if has_optimizer else "; no optimizer state in it (a new optimizer starts from scratch)"))
+        return checkpoint["optimizer"] if has_optimizer else None
+
+    def _load_weakalign_transform(self, path):
+        """A weakalign checkpoint's FeatureRegression.* into the TransformNet (reference model.py:331-345)."""
+        try:
+            data = torch.load(path, map_location="cpu")
+            init_from_weakalign_model(data["state_dict"], None, affine_regressor=self._transform_net())
+            self.logger.info("TransformNet initialised from the weakalign model {}".format(path))
+        except (KeyboardInterrupt, SystemExit):
+            raise
+        except Exception as e:   # noqa: BLE001 - reference model.py:344 ignores any failure here
+            self.logger.info("TransformNet NOT initialised from {} ({})".format(path, type(e).__name__))
 
     def _load_network(self, net, model_data):
         """reference model.py:347-386 fall-back chain."""
@@ -184,7 +205,7 @@ class Os2dModel(nn.Module):
                 return True
             except Exception:   # noqa: BLE001 - mirrors the reference's permissive loader
                 continue
-        self.logger.info("Could not init anything. Starting from scratch.")
+        self.logger.info("none of the known checkpoint layouts fits this network: it keeps its initial weights")
         return False
 
 

@@ -276,6 +276,17 @@ int os2d_detect_pyramid(const float* const* loc, const float* const* cls, const 
                         float score_threshold, float iou_threshold, int nms_max_batch, int passes, float* out_boxes,
                         float* out_scores, int* out_index, float* out_default, float* out_corners, int* out_count,
                         int* unfinished, void* workspace, size_t workspace_bytes, void* stream);
+/* The same with MERGED LABELS - several head rows per label (class-image views: reference os2d/engine/evaluate.py:241-269
+ * builds 4 - 8 rows per class, box_coder.py:483-487 merges the rows that carry one class id before NMS, evaluate.py:294).
+ *   G labels of at most V rows;  slot_rows DEVICE int [G][V]: head row (< B) of view v of label g, -1 = no such view.
+ * A label's candidate list is its rows in slot order, each row level by level (the reference's order); outputs are
+ * [G, V*N, ...], out_index = slot * N + candidate number of that row.  Limits as above with V*N candidates per label.   */
+int os2d_detect_pyramid_merged(const float* const* loc, const float* const* cls, const float* const* corners, int B, int L,
+                               const int* hw, int stride, int rec_field, const float* img_wh, const float* scale_xy,
+                               float score_threshold, float iou_threshold, int nms_max_batch, int passes, int G, int V,
+                               const int* slot_rows, float* out_boxes, float* out_scores, int* out_index, float* out_default,
+                               float* out_corners, int* out_count, int* unfinished, void* workspace, size_t workspace_bytes,
+                               void* stream);
 
 #ifdef __cplusplus
 }

@@ -71,6 +71,8 @@ SIGNATURES = {
     "os2d_detect_pyramid_workspace_bytes": (_i, [_i, _i, _i, ctypes.POINTER(_sz)]),
     "os2d_detect_pyramid": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                  _vp, _vp, _sz, _vp]),
+    "os2d_detect_pyramid_merged": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _f, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp,
+                                        _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
 

@@ -24,6 +24,11 @@
 //                                      candidates per step (boxes gathered from L2 through the sorted ids, one step ahead)
 //   pyr_finalize  grid (B):            final order (one stable sort by score when the last pass had several chunks),
 //                                      compacted outputs
+//
+// MERGED LABELS (class-image views: reference os2d/engine/evaluate.py:241-269 builds 4 - 8 head rows per label, box_coder.py:
+// 483-487 merges rows with the same class id before NMS): a label's candidate list is its rows in row order, each row level
+// by level.  The kernels work on G labels x V slots: slot_rows[g * V + v] names the head row of view v of label g (-1: none),
+// candidate j of label g = (slot j / N, location j % N); everything after pyr_decode just sees G "classes" of V * N candidates.
 #include "os2d_common.h"
 #include "../../include/os2d_hip.h"
 
@@ -54,10 +59,16 @@ __device__ __forceinline__ unsigned int score_key(float s) {
 // ---- 1a. candidates: decode, clip, validity, map to the output image (one thread per candidate)
 __global__ __launch_bounds__(256) void pyr_decode_kernel(LevelTable T, int N, float stride, float half_box, float score_thr,
                                                          float4* __restrict__ boxes, float* __restrict__ scores,
-                                                         unsigned int* __restrict__ keys) {
-  const int b = blockIdx.y;
+                                                         unsigned int* __restrict__ keys, const int* __restrict__ slot_rows) {
+  // blockIdx.y = slot (label * V + view); its candidates are written at [slot][N], i.e. label-major [G][V * N]
+  const int slot = blockIdx.y;
+  const int b = slot_rows ? slot_rows[slot] : slot;      // head row the slot reads
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= N) return;
+  if (b < 0) {                                           // a label with fewer views than V: no candidates here
+    keys[(size_t)slot * N + g] = 0xffffffffu;
+    return;
+  }
   int l = 0;
   while (l + 1 < T.L && g >= T.off[l + 1]) ++l;
   const int n = g - T.off[l], HW = T.H[l] * T.W[l];
@@ -69,9 +80,9 @@ __global__ __launch_bounds__(256) void pyr_decode_kernel(LevelTable T, int N, fl
   bx.y *= T.sy[l];
   bx.z *= T.sx[l];
   bx.w *= T.sy[l];
-  boxes[(size_t)b * N + g] = bx;
-  scores[(size_t)b * N + g] = s;
-  keys[(size_t)b * N + g] = valid ? score_key(s) : 0xffffffffu;   // a valid key is never 0xffffffff (that would be score -NaN)
+  boxes[(size_t)slot * N + g] = bx;
+  scores[(size_t)slot * N + g] = s;
+  keys[(size_t)slot * N + g] = valid ? score_key(s) : 0xffffffffu;   // a valid key is never 0xffffffff (that would be score -NaN)
 }
 
 // ---- 1b. the valid candidates of a class, compacted in list order (ballot + prefix, NTHR candidates per round)
@@ -304,7 +315,8 @@ __global__ __launch_bounds__(NTHR) void pyr_finalize_kernel(int passes, int N, i
                                                            int* __restrict__ out_index, int* __restrict__ out_count,
                                                            int* __restrict__ unfinished, LevelTable T, float stride,
                                                            float half_box, float4* __restrict__ out_default,
-                                                           float* __restrict__ out_corners) {
+                                                           float* __restrict__ out_corners, int N1 /*candidates per head row*/,
+                                                           int V, const int* __restrict__ slot_rows) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned int* skey = reinterpret_cast<unsigned int*>(smem);                        // [NP2]
   unsigned short* spos = reinterpret_cast<unsigned short*>(smem + (size_t)NP2 * 4);  // [NP2]
@@ -378,15 +390,17 @@ __global__ __launch_bounds__(NTHR) void pyr_finalize_kernel(int passes, int N, i
     out_index[(size_t)b * N + s] = g;
     // the anchor of the detection (reference box_coder.py:17-59, field "default_boxes") and the corners of its transformed
     // template (field "transform_corners"), mapped to the output image like the box
+    const int view = g / N1, g1 = g - view * N1;       // candidate g of the label = (view, candidate of that head row)
     int l = 0;
-    while (l + 1 < T.L && g >= T.off[l + 1]) ++l;
-    const int nloc = g - T.off[l], HWl = T.H[l] * T.W[l];
+    while (l + 1 < T.L && g1 >= T.off[l + 1]) ++l;
+    const int nloc = g1 - T.off[l], HWl = T.H[l] * T.W[l];
     const int hh = nloc / T.W[l], ww = nloc - hh * T.W[l];
     const float ecx = stride * ((float)ww + 0.5f), ecy = stride * ((float)hh + 0.5f);
     out_default[(size_t)b * N + s] = make_float4((ecx - half_box) * T.sx[l], (ecy - half_box) * T.sy[l],
                                                  (ecx + half_box) * T.sx[l], (ecy + half_box) * T.sy[l]);
     if (out_corners != nullptr) {
-      const float* cp = T.corners[l] + (size_t)b * 8 * HWl + nloc;
+      const int row = slot_rows ? slot_rows[b * V + view] : b;
+      const float* cp = T.corners[l] + (size_t)row * 8 * HWl + nloc;
 #pragma unroll
       for (int k = 0; k < 8; ++k) out_corners[((size_t)b * N + s) * 8 + k] = cp[(size_t)k * HWl] * ((k & 1) ? T.sy[l] : T.sx[l]);
     }
@@ -454,19 +468,22 @@ int os2d_detect_pyramid_workspace_bytes(int B, int N, int passes, size_t* bytes)
   return 0;
 }
 
-int os2d_detect_pyramid(const float* const* loc, const float* const* cls, const float* const* corners, int B, int L,
-                        const int* hw, int stride, int rec_field, const float* img_wh, const float* scale_xy,
-                        float score_threshold, float iou_threshold, int nms_max_batch, int passes, float* out_boxes,
-                        float* out_scores, int* out_index, float* out_default, float* out_corners, int* out_count,
-                        int* unfinished, void* workspace, size_t workspace_bytes, void* stream) {
+// B head rows in loc / cls / corners; G labels of at most V rows each (slot_rows: DEVICE int [G * V], NULL = every row its
+// own label, G = B, V = 1); outputs are [G][V * N]
+static int detect_pyramid_impl(const float* const* loc, const float* const* cls, const float* const* corners, int B, int L,
+                               const int* hw, int stride, int rec_field, const float* img_wh, const float* scale_xy,
+                               float score_threshold, float iou_threshold, int nms_max_batch, int passes, float* out_boxes,
+                               float* out_scores, int* out_index, float* out_default, float* out_corners, int* out_count,
+                               int* unfinished, void* workspace, size_t workspace_bytes, void* stream, int G, int V,
+                               const int* slot_rows) {
   if (!loc || !cls || !hw || !img_wh || !scale_xy || !out_boxes || !out_scores || !out_index || !out_default || !out_count ||
-      !unfinished || !workspace || B < 1 || stride < 1 || rec_field < 1 || passes < 1 || passes > 16 ||
-      ((corners != nullptr) != (out_corners != nullptr))) {
+      !unfinished || !workspace || B < 1 || G < 1 || V < 1 || stride < 1 || rec_field < 1 || passes < 1 || passes > 16 ||
+      ((corners != nullptr) != (out_corners != nullptr)) || (!slot_rows && (G != B || V != 1))) {
     os2d_set_error("os2d_detect_pyramid: bad arguments");
     return -1;
   }
   LevelTable T;
-  int N = 0;
+  int N1 = 0;
   if (L < 1 || L > MAX_LEVELS) {
     os2d_set_error("os2d_detect_pyramid: %d levels (at most %d)", L, MAX_LEVELS);
     return -3;
@@ -485,20 +502,21 @@ int os2d_detect_pyramid(const float* const* loc, const float* const* cls, const 
     }
     T.H[l] = hw[2 * l];
     T.W[l] = hw[2 * l + 1];
-    T.off[l] = N;
-    N += hw[2 * l] * hw[2 * l + 1];
+    T.off[l] = N1;
+    N1 += hw[2 * l] * hw[2 * l + 1];
     T.img_w[l] = img_wh[2 * l];
     T.img_h[l] = img_wh[2 * l + 1];
     T.sx[l] = scale_xy[2 * l];
     T.sy[l] = scale_xy[2 * l + 1];
   }
-  T.off[L] = N;
+  T.off[L] = N1;
   T.L = L;
-  if (!os2d_detect_pyramid_supported(L, N, nms_max_batch)) {
-    os2d_set_error("os2d_detect_pyramid: unsupported size (N=%d candidates per class, nms_max_batch=%d)", N, nms_max_batch);
+  if ((long long)N1 * V > (1 << 22) || !os2d_detect_pyramid_supported(L, N1 * V, nms_max_batch)) {
+    os2d_set_error("os2d_detect_pyramid: unsupported size (%d candidates per label, nms_max_batch=%d)", N1 * V, nms_max_batch);
     return -3;
   }
-  const Carve c = carve(B, N, passes);
+  const int N = N1 * V;                  // candidates per label
+  const Carve c = carve(G, N, passes);
   if (workspace_bytes < c.total || (reinterpret_cast<uintptr_t>(workspace) & 255)) {
     os2d_set_error("os2d_detect_pyramid: workspace too small or not 256-byte aligned (%zu B, need %zu B)", workspace_bytes, c.total);
     return -2;
@@ -516,16 +534,16 @@ int os2d_detect_pyramid(const float* const* loc, const float* const* cls, const 
   const float half_box = 0.5f * (float)(stride * (OS2D_T - 1) + rec_field);
 
   hipError_t e = hipMemsetAsync(unfinished, 0, sizeof(int), st);
-  if (e == hipSuccess) e = hipMemsetAsync(counts, 0, (size_t)(passes + 1) * B * MAX_CHUNKS * sizeof(int), st);
+  if (e == hipSuccess) e = hipMemsetAsync(counts, 0, (size_t)(passes + 1) * G * MAX_CHUNKS * sizeof(int), st);
   if (e != hipSuccess) {
     os2d_set_error("hipMemsetAsync: %s", hipGetErrorString(e));
     return -4;
   }
-  hipLaunchKernelGGL(pyr_decode_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, T, N, (float)stride, half_box,
-                     score_threshold, boxes, scores, keys);
+  hipLaunchKernelGGL(pyr_decode_kernel, dim3((N1 + 255) / 256, G * V), dim3(256), 0, st, T, N1, (float)stride, half_box,
+                     score_threshold, boxes, scores, keys, slot_rows);
   int rc = check("pyr_decode");
   if (rc) return rc;
-  hipLaunchKernelGGL(pyr_compact_kernel, dim3(B), dim3(NTHR), 0, st, N, M, keys, ids[0], counts, final_pass);
+  hipLaunchKernelGGL(pyr_compact_kernel, dim3(G), dim3(NTHR), 0, st, N, M, keys, ids[0], counts, final_pass);
   if ((rc = check("pyr_compact"))) return rc;
   const int NP2 = next_pow2(min(M, N));
   const size_t lds = (size_t)NP2 * 6 + (((size_t)M * 2 + 15) & ~(size_t)15) + (size_t)KCAP * 16;
@@ -540,14 +558,40 @@ int os2d_detect_pyramid(const float* const* loc, const float* const* cls, const 
   const int chunks0 = (N + M - 1) / M;
   for (int p = 0; p < passes; ++p) {
     // pass 0 may need every chunk; a later pass works on the survivors: at most as many chunks as the pass before
-    hipLaunchKernelGGL(pyr_chunk_nms_kernel, dim3(chunks0, B), dim3(NTHR), lds, st, p, N, M, NP2, iou_threshold, boxes, keys,
+    hipLaunchKernelGGL(pyr_chunk_nms_kernel, dim3(chunks0, G), dim3(NTHR), lds, st, p, N, M, NP2, iou_threshold, boxes, keys,
                        ids[p & 1], ids[(p + 1) & 1], sorted, counts, final_pass);
     if ((rc = check("pyr_chunk_nms"))) return rc;
   }
-  hipLaunchKernelGGL(pyr_finalize_kernel, dim3(B), dim3(NTHR), (size_t)16384 * 6, st, passes, N, M, 16384, boxes, scores, keys,
+  hipLaunchKernelGGL(pyr_finalize_kernel, dim3(G), dim3(NTHR), (size_t)16384 * 6, st, passes, N, M, 16384, boxes, scores, keys,
                      ids[0], ids[1], counts, final_pass, reinterpret_cast<float4*>(out_boxes), out_scores, out_index, out_count,
-                     unfinished, T, (float)stride, half_box, reinterpret_cast<float4*>(out_default), out_corners);
+                     unfinished, T, (float)stride, half_box, reinterpret_cast<float4*>(out_default), out_corners, N1, V,
+                     slot_rows);
   return check("pyr_finalize");
+}
+
+int os2d_detect_pyramid(const float* const* loc, const float* const* cls, const float* const* corners, int B, int L,
+                        const int* hw, int stride, int rec_field, const float* img_wh, const float* scale_xy,
+                        float score_threshold, float iou_threshold, int nms_max_batch, int passes, float* out_boxes,
+                        float* out_scores, int* out_index, float* out_default, float* out_corners, int* out_count,
+                        int* unfinished, void* workspace, size_t workspace_bytes, void* stream) {
+  return detect_pyramid_impl(loc, cls, corners, B, L, hw, stride, rec_field, img_wh, scale_xy, score_threshold, iou_threshold,
+                             nms_max_batch, passes, out_boxes, out_scores, out_index, out_default, out_corners, out_count,
+                             unfinished, workspace, workspace_bytes, stream, B, 1, nullptr);
+}
+
+int os2d_detect_pyramid_merged(const float* const* loc, const float* const* cls, const float* const* corners, int B, int L,
+                               const int* hw, int stride, int rec_field, const float* img_wh, const float* scale_xy,
+                               float score_threshold, float iou_threshold, int nms_max_batch, int passes, int G, int V,
+                               const int* slot_rows, float* out_boxes, float* out_scores, int* out_index, float* out_default,
+                               float* out_corners, int* out_count, int* unfinished, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  if (!slot_rows) {
+    os2d_set_error("os2d_detect_pyramid_merged: slot_rows is required");
+    return -1;
+  }
+  return detect_pyramid_impl(loc, cls, corners, B, L, hw, stride, rec_field, img_wh, scale_xy, score_threshold, iou_threshold,
+                             nms_max_batch, passes, out_boxes, out_scores, out_index, out_default, out_corners, out_count,
+                             unfinished, workspace, workspace_bytes, stream, G, V, slot_rows);
 }
 
 }  // extern "C"

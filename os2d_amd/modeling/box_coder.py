@@ -373,13 +373,14 @@ class Os2dBoxCoder(object):
         return result
 
     def _decode_pyramid_fused(self, loc_pyr, cls_pyr, size_pyr, class_ids, score_thr, iou_thr, inverse, corners_pyr):
-        """Several levels, one row per label, identity / ``ResizeBoxes`` mappings: the whole per-label chain, incl. the
-        reference's chunk-and-repeat NMS for lists longer than ``nms_max_batch``, runs on the device (os2d_detect_pyramid:
-        one launch per NMS pass, a work-group per (chunk, class)); None when the generic path has to be used."""
-        if not self.use_fused_level_kernel or len(loc_pyr) < 2:
-            return None
+        """Several levels and / or merged labels (class-image views: several head rows with one class id, reference
+        box_coder.py:483-487), identity / ``ResizeBoxes`` mappings: the whole per-label chain, incl. the reference's
+        chunk-and-repeat NMS for lists longer than ``nms_max_batch``, runs on the device (os2d_detect_pyramid /
+        os2d_detect_pyramid_merged: one launch per NMS pass, a work-group per (chunk, label)); None when the generic path has
+        to be used."""
         ids = [int(c) for c in class_ids]
-        if len(set(ids)) != len(ids):
+        merged = len(set(ids)) != len(ids)
+        if not self.use_fused_level_kernel or (len(loc_pyr) < 2 and not merged):
             return None
         ts = list(inverse) if inverse is not None else [None] * len(loc_pyr)
         if any(t is not None and not isinstance(t, ResizeBoxes) for t in ts) or len({t is None for t in ts}) != 1:
@@ -395,8 +396,13 @@ class Os2dBoxCoder(object):
         L = len(loc_pyr)
         fms = [self.get_feature_map_size(s) for s in size_pyr]
         hws = [fm.h * fm.w for fm in fms]
-        N = sum(hws)
-        if not lib.os2d_detect_pyramid_supported(L, N, int(self.nms_max_batch)):
+        N1 = sum(hws)                                         # candidates per head row
+        # labels in the reference's iteration order (``set(class_ids)``, box_coder.py:483), each with its rows in row order
+        labels = list(set(ids))
+        rows_of = {l: [i for i, c in enumerate(ids) if c == l] for l in labels}
+        G, V = len(labels), max(len(r) for r in rows_of.values())
+        N = N1 * V                                            # candidates per label
+        if N > (1 << 22) or not lib.os2d_detect_pyramid_supported(L, N, int(self.nms_max_batch)):
             return None
         dev = cls_pyr[0].device
         B = len(ids)
@@ -413,13 +419,13 @@ class Os2dBoxCoder(object):
         out_size = ts[0].target_size if ts[0] is not None else size_pyr[0]
         passes = int(self.fused_pyramid_passes)
         nbytes = ctypes.c_size_t()
-        _lib.check(lib.os2d_detect_pyramid_workspace_bytes(B, N, passes, ctypes.byref(nbytes)), "os2d_detect_pyramid_workspace_bytes")
+        _lib.check(lib.os2d_detect_pyramid_workspace_bytes(G, N, passes, ctypes.byref(nbytes)), "os2d_detect_pyramid_workspace_bytes")
         ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-        out_boxes = torch.empty(B, N, 4, dtype=torch.float32, device=dev)
-        out_scores = torch.empty(B, N, dtype=torch.float32, device=dev)
-        out_index = torch.empty(B, N, dtype=torch.int32, device=dev)
-        out_count = torch.empty(B, dtype=torch.int32, device=dev)
-        out_default = torch.empty(B, N, 4, dtype=torch.float32, device=dev)
+        out_boxes = torch.empty(G, N, 4, dtype=torch.float32, device=dev)
+        out_scores = torch.empty(G, N, dtype=torch.float32, device=dev)
+        out_index = torch.empty(G, N, dtype=torch.int32, device=dev)
+        out_count = torch.empty(G, dtype=torch.int32, device=dev)
+        out_default = torch.empty(G, N, 4, dtype=torch.float32, device=dev)
         unfinished = torch.empty(1, dtype=torch.int32, device=dev)
         c_loc = (ctypes.c_void_p * L)(*[t.data_ptr() for t in locs])
         c_cls = (ctypes.c_void_p * L)(*[t.data_ptr() for t in clss])
@@ -427,33 +433,38 @@ class Os2dBoxCoder(object):
         if corners_pyr is not None:
             cors = [k.reshape(B, 8, hw).float().contiguous() for k, hw in zip(corners_pyr, hws)]
             c_cor = (ctypes.c_void_p * L)(*[t.data_ptr() for t in cors])
-            out_corners = torch.empty(B, N, 8, dtype=torch.float32, device=dev)
+            out_corners = torch.empty(G, N, 8, dtype=torch.float32, device=dev)
         c_hw = (ctypes.c_int * (2 * L))(*[v for fm in fms for v in (fm.h, fm.w)])
         c_img = (ctypes.c_float * (2 * L))(*[float(v) for s_ in size_pyr for v in (s_.w, s_.h)])
         c_scale = (ctypes.c_float * (2 * L))(*[float(v) for r in ratios for v in r])
+        identity = not merged and labels == ids          # one row per label, already in the reference's label order
         with torch.cuda.device(dev):
-            _lib.check(lib.os2d_detect_pyramid(c_loc, c_cls, c_cor, B, L, c_hw, self._stride, self._rec_field, c_img, c_scale,
-                                               ctypes.c_float(score_thr), ctypes.c_float(iou_thr), int(self.nms_max_batch),
-                                               passes, _lib.ptr(out_boxes), _lib.ptr(out_scores), _lib.ptr(out_index),
-                                               _lib.ptr(out_default), _lib.ptr(out_corners), _lib.ptr(out_count),
-                                               _lib.ptr(unfinished), _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
-                       "os2d_detect_pyramid")
-        rank = {l: k for k, l in enumerate(set(ids))}      # the reference iterates ``set(class_ids)`` (box_coder.py:483)
-        order = sorted(range(B), key=lambda i: rank[ids[i]])
-        counts = out_count
-        perm = None
-        if order != list(range(B)):
-            perm = torch.tensor(order, dtype=torch.long, device=dev)
-            counts = out_count[perm]
-        mask = torch.arange(N, device=dev).unsqueeze(0) < counts.unsqueeze(1)
+            if identity:
+                _lib.check(lib.os2d_detect_pyramid(c_loc, c_cls, c_cor, B, L, c_hw, self._stride, self._rec_field, c_img, c_scale,
+                                                   ctypes.c_float(score_thr), ctypes.c_float(iou_thr), int(self.nms_max_batch),
+                                                   passes, _lib.ptr(out_boxes), _lib.ptr(out_scores), _lib.ptr(out_index),
+                                                   _lib.ptr(out_default), _lib.ptr(out_corners), _lib.ptr(out_count),
+                                                   _lib.ptr(unfinished), _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
+                           "os2d_detect_pyramid")
+            else:
+                table = [(rows_of[l] + [-1] * V)[:V] for l in labels]
+                slot_rows = torch.tensor(table, dtype=torch.int32).to(dev)
+                _lib.check(lib.os2d_detect_pyramid_merged(c_loc, c_cls, c_cor, B, L, c_hw, self._stride, self._rec_field, c_img,
+                                                          c_scale, ctypes.c_float(score_thr), ctypes.c_float(iou_thr),
+                                                          int(self.nms_max_batch), passes, G, V, _lib.ptr(slot_rows),
+                                                          _lib.ptr(out_boxes), _lib.ptr(out_scores), _lib.ptr(out_index),
+                                                          _lib.ptr(out_default), _lib.ptr(out_corners), _lib.ptr(out_count),
+                                                          _lib.ptr(unfinished), _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
+                           "os2d_detect_pyramid_merged")
+                slot_rows.record_stream(torch.cuda.current_stream(dev))
+        mask = torch.arange(N, device=dev).unsqueeze(0) < out_count.unsqueeze(1)
         row, pos = mask.nonzero(as_tuple=True)                   # the one host synchronisation: sizes the result
         if int(unfinished.item()) != 0:
-            return None          # some class needs more NMS passes than were launched: generic path (exact, slower)
-        src_row = perm[row] if perm is not None else row
-        flat = src_row * N + pos
+            return None          # some label needs more NMS passes than were launched: generic path (exact, slower)
+        flat = row * N + pos
         result = BoxList(out_boxes.view(-1, 4)[flat], out_size)
         result.add_field("scores", out_scores.view(-1)[flat])
-        result.add_field("labels", torch.tensor([ids[i] for i in order], dtype=torch.long, device=dev)[row])
+        result.add_field("labels", torch.tensor(labels, dtype=torch.long, device=dev)[row])
         result.add_field("default_boxes", BoxList(out_default.view(-1, 4)[flat], out_size))
         if out_corners is not None:
             result.add_field("transform_corners", out_corners.view(-1, 8)[flat])

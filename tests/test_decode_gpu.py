@@ -382,3 +382,54 @@ def test_fused_pyramid_full_size_seven_levels(device):
                                    transform_corners_pyramid=corners)
     _assert_same_detections(fused, generic)
     assert len(fused) > 100
+
+
+@pytest.mark.parametrize("max_batch,single_level", [(10000, False), (300, False), (10000, True), (97, True)])
+def test_fused_pyramid_with_merged_labels_matches_generic_chain(max_batch, single_level, device):
+    """Merged labels (class-image views: several head rows carry one class id, reference evaluate.py:241-269,294 +
+    box_coder.py:483-487) through os2d_detect_pyramid_merged: a label's rows are NMS-ed together, its candidate list being
+    its rows in row order, each row level by level.  Ragged view counts (3 / 1 / 2 rows), interleaved and unsorted ids,
+    ties across the rows of a label, several chunks and passes; identical to the generic chain bit for bit."""
+    from os2d_amd.modeling.box_coder import ResizeBoxes
+    from os2d_amd.structures.feature_map import FeatureMapSize
+    levels = [(15, 20)] if single_level else [(9, 12), (15, 20), (23, 30)]
+    B = 6
+    sizes, locs, clss, corners = _pyramid_inputs(levels, B, 31, device)
+    ids = [7, 2, 7, 40, 2, 7]                          # label 7: rows 0, 2, 5; label 2: rows 1, 4; label 40: row 3
+    clss[0][2, 5:60] = clss[0][0, 17]                  # ties between two rows of label 7: list (row) order decides
+    clss[-1][4, :] = 0.3                               # a whole level of equal scores in label 2's second row
+    orig = FeatureMapSize(w=640, h=411)
+    for inverse in (None, [ResizeBoxes(orig) for _ in levels]):
+        coder = _coder()
+        coder.nms_max_batch = max_batch
+        coder.fused_pyramid_passes = 8
+        thr = 0.1
+        if single_level:
+            assert coder._decode_single_level_fused(locs, clss, sizes, ids, thr, 0.3, inverse, corners) is None    # one row per label only
+        fused = coder._decode_pyramid_fused(locs, clss, sizes, ids, thr, 0.3, inverse, corners)
+        assert fused is not None, "merged labels must take the device path"
+        coder.use_fused_level_kernel = False
+        generic = coder.decode_pyramid(locs, clss, sizes, ids, nms_score_threshold=thr, inverse_box_transforms=inverse,
+                                       transform_corners_pyramid=corners)
+        _assert_same_detections(fused, generic)
+        assert set(fused.get_field("labels").tolist()) == {2, 7, 40}
+
+
+def test_fused_pyramid_merged_labels_full_size(device):
+    """The evaluation's shape with class-image augmentation: 7 levels of a 1280x960 image x 4 labels x 8 views = 32 head
+    rows, 316,640 candidates per label (32 chunks of 10000 in the first pass), reference defaults."""
+    from os2d_amd.modeling.box_coder import ResizeBoxes
+    from os2d_amd.structures.feature_map import FeatureMapSize
+    levels = [(30, 40), (38, 50), (48, 64), (60, 80), (72, 96), (84, 112), (96, 128)]
+    sizes, locs, clss, corners = _pyramid_inputs(levels, 32, 13, device, loc_scale=1.0)
+    inverse = [ResizeBoxes(FeatureMapSize(w=1280, h=960)) for _ in levels]
+    ids = [c for c in (3, 0, 9, 5) for _ in range(8)]
+    coder = _coder()
+    coder.fused_pyramid_passes = 4
+    fused = coder._decode_pyramid_fused(locs, clss, sizes, ids, float("-inf"), 0.3, inverse, corners)
+    assert fused is not None
+    coder.use_fused_level_kernel = False
+    generic = coder.decode_pyramid(locs, clss, sizes, ids, nms_score_threshold=float("-inf"), inverse_box_transforms=inverse,
+                                   transform_corners_pyramid=corners)
+    _assert_same_detections(fused, generic)
+    assert len(fused) > 100

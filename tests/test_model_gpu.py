@@ -120,7 +120,11 @@ def test_detect_with_class_image_augmentation(device):
     head = E.build_class_head(net, views)
     assert head.class_batch_size == 16
     coder = net.build_box_coder()
+    calls = []
+    fused_impl = coder._decode_pyramid_fused
+    coder._decode_pyramid_fused = lambda *a, **k: (calls.append(fused_impl(*a, **k)) or calls[-1])
     det = E.detect(net, coder, levels, head, class_ids=view_ids, nms_score_threshold=0.0)
+    assert len(calls) == 1 and calls[0] is not None, "merged labels go through os2d_detect_pyramid_merged, not the generic chain"
     lab = det.get_field("labels").cpu()
     assert set(lab.tolist()) <= {2, 5} and lab.tolist() == sorted(lab.tolist())
     # oracle: per class, the 8 views are 8 "levels" of the same label

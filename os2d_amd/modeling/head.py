@@ -151,9 +151,18 @@ class _StreamOrdered(object):
 
 
 def spectra_cache_cap_bytes():
-    """Upper bound for the cached weight spectra of precision "fft" over all transform sizes (least recently used sizes
-    are dropped first; 722 MB for the 64 x 96 transform of a 60 x 80 map).  $OS2D_FFT_CACHE_BYTES, default 16 GiB."""
-    return int(os.environ.get("OS2D_FFT_CACHE_BYTES", 16 << 30))
+    """Upper bound for the cached weight spectra of the frequency-domain modes over all transform sizes (least recently used
+    sizes are dropped first; 654 MB for the 64 x 84 transform of a 60 x 80 map).  $OS2D_FFT_CACHE_BYTES; default: a quarter of
+    the device's memory, at most 64 GiB - a dataset fed at its own aspect ratios at 7 pyramid scales (reference
+    os2d/data/dataloader.py:326) meets ~50 transform sizes = ~30 GB (tools/bench_size_churn.py), which an MI355X keeps resident
+    in its 288 GB; with a smaller cap than the working set an LRU cache misses on EVERY call of a cyclic access pattern."""
+    env = os.environ.get("OS2D_FFT_CACHE_BYTES")
+    if env:
+        return int(env)
+    total = 64 << 30
+    if torch.cuda.is_available():
+        total = torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory
+    return int(min(64 << 30, total // 4))
 
 
 def split_rows_f16(T):
@@ -354,11 +363,12 @@ class TransformationNet(nn.Module):
 
     def spectra(self, H, W, split=False):
         """Frequency-domain form of the 7x7 layer for an H x W map (precision "fft"; ``split``: "fftx3", the weight spectra
-        pre-split into fp16 hi + lo with per-row power-of-two scales for os2d_spectral_gemm_f16): (wspec, twQ, twP, nbins) or None when
-        the map does not fit the in-LDS transform.  The BatchNorm-folded 7x7 filters are centred on the origin of the
+        pre-split into fp16 hi + lo with per-row power-of-two scales for os2d_spectral_gemm_f16): (wspec, twQ, twP, nbins); None only
+        when the library has no transform plan for the map (every map up to the 209-column limit has one: maps beyond one
+        in-LDS transform are cut into overlap-save tiles, os2d_fft_tiles, and P x Q is then a tile's size).  The BatchNorm-folded 7x7 filters are centred on the origin of the
         P x Q grid (tap (t, s) at ((3 - t) mod P, (3 - s) mod Q): the circular convolution then IS the zero-padded
-        correlation of head.py:619 for the first H x W samples), transformed once with torch.fft in float64 and packed for
-        os2d_spectral_gemm; the twiddle tables are exact float64 values rounded once.  Cached per TRANSFORM size (P, Q) -
+        correlation of head.py:619 for the first H x W samples), transformed once in float64 (a 7-term DFT per axis) and
+        packed for os2d_spectral_gemm; the twiddle tables are exact float64 values rounded once.  Cached per TRANSFORM size (P, Q) -
         sizes are products of 2s and 3s, so the many map sizes of a dataset share a few tens of them - until a parameter
         changes, least recently used first out above ``spectra_cache_cap_bytes()`` (722 MB for 60 x 80; event-tracked like
         ``packed``)."""
@@ -388,13 +398,20 @@ class TransformationNet(nn.Module):
                 wscale = wbuf[nunits * 16:].view(torch.float32)
             else:
                 packed = torch.zeros(G, 2, 225, 8, 64, dtype=torch.complex64, device=dev)
-            ti = (3 - torch.arange(7, device=dev)) % P
-            si = (3 - torch.arange(7, device=dev)) % Q
+            # the spectrum of a 7 x 7 filter is a 7-term DFT per axis: K = Ep w Eq^T with Ep[u][t] = exp(-2 pi i u pos_t / P),
+            # pos_t = (3 - t) mod P (the filter centred on the origin), Eq likewise over the V = Q/2 + 1 kept columns - two
+            # small float64 / complex128 matrix products per (o, c) instead of a P x Q transform of a map that is 99 % zeros
+            # (round 2: torch.fft.rfft2 of [64, 225, P, Q] float64, ~50 ms per transform size; same values to 1e-14)
+            def dft(n, nout):
+                pos = (3 - torch.arange(7, device=dev)) % n
+                m = (torch.arange(nout, device=dev).view(-1, 1) * pos.view(1, -1)) % n     # exact integer phase index
+                ang = m.double() * (-2.0 * torch.pi / n)
+                return torch.complex(torch.cos(ang), torch.sin(ang))
+            Ep, EqT = dft(P, P), dft(Q, V).t().contiguous()
             for half in range(2):                               # 64 output channels at a time bounds the float64 transient
-                k = torch.zeros(64, 225, P, Q, dtype=torch.float64, device=dev)
-                k[:, :, ti.view(-1, 1), si.view(1, -1)] = w1[64 * half:64 * half + 64]
-                K = torch.fft.rfft2(k).reshape(64, 225, P * V)
-                del k
+                wc = w1[64 * half:64 * half + 64].to(torch.complex128)              # [64,225,7,7]
+                K = torch.matmul(Ep, torch.matmul(wc, EqT)).reshape(64, 225, P * V)
+                del wc
                 if split:
                     # row o scaled by the power of two that puts its largest |Kr|, |Ki| in (16384, 32768]; fp16 hi + lo of
                     # (Kr, Ki); units of 4 channels x (re, im): [g][half][k-step][bin][channel group][hi|lo][o][8 halves]

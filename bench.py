@@ -56,8 +56,10 @@ Prints ONE JSON line on rank 0 with the driver's contract fields plus
                  [225 x pairs] over the P*(Q/2+1) bins of the transform, 8 real FLOPs per complex multiply-add; its
                  operands are streamed once from HBM, so the HBM view of the same launch is given as well);
                  direct modes: the conv 7x7 225->128 MFMA implicit GEMM.  `traffic` / `hbm_gbps` /
-                 `mfma_pipe_busy` / `effective_clock_ghz` are REPLAYED from the committed rocprofv3 PMC passes
-                 (profiles/conv1_traffic_<precision>.json, see `counters_source`), scaled to the class count of the run
+                 `mfma_pipe_busy` / `effective_clock_ghz` are LIVE at N = 1: the run spawns rocprofv3 PMC passes (FETCH_SIZE,
+                 WRITE_SIZE, SQ / GRBM: one pass each) over a 3-step child run of the same workload and merges them
+                 (`live_counters`, `counters_source`); if the profiler is unavailable they fall back to the committed passes
+                 (profiles/*_traffic_<precision>.json) and say so
   stages_ms    - mean duration of every stage of the step (same events)
   sweep        - see above (N = 1)
   end_to_end   - secondary: backbone + head + decode/NMS per image, and the one-off class-head construction (N=1 only)
@@ -114,6 +116,8 @@ def parse():
     ap.add_argument("--no-other-gather", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the 256-class V1 / 1024-class / pyramid lines (N=1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-live-counters", action="store_true",
+                    help="skip the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE / SQ) the N=1 run spawns over a short child run")
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="skip the secondary end-to-end leg (backbone + class-head build + head + decode/NMS)")
     return ap.parse_args()
@@ -160,6 +164,82 @@ def replayed_counters(precision):
         t = json.load(f)
     t["path"] = os.path.relpath(path, REPO)
     return t
+
+
+PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"))
+PMC_KERNELS = {"spectral_gemm_f16_kernel": "%spectral_gemm_f16_kernel%", "spectral_gemm_kernel": "%spectral_gemm_kernel%",
+               "corr_f16x3_kernel": "%corr_f16x3_kernel%", "conv_f16x3_kernel<5>": "%conv_f16x3_kernelILi5%",
+               "conv_f16x3_kernel<7>": "%conv_f16x3_kernelILi7%", "fft_forward_kernel": "%fft_forward_kernel%",
+               "fft_inverse_kernel": "%fft_inverse_kernel%", "sample_decode_kernel": "%sample_decode_kernel%",
+               "conv3_f16x3_kernel": "%conv3_f16x3_kernel%"}
+
+
+def live_counters(precision, classes, keep_dir=None, timeout_s=150):
+    """HBM traffic and matrix-pipe counters of the step's kernels, measured NOW: rocprofv3 PMC passes over a short child run
+    of this very script (same workload, 3 steps), one pass per counter group as the HBM / rocprofv3 section of
+    MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE never share a pass; --kernel-trace only, no other trace
+    domain next to --pmc).  Returns {"kernels": {name: {counter: mean per launch, "avg_launch_us": .., "launches": n}},
+    "passes": [...], "seconds": t} or {"error": ...} - the bench line never depends on it."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return {"error": "rocprofv3 not found"}
+    root = tempfile.mkdtemp(prefix="os2d_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "1", "--precision", precision,
+             "--classes", str(classes), "--no-cpu-baseline", "--no-other-precision", "--no-end-to-end", "--no-sweep", "--no-live-counters"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    out = {"kernels": {}, "passes": [], "child": " ".join(child[1:])}
+    t0 = time.perf_counter()
+    try:
+        for group in PMC_PASSES:
+            d = os.path.join(root, "pmc_" + "_".join(group))
+            cmd = [rocprof, "--pmc"] + list(group) + ["--kernel-trace", "-d", d, "-o", "pmc", "--"] + child
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            out["passes"].append({"counters": list(group), "rc": r.returncode, "databases": len(dbs)})
+            if r.returncode != 0 or not dbs:
+                out["passes"][-1]["tail"] = r.stdout.decode("utf-8", "replace")[-400:]
+                continue
+            cur = sqlite3.connect(dbs[0]).cursor()
+            for name, like in PMC_KERNELS.items():
+                row = cur.execute("select count(*), avg(d.end - d.start) from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s "
+                                  "on d.kernel_id = s.id where s.kernel_name like ?", (like,)).fetchone()
+                if not row or not row[0]:
+                    continue
+                k = out["kernels"].setdefault(name, {})
+                k["launches"], k["avg_launch_us_" + group[0]] = int(row[0]), round(row[1] / 1e3, 2)
+                for c in group:
+                    v = cur.execute("select avg(e.value) from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id = p.id "
+                                    "join rocpd_kernel_dispatch d on e.event_id = d.event_id join rocpd_info_kernel_symbol s "
+                                    "on d.kernel_id = s.id where p.name = ? and s.kernel_name like ?", (c, like)).fetchone()
+                    if v and v[0] is not None:
+                        k[c] = float(v[0])
+        for k in out["kernels"].values():
+            if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+                # KiB per launch; gfx950: FETCH_SIZE counts wide coalesced reads at half their bytes (the guide's correction)
+                k["hbm_bytes_per_launch"] = int((2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0)
+            if k.get("SQ_VALU_MFMA_BUSY_CYCLES") and k.get("GRBM_GUI_ACTIVE"):
+                # SQ_VALU_MFMA_BUSY_CYCLES counts units of 32 cycles summed over the 1024 SIMDs of the chip
+                k["mfma_pipe_busy"] = round(k["SQ_VALU_MFMA_BUSY_CYCLES"] * 32 / (1024 * k["GRBM_GUI_ACTIVE"]), 4)
+                us = k.get("avg_launch_us_SQ_VALU_MFMA_BUSY_CYCLES")
+                if us:
+                    k["effective_clock_ghz"] = round(k["GRBM_GUI_ACTIVE"] / us / 1e3, 3)
+    except Exception as e:   # noqa: BLE001 - a profiler problem must never cost the bench line
+        out["error"] = "{}: {}".format(type(e).__name__, e)
+    out["seconds"] = round(time.perf_counter() - t0, 1)
+    if keep_dir:
+        try:
+            os.makedirs(keep_dir, exist_ok=True)
+            with open(os.path.join(keep_dir, "live_counters_{}.json".format(precision)), "w") as f:
+                json.dump(out, f, indent=1)
+        except OSError:
+            pass
+    shutil.rmtree(root, ignore_errors=True)
+    return out
 
 
 def end_to_end(dev, B, P, inverse, state, precision, arch="resnet50", steps=5, warmup=2):
@@ -333,7 +413,12 @@ class Workload(object):
                     else:
                         l, c, _, _ = head(self.fm)
                         loc, cls = [l[0].flatten(2)], [c[0].flatten(1)]
-                    dets = self.coder.decode_pyramid(loc, cls, self.img_sizes, self.local_ids,
+                    inverse = None
+                    if len(self.img_sizes) > 1:          # the levels of a pyramid are merged in the frame of the 1280x960 image
+                        from os2d_amd.modeling.box_coder import ResizeBoxes
+                        from os2d_amd.structures.feature_map import FeatureMapSize
+                        inverse = [ResizeBoxes(FeatureMapSize(w=16 * W_FM, h=16 * H_FM)) for _ in self.img_sizes]
+                    dets = self.coder.decode_pyramid(loc, cls, self.img_sizes, self.local_ids, inverse_box_transforms=inverse,
                                                      nms_score_threshold=float("-inf"))      # reference eval default (config.py:198)
                     return all_gather_detections(dets)
                 if runner is not None:
@@ -463,6 +548,9 @@ class Workload(object):
              "timing": "HIP events on the launch stream, this run"}
         if f16:
             r["executed_frac_of_peak"] = round(3 * (256.0 / 225.0) * flops / seconds / peak, 4)
+            # operands once (fp16 hi + lo = 4 B per value: image map C x HW, class maps B x C x 256 rows) + the fp32 correlation
+            # tensor B x 225 x HW and the per-location inverse norms; `traffic` (live PMC) over this = operand re-fetch
+            r["algorithmic_bytes"] = 4 * C_FEAT * H_FM * W_FM + 4 * self.B_local * C_FEAT * 256 + 4 * self.B_local * 226 * H_FM * W_FM
         return r
 
     def roofline_fft_whole(self, seconds, precision="fft"):
@@ -702,6 +790,35 @@ def main():
             from os2d_amd.utils import synthetic
             result["end_to_end_resnet101_v1_256"] = end_to_end(dev, 256, 4, False, synthetic.make_transform_net_state(4, seed=1),
                                                                args.precision, arch="resnet101", steps=3, warmup=1)
+    if single and not args.no_live_counters and not args.pyramid:
+        # HBM bytes / matrix-pipe counters of THIS workload measured now (rocprofv3 PMC passes over a short child run), merged
+        # into the roofline objects in place of the replayed figures
+        lc = live_counters(args.precision, classes_total, keep_dir=os.path.join(REPO, "gpurun_out", "live_counters")
+                           if os.path.isdir(os.path.join(REPO, "gpurun_out")) else None)
+        result["live_counters"] = lc
+        names = {"roofline": ("spectral_gemm_f16_kernel" if effective == "fftx3" else "spectral_gemm_kernel" if effective == "fft"
+                              else "conv_f16x3_kernel<7>"), "roofline_corr": "corr_f16x3_kernel"}
+        for key, kname in names.items():
+            k, r = lc.get("kernels", {}).get(kname), result.get(key)
+            if not (k and r and "hbm_bytes_per_launch" in k):
+                continue
+            seconds = r["avg_launch_ms"] * 1e-3
+            r["traffic"] = k["hbm_bytes_per_launch"]
+            r["hbm_gbps"] = round(k["hbm_bytes_per_launch"] / seconds / 1e9, 1)
+            for c in ("mfma_pipe_busy", "effective_clock_ghz"):
+                if c in k:
+                    r[c] = k[c]
+            r["counters_source"] = ("LIVE: rocprofv3 PMC passes of this run over a 3-step child run of the same workload ({} launches of {}; "
+                                    "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes)".format(k.get("launches"), kname))
+    if "other_precisions" in result:
+        f32 = [o for o in result["other_precisions"] if o["precision"] == "f32"]
+        if f32:
+            result["f32_pairs_per_s"] = f32[0]["value"]       # the strictly-fp32 mode (v_mfma_f32_32x32x2_f32 everywhere), same run
+    # the figures a reader looks for first go first: a truncated copy of the line still shows them
+    front = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+             "dtype", "data", "f32_pairs_per_s", "stages_ms", "roofline", "roofline_corr", "cpu_baseline", "speedup_vs_cpu_baseline",
+             "config", "scaling_reference"]
+    result = {**{k: result[k] for k in front if k in result}, **{k: v for k, v in result.items() if k not in front}}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if use_dist:

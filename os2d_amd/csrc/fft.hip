@@ -189,7 +189,9 @@ __device__ __forceinline__ f32x2* fft_any(int r1, int r2, f32x2* a, f32x2* b, in
 
 // LDS (in complex numbers): twiddles Q + P | rows A, B: 2 x (HP x Q), HP = ceil(H/2) row pairs | columns C: V x PS.
 // The second column buffer D aliases A|B (the row stage is finished by then).
-template <int FFT_EPT>
+// TILED = false: the whole map in one transform (offsets 0, one image per (pair, channel)) - the address arithmetic of the
+// tiles is compiled out (it cost the 60 x 80 benchmark map 10 % of this kernel: 0.25 -> 0.28 ms per 64 classes)
+template <int FFT_EPT, bool TILED>
 __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 6 ? 4 : 2) void fft_forward_kernel(const float* __restrict__ corr,   // [NB][C][H*W]
                                                              const float* __restrict__ inv,    // [NB][H*W]
                                                              f32x2* __restrict__ X,            // [C][NB][NBINS]
@@ -217,16 +219,16 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 6 ? 4 : 2) void fft_forward_ker
   // index (a multiply-high each): held across the image loop they cost 3 registers per element and spill
   // the tile's window starts at map row Y0 / column X0 (negative along a tiled axis: the halo above / left of the map is zero)
 #define FFT_TILE(IT)                                                                                              \
-  const int m_ = div_magic((IT), pl.inv_t), t_ = (IT)-m_ * pl.T;                                                  \
-  const int ty_ = div_magic(t_, pl.inv_tx), tx_ = t_ - ty_ * pl.TX;                                               \
-  const int Y0 = ty_ * pl.TH - pl.oy, X0 = tx_ * pl.TW - pl.ox;
+  const int m_ = TILED ? div_magic((IT), pl.inv_t) : (IT), t_ = TILED ? (IT)-m_ * pl.T : 0;                       \
+  const int ty_ = TILED ? div_magic(t_, pl.inv_tx) : 0, tx_ = TILED ? t_ - ty_ * pl.TX : 0;                       \
+  const int Y0 = TILED ? ty_ * pl.TH - pl.oy : 0, X0 = TILED ? tx_ * pl.TW - pl.ox : 0;
 #define FFT_ELEM(TID, K)                                                                                          \
   const int i_ = (TID) + (K)*FFT_THR;                                                                             \
   const int p_ = (int)__umulhi((unsigned)i_, pl.inv_q), w_ = i_ - p_ * Q;                                         \
   const int r_ = Y0 + 2 * p_, c_ = X0 + w_;                                                                       \
-  const bool in_ = i_ < nelem && w_ < LW && c_ >= 0 && c_ < W;                                                    \
-  const bool e0_ = in_ && r_ >= 0 && r_ < H && 2 * p_ < LH;                                                       \
-  const bool e1_ = in_ && r_ + 1 >= 0 && r_ + 1 < H && 2 * p_ + 1 < LH;                                           \
+  const bool in_ = i_ < nelem && (TILED ? (w_ < LW && c_ >= 0 && c_ < W) : (w_ < W));                             \
+  const bool e0_ = in_ && (TILED ? (r_ >= 0 && r_ < H && 2 * p_ < LH) : true);                                    \
+  const bool e1_ = in_ && (TILED ? (r_ + 1 >= 0 && r_ + 1 < H && 2 * p_ + 1 < LH) : (r_ + 1 < H));                \
   const int edst_ = p_ * QS + w_;
   // RAW values only are held (correlation + inverse norm of the even and the odd row): any arithmetic here would make the
   // compiler wait for each load right where it is issued; addresses are clamped instead of predicated (no branches)
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 6 ? 4 : 2) void fft_forward_ker
     // X[c][pair][bin]: the 64 pairs a GEMM work-group reads for one channel lie in ONE 1.4 MB stretch (22 KB apart), not 5 MB
     // apart - its load instructions then need one address translation instead of one per pair
     const int nb_ = m_ / C;
-    f32x2* dst = X + ((size_t)(m_ - nb_ * C) * (images / C) + (size_t)nb_ * pl.T + t_) * NBINS;
+    f32x2* dst = X + ((size_t)(m_ - nb_ * C) * (images / C) + (TILED ? (size_t)nb_ * pl.T + t_ : (size_t)nb_)) * NBINS;
     for (int u = wv; u < P; u += NWV)
       for (int v = lane; v < V; v += 64) dst[u * V + v] = Rc[v * PS + u];
     for (int i = P * V + tid; i < NBINS; i += FFT_THR) dst[i] = f32x2{0.f, 0.f};
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 6 ? 4 : 2) void fft_forward_ker
 // stores instead of 2-byte ones (measured at 64 pairs, 60x80: 0.377 ms with 2-byte stores, 0.318 ms with GRPT = 4, which
 // spills 20 registers at the 128-VGPR budget of two work-groups per CU, 0.288 ms with GRPT = 2; 0.282 ms without stores);
 // CPT == 0 (maps with more than 512 * 10 cells): one channel per iteration, 2-byte stores.
-template <int FFT_EPT, int CPT, int GRPT>
+template <int FFT_EPT, int CPT, int GRPT, bool TILED>
 __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_kernel(const f32x2* __restrict__ Y,      // [NB][Cout][NBINS]
                                                              const float* __restrict__ bp,     // [3][MTP]: bias | - | 2^out_exp
                                                              int MTP, char* __restrict__ out,  // SHB [NB][Cout/8][2][PLANE] x 16 B
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
   constexpr int NACC = CPT > 0 ? CPT : 1, NR = GRP == 4 ? 2 : 1;
   // GRP == 2 keeps the first channel of a pair as ONE register per cell (hi | lo << 16) and recombines at the second
   unsigned hreg[NACC][NR] = {}, lreg[GRP == 4 ? NACC : 1][NR] = {};
-  const int ngroups = images / GRP, cells = pl.TH * pl.TW;
+  const int ngroups = images / GRP, cells = TILED ? pl.TH * pl.TW : H * W;
   // XCD-aware order (work-group L runs on XCD L % 8, one L2 per XCD): every XCD takes a contiguous range of channel
   // groups, so the 8 / GRP work-groups that fill the 16-byte units of one (class, 8-channel group) with their 4- / 8-byte
   // pieces run on ONE XCD at about the same time and the pieces merge in its L2 (with the round-robin order each piece
@@ -354,9 +356,10 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
     const int img = it;
     const int nxt = ((it + 1) % GRP) ? it + 1 : (it / GRP + (int)gridDim.x) * GRP;
     const int pr = img / Cout, o = img - pr * Cout;               // pair' = nb * T + tile
-    const int nb = div_magic(pr, pl.inv_t), tile = pr - nb * pl.T;
-    const int ty = div_magic(tile, pl.inv_tx), tx = tile - ty * pl.TX;
-    const int y0 = ty * pl.TH, x0 = tx * pl.TW, oy = pl.oy, ox = pl.ox;
+    const int nb = TILED ? div_magic(pr, pl.inv_t) : pr, tile = TILED ? pr - nb * pl.T : 0;
+    const int ty = TILED ? div_magic(tile, pl.inv_tx) : 0, tx = TILED ? tile - ty * pl.TX : 0;
+    const int y0 = TILED ? ty * pl.TH : 0, x0 = TILED ? tx * pl.TW : 0, oy = TILED ? pl.oy : 0, ox = TILED ? pl.ox : 0;
+    const int TW_ = TILED ? pl.TW : W, TH_ = TILED ? pl.TH : H;
     // the per-thread addresses below are cheap to recompute per image; an opaque copy of the thread index keeps the
     // compiler from hoisting ~50 registers of them out of the image loop (and spilling them at the 128-register budget)
     int tl = tid;
@@ -416,9 +419,9 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
       for (int k = 0; k < CPT; ++k) {
         __builtin_amdgcn_sched_barrier(0);                 // keep the unrolled iterations apart: register pressure
         const int i = tl + k * FFT_THR;
-        const int th = div_magic(i, pl.inv_tw), tw = i - th * pl.TW;      // cell of the tile: i / TW, i % TW
+        const int th = div_magic(i, pl.inv_tw), tw = i - th * TW_;        // cell of the tile: i / TW, i % TW
         const int h = y0 + th, w = x0 + tw;                               // ... of the map
-        if (i < cells && h < H && w < W) {
+        if (i < cells && (!TILED || (h < H && w < W))) {
           const f32x2 z = R[((th + oy) >> 1) * QS + tw + ox];
           float t = (((th + oy) & 1) ? z[1] : z[0]) * norm + bias;
           t = fmaxf(t, 0.f) * osc;
@@ -454,8 +457,8 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
     } else {
       _Float16* hi = reinterpret_cast<_Float16*>(hi_unit) + slot;
       _Float16* lo = reinterpret_cast<_Float16*>(lo_unit) + slot;
-      for (int th = wv; th < pl.TH && y0 + th < H; th += NWV)
-        for (int tw = lane; tw < pl.TW && x0 + tw < W; tw += 64) {
+      for (int th = wv; th < TH_ && y0 + th < H; th += NWV)
+        for (int tw = lane; tw < TW_ && x0 + tw < W; tw += 64) {
           const int h = y0 + th, w = x0 + tw;
           const f32x2 z = R[((th + oy) >> 1) * QS + tw + ox];
           float t = (((th + oy) & 1) ? z[1] : z[0]) * norm + bias;
@@ -657,7 +660,8 @@ int os2d_launch_fft_forward(const float* corr, const float* inv, float* X, const
   if (lds < (size_t)OS2D_DIAG_FFT_LDS_MIN) lds = OS2D_DIAG_FFT_LDS_MIN;
 #endif
   const int ept = (((pl.LH + 1) / 2) * pl.Q + FFT_THR - 1) / FFT_THR;
-  auto kern = ept <= 6 ? fft_forward_kernel<6> : ept <= 10 ? fft_forward_kernel<10> : fft_forward_kernel<14>;
+  auto kern = pl.T > 1 ? (ept <= 6 ? fft_forward_kernel<6, true> : ept <= 10 ? fft_forward_kernel<10, true> : fft_forward_kernel<14, true>)
+                       : (ept <= 6 ? fft_forward_kernel<6, false> : ept <= 10 ? fft_forward_kernel<10, false> : fft_forward_kernel<14, false>);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) {
     os2d_set_error("hipFuncSetAttribute(fft_forward): %s", hipGetErrorString(e));
@@ -686,12 +690,15 @@ int os2d_launch_fft_inverse(const float* Y, const float* bp, int MTP, void* out,
 #endif
   constexpr int CPT = 10, GRP = OS2D_FFT_GRP;
   const bool grouped = Cout % GRP == 0 && pl.TH * pl.TW <= CPT * FFT_THR && ept <= 10;
-  auto kern = grouped ? (ept <= 6   ? fft_inverse_kernel<6, CPT, GRP>
-                         : ept <= 8 ? fft_inverse_kernel<8, CPT, GRP>
-                                    : fft_inverse_kernel<10, CPT, GRP>)
-                      : (ept <= 6    ? fft_inverse_kernel<6, 0, 1>
-                         : ept <= 10 ? fft_inverse_kernel<10, 0, 1>
-                                     : fft_inverse_kernel<14, 0, 1>);
+#define OS2D_INV_KERN(T_)                                                                        \
+  (grouped ? (ept <= 6   ? fft_inverse_kernel<6, CPT, GRP, T_>                                   \
+              : ept <= 8 ? fft_inverse_kernel<8, CPT, GRP, T_>                                   \
+                         : fft_inverse_kernel<10, CPT, GRP, T_>)                                 \
+           : (ept <= 6    ? fft_inverse_kernel<6, 0, 1, T_>                                      \
+              : ept <= 10 ? fft_inverse_kernel<10, 0, 1, T_>                                     \
+                          : fft_inverse_kernel<14, 0, 1, T_>))
+  auto kern = pl.T > 1 ? OS2D_INV_KERN(true) : OS2D_INV_KERN(false);
+#undef OS2D_INV_KERN
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) {
     os2d_set_error("hipFuncSetAttribute(fft_inverse): %s", hipGetErrorString(e));

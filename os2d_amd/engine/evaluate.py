@@ -88,6 +88,8 @@ def detect(net, box_coder, image_levels, class_head, class_ids, orig_size=None, 
     s = extract_scores(net, image_levels, class_head, per_level_streams)
     a = image_index
     inverse = None
+    if orig_size is None and len({(z.w, z.h) for z in s["img_sizes"]}) > 1:
+        orig_size = s["img_sizes"][0]       # levels of different sizes can only be merged in a common frame: the first level's
     if orig_size is not None:
         inverse = [ResizeBoxes(orig_size) for _ in image_levels]
     return box_coder.decode_pyramid([l[a] for l in s["loc"]], [c[a] for c in s["cls"]], s["img_sizes"], class_ids,

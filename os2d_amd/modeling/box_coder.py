@@ -209,6 +209,12 @@ class Os2dBoxCoder(object):
         Returns a BoxList with fields scores, labels, default_boxes (and transform_corners if given)."""
         num_classes = len(class_ids)
         dev = cls_scores_pyramid[0].device
+        if inverse_box_transforms is None:
+            # the reference concatenates the levels of a label with cat_boxlist, which asserts one common image size
+            # (bounding_box.py:390-437): levels of different sizes need transforms into a common frame
+            assert len({(s_.w, s_.h) for s_ in img_size_pyramid}) <= 1, \
+                "pyramid levels live on different image sizes ({}): pass inverse_box_transforms to map them to one image size " \
+                "before they are merged".format(sorted({(s_.w, s_.h) for s_ in img_size_pyramid}))
         fused = self._decode_single_level_fused(loc_scores_pyramid, cls_scores_pyramid, img_size_pyramid, class_ids,
                                                 nms_score_threshold, nms_iou_threshold, inverse_box_transforms,
                                                 transform_corners_pyramid)
@@ -388,10 +394,7 @@ class Os2dBoxCoder(object):
         if ts[0] is not None and len({(t.target_size.w, t.target_size.h) for t in ts}) != 1:
             return None
         if ts[0] is None and len({(s_.w, s_.h) for s_ in size_pyr}) != 1:
-            # levels of different image sizes and nothing that maps them to a common frame: the reference's cat_boxlist
-            # refuses to concatenate them (reference structures/bounding_box.py:390-437) - the generic chain raises the same
-            # assertion; labelling the result with the first level's size here would hide it
-            return None
+            return None      # decode_pyramid asserts this before it gets here (reference cat_boxlist, bounding_box.py:390-437)
         lib = _lib.load()
         L = len(loc_pyr)
         fms = [self.get_feature_map_size(s) for s in size_pyr]

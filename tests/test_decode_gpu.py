@@ -331,7 +331,12 @@ def test_fused_pyramid_equals_generic_path(max_batch, thr, device):
     clss[3][1, :] = 0.25                             # a whole level of equal scores
     ids = [11, 3, 8, 40, 5]
     orig = FeatureMapSize(w=700, h=433)
-    for inverse in (None, [ResizeBoxes(orig) for _ in levels]):
+    for inverse in ([ResizeBoxes(orig) for _ in levels], None):
+        if inverse is None:
+            # without transforms back to a common frame only levels of ONE image size can be merged (the reference's cat_boxlist
+            # asserts it, bounding_box.py:390-437; so does decode_pyramid here): four "levels" of the same size
+            sizes, locs, clss, corners = _pyramid_inputs([levels[2]] * 4, B, 78, device)
+            clss[2][0, 100:140] = clss[1][0, 7]
         coder = _coder()
         coder.nms_max_batch = max_batch
         coder.fused_pyramid_passes = 6
@@ -349,7 +354,7 @@ def test_fused_pyramid_falls_back_when_more_passes_are_needed(device):
     """Sparse boxes + a tiny ``nms_max_batch``: the chunk-and-repeat scheme needs more passes than the device path was
     told to launch -> `unfinished` is reported and decode_pyramid transparently uses the generic path; with enough passes
     the device path gives the same result."""
-    levels = [(12, 16), (20, 24)]
+    levels = [(20, 24), (20, 24)]          # one image size: no transforms are needed to merge the levels
     sizes, locs, clss, corners = _pyramid_inputs(levels, 2, 5, device, loc_scale=0.3)
     coder = _coder()
     coder.nms_max_batch = 64
@@ -399,7 +404,10 @@ def test_fused_pyramid_with_merged_labels_matches_generic_chain(max_batch, singl
     clss[0][2, 5:60] = clss[0][0, 17]                  # ties between two rows of label 7: list (row) order decides
     clss[-1][4, :] = 0.3                               # a whole level of equal scores in label 2's second row
     orig = FeatureMapSize(w=640, h=411)
-    for inverse in (None, [ResizeBoxes(orig) for _ in levels]):
+    for inverse in ([ResizeBoxes(orig) for _ in levels], None):
+        if inverse is None and not single_level:      # levels of one image size (see test_fused_pyramid_equals_generic_path)
+            sizes, locs, clss, corners = _pyramid_inputs([levels[1]] * 3, B, 32, device)
+            clss[0][2, 5:60] = clss[0][0, 17]
         coder = _coder()
         coder.nms_max_batch = max_batch
         coder.fused_pyramid_passes = 8
@@ -433,3 +441,16 @@ def test_fused_pyramid_merged_labels_full_size(device):
                                    transform_corners_pyramid=corners)
     _assert_same_detections(fused, generic)
     assert len(fused) > 100
+
+
+def test_levels_of_different_image_sizes_need_transforms(device):
+    """The reference merges the levels of a label with cat_boxlist, which asserts that all of them live on one image size
+    (bounding_box.py:390-437): without inverse_box_transforms a multi-size pyramid is an error there and here - on the device
+    path and on the generic chain alike (the fused path used to label the result with the first level's size)."""
+    levels = [(9, 12), (15, 20)]
+    sizes, locs, clss, corners = _pyramid_inputs(levels, 2, 3, device)
+    for fused in (True, False):
+        coder = _coder()
+        coder.use_fused_level_kernel = fused
+        with pytest.raises(AssertionError, match="image size"):
+            coder.decode_pyramid(locs, clss, sizes, [0, 1], nms_score_threshold=0.0)

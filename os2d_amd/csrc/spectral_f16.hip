@@ -37,6 +37,11 @@ constexpr int SH_STAGE = SH_WB * 2 * 2 * 64;   // 16-byte units of one operand s
 constexpr int SH_WRING = OS2D_SH_WRING;        // weight stages in LDS (ring): the DMA of k-step s + WRING - 1 is in flight
                                                // while k-step s is multiplied; the spectra are two k-steps ahead in registers
 
+__device__ __forceinline__ f32x16 sh_keep(half8 x, half8 y, f32x16 acc) {     // OS2D_DIAG_SH_NOMFMA: operands stay live
+  asm volatile("" ::"v"(x), "v"(y));
+  return acc;
+}
+
 // barrier for data exchanged through LDS that leaves the wave's global loads in flight (see fft.hip)
 __device__ __forceinline__ void sh_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -76,6 +81,9 @@ __global__ __launch_bounds__(SH_THR, 2) void spectral_gemm_f16_kernel(const u32x
   typedef void __attribute__((address_space(3))) * lptr_t;
   // weights of k-step s for this work-group's 4 bins: 1024 contiguous units
   const u32x4* wbase = w16 + ((size_t)(g * 2 + half) * KS) * (SH_BINS * 256) + bh * SH_STAGE;
+#ifdef OS2D_DIAG_SH_NOW      /* diagnostic: no weight DMA */
+#define SH_DMA_W(S) {}
+#else
 #define SH_DMA_W(S)                                                                                                 \
   {                                                                                                                 \
     const u32x4* src_ = wbase + (size_t)(S) * (SH_BINS * 256);                                                      \
@@ -84,6 +92,7 @@ __global__ __launch_bounds__(SH_THR, 2) void spectral_gemm_f16_kernel(const u32x
       __builtin_amdgcn_global_load_lds((gptr_t)(src_ + u_ + lane), (lptr_t)(ldsW + ((S) % SH_WRING) * SH_STAGE + u_), 16, 0, 0); \
     }                                                                                                               \
   }
+#endif
   // spectra of k-step s: this thread owns pair xn, bins 2 xj / 2 xj + 1 and the 4 channels of group xg.  A wave covers 16
   // pairs x (2 bin pairs x 2 channel groups): the rows of different pairs lie 5 MB apart, and a load instruction that touches
   // 64 of them (one pair per lane) spends its time in address translation, not in the memory system
@@ -91,6 +100,12 @@ __global__ __launch_bounds__(SH_THR, 2) void spectral_gemm_f16_kernel(const u32x
   const bool xn_ok = nb0 + xn < NB;
   const f32x2* xrow = X + (size_t)min(nb0 + xn, NB - 1) * NBINS + bin0 + 2 * xj;
   u32x4 pfa[4], pfb[4];     // two k-steps of spectra in flight (even / odd k-steps)
+#ifdef OS2D_DIAG_SH_NOX      /* diagnostic: no global loads of the spectra (tools/diag_spectral.sh) */
+#define SH_LOAD_X(S, pfx)                                                                                           \
+  {                                                                                                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) pfx[i_] = u32x4{(unsigned)(S), 1u, 2u, (unsigned)lane};        \
+  }
+#else
 #define SH_LOAD_X(S, pfx)                                                                                           \
   {                                                                                                                 \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                              \
@@ -98,6 +113,18 @@ __global__ __launch_bounds__(SH_THR, 2) void spectral_gemm_f16_kernel(const u32x
       pfx[i_] = *reinterpret_cast<const u32x4*>(xrow + (size_t)c_ * NB * NBINS);                                    \
     }                                                                                                               \
   }
+#endif
+#ifdef OS2D_DIAG_SH_NOSPLIT  /* diagnostic: no scale / split arithmetic (raw bits as halves) */
+#define SH_SPLIT_VALUE                                                                                              \
+  h_[2 * i_ + p_] = __builtin_bit_cast(_Float16, (unsigned short)(ok_ ? raw_ : 0u));                                \
+  l_[2 * i_ + p_] = __builtin_bit_cast(_Float16, (unsigned short)(raw_ >> 16));
+#else
+#define SH_SPLIT_VALUE                                                                                              \
+  const float v_ = ok_ ? __uint_as_float(raw_) * xscale : 0.f;                                                      \
+  const _Float16 hv_ = (_Float16)v_;                                                                                \
+  h_[2 * i_ + p_] = hv_;                                                                                            \
+  l_[2 * i_ + p_] = (_Float16)(v_ - (float)hv_);
+#endif
 #define SH_STORE_X(S, pfx)                                                                                          \
   {                                                                                                                 \
     _Pragma("unroll") for (int b2_ = 0; b2_ < 2; ++b2_) {                                                           \
@@ -106,10 +133,7 @@ __global__ __launch_bounds__(SH_THR, 2) void spectral_gemm_f16_kernel(const u32x
         const bool ok_ = xn_ok && (S)*SH_KC + xg * 4 + i_ < C;                                                      \
         _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_) {                                                          \
           const unsigned raw_ = pfx[i_][2 * b2_ + p_];   /* (scalar copy first: see the ext-vector note in corr_f16x3.hip) */ \
-          const float v_ = ok_ ? __uint_as_float(raw_) * xscale : 0.f;                                              \
-          const _Float16 hv_ = (_Float16)v_;                                                                        \
-          h_[2 * i_ + p_] = hv_;                                                                                    \
-          l_[2 * i_ + p_] = (_Float16)(v_ - (float)hv_);                                                            \
+          SH_SPLIT_VALUE                                                                                            \
         }                                                                                                           \
       }                                                                                                             \
       u32x4* dst_ = ldsX + ((S)&1) * SH_STAGE + (((2 * xj + b2_) * 2 + xg) * 2) * 64 + xn;                          \
@@ -118,6 +142,11 @@ __global__ __launch_bounds__(SH_THR, 2) void spectral_gemm_f16_kernel(const u32x
     }                                                                                                               \
   }
 
+#ifdef OS2D_DIAG_SH_NOMFMA   /* diagnostic: fragments are read and derived, the matrix instructions are skipped */
+#define SH_MM(x_, y_, acc_) sh_keep(x_, y_, acc_)
+#else
+#define SH_MM(x_, y_, acc_) __builtin_amdgcn_mfma_f32_32x32x16_f16(x_, y_, acc_, 0, 0, 0)
+#endif
 #define SH_COMPUTE(S)                                                                                               \
   {                                                                                                                 \
     const u32x4* aB = ldsW + ((S) % SH_WRING) * SH_STAGE + ((wv * 2 + hw) * 2) * 64 + l31; /* [bin = wv][group = hw][hi|lo][o] */ \
@@ -138,15 +167,15 @@ __global__ __launch_bounds__(SH_THR, 2) void spectral_gemm_f16_kernel(const u32x
       }                                                                                                             \
       const half8 arh = __builtin_bit_cast(half8, rh), arl = __builtin_bit_cast(half8, rl);                         \
       const half8 aih = __builtin_bit_cast(half8, ih), ail = __builtin_bit_cast(half8, il);                         \
-      _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                               \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                 \
         /* the spectra are the ROW operand: the accumulator registers run over the pairs, the lanes over the output channels - a \
            store instruction then stays inside one pair's rows (22 KB apart) instead of touching 32 pairs (3 MB apart) */    \
-        yr[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhf[b], arl, yr[a][b], 0, 0, 0);                          \
-        yr[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(blf[b], arh, yr[a][b], 0, 0, 0);                          \
-        yr[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhf[b], arh, yr[a][b], 0, 0, 0);                          \
-        yi[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhf[b], ail, yi[a][b], 0, 0, 0);                          \
-        yi[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(blf[b], aih, yi[a][b], 0, 0, 0);                          \
-        yi[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhf[b], aih, yi[a][b], 0, 0, 0);                          \
+        yr[a][b] = SH_MM(bhf[b], arl, yr[a][b]);                          \
+        yr[a][b] = SH_MM(blf[b], arh, yr[a][b]);                          \
+        yr[a][b] = SH_MM(bhf[b], arh, yr[a][b]);                          \
+        yi[a][b] = SH_MM(bhf[b], ail, yi[a][b]);                          \
+        yi[a][b] = SH_MM(blf[b], aih, yi[a][b]);                          \
+        yi[a][b] = SH_MM(bhf[b], aih, yi[a][b]);                          \
       }                                                                                                             \
     }                                                                                                               \
   }
@@ -202,7 +231,11 @@ __global__ __launch_bounds__(SH_THR, 2) void spectral_gemm_f16_kernel(const u32x
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int nb = nb0 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hw;
+#ifdef OS2D_DIAG_SH_NOY       /* diagnostic: no output stores (kept alive by an impossible condition) */
+        if (nb < NB && yr[a][b][r] == 123.456f) {
+#else
         if (nb < NB) {
+#endif
           const float vr = yr[a][b][r], vi = yi[a][b][r];
           Y[((size_t)nb * Cout + o) * NBINS + bin] = f32x2{vr * sc, vi * sc};
         }

@@ -10,6 +10,8 @@ MI355X-first differences from the reference loop:
   * nothing synchronises with the host until the caller asks for the results (the reference calls
     ``torch.cuda.synchronize()`` twice per level, evaluate.py:312,332).
 """
+import os
+
 import torch
 
 from ..structures.feature_map import FeatureMapSize
@@ -49,6 +51,7 @@ class PyramidHeadRunner(object):
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self._num_streams = num_streams
+        self.largest_first = os.environ.get("OS2D_PYRAMID_ORDER", "largest") != "given"     # queue order of the levels
 
     def _stream(self, i):
         n = self._num_streams
@@ -68,20 +71,26 @@ class PyramidHeadRunner(object):
                                       # stream, BEFORE the event every level stream waits on
         ready = torch.cuda.Event()
         ready.record(main)
-        locs, clss, corners_l, sizes = [], [], [], []
+        n = len(level_inputs)
+        locs, clss, corners_l, sizes = [None] * n, [None] * n, [None] * n, [None] * n
         done = []
+        # the LARGEST level is queued first: its kernel chain is the longest (31 % of the locations of the 7-scale pyramid sit
+        # in the 96 x 128 level), and the small levels queued behind it fill the CUs its kernels' tails leave idle; queued
+        # last it would run its chain alone at the end.  Results are returned in the caller's level order.
+        order = sorted(range(n), key=lambda i: -(level_inputs[i].size(-1) * level_inputs[i].size(-2))) if self.largest_first else range(n)
         with torch.no_grad():
-            for i, x in enumerate(level_inputs):
+            for i in order:
+                x = level_inputs[i]
                 st = self._stream(i)
                 st.wait_event(ready)
                 with torch.cuda.stream(st):
                     fm = x if inputs_are_features else self.features(x)
                     loc, cls, _, corners = self.head(fm)
                     A, B = cls.size(0), cls.size(1)
-                    locs.append(loc.reshape(A, B, 4, -1) if loc is not None else None)
-                    clss.append(cls.reshape(A, B, -1))
-                    corners_l.append(corners.reshape(A, B, 8, -1) if corners is not None else None)
-                    sizes.append(FeatureMapSize(img=fm))
+                    locs[i] = loc.reshape(A, B, 4, -1) if loc is not None else None
+                    clss[i] = cls.reshape(A, B, -1)
+                    corners_l[i] = corners.reshape(A, B, 8, -1) if corners is not None else None
+                    sizes[i] = FeatureMapSize(img=fm)
                     # caching-allocator bookkeeping: the input was allocated on the caller's stream and is read on
                     # `st`; the outputs are allocated on `st` and will be read on the caller's stream
                     x.record_stream(st)

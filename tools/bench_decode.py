@@ -64,3 +64,16 @@ if "--pyramid" in sys.argv:
                                    nms_iou_threshold=0.3, inverse_box_transforms=inverse, transform_corners_pyramid=cor_p)
         torch.cuda.synchronize()
     print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=10, max_name_column_width=60))
+    # merged labels (class-image views, reference evaluate.py:241-269): B head rows = B / V labels x V views, 7 levels
+    if "--views" in sys.argv:
+        V = int(sys.argv[sys.argv.index("--views") + 1])
+        ids = [b // V for b in range(B)]
+        for fused in (False, True):
+            coder.use_fused_level_kernel = fused
+            for it in range(3):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                res = coder.decode_pyramid(loc_p, cls_p, sizes, class_ids=ids, nms_score_threshold=thr,
+                                           nms_iou_threshold=0.3, inverse_box_transforms=inverse, transform_corners_pyramid=cor_p)
+                torch.cuda.synchronize(); dt = time.perf_counter() - t0
+                print("pyramid decode, merged labels ({}) {} labels x {} views thr={}: {:.2f} ms, {} detections".format(
+                    "os2d_detect_pyramid_merged" if fused else "generic chain", B // V, V, thr, dt * 1e3, len(res)))

@@ -23,9 +23,12 @@ SOURCES = ["abi.hip", "prep.hip", "corr_mfma.hip", "conv_mfma.hip", "conv_f16x3.
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 # No packed-FP32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) in the translation units listed in
-# NO_PACKED_FP32.  Measured on MI355X (rounds 2 and 3): kernels made of these instructions return wrong
-# values in 16-lane groups of single registers whenever MFMA-heavy kernels of OTHER streams run at the same time (never
-# alone, never on one stream).  Round-3 discrimination runs: tools/diag_packed_fp32.sh, results in DESIGN.md section 8.
+# NO_PACKED_FP32 - all of them.  Measured on MI355X (profiles/r03_packed_fp32/): such instructions
+# occasionally return wrong values in lanes 48 - 63 of a wave while waves of ANOTHER kernel on the same CU issue fp16 MFMA
+# instructions at full rate (other HIP streams); a register-only victim without LDS, barriers or memory accesses reproduces
+# it (tools/repro_packed_fp32.hip), scalar v_fma_f32 code never does, fp32-MFMA / plain-VALU neighbours never trigger it, and
+# the library's transforms fail identically with full __syncthreads() barriers - it is not a race of ours.  Any kernel of the
+# library can meet another stream's conv / correlation / spectral-GEMM waves under the per-level-stream pyramid runner.
 PACKED_OFF = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 NO_PACKED_FP32 = set(SOURCES)             # which translation units are compiled without the packed instructions
 FLAGS += os.environ.get("OS2D_EXTRA_HIPCC_FLAGS", "").split()      # kernel experiments (-DOS2D_DIAG_...); part of the source hash

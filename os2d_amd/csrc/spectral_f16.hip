@@ -15,8 +15,19 @@
 //     [Ki, Kr] = half swap within each dword (8 VALU operations per fragment pair against 6 matrix instructions);
 //   the accumulators are multiplied by 2^-(wexp[o] + xexp) before the store, so Y is what the fp32 kernel produces (up to
 //     the 2^-22 relative error of a split product) and the inverse transform is unchanged.
-// Work decomposition, XCD-aware order and the Y layout are those of spectral_gemm_kernel: 4 waves = 4 bins x 64 output
-// channels x 64 pairs per work-group, two work-groups per CU (64 KB of LDS each), K loop in double-buffered k-steps.
+//
+// Work decomposition (round 3; the round-2 kernel and the intermediate steps are timed in profiles/r03_spectral_gemm_*.txt):
+//   work-group = 8 waves = 4 consecutive bins x ALL 128 output channels x 64 pairs, one per CU (128 KB of LDS: weight ring
+//     3 x 32 KB + spectra 2 x 16 KB).  Round 2 ran two 4-wave groups of 64 output channels each, and each fetched, scaled and
+//     split the same spectra: component-removal builds (tools/diag_spectral.sh) put the spectra loads at 0.10 of the launch's
+//     0.39 ms at 64 pairs and at 2.5 of 5.6 ms at 1024;
+//   wave = a 32 x 32 (pairs x output channels) tile of all FOUR bins (ot = wv & 3, pt = wv >> 2): a lane owns the 4 bins of a
+//     (pair, channel) row = 32 contiguous bytes (round 2: a wave = one bin of the whole tile, 8-byte stores; the stores were
+//     0.12 of the 0.39 ms, 2.3 of the 5.6 ms);
+//   spectra in the QUAD layout (include/os2d_hip.h, OS2D_SPECTRA_QUADS): X [bins/4][c][pair][4], Y [bins/4][pair][o][4] - a
+//     load instruction of this kernel touches two 512-byte runs (16 pairs x 32 B for two channel groups) instead of 32 pieces
+//     of 32 bytes 22 KB apart, a store instruction two 1 KB runs (32 output channels x 32 B for two pairs) instead of 64 pieces.
+// XCD-aware order: the pair tiles of a bin group (which share the weight spectra) run on one XCD at about the same time.
 #include "os2d_common.h"
 
 namespace {
@@ -24,57 +35,57 @@ namespace {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
-constexpr int SH_THR = 256;
-constexpr int SH_WB = 4;        // bins (= waves) per work-group
+constexpr int SH_THR = 512;
+constexpr int SH_WB = 4;        // bins per work-group
 constexpr int SH_BINS = 8;      // bins per group of the packed weight layout
 constexpr int SH_OH = 64, SH_NB = 64;
 constexpr int SH_KC = 8;        // channels per k-step
-constexpr int SH_STAGE = SH_WB * 2 * 2 * 64;   // 16-byte units of one operand stage: [bin][group][hi|lo][row]: 1024 = 16 KB
+constexpr int SH_STAGE = SH_WB * 2 * 2 * 64;   // 16-byte units of one operand stage of 64 rows: [bin][group][hi|lo][row]: 16 KB
+constexpr int SH_WSTAGE = 2 * SH_STAGE;        // weights of both output-channel halves: 32 KB
 #ifndef OS2D_SH_WRING
 #define OS2D_SH_WRING 3
-#endif
-#ifndef OS2D_SH_WAVE_BINS
-#define OS2D_SH_WAVE_BINS 1                    // 1: a wave multiplies a 32 x 32 tile of all four bins (32-byte stores); 0: round 2
 #endif
 constexpr int SH_WRING = OS2D_SH_WRING;        // weight stages in LDS (ring): the DMA of k-step s + WRING - 1 is in flight
                                                // while k-step s is multiplied; the spectra are two k-steps ahead in registers
 
-__device__ __forceinline__ f32x16 sh_keep(half8 x, half8 y, f32x16 acc) {     // OS2D_DIAG_SH_NOMFMA: operands stay live
+#ifdef OS2D_DIAG_SH_NOMFMA   /* diagnostic: fragments are read and derived, the matrix instructions are skipped */
+__device__ __forceinline__ f32x16 sh_keep(half8 x, half8 y, f32x16 acc) {
   asm volatile("" ::"v"(x), "v"(y));
   return acc;
 }
+#define SH_MM(x_, y_, acc_) sh_keep(x_, y_, acc_)
+#else
+#define SH_MM(x_, y_, acc_) __builtin_amdgcn_mfma_f32_32x32x16_f16(x_, y_, acc_, 0, 0, 0)
+#endif
 
 // barrier for data exchanged through LDS that leaves the wave's global loads in flight (see fft.hip)
 __device__ __forceinline__ void sh_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__global__ __launch_bounds__(SH_THR, 2) void spectral_gemm_f16_kernel(const u32x4* w16,            // [G][2][KS][8][2][2][64] units
+__global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x4* w16,            // [G][2][KS][8][2][2][64] units
                                                                       const float* __restrict__ wscale,  // [128] 2^-wexp[o]
-                                                                      const f32x2* __restrict__ X,       // [C][NB][NBINS]
-                                                                      f32x2* __restrict__ Y,             // [NB][Cout][NBINS]
+                                                                      const f32x2* __restrict__ X,       // [NBINS/4][C][NB][4]
+                                                                      f32x2* __restrict__ Y,             // [NBINS/4][NB][Cout][4]
                                                                       int NB, int C, int Cout, int NBINS, int G, float xscale,
                                                                       int nunits) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u32x4* ldsW = reinterpret_cast<u32x4*>(smem);                 // [SH_WRING][SH_STAGE]
-  u32x4* ldsX = ldsW + SH_WRING * SH_STAGE;                     // [2][SH_STAGE]
+  u32x4* ldsW = reinterpret_cast<u32x4*>(smem);                 // [SH_WRING][SH_WSTAGE]
+  u32x4* ldsX = ldsW + SH_WRING * SH_WSTAGE;                    // [2][SH_STAGE]
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hw = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int per = gridDim.x >> 3;
-  const int lidx = (blockIdx.x & 7) * per + (blockIdx.x >> 3);   // XCD-aware order, see spectral_gemm_kernel
+  const int lidx = (blockIdx.x & 7) * per + (blockIdx.x >> 3);   // XCD-aware order
   if (lidx >= nunits) return;
   constexpr int NBH = SH_BINS / SH_WB;
   const int bh = lidx % NBH, lg = lidx / NBH;
   const int nbt = (NB + SH_NB - 1) / SH_NB;
-  const int half = lg & 1, bt = (lg >> 1) % nbt, g = (lg >> 1) / nbt;
+  const int bt = lg % nbt, g = lg / nbt;
   const int nb0 = bt * SH_NB, bin0 = g * SH_BINS + bh * SH_WB;
   const int KS = (C + SH_KC - 1) / SH_KC;
+  const int ot = wv & 3, pt = wv >> 2;        // the wave's tile: output channels 32 ot .., pairs 32 pt ..
+  const int wq = wv & 3, wh = wv >> 2;        // its share of the staging: quarter wq of output-channel half wh / channels 2 wh ..
 
-#if OS2D_SH_WAVE_BINS
-  // wave = one 32 x 32 (pairs x output channels) tile of ALL FOUR bins of the work-group (ot = output-channel tile, pt = pair
-  // tile): a lane then owns the 4 consecutive bins of a (pair, channel) row and stores them as 32 contiguous bytes.  Round 2
-  // gave a wave ONE bin of the whole 64 x 64 tile: 8-byte stores scattered over 32 rows per instruction - diagnostic builds
-  // (tools/diag_spectral.sh) put the stores at 0.12 ms of the launch's 0.39 ms at 64 pairs and 2.3 of 5.6 ms at 1024.
-  const int ot = wv & 1, pt = wv >> 1;
   f32x16 yr[SH_WB], yi[SH_WB];
 #pragma unroll
   for (int j = 0; j < SH_WB; ++j)
@@ -83,53 +94,48 @@ __global__ __launch_bounds__(SH_THR, 2) void spectral_gemm_f16_kernel(const u32x
       yr[j][r] = 0.f;
       yi[j][r] = 0.f;
     }
-#else
-  f32x16 yr[2][2], yi[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        yr[a][b][r] = 0.f;
-        yi[a][b][r] = 0.f;
-      }
-#endif
 
   typedef const void __attribute__((address_space(1))) * gptr_t;
   typedef void __attribute__((address_space(3))) * lptr_t;
-  // weights of k-step s for this work-group's 4 bins: 1024 contiguous units
-  const u32x4* wbase = w16 + ((size_t)(g * 2 + half) * KS) * (SH_BINS * 256) + bh * SH_STAGE;
-#ifdef OS2D_DIAG_SH_NOW      /* diagnostic: no weight DMA */
+  // weights of k-step s for this work-group's 4 bins: 1024 contiguous units per output-channel half (waves 0-3 stage half 0,
+  // waves 4-7 half 1)
+  const u32x4* wbase = w16 + ((size_t)(g * 2 + wh) * KS) * (SH_BINS * 256) + bh * SH_STAGE;
+#ifdef OS2D_DIAG_SH_NOW      /* diagnostic: no weight DMA (tools/diag_spectral.sh) */
 #define SH_DMA_W(S) {}
 #else
 #define SH_DMA_W(S)                                                                                                 \
   {                                                                                                                 \
     const u32x4* src_ = wbase + (size_t)(S) * (SH_BINS * 256);                                                      \
     _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) {                                                              \
-      const int u_ = (wv * 4 + k_) * 64;                                                                            \
-      __builtin_amdgcn_global_load_lds((gptr_t)(src_ + u_ + lane), (lptr_t)(ldsW + ((S) % SH_WRING) * SH_STAGE + u_), 16, 0, 0); \
+      const int u_ = (wq * 4 + k_) * 64;                                                                            \
+      __builtin_amdgcn_global_load_lds((gptr_t)(src_ + u_ + lane),                                                  \
+                                       (lptr_t)(ldsW + ((S) % SH_WRING) * SH_WSTAGE + wh * SH_STAGE + u_), 16, 0, 0); \
     }                                                                                                               \
   }
 #endif
-  // spectra of k-step s: this thread owns pair xn, bins 2 xj / 2 xj + 1 and the 4 channels of group xg.  A wave covers 16
-  // pairs x (2 bin pairs x 2 channel groups): the rows of different pairs lie 5 MB apart, and a load instruction that touches
-  // 64 of them (one pair per lane) spends its time in address translation, not in the memory system
-  const int xn = wv * 16 + (lane & 15), xj = (lane >> 4) & 1, xg = lane >> 5;
+  // spectra of k-step s: this thread owns pair xn, bins 2 xj / 2 xj + 1 and TWO channels (xg * 4 + wh * 2 + {0, 1}).  In the
+  // quad layout the 16 pairs x 2 bin pairs of a half-wave are 512 consecutive bytes
+  const int xn = wq * 16 + (lane & 15), xj = (lane >> 4) & 1, xg = lane >> 5;
   const bool xn_ok = nb0 + xn < NB;
+#ifdef OS2D_DIAG_SPECTRA_ROWS   /* diagnostic: the round-2 row layout X [C][NB][NBINS], Y [NB][Cout][NBINS] (A/B timing of the layouts) */
   const f32x2* xrow = X + (size_t)min(nb0 + xn, NB - 1) * NBINS + bin0 + 2 * xj;
-  u32x4 pfa[4], pfb[4];     // two k-steps of spectra in flight (even / odd k-steps)
-#ifdef OS2D_DIAG_SH_NOX      /* diagnostic: no global loads of the spectra (tools/diag_spectral.sh) */
+  const size_t xcs = (size_t)NB * NBINS;
+#else
+  const f32x2* xrow = X + ((size_t)(bin0 >> 2) * C * NB + min(nb0 + xn, NB - 1)) * 4 + 2 * xj;
+  const size_t xcs = (size_t)NB * 4;          // channel stride
+#endif
+  u32x4 pfa[2], pfb[2];     // two k-steps of spectra in flight (even / odd k-steps)
+#ifdef OS2D_DIAG_SH_NOX      /* diagnostic: no global loads of the spectra */
 #define SH_LOAD_X(S, pfx)                                                                                           \
   {                                                                                                                 \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) pfx[i_] = u32x4{(unsigned)(S), 1u, 2u, (unsigned)lane};        \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) pfx[i_] = u32x4{(unsigned)(S), 1u, 2u, (unsigned)lane};        \
   }
 #else
 #define SH_LOAD_X(S, pfx)                                                                                           \
   {                                                                                                                 \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                              \
-      const int c_ = min((S)*SH_KC + xg * 4 + i_, C - 1);                                                           \
-      pfx[i_] = *reinterpret_cast<const u32x4*>(xrow + (size_t)c_ * NB * NBINS);                                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                              \
+      const int c_ = min((S)*SH_KC + xg * 4 + wh * 2 + i_, C - 1);                                                  \
+      pfx[i_] = *reinterpret_cast<const u32x4*>(xrow + (size_t)c_ * xcs);                                           \
     }                                                                                                               \
   }
 #endif
@@ -147,30 +153,24 @@ __global__ __launch_bounds__(SH_THR, 2) void spectral_gemm_f16_kernel(const u32x
 #define SH_STORE_X(S, pfx)                                                                                          \
   {                                                                                                                 \
     _Pragma("unroll") for (int b2_ = 0; b2_ < 2; ++b2_) {                                                           \
-      half8 h_, l_;                                                                                                 \
-      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                            \
-        const bool ok_ = xn_ok && (S)*SH_KC + xg * 4 + i_ < C;                                                      \
+      half4 h_, l_;                                                                                                 \
+      _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                            \
+        const bool ok_ = xn_ok && (S)*SH_KC + xg * 4 + wh * 2 + i_ < C;                                             \
         _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_) {                                                          \
           const unsigned raw_ = pfx[i_][2 * b2_ + p_];   /* (scalar copy first: see the ext-vector note in corr_f16x3.hip) */ \
           SH_SPLIT_VALUE                                                                                            \
         }                                                                                                           \
       }                                                                                                             \
-      u32x4* dst_ = ldsX + ((S)&1) * SH_STAGE + (((2 * xj + b2_) * 2 + xg) * 2) * 64 + xn;                          \
-      *reinterpret_cast<half8*>(dst_) = h_;                                                                         \
-      *reinterpret_cast<half8*>(dst_ + 64) = l_;                                                                    \
+      char* dst_ = reinterpret_cast<char*>(ldsX + ((S)&1) * SH_STAGE + (((2 * xj + b2_) * 2 + xg) * 2) * 64 + xn) + wh * 8; \
+      *reinterpret_cast<half4*>(dst_) = h_;              /* channels 2 wh, 2 wh + 1 of the unit (re, im each) */      \
+      *reinterpret_cast<half4*>(dst_ + 64 * 16) = l_;                                                               \
     }                                                                                                               \
   }
-
-#ifdef OS2D_DIAG_SH_NOMFMA   /* diagnostic: fragments are read and derived, the matrix instructions are skipped */
-#define SH_MM(x_, y_, acc_) sh_keep(x_, y_, acc_)
-#else
-#define SH_MM(x_, y_, acc_) __builtin_amdgcn_mfma_f32_32x32x16_f16(x_, y_, acc_, 0, 0, 0)
-#endif
-#if OS2D_SH_WAVE_BINS
 #define SH_COMPUTE(S)                                                                                               \
   {                                                                                                                 \
-    const u32x4* aB = ldsW + ((S) % SH_WRING) * SH_STAGE + (hw * 2) * 64 + ot * 32 + l31; /* [bin][group = hw][hi|lo][o] */ \
-    const u32x4* bB = ldsX + ((S)&1) * SH_STAGE + (hw * 2) * 64 + pt * 32 + l31;          /* ... [pair] */                   \
+    /* [half][bin][group = hw][hi|lo][o 64] and [bin][group][hi|lo][pair 64] */                                     \
+    const u32x4* aB = ldsW + ((S) % SH_WRING) * SH_WSTAGE + (ot >> 1) * SH_STAGE + (hw * 2) * 64 + (ot & 1) * 32 + l31; \
+    const u32x4* bB = ldsX + ((S)&1) * SH_STAGE + (hw * 2) * 64 + pt * 32 + l31;                                    \
     _Pragma("unroll") for (int j = 0; j < SH_WB; ++j) {                                                             \
       const half8 bhf = *reinterpret_cast<const half8*>(bB + j * 256);                                              \
       const half8 blf = *reinterpret_cast<const half8*>(bB + j * 256 + 64);                                         \
@@ -193,40 +193,6 @@ __global__ __launch_bounds__(SH_THR, 2) void spectral_gemm_f16_kernel(const u32x
       yi[j] = SH_MM(bhf, aih, yi[j]);                                                                               \
     }                                                                                                               \
   }
-#else
-#define SH_COMPUTE(S)                                                                                               \
-  {                                                                                                                 \
-    const u32x4* aB = ldsW + ((S) % SH_WRING) * SH_STAGE + ((wv * 2 + hw) * 2) * 64 + l31; /* [bin = wv][group = hw][hi|lo][o] */ \
-    const u32x4* bB = ldsX + ((S)&1) * SH_STAGE + ((wv * 2 + hw) * 2) * 64 + l31;          /* ... [pair] */                    \
-    half8 bhf[2], blf[2];                                                                                           \
-    _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                                 \
-      bhf[b] = *reinterpret_cast<const half8*>(bB + b * 32);                                                        \
-      blf[b] = *reinterpret_cast<const half8*>(bB + 64 + b * 32);                                                   \
-    }                                                                                                               \
-    _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                                 \
-      const u32x4 kh = aB[a * 32], kl = aB[64 + a * 32]; /* [Kr, Ki] x 4 channels, hi and lo */                     \
-      u32x4 rh, rl, ih, il;                                                                                         \
-      _Pragma("unroll") for (int d = 0; d < 4; ++d) {                                                               \
-        rh[d] = kh[d] ^ 0x80000000u; /* [Kr, -Ki] */                                                                \
-        rl[d] = kl[d] ^ 0x80000000u;                                                                                \
-        ih[d] = __builtin_amdgcn_alignbit(kh[d], kh[d], 16); /* [Ki, Kr] */                                         \
-        il[d] = __builtin_amdgcn_alignbit(kl[d], kl[d], 16);                                                        \
-      }                                                                                                             \
-      const half8 arh = __builtin_bit_cast(half8, rh), arl = __builtin_bit_cast(half8, rl);                         \
-      const half8 aih = __builtin_bit_cast(half8, ih), ail = __builtin_bit_cast(half8, il);                         \
-      _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                 \
-        /* the spectra are the ROW operand: the accumulator registers run over the pairs, the lanes over the output channels - a \
-           store instruction then stays inside one pair's rows (22 KB apart) instead of touching 32 pairs (3 MB apart) */    \
-        yr[a][b] = SH_MM(bhf[b], arl, yr[a][b]);                          \
-        yr[a][b] = SH_MM(blf[b], arh, yr[a][b]);                          \
-        yr[a][b] = SH_MM(bhf[b], arh, yr[a][b]);                          \
-        yi[a][b] = SH_MM(bhf[b], ail, yi[a][b]);                          \
-        yi[a][b] = SH_MM(blf[b], aih, yi[a][b]);                          \
-        yi[a][b] = SH_MM(bhf[b], aih, yi[a][b]);                          \
-      }                                                                                                             \
-    }                                                                                                               \
-  }
-#endif
   // one k-step: spectra of step S+2 -> registers PN (the registers PC hold step S+1, loaded one step ago), weights of step
   // S + WRING - 1 -> LDS ring; multiply step S; split + store step S+1 into the other spectra buffer; barrier.  Per wave the
   // memory operations complete in issue order and the weights of a step are issued BEFORE its spectra: when the spectra of
@@ -265,203 +231,10 @@ __global__ __launch_bounds__(SH_THR, 2) void spectral_gemm_f16_kernel(const u32x
 #undef SH_DMA_W
 #undef SH_LOAD_X
 #undef SH_STORE_X
+#undef SH_SPLIT_VALUE
 
-  // ---- epilogue: undo the operand scales, Y[pair][o][bin] (as spectral_gemm_kernel)
-  const float inv_x = 1.0f / xscale;
-#if OS2D_SH_WAVE_BINS
-  {
-    const int o = half * SH_OH + ot * 32 + l31;
-    if (o < Cout) {
-      const float sc = wscale[o] * inv_x;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int nb = nb0 + pt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hw;
-#ifdef OS2D_DIAG_SH_NOY       /* diagnostic: no output stores (kept alive by an impossible condition) */
-        if (nb < NB && yr[0][r] == 123.456f) {
-#else
-        if (nb < NB) {
-#endif
-          // bins bin0 .. bin0 + 3 of row (nb, o): 32 contiguous, 32-byte aligned bytes (bin0 is a multiple of 4, NBINS of 8)
-          float4* dst = reinterpret_cast<float4*>(Y + ((size_t)nb * Cout + o) * NBINS + bin0);
-          dst[0] = make_float4(yr[0][r] * sc, yi[0][r] * sc, yr[1][r] * sc, yi[1][r] * sc);
-          dst[1] = make_float4(yr[2][r] * sc, yi[2][r] * sc, yr[3][r] * sc, yi[3][r] * sc);
-        }
-      }
-    }
-  }
-#else
-  const int bin = bin0 + wv;
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int o = half * SH_OH + a * 32 + l31;
-    if (o >= Cout) continue;
-    const float sc = wscale[o] * inv_x;
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int nb = nb0 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hw;
-#ifdef OS2D_DIAG_SH_NOY       /* diagnostic: no output stores (kept alive by an impossible condition) */
-        if (nb < NB && yr[a][b][r] == 123.456f) {
-#else
-        if (nb < NB) {
-#endif
-          const float vr = yr[a][b][r], vi = yi[a][b][r];
-          Y[((size_t)nb * Cout + o) * NBINS + bin] = f32x2{vr * sc, vi * sc};
-        }
-      }
-  }
-#endif
-}
-
-
-// ---- the same with ONE 8-wave work-group per (bin quad, pair tile): both output-channel halves share the spectra stage, so
-// the spectra are fetched, scaled and split ONCE per 128 output channels instead of once per 64 (diagnostic builds put the
-// spectra loads at 0.10 of the launch's 0.39 ms at 64 pairs and 2.5 of 5.6 ms at 1024, tools/diag_spectral.sh).  Waves:
-// ot = wv & 3 (output-channel tile of 32), pt = wv >> 2 (pair tile of 32), all four bins each (as above).  LDS: weight ring
-// 3 x 32 KB ([half][bin][group][hi|lo][64]) + spectra 2 x 16 KB = 128 KB: one work-group (8 waves) per CU.
-#ifndef OS2D_SH_WG8
-#define OS2D_SH_WG8 1
-#endif
-#if OS2D_SH_WG8
-constexpr int S8_THR = 512;
-constexpr int S8_WSTAGE = 2 * SH_STAGE;
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-
-__global__ __launch_bounds__(S8_THR, 1) void spectral_gemm_f16_kernel8(const u32x4* w16, const float* __restrict__ wscale,
-                                                                       const f32x2* __restrict__ X, f32x2* __restrict__ Y, int NB,
-                                                                       int C, int Cout, int NBINS, int G, float xscale, int nunits) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u32x4* ldsW = reinterpret_cast<u32x4*>(smem);                 // [SH_WRING][S8_WSTAGE]
-  u32x4* ldsX = ldsW + SH_WRING * S8_WSTAGE;                    // [2][SH_STAGE]
-  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hw = lane >> 5;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int per = gridDim.x >> 3;
-  const int lidx = (blockIdx.x & 7) * per + (blockIdx.x >> 3);   // XCD-aware order: the class tiles of a bin group share an L2
-  if (lidx >= nunits) return;
-  constexpr int NBH = SH_BINS / SH_WB;
-  const int bh = lidx % NBH, lg = lidx / NBH;
-  const int nbt = (NB + SH_NB - 1) / SH_NB;
-  const int bt = lg % nbt, g = lg / nbt;
-  const int nb0 = bt * SH_NB, bin0 = g * SH_BINS + bh * SH_WB;
-  const int KS = (C + SH_KC - 1) / SH_KC;
-  const int ot = wv & 3, pt = wv >> 2, wq = wv & 3, wh = wv >> 2;
-  f32x16 yr[SH_WB], yi[SH_WB];
-#pragma unroll
-  for (int j = 0; j < SH_WB; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      yr[j][r] = 0.f;
-      yi[j][r] = 0.f;
-    }
-  typedef const void __attribute__((address_space(1))) * gptr_t;
-  typedef void __attribute__((address_space(3))) * lptr_t;
-  // weights: waves 0-3 stage the 1024 units of output-channel half 0, waves 4-7 those of half 1
-  const u32x4* wbase = w16 + ((size_t)(g * 2 + wh) * KS) * (SH_BINS * 256) + bh * SH_STAGE;
-#ifdef OS2D_DIAG_SH_NOW
-#define S8_DMA_W(S) {}
-#else
-#define S8_DMA_W(S)                                                                                                 \
-  {                                                                                                                 \
-    const u32x4* src_ = wbase + (size_t)(S) * (SH_BINS * 256);                                                      \
-    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) {                                                              \
-      const int u_ = (wq * 4 + k_) * 64;                                                                            \
-      __builtin_amdgcn_global_load_lds((gptr_t)(src_ + u_ + lane),                                                  \
-                                       (lptr_t)(ldsW + ((S) % SH_WRING) * S8_WSTAGE + wh * SH_STAGE + u_), 16, 0, 0); \
-    }                                                                                                               \
-  }
-#endif
-  // spectra: this thread owns pair xn, bins 2 xj / 2 xj + 1 and TWO channels (xg * 4 + wh * 2 + {0, 1}) of the k-step
-  const int xn = wq * 16 + (lane & 15), xj = (lane >> 4) & 1, xg = lane >> 5;
-  const bool xn_ok = nb0 + xn < NB;
-  const f32x2* xrow = X + (size_t)min(nb0 + xn, NB - 1) * NBINS + bin0 + 2 * xj;
-  u32x4 pfa[2], pfb[2];
-#ifdef OS2D_DIAG_SH_NOX
-#define S8_LOAD_X(S, pfx)                                                                                           \
-  {                                                                                                                 \
-    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) pfx[i_] = u32x4{(unsigned)(S), 1u, 2u, (unsigned)lane};        \
-  }
-#else
-#define S8_LOAD_X(S, pfx)                                                                                           \
-  {                                                                                                                 \
-    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                              \
-      const int c_ = min((S)*SH_KC + xg * 4 + wh * 2 + i_, C - 1);                                                  \
-      pfx[i_] = *reinterpret_cast<const u32x4*>(xrow + (size_t)c_ * NB * NBINS);                                    \
-    }                                                                                                               \
-  }
-#endif
-#define S8_STORE_X(S, pfx)                                                                                          \
-  {                                                                                                                 \
-    _Pragma("unroll") for (int b2_ = 0; b2_ < 2; ++b2_) {                                                           \
-      half4 h_, l_;                                                                                                 \
-      _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                            \
-        const bool ok_ = xn_ok && (S)*SH_KC + xg * 4 + wh * 2 + i_ < C;                                             \
-        _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_) {                                                          \
-          const unsigned raw_ = pfx[i_][2 * b2_ + p_];                                                              \
-          SH_SPLIT_VALUE                                                                                            \
-        }                                                                                                           \
-      }                                                                                                             \
-      char* dst_ = reinterpret_cast<char*>(ldsX + ((S)&1) * SH_STAGE + (((2 * xj + b2_) * 2 + xg) * 2) * 64 + xn) + wh * 8; \
-      *reinterpret_cast<half4*>(dst_) = h_;              /* the unit's channels 2 wh, 2 wh + 1 (re, im each) */      \
-      *reinterpret_cast<half4*>(dst_ + 64 * 16) = l_;                                                               \
-    }                                                                                                               \
-  }
-#define S8_COMPUTE(S)                                                                                               \
-  {                                                                                                                 \
-    const u32x4* aB = ldsW + ((S) % SH_WRING) * S8_WSTAGE + (ot >> 1) * SH_STAGE + (hw * 2) * 64 + (ot & 1) * 32 + l31; \
-    const u32x4* bB = ldsX + ((S)&1) * SH_STAGE + (hw * 2) * 64 + pt * 32 + l31;                                    \
-    _Pragma("unroll") for (int j = 0; j < SH_WB; ++j) {                                                             \
-      const half8 bhf = *reinterpret_cast<const half8*>(bB + j * 256);                                              \
-      const half8 blf = *reinterpret_cast<const half8*>(bB + j * 256 + 64);                                         \
-      const u32x4 kh = aB[j * 256], kl = aB[j * 256 + 64];                                                          \
-      u32x4 rh, rl, ih, il;                                                                                         \
-      _Pragma("unroll") for (int d = 0; d < 4; ++d) {                                                               \
-        rh[d] = kh[d] ^ 0x80000000u;                                                                                \
-        rl[d] = kl[d] ^ 0x80000000u;                                                                                \
-        ih[d] = __builtin_amdgcn_alignbit(kh[d], kh[d], 16);                                                        \
-        il[d] = __builtin_amdgcn_alignbit(kl[d], kl[d], 16);                                                        \
-      }                                                                                                             \
-      const half8 arh = __builtin_bit_cast(half8, rh), arl = __builtin_bit_cast(half8, rl);                         \
-      const half8 aih = __builtin_bit_cast(half8, ih), ail = __builtin_bit_cast(half8, il);                         \
-      yr[j] = SH_MM(bhf, arl, yr[j]);                                                                               \
-      yr[j] = SH_MM(blf, arh, yr[j]);                                                                               \
-      yr[j] = SH_MM(bhf, arh, yr[j]);                                                                               \
-      yi[j] = SH_MM(bhf, ail, yi[j]);                                                                               \
-      yi[j] = SH_MM(blf, aih, yi[j]);                                                                               \
-      yi[j] = SH_MM(bhf, aih, yi[j]);                                                                               \
-    }                                                                                                               \
-  }
-#define S8_STEP(S, PC, PN)                                                                                          \
-  {                                                                                                                 \
-    if ((S) + SH_WRING - 1 < KS) S8_DMA_W((S) + SH_WRING - 1)                                                       \
-    if ((S) + 2 < KS) S8_LOAD_X((S) + 2, PN)                                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                                              \
-    S8_COMPUTE(S)                                                                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                                              \
-    if ((S) + 1 < KS) S8_STORE_X((S) + 1, PC)                                                                       \
-    sh_lds_barrier();                                                                                               \
-  }
-  S8_DMA_W(0)
-  S8_LOAD_X(0, pfb)
-  if (1 < KS) {
-    S8_DMA_W(1)
-    S8_LOAD_X(1, pfa)
-  }
-#pragma unroll
-  for (int s = 2; s < SH_WRING - 1; ++s)
-    if (s < KS) S8_DMA_W(s)
-  S8_STORE_X(0, pfb)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  sh_lds_barrier();
-  for (int s = 0; s < KS; s += 2) {
-    S8_STEP(s, pfa, pfb)
-    if (s + 1 < KS) S8_STEP(s + 1, pfb, pfa)
-  }
-#undef S8_STEP
-#undef S8_COMPUTE
-#undef S8_DMA_W
-#undef S8_LOAD_X
-#undef S8_STORE_X
+  // ---- epilogue: undo the operand scales; Y[bin / 4][pair][o][bin % 4]: the lane's 4 bins are 32 contiguous bytes, the 32
+  // lanes of a half-wave (32 consecutive output channels of one pair) 1 KB
   const float inv_x = 1.0f / xscale;
   const int o = ot * 32 + l31;
   if (o < Cout) {
@@ -469,19 +242,22 @@ __global__ __launch_bounds__(S8_THR, 1) void spectral_gemm_f16_kernel8(const u32
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int nb = nb0 + pt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hw;
-#ifdef OS2D_DIAG_SH_NOY
+#ifdef OS2D_DIAG_SH_NOY       /* diagnostic: no output stores (kept alive by an impossible condition) */
       if (nb < NB && yr[0][r] == 123.456f) {
 #else
       if (nb < NB) {
 #endif
+#ifdef OS2D_DIAG_SPECTRA_ROWS
         float4* dst = reinterpret_cast<float4*>(Y + ((size_t)nb * Cout + o) * NBINS + bin0);
+#else
+        float4* dst = reinterpret_cast<float4*>(Y + (((size_t)(bin0 >> 2) * NB + nb) * Cout + o) * 4);
+#endif
         dst[0] = make_float4(yr[0][r] * sc, yi[0][r] * sc, yr[1][r] * sc, yi[1][r] * sc);
         dst[1] = make_float4(yr[2][r] * sc, yi[2][r] * sc, yr[3][r] * sc, yi[3][r] * sc);
       }
     }
   }
 }
-#endif
 
 }  // namespace
 
@@ -491,7 +267,7 @@ size_t os2d_spectral_weight16_size(int C, int NBINS) {
   return (size_t)(NBINS / SH_BINS) * 2 * KS * SH_BINS * 256 * 16 + 128 * sizeof(float);
 }
 
-// largest power-of-two scale of the input spectra that cannot overflow fp16: |X| <= H * W
+// largest power-of-two scale of the input spectra that cannot overflow fp16: |X| <= H * W (samples of one transform window)
 float os2d_spectral_xscale_for(int H, int W) {
   float s = 1.0f;
   while (s * 2.0f * (float)H * (float)W <= 65504.0f) s *= 2.0f;
@@ -505,37 +281,19 @@ int os2d_launch_spectral_gemm_f16(const void* w16, const float* X, float* Y, int
     return -3;
   }
   const int G = NBINS / SH_BINS, nbt = (NB + SH_NB - 1) / SH_NB;
+  const size_t lds = (size_t)(SH_WRING * SH_WSTAGE + 2 * SH_STAGE) * 16;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spectral_gemm_f16_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) {
+    os2d_set_error("hipFuncSetAttribute(spectral_gemm_f16): %s", hipGetErrorString(e));
+    return -4;
+  }
+  const long long units = (long long)G * nbt * (SH_BINS / SH_WB);
   const size_t KS = (size_t)(C + SH_KC - 1) / SH_KC;
   const float* wscale = reinterpret_cast<const float*>(static_cast<const char*>(w16) + (size_t)G * 2 * KS * SH_BINS * 256 * 16);
-  hipError_t e;
-#if OS2D_SH_WG8
-  {
-    const size_t lds = (size_t)(SH_WRING * S8_WSTAGE + 2 * SH_STAGE) * 16;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(spectral_gemm_f16_kernel8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      os2d_set_error("hipFuncSetAttribute(spectral_gemm_f16): %s", hipGetErrorString(e));
-      return -4;
-    }
-    const long long units = (long long)G * nbt * (SH_BINS / SH_WB);
-    dim3 grid((unsigned)((units + 7) / 8 * 8));
-    hipLaunchKernelGGL(spectral_gemm_f16_kernel8, grid, dim3(S8_THR), lds, stream, static_cast<const u32x4*>(w16), wscale,
-                       reinterpret_cast<const f32x2*>(X), reinterpret_cast<f32x2*>(Y), NB, C, Cout, NBINS, G, xscale, (int)units);
-  }
-#else
-  {
-    const size_t lds = (size_t)(SH_WRING + 2) * SH_STAGE * 16;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(spectral_gemm_f16_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      os2d_set_error("hipFuncSetAttribute(spectral_gemm_f16): %s", hipGetErrorString(e));
-      return -4;
-    }
-    const long long units = 2LL * G * nbt * (SH_BINS / SH_WB);
-    dim3 grid((unsigned)((units + 7) / 8 * 8));
-    hipLaunchKernelGGL(spectral_gemm_f16_kernel, grid, dim3(SH_THR), lds, stream, static_cast<const u32x4*>(w16), wscale,
-                       reinterpret_cast<const f32x2*>(X), reinterpret_cast<f32x2*>(Y), NB, C, Cout, NBINS, G, xscale, (int)units);
-  }
-#endif
+  dim3 grid((unsigned)((units + 7) / 8 * 8));
+  hipLaunchKernelGGL(spectral_gemm_f16_kernel, grid, dim3(SH_THR), lds, stream, static_cast<const u32x4*>(w16), wscale,
+                     reinterpret_cast<const f32x2*>(X), reinterpret_cast<f32x2*>(Y), NB, C, Cout, NBINS, G, xscale, (int)units);
   e = hipGetLastError();
   if (e != hipSuccess) {
     os2d_set_error("spectral_gemm_f16 launch: %s", hipGetErrorString(e));

@@ -241,18 +241,16 @@ int os2d_fft_forward(const float* corr, const float* inv_norm, float* X, const f
                      int H, int W, void* stream);
 int os2d_fft_inverse(const float* Y, const float* packed_b, void* out, const float* twQ, const float* twP, int NB, int Cout,
                      int H, int W, int* status, void* stream);
-/* Layout of the spectra between the transforms and the per-bin GEMM.  The transforms want the bins of one (pair, channel)
- * together, the GEMM the pairs / channels of one bin: one side has to gather.
- *   OS2D_SPECTRA_ROWS   X [C,NBT,nbins], Y [NBT,Cout,nbins] (above): contiguous for the transforms; os2d_spectral_gemm
- *   OS2D_SPECTRA_QUADS  X [nbins/4, C, NBT, 4], Y [nbins/4, NBT, Cout, 4]: the 4 bins x 64 pairs a GEMM work-group needs of a
- *                       channel are 2 KB of consecutive bytes and its output rows of a pair 4 KB (64-lane loads / stores that
- *                       touch 1 - 2 runs instead of 32 pieces 22 KB apart), the transforms write / read 32-byte pieces;
- *                       os2d_spectral_gemm_f16 (measured in round 3: the scattered loads and stores were 0.22 of the GEMM's
- *                       0.39 ms at 64 pairs and 4.8 of 5.6 ms at 1024)                                                    */
+/* Layout of the OUTPUT spectra between the per-bin GEMM and the inverse transform.  The transform wants the bins of one
+ * (pair, channel) together, the GEMM the pairs / channels of one bin: one side has to gather.
+ *   OS2D_SPECTRA_ROWS   Y [NBT,Cout,nbins] (above): contiguous for the transform; os2d_spectral_gemm writes it
+ *   OS2D_SPECTRA_QUADS  Y [nbins/4, NBT, Cout, 4]: the output rows of a pair for 4 bins are 4 KB of consecutive bytes (a 64-lane
+ *                       store of the GEMM writes two 1 KB runs instead of 64 pieces 22 KB apart), the inverse transform gathers
+ *                       32-byte pieces; os2d_spectral_gemm_f16 writes it (round 3: the scattered stores were 0.12 of the GEMM's
+ *                       0.39 ms at 64 pairs and 2.3 of 5.6 ms at 1024; the inverse transform takes 0.198 ms either way).
+ * The input spectra X are always [C,NBT,nbins].                                                                           */
 #define OS2D_SPECTRA_ROWS 0
 #define OS2D_SPECTRA_QUADS 1
-int os2d_fft_forward_ex(const float* corr, const float* inv_norm, float* X, const float* twQ, const float* twP, int NB, int C,
-                        int H, int W, int layout, void* stream);
 int os2d_fft_inverse_ex(const float* Y, const float* packed_b, void* out, const float* twQ, const float* twP, int NB, int Cout,
                         int H, int W, int* status, int layout, void* stream);
 int os2d_spectral_gemm(const float* wspec, const float* X, float* Y, int NB, int C, int Cout, int nbins, void* stream);
@@ -262,7 +260,8 @@ int os2d_spectral_gemm(const float* wspec, const float* X, float* Y, int NB, int
  * os2d_spectral_weight16_bytes(C, nbins) bytes.  The input spectra are scaled by os2d_spectral_xscale(H, W) (largest power of
  * two with xscale * H * W <= 65504: |X| <= H * W because every sample of the normalised maps is <= 1) and split on the fly;
  * Y is returned unscaled, with the values os2d_spectral_gemm returns (up to the 2^-22 relative error of a split product).
- * X and Y are in the OS2D_SPECTRA_QUADS layout (X [nbins/4, C, NB, 4], Y [nbins/4, NB, Cout, 4] complex64).              */
+ * X is [C, NB, nbins] as for os2d_spectral_gemm; Y is written in the OS2D_SPECTRA_QUADS layout ([nbins/4, NB, Cout, 4]
+ * complex64): hand it to os2d_fft_inverse_ex(..., OS2D_SPECTRA_QUADS).                                                    */
 size_t os2d_spectral_weight16_bytes(int C, int nbins);
 float os2d_spectral_xscale(int H, int W);
 int os2d_spectral_gemm_f16(const void* w16, const float* X, float* Y, int NB, int C, int Cout, int nbins, float xscale,

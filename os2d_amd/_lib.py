@@ -46,7 +46,6 @@ SIGNATURES = {
     "os2d_fft_tiles": (_i, [_i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "os2d_fft_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "os2d_fft_inverse": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "os2d_fft_forward_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "os2d_fft_inverse_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "os2d_class_split": (_i, [_vp, _vp, _i, _i, _vp]),
     "os2d_class_split_bytes": (_sz, [_i, _i]),

@@ -444,13 +444,13 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
       // per bin on the fp32 matrix cores -> inverse FFT + bias + ReLU + split into the activation buffer of the 5x5 layer
       if ((rc = os2d_launch_border_zero_shb_planes(h1, NB * 16 * 2, H, W, st))) return rc;
       mark(b0, 10);
-      // the split-half GEMM reads / writes the spectra in quads of bins (include/os2d_hip.h, OS2D_SPECTRA_QUADS)
+      // the split-half GEMM writes its output spectra in quads of bins (include/os2d_hip.h, OS2D_SPECTRA_QUADS)
 #ifdef OS2D_DIAG_SPECTRA_ROWS
       const int layout = OS2D_SPECTRA_ROWS;
 #else
       const int layout = precision == OS2D_PRECISION_FFTX3 ? OS2D_SPECTRA_QUADS : OS2D_SPECTRA_ROWS;
 #endif
-      if ((rc = os2d_launch_fft_forward(corr, invn, xspec, twQ, twP, NB, OS2D_K, H, W, layout, st))) return rc;
+      if ((rc = os2d_launch_fft_forward(corr, invn, xspec, twQ, twP, NB, OS2D_K, H, W, st))) return rc;
       mark(b0, 11);
       if (precision == OS2D_PRECISION_FFTX3) {
         // |X| <= number of samples of a window (every sample of the normalised maps is <= 1): tiles[4] x tiles[5]
@@ -609,19 +609,13 @@ int os2d_fft_tiles(int H, int W, int* tiles_y, int* tiles_x, int* tile_h, int* t
   return 0;
 }
 
-int os2d_fft_forward_ex(const float* corr, const float* inv_norm, float* X, const float* twQ, const float* twP, int NB, int C,
-                        int H, int W, int layout, void* stream) {
-  if (!corr || !inv_norm || !X || !twQ || !twP || NB < 1 || C < 1 || H < 1 || W < 1 ||
-      (layout != OS2D_SPECTRA_ROWS && layout != OS2D_SPECTRA_QUADS)) {
+int os2d_fft_forward(const float* corr, const float* inv_norm, float* X, const float* twQ, const float* twP, int NB, int C,
+                     int H, int W, void* stream) {
+  if (!corr || !inv_norm || !X || !twQ || !twP || NB < 1 || C < 1 || H < 1 || W < 1) {
     os2d_set_error("os2d_fft_forward: bad arguments");
     return -1;
   }
-  return os2d_launch_fft_forward(corr, inv_norm, X, twQ, twP, NB, C, H, W, layout, S(stream));
-}
-
-int os2d_fft_forward(const float* corr, const float* inv_norm, float* X, const float* twQ, const float* twP, int NB, int C,
-                     int H, int W, void* stream) {
-  return os2d_fft_forward_ex(corr, inv_norm, X, twQ, twP, NB, C, H, W, OS2D_SPECTRA_ROWS, stream);
+  return os2d_launch_fft_forward(corr, inv_norm, X, twQ, twP, NB, C, H, W, S(stream));
 }
 
 int os2d_fft_inverse_ex(const float* Y, const float* packed_b, void* out, const float* twQ, const float* twP, int NB, int Cout,

@@ -196,13 +196,10 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 6 ? 4 : 2) void fft_forward_ker
                                                              const float* __restrict__ inv,    // [NB][H*W]
                                                              f32x2* __restrict__ X,            // [C][NB][NBINS]
                                                              const f32x2* __restrict__ twQ, const f32x2* __restrict__ twP,
-                                                             FftPlan pl, int C, int H, int W, int NBINS, int images, int quad,
-                                                             unsigned inv_nbt) {
-  // images = NB * C * T.  Row layout (quad == 0): iteration `it` -> map it / T (= nb * C + c), tile it % T, spectra written as
-  // X[c][pair'][bin] (pair' = nb * T + tile).  Quad layout (quad == 1, what os2d_spectral_gemm_f16 reads): X[bin / 4][c][pair']
-  // [bin % 4] - the 64 pairs x 4 bins a GEMM work-group needs of a channel are 2 KB of consecutive bytes instead of 64 pieces
-  // of 32 bytes 22 KB apart; iterations then run pair-fastest (it -> channel it / NBT, pair' it % NBT), so that the 32-byte
-  // pieces of a 128-byte line (4 neighbouring pairs) are written by work-groups that run at about the same time
+                                                             FftPlan pl, int C, int H, int W, int NBINS, int images) {
+  // images = NB * C * T: iteration `it` -> map it / T (= nb * C + c), tile it % T; spectra written as X[c][pair'][bin] with
+  // pair' = nb * T + tile.  (Round 3 also tried X in quads of bins like Y below: the split-half GEMM's loads got 0.03 ms
+  // cheaper per 64 pairs and this kernel's stores - 688 pieces of 32 bytes 460 KB apart per image - 0.04 ms dearer.)
   const int NBT = images / C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int P = pl.P, Q = pl.Q, V = pl.V, PS = pl.PS, QS = pl.QS, HP = (pl.LH + 1) >> 1, HW = H * W, LH = pl.LH, LW = pl.LW;
@@ -225,11 +222,7 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 6 ? 4 : 2) void fft_forward_ker
   // index (a multiply-high each): held across the image loop they cost 3 registers per element and spill
   // the tile's window starts at map row Y0 / column X0 (negative along a tiled axis: the halo above / left of the map is zero)
 #define FFT_TILE(IT)                                                                                              \
-  const int cq_ = div_magic((IT), inv_nbt), pq_ = (IT)-cq_ * NBT;         /* quad order: (channel, pair') */       \
-  const int mr_ = TILED ? div_magic((IT), pl.inv_t) : (IT);               /* row order: (map, tile) */             \
-  const int nbq_ = TILED ? div_magic(pq_, pl.inv_t) : pq_;                                                        \
-  const int m_ = quad ? nbq_ * C + cq_ : mr_;                                                                     \
-  const int t_ = TILED ? (quad ? pq_ - nbq_ * pl.T : (IT)-mr_ * pl.T) : 0;                                        \
+  const int m_ = TILED ? div_magic((IT), pl.inv_t) : (IT), t_ = TILED ? (IT)-m_ * pl.T : 0;                       \
   const int ty_ = TILED ? div_magic(t_, pl.inv_tx) : 0, tx_ = TILED ? t_ - ty_ * pl.TX : 0;                       \
   const int Y0 = TILED ? ty_ * pl.TH - pl.oy : 0, X0 = TILED ? tx_ * pl.TW - pl.ox : 0;
 #define FFT_ELEM(TID, K)                                                                                          \
@@ -303,17 +296,7 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 6 ? 4 : 2) void fft_forward_ker
     // ---- store the half spectrum (bin = u * V + v, v fastest) + zero padding bins
     const int nb_ = m_ / C, ch_ = m_ - nb_ * C;
     const size_t pair_ = TILED ? (size_t)nb_ * pl.T + t_ : (size_t)nb_;
-    if (quad) {
-      // X[bin / 4][c][pair'][bin % 4]: 4 neighbouring lanes fill one 32-byte piece
-      f32x2* dst = X + ((size_t)ch_ * NBT + pair_) * 4;
-      const size_t qstride = (size_t)C * NBT * 4;
-      for (int u = wv; u < P; u += NWV)
-        for (int v = lane; v < V; v += 64) {
-          const int b = u * V + v;
-          dst[(size_t)(b >> 2) * qstride + (b & 3)] = Rc[v * PS + u];
-        }
-      for (int i = P * V + tid; i < NBINS; i += FFT_THR) dst[(size_t)(i >> 2) * qstride + (i & 3)] = f32x2{0.f, 0.f};
-    } else {
+    {
       // X[c][pair'][bin]: the 64 pairs a GEMM work-group reads for one channel lie in ONE 1.4 MB stretch (22 KB apart), not 5 MB
       // apart - its load instructions then need one address translation instead of one per pair
       f32x2* dst = X + ((size_t)ch_ * NBT + pair_) * NBINS;
@@ -341,6 +324,7 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
   // images = NB * T * Cout: image -> (pair' = nb * T + tile, output channel); RH = rows of the inverse that are needed.
   // quad == 0: Y[pair'][o][bin]; quad == 1 (what os2d_spectral_gemm_f16 writes): Y[bin / 4][pair'][o][bin % 4] - the GEMM
   // then stores 1 KB runs (32 lanes = 32 consecutive output channels x 32 bytes) and this kernel gathers 32-byte pieces
+  // (its loads are prefetched a whole image ahead: measured 0.198 ms per 64 pairs in either layout)
   const int NBT = images / Cout;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int P = pl.P, Q = pl.Q, V = pl.V, PS = pl.PS, QS = pl.QS, RH = pl.RH, HP = (RH + 1) >> 1;
@@ -680,7 +664,7 @@ int os2d_fft_plan(int H, int W, int* P, int* Q, int* nbins, int* tiles) {
 }
 
 int os2d_launch_fft_forward(const float* corr, const float* inv, float* X, const float* twQ, const float* twP, int NB, int C,
-                            int H, int W, int layout, hipStream_t stream) {
+                            int H, int W, hipStream_t stream) {
   FftPlan pl;
   size_t lds;
   if (!make_plan(H, W, &pl, &lds)) {
@@ -703,7 +687,7 @@ int os2d_launch_fft_forward(const float* corr, const float* inv, float* X, const
   const int grid = images < 256 * per_cu * 4 ? images : 256 * per_cu * 4;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(FFT_THR), lds, stream, corr, inv, reinterpret_cast<f32x2*>(X),
                      reinterpret_cast<const f32x2*>(twQ), reinterpret_cast<const f32x2*>(twP), pl, C, H, W,
-                     os2d_round_up(pl.P * pl.V, 8), images, layout ? 1 : 0, magic_div((unsigned)(NB * pl.T)));
+                     os2d_round_up(pl.P * pl.V, 8), images);
   return check("fft_forward");
 }
 

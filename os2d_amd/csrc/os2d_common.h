@@ -149,9 +149,9 @@ int os2d_launch_detect_level(const float* loc, const float* cls, int B, int H, i
 // fft.hip
 int os2d_fft_plan(int H, int W, int* P, int* Q, int* nbins, int* tiles /* [6]: TY, TX, TH, TW, window rows, window columns */);
 int os2d_launch_fft_forward(const float* corr, const float* inv, float* X, const float* twQ, const float* twP, int NB, int C,
-                            int H, int W, int layout /* OS2D_SPECTRA_ROWS | OS2D_SPECTRA_QUADS */, hipStream_t stream);
+                            int H, int W, hipStream_t stream);
 int os2d_launch_fft_inverse(const float* Y, const float* bp, int MTP, void* out, const float* twQ, const float* twP, int NB,
-                            int Cout, int H, int W, int* status, int layout, hipStream_t stream);
+                            int Cout, int H, int W, int* status, int layout /* OS2D_SPECTRA_ROWS | OS2D_SPECTRA_QUADS */, hipStream_t stream);
 // spectral.hip
 size_t os2d_spectral_weight_floats(int C, int Cout, int NBINS);
 int os2d_launch_spectral_gemm(const float* wspec, const float* X, float* Y, int NB, int C, int Cout, int NBINS,

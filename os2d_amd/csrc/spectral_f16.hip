@@ -24,9 +24,11 @@
 //   wave = a 32 x 32 (pairs x output channels) tile of all FOUR bins (ot = wv & 3, pt = wv >> 2): a lane owns the 4 bins of a
 //     (pair, channel) row = 32 contiguous bytes (round 2: a wave = one bin of the whole tile, 8-byte stores; the stores were
 //     0.12 of the 0.39 ms, 2.3 of the 5.6 ms);
-//   spectra in the QUAD layout (include/os2d_hip.h, OS2D_SPECTRA_QUADS): X [bins/4][c][pair][4], Y [bins/4][pair][o][4] - a
-//     load instruction of this kernel touches two 512-byte runs (16 pairs x 32 B for two channel groups) instead of 32 pieces
-//     of 32 bytes 22 KB apart, a store instruction two 1 KB runs (32 output channels x 32 B for two pairs) instead of 64 pieces.
+//   output spectra in QUADS of bins (include/os2d_hip.h, OS2D_SPECTRA_QUADS): Y [bins/4][pair][o][4] - a store instruction
+//     writes two 1 KB runs (32 output channels x 32 B for two pairs) instead of 64 pieces 22 KB apart; the inverse transform
+//     gathers 32-byte pieces at no measurable cost (its loads run a whole image ahead).  The INPUT spectra stay in rows
+//     X [c][pair][bin]: in quads this kernel's loads were 0.03 ms cheaper per 64 pairs, but the forward transform's stores
+//     (688 pieces of 32 bytes per image, 460 KB apart) 0.04 ms dearer (profiles/r03_spectral_layouts.txt).
 // XCD-aware order: the pair tiles of a bin group (which share the weight spectra) run on one XCD at about the same time.
 #include "os2d_common.h"
 
@@ -65,7 +67,7 @@ __device__ __forceinline__ void sh_lds_barrier() { asm volatile("s_waitcnt lgkmc
 
 __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x4* w16,            // [G][2][KS][8][2][2][64] units
                                                                       const float* __restrict__ wscale,  // [128] 2^-wexp[o]
-                                                                      const f32x2* __restrict__ X,       // [NBINS/4][C][NB][4]
+                                                                      const f32x2* __restrict__ X,       // [C][NB][NBINS]
                                                                       f32x2* __restrict__ Y,             // [NBINS/4][NB][Cout][4]
                                                                       int NB, int C, int Cout, int NBINS, int G, float xscale,
                                                                       int nunits) {
@@ -113,17 +115,13 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
     }                                                                                                               \
   }
 #endif
-  // spectra of k-step s: this thread owns pair xn, bins 2 xj / 2 xj + 1 and TWO channels (xg * 4 + wh * 2 + {0, 1}).  In the
-  // quad layout the 16 pairs x 2 bin pairs of a half-wave are 512 consecutive bytes
+  // spectra of k-step s: this thread owns pair xn, bins 2 xj / 2 xj + 1 and TWO channels (xg * 4 + wh * 2 + {0, 1}).  A wave
+  // covers 16 pairs x (2 bin pairs x 2 channel groups): with one pair per lane a load instruction would touch 64 rows 5 MB
+  // apart and spend its time in address translation, not in the memory system
   const int xn = wq * 16 + (lane & 15), xj = (lane >> 4) & 1, xg = lane >> 5;
   const bool xn_ok = nb0 + xn < NB;
-#ifdef OS2D_DIAG_SPECTRA_ROWS   /* diagnostic: the round-2 row layout X [C][NB][NBINS], Y [NB][Cout][NBINS] (A/B timing of the layouts) */
   const f32x2* xrow = X + (size_t)min(nb0 + xn, NB - 1) * NBINS + bin0 + 2 * xj;
-  const size_t xcs = (size_t)NB * NBINS;
-#else
-  const f32x2* xrow = X + ((size_t)(bin0 >> 2) * C * NB + min(nb0 + xn, NB - 1)) * 4 + 2 * xj;
-  const size_t xcs = (size_t)NB * 4;          // channel stride
-#endif
+  const size_t xcs = (size_t)NB * NBINS;      // channel stride of X [C][NB][NBINS]
   u32x4 pfa[2], pfb[2];     // two k-steps of spectra in flight (even / odd k-steps)
 #ifdef OS2D_DIAG_SH_NOX      /* diagnostic: no global loads of the spectra */
 #define SH_LOAD_X(S, pfx)                                                                                           \

@@ -89,12 +89,6 @@ def fft_tiles(H, W):
     return tuple(x.value for x in v)
 
 
-def x_rows_to_quads(X):
-    """X [C, NBT, nbins, 2] (OS2D_SPECTRA_ROWS) -> [nbins/4, C, NBT, 4, 2] (OS2D_SPECTRA_QUADS, what os2d_spectral_gemm_f16 reads)."""
-    C, NBT, nbins, _ = X.shape
-    return X.view(C, NBT, nbins // 4, 4, 2).permute(2, 0, 1, 3, 4).contiguous()
-
-
 def y_quads_to_rows(Yq, NBT, Cout, nbins):
     """Y [nbins/4, NBT, Cout, 4, 2] (OS2D_SPECTRA_QUADS, what os2d_spectral_gemm_f16 writes) -> [NBT, Cout, nbins, 2]."""
     return Yq.view(nbins // 4, NBT, Cout, 4, 2).permute(1, 2, 0, 3, 4).reshape(NBT, Cout, nbins, 2).contiguous()
@@ -276,9 +270,8 @@ def test_split_half_spectral_gemm_matches_float64(H, W, NB, device):
         else:
             xs = lib.os2d_spectral_xscale(H, W)
             assert xs * H * W <= 65504 < 2 * xs * H * W
-            Xq = x_rows_to_quads(Xd)               # the split-half GEMM works on the quad layout (OS2D_SPECTRA_QUADS)
-            Yq = torch.full((nbins // 4, NB, 128, 4, 2), float("nan"), device=device)
-            _lib.check(lib.os2d_spectral_gemm_f16(_lib.ptr(w16), _lib.ptr(Xq), _lib.ptr(Yq), NB, 225, 128, nbins, xs, st), "gemm16")
+            Yq = torch.full((nbins // 4, NB, 128, 4, 2), float("nan"), device=device)      # written in quads of bins (OS2D_SPECTRA_QUADS)
+            _lib.check(lib.os2d_spectral_gemm_f16(_lib.ptr(w16), _lib.ptr(Xd), _lib.ptr(Yq), NB, 225, 128, nbins, xs, st), "gemm16")
             Y = y_quads_to_rows(Yq, NB, 128, nbins)
         got = torch.view_as_complex(Y.cpu()[:, :, :P * V].contiguous()).to(torch.complex128)
         err = float((got - ref).abs().max())
@@ -286,25 +279,18 @@ def test_split_half_spectral_gemm_matches_float64(H, W, NB, device):
         assert err <= 2e-6 * scale, name
 
 
-@pytest.mark.parametrize("H,W,NB,C", [(60, 80, 3, 5), (30, 40, 70, 3), (96, 128, 2, 3), (11, 13, 5, 2), (157, 209, 1, 2)])
-def test_quad_layout_of_the_transforms_equals_the_row_layout(H, W, NB, C, device):
-    """OS2D_SPECTRA_QUADS (X [nbins/4, C, NBT, 4], Y [nbins/4, NBT, Cout, 4]: what the split-half GEMM reads / writes) against
-    OS2D_SPECTRA_ROWS, which the tests above pin to torch.fft: the forward transform writes the same values to the permuted
-    places, the inverse transform gives the same bytes from a permuted input - untiled and tiled maps, more than 64 pairs."""
+@pytest.mark.parametrize("H,W,NB", [(60, 80, 3), (30, 40, 70), (96, 128, 2), (11, 13, 5), (157, 209, 1)])
+def test_quad_layout_of_the_inverse_transform_equals_the_row_layout(H, W, NB, device):
+    """OS2D_SPECTRA_QUADS (Y [nbins/4, NBT, Cout, 4]: what the split-half GEMM writes) against OS2D_SPECTRA_ROWS, which the
+    test above pins to torch.fft: the inverse transform gives the same bytes from the permuted input - untiled and tiled
+    maps, more than 64 pairs."""
     lib = _lib.load()
     P, Q, nbins = fft_sizes(H, W)
     TY, TX, _, _ = fft_tiles(H, W)
     NBT = NB * TY * TX
     g = torch.Generator().manual_seed(H + 7 * W)
-    corr = (torch.rand(NB, C, H, W, generator=g) - 0.3).to(device)
-    inv = (0.5 + torch.rand(NB, H, W, generator=g)).to(device)
     tq, tp = twiddles(Q, device), twiddles(P, device)
     st = _lib.current_stream(device)
-    Xr = torch.full((C, NBT, nbins, 2), float("nan"), device=device)
-    Xq = torch.full((nbins // 4, C, NBT, 4, 2), float("nan"), device=device)
-    _lib.check(lib.os2d_fft_forward_ex(_lib.ptr(corr), _lib.ptr(inv), _lib.ptr(Xr), _lib.ptr(tq), _lib.ptr(tp), NB, C, H, W, 0, st), "fwd rows")
-    _lib.check(lib.os2d_fft_forward_ex(_lib.ptr(corr), _lib.ptr(inv), _lib.ptr(Xq), _lib.ptr(tq), _lib.ptr(tp), NB, C, H, W, 1, st), "fwd quads")
-    assert torch.equal(Xq, x_rows_to_quads(Xr))
     Cout = 128
     Yr = torch.randn(NBT, Cout, nbins, 2, generator=g).to(device)
     bp = torch.zeros(3 * 128)

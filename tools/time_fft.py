@@ -23,7 +23,6 @@ def t(f, n=10):
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 fwd = lambda: _lib.check(lib.os2d_fft_forward(_lib.ptr(corr), _lib.ptr(inv), _lib.ptr(X), _lib.ptr(tq), _lib.ptr(tp), NB, C, H, W, st), "f")
-fwdq = lambda: _lib.check(lib.os2d_fft_forward_ex(_lib.ptr(corr), _lib.ptr(inv), _lib.ptr(X), _lib.ptr(tq), _lib.ptr(tp), NB, C, H, W, 1, st), "fq")
 invq = lambda: _lib.check(lib.os2d_fft_inverse_ex(_lib.ptr(Y), _lib.ptr(bp), _lib.ptr(out), _lib.ptr(tq), _lib.ptr(tp), NB, Cout, H, W, _lib.ptr(status), 1, st), "iq")
 gem = lambda: _lib.check(lib.os2d_spectral_gemm(_lib.ptr(Wsp), _lib.ptr(X), _lib.ptr(Y), NB, C, Cout, nbins, st), "g")
 inv_ = lambda: _lib.check(lib.os2d_fft_inverse(_lib.ptr(Y), _lib.ptr(bp), _lib.ptr(out), _lib.ptr(tq), _lib.ptr(tp), NB, Cout, H, W, _lib.ptr(status), st), "i")
@@ -32,5 +31,5 @@ W16.view(torch.float32)[-128:] = 1.0
 xs = lib.os2d_spectral_xscale(H, W)
 gem16 = lambda: _lib.check(lib.os2d_spectral_gemm_f16(_lib.ptr(W16), _lib.ptr(X), _lib.ptr(Y), NB, C, Cout, nbins, xs, st), "g16")
 X.normal_()
-print("TIME lib={} NB={} P={} Q={} bins={}: forward {:.3f} ms (quad layout {:.3f}), spectral GEMM {:.3f} ms (split-half: {:.3f} ms), inverse {:.3f} ms (quad layout {:.3f})".format(
-    os.environ.get("OS2D_HIP_LIB", "product"), NB, P, Q, nbins, t(fwd), t(fwdq), t(gem), t(gem16), t(inv_), t(invq)))
+print("TIME lib={} NB={} P={} Q={} bins={}: forward {:.3f} ms, spectral GEMM {:.3f} ms (split-half: {:.3f} ms), inverse {:.3f} ms (quad layout {:.3f})".format(
+    os.environ.get("OS2D_HIP_LIB", "product"), NB, P, Q, nbins, t(fwd), t(gem), t(gem16), t(inv_), t(invq)))

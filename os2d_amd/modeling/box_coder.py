@@ -386,8 +386,10 @@ class Os2dBoxCoder(object):
         to be used."""
         ids = [int(c) for c in class_ids]
         merged = len(set(ids)) != len(ids)
-        if not self.use_fused_level_kernel or (len(loc_pyr) < 2 and not merged):
+        if not self.use_fused_level_kernel:
             return None
+        # (a single level with one row per label normally took os2d_detect_level before this is called; levels beyond that
+        # kernel's LDS budget - more than ~5,900 locations, e.g. 72 x 96 - come here as a pyramid of one level)
         ts = list(inverse) if inverse is not None else [None] * len(loc_pyr)
         if any(t is not None and not isinstance(t, ResizeBoxes) for t in ts) or len({t is None for t in ts}) != 1:
             return None

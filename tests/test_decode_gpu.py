@@ -454,3 +454,19 @@ def test_levels_of_different_image_sizes_need_transforms(device):
         coder.use_fused_level_kernel = fused
         with pytest.raises(AssertionError, match="image size"):
             coder.decode_pyramid(locs, clss, sizes, [0, 1], nms_score_threshold=0.0)
+
+
+def test_single_level_beyond_the_level_kernel_takes_the_pyramid_path(device):
+    """os2d_detect_level keeps a whole level in LDS and stops at ~5,900 locations (60 x 80 fits, 72 x 96 does not): such a
+    level is decoded as a pyramid of one level on the device (os2d_detect_pyramid), not through the generic chain."""
+    levels = [(72, 96)]
+    sizes, locs, clss, corners = _pyramid_inputs(levels, 3, 21, device)
+    ids = [5, 1, 9]
+    coder = _coder()
+    assert coder._decode_single_level_fused(locs, clss, sizes, ids, 0.0, 0.3, None, corners) is None
+    fused = coder._decode_pyramid_fused(locs, clss, sizes, ids, 0.0, 0.3, None, corners)
+    assert fused is not None
+    coder.use_fused_level_kernel = False
+    generic = coder.decode_pyramid(locs, clss, sizes, ids, nms_score_threshold=0.0, transform_corners_pyramid=corners)
+    _assert_same_detections(fused, generic)
+    assert len(fused) > 0

@@ -22,25 +22,30 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
-constexpr int NTHR = 512;
 constexpr int GC = 4;                    // 8-channel groups per K chunk (32 channels)
 constexpr int CH_UNITS = GC * 2 * 256;   // 16-byte units of one class-operand chunk: 2048 = 32 KB
-constexpr int NPF = CH_UNITS / NTHR;     // 4 class units per thread
 
 // NI = 32-column tiles per wave: 2 -> 256 positions per work-group (the throughput shape), 1 -> 128 positions (twice the
 // work-groups, half the MFMAs per K chunk: for a handful of classes, where the chip is empty and a group's serial K loop
 // is what a call waits for).  Every output accumulates the same products in the same order in both shapes.
-template <int NI>
-__global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  // [A][CGP][2][HW]  (no __restrict__, see
+//
+// WNW = waves along the positions (the rows are always split over 2 waves): 4 -> 8 waves of 128 x 64 (128 accumulators per
+// lane, two waves per SIMD); 2 -> 4 waves of 128 x 128 (NI = 4: 256 accumulators, one wave per SIMD with the whole register
+// file: 24 fragment reads per 48 matrix instructions become 32 per 96 - a third less LDS traffic per MFMA, which is what the
+// live counters say bounds the 8-wave shape: matrix pipe 0.58 busy with 2/3 of the LDS bandwidth in use).
+template <int NI, int WNW>
+__global__ __launch_bounds__(128 * WNW, WNW == 2 ? 1 : 2) void corr_f16x3_kernel(const u32x4* fs,  // [A][CGP][2][HW]  (no __restrict__, see
                                                              const u32x4* qs,  // [B][CGP][2][256]   conv_f16x3.hip)
                                                              float* __restrict__ corr, char* __restrict__ rshb,
                                                              float* __restrict__ invn /*[A*B][HW] 1/(norm+eps) or NULL*/, int A,
                                                              int B, int CGP /*channel groups, padded to a multiple of GC*/,
                                                              int H, int W, int PLANE, float unscale) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
-  constexpr int NT = 128 * NI;           // positions per work-group
+  constexpr int NTHR = 128 * WNW;
+  constexpr int NT = WNW * 32 * NI;      // positions per work-group
   constexpr int BUNITS = GC * 2 * NT;    // 16-byte units of one image-operand chunk
-  constexpr int NPFB = BUNITS / NTHR;    // image units per thread (4 or 2)
+  constexpr int NPF = CH_UNITS / NTHR;   // class units per thread (4 or 8)
+  constexpr int NPFB = BUNITS / NTHR;    // image units per thread
   u32x4* ldsA = smem16;                 // [2][CH_UNITS]
   u32x4* ldsB = smem16 + 2 * CH_UNITS;  // [2][BUNITS]
   __shared__ float red[2][NT];
@@ -48,7 +53,7 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
   const int HW = H * W;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, hw = lane >> 5;
-  const int wm = wid >> 2, wn = wid & 3;  // wave tile: rows [wm*128,+128), cols [wn*32*NI,+32*NI)
+  const int wm = wid / WNW, wn = wid % WNW;  // wave tile: rows [wm*128,+128), cols [wn*32*NI,+32*NI)
   // XCD-aware work mapping (work-group L runs on XCD L % 8): XCD x gets the contiguous range [x*per, (x+1)*per) of the
   // logical order (image, group of 4 classes, position tile, class in group).  The 32 groups resident on an XCD (one per
   // CU) are then ~8 tiles x 4 classes marching through K together: 12 MB of distinct operand bytes per 32 groups in
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
   const char* baseB0 = reinterpret_cast<const char*>(fa) + ((size_t)((wv * 64) / NT) * HW + n0) * 16;
 #define CF_DMA1(T, K)                                                                                             \
   {                                                                                                               \
-    {                                                                                                             \
+    if ((K) < NPF) {                                                                                              \
       const char* ga_ = baseA0 + ((size_t)(T)*CH_UNITS + (size_t)(K)*NTHR) * 16;                                  \
       __builtin_amdgcn_global_load_lds((gptr_t)(ga_ + voffA), (lptr_t)(ldsA + ((T)&1) * CH_UNITS + (K)*NTHR + wv * 64), 16, 0, 0); \
     }                                                                                                             \
@@ -106,16 +111,14 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
   }
 #define CF_DMA(T)                                                                                                 \
   {                                                                                                               \
-    _Pragma("unroll") for (int k = 0; k < NPF; ++k) CF_DMA1(T, k)                                                 \
+    _Pragma("unroll") for (int k = 0; k < (NPF > NPFB ? NPF : NPFB); ++k) CF_DMA1(T, k)                            \
   }
 #define CF_NOHOOK(MI)
 #define CF_COMPUTE(T) CF_COMPUTE_H(T, CF_NOHOOK)
 #if defined(OS2D_DIAG_CORR_NO_MFMA)  /* diagnostic builds only: DMA + barriers, no fragment reads / MFMAs */
 #define CF_COMPUTE_H(T, HOOK)                                                                                     \
   {                                                                                                               \
-    const int ks = 0;                                                                                             \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) { HOOK(mi) }                                                 \
-    (void)ks;                                                                                                     \
+    _Pragma("unroll") for (int mi = 0; mi < 8; ++mi) { HOOK(mi) }                                                 \
   }
 #else
 #define CF_COMPUTE_H(T, HOOK)                                                                                     \
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bl_[ni], acc[mi][ni], 0, 0, 0);               \
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bh_[ni], acc[mi][ni], 0, 0, 0);               \
         }                                                                                                         \
-        if (ks == 0) { HOOK(mi) }                                                                                 \
+        HOOK(ks * 4 + mi)          /* eight places per chunk to issue a piece of the next chunk's DMA */          \
       }                                                                                                           \
     }                                                                                                             \
   }
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(NTHR, 2) void corr_f16x3_kernel(const u32x4* fs,  /
 #define CF_PF_HOOK(MI)
 #else
 #define CF_PF_HOOK(MI)                                                                                            \
-  {                                                                                                               \
+  if ((MI) < (NPF > NPFB ? NPF : NPFB)) {                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
     CF_DMA1(t + 1, MI)                                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
@@ -339,6 +342,9 @@ __global__ __launch_bounds__(256) void split_qp_kernel(const float* __restrict__
   *reinterpret_cast<half8*>(o + 256) = lo;
 }
 
+#ifndef OS2D_CORR_W4
+#define OS2D_CORR_W4 0
+#endif
 constexpr int SCALE_LOG2 = 12;  // operands are L2-normalised (|x| <= 1): hi <= 4096, lo >= 2^-11 * 2^12 * x stays normal
 
 int check(const char* what) {
@@ -368,13 +374,13 @@ int os2d_launch_split_qp(const float* qp, void* qs, int B, int C, hipStream_t st
 
 namespace {
 
-template <int NI>
+template <int NI, int WNW>
 int launch_corr(const void* fs, const void* qs, float* corr, void* rshb, float* invn, int A, int B, int C, int H, int W,
                 hipStream_t stream) {
-  constexpr int NT = 128 * NI;
+  constexpr int NT = WNW * 32 * NI, NTHR = 128 * WNW;
   const int HW = H * W;
   const size_t lds = (size_t)(2 * CH_UNITS + 2 * GC * 2 * NT) * 16;  // 128 KB (NI = 2) / 96 KB dynamic (+ static)
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_f16x3_kernel<NI>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_f16x3_kernel<NI, WNW>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) {
     os2d_set_error("hipFuncSetAttribute(corr f16x3): %s", hipGetErrorString(e));
@@ -382,7 +388,7 @@ int launch_corr(const void* fs, const void* qs, float* corr, void* rshb, float* 
   }
   const long long groups = (long long)((HW + NT - 1) / NT) * B * A;
   dim3 grid((unsigned)((groups + 7) / 8 * 8));  // multiple of 8: every XCD gets the same number of logical slots
-  hipLaunchKernelGGL(corr_f16x3_kernel<NI>, grid, dim3(NTHR), lds, stream, reinterpret_cast<const u32x4*>(fs),
+  hipLaunchKernelGGL((corr_f16x3_kernel<NI, WNW>), grid, dim3(NTHR), lds, stream, reinterpret_cast<const u32x4*>(fs),
                      reinterpret_cast<const u32x4*>(qs), corr, reinterpret_cast<char*>(rshb), invn, A, B,
                      os2d_round_up((C + 7) / 8, GC), H, W,
                      os2d_plane(H, W), ldexpf(1.0f, -2 * SCALE_LOG2));
@@ -395,6 +401,10 @@ int os2d_launch_corr_f16x3(const void* fs, const void* qs, float* corr, void* rs
                            int W,
                            hipStream_t stream) {
   // the 128-position shape as long as its work-groups still fit the chip in one round (see the kernel's comment)
-  if ((long long)((H * W + 127) / 128) * B * A <= 256) return launch_corr<1>(fs, qs, corr, rshb, invn, A, B, C, H, W, stream);
-  return launch_corr<2>(fs, qs, corr, rshb, invn, A, B, C, H, W, stream);
+  if ((long long)((H * W + 127) / 128) * B * A <= 256) return launch_corr<1, 4>(fs, qs, corr, rshb, invn, A, B, C, H, W, stream);
+#if OS2D_CORR_W4
+  return launch_corr<4, 2>(fs, qs, corr, rshb, invn, A, B, C, H, W, stream);     // 4 waves of 128 x 128
+#else
+  return launch_corr<2, 4>(fs, qs, corr, rshb, invn, A, B, C, H, W, stream);     // 8 waves of 128 x 64
+#endif
 }

@@ -143,6 +143,8 @@ __global__ __launch_bounds__(NTHR) void pyr_chunk_nms_kernel(int pass, int N, in
   __shared__ unsigned int vote[NWAVE][64];
   __shared__ int cnt_in[MAX_CHUNKS], cnt_prev[MAX_CHUNKS];
   __shared__ int kept_count;
+  __shared__ unsigned short surv[NTHR];   // positions (inside the window) of a batch's survivors, in sorted order
+  __shared__ int wave_cnt[NWAVE];
 
   const int ch = blockIdx.x, b = blockIdx.y, B = gridDim.y;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -242,9 +244,14 @@ __global__ __launch_bounds__(NTHR) void pyr_chunk_nms_kernel(int pass, int N, in
   for (int i = tid; i < n; i += NTHR) srt[i] = list_at(in, cnt_in, M, j0 + spos[i]);
   __syncthreads();
 
-  // ---- greedy NMS, 64 candidates per step (see detect.hip).  The candidates' boxes are staged in sorted order through a
-  // window in LDS (the storage of the sort keys, dead by now): all threads gather WIN boxes at once (two dependent global
-  // loads each, many in flight), so the serial chain of the 64-candidate steps has no global-memory latency in it.
+  // ---- greedy NMS in sorted order.  The candidates' boxes are staged in sorted order through a window in LDS (the storage of
+  // the sort keys, dead by now): all threads gather WIN boxes at once (two dependent global loads each, many in flight).
+  // Round 3: a window is worked off in BATCHES of 1024 candidates - (1) every thread tests its own candidate against the
+  // whole kept list (broadcast reads of the kept boxes: no cross-lane traffic, no barrier per 64 candidates); most
+  // candidates die here; (2) the batch's survivors are compacted in order and resolved 64 at a time the way detect.hip does
+  // (votes only against the boxes kept SINCE the batch started, in-order resolve in wave 0).  Exactly the greedy decisions
+  // of the 64-per-step loop of round 2, which paid two work-group barriers per 64 candidates whether or not any of them was
+  // still alive: 157 steps per 10,000-candidate chunk, now ~16 for the first batch (empty kept list) + ~1 per later batch.
   float4* wbox = reinterpret_cast<float4*>(smem);   // [WIN] = NP2full * 4 bytes / 16
   const int WIN = NP2full >> 2;
   for (int w0 = 0; w0 < n; w0 += WIN) {
@@ -252,49 +259,79 @@ __global__ __launch_bounds__(NTHR) void pyr_chunk_nms_kernel(int pass, int N, in
     __syncthreads();
     for (int i = tid; i < wn; i += NTHR) wbox[i] = bx[srt[w0 + i]];
     __syncthreads();
-    for (int base = 0; base < wn; base += 64) {
-      const int nk = kept_count;
-      const int idx = w0 + base + lane;
-      const bool valid = base + lane < wn;
-      const float4 me = valid ? wbox[base + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = 0; base < wn; base += NTHR) {
+      const int nk0 = kept_count;                       // kept before this batch (uniform: read right after a barrier)
+      const int ci = base + tid;
+      const bool in_batch = ci < wn;
+      const float4 me = in_batch ? wbox[ci] : make_float4(0.f, 0.f, 0.f, 0.f);
       const float my_area = os2d_box_area(me);
-      unsigned int v = 0u;
-      const int nk_lds = min(nk, KCAP);
-      for (int j = wv; j < nk_lds; j += NWAVE) {
+      bool dead = !in_batch;
+      const int nk0_lds = min(nk0, KCAP);
+      for (int j = 0; j < nk0_lds; ++j) {
         const float4 kbx = kbox[j];
-        v |= os2d_iou_gt(kbx, os2d_box_area(kbx), me, my_area, iou_thr) ? 1u : 0u;
+        dead |= os2d_iou_gt(kbx, os2d_box_area(kbx), me, my_area, iou_thr);
       }
-      for (int j = KCAP + wv; j < nk; j += NWAVE) {
+      for (int j = KCAP; j < nk0; ++j) {
         const float4 kbx = bx[srt[kpos[j]]];
-        v |= os2d_iou_gt(kbx, os2d_box_area(kbx), me, my_area, iou_thr) ? 1u : 0u;
+        dead |= os2d_iou_gt(kbx, os2d_box_area(kbx), me, my_area, iou_thr);
       }
-      vote[wv][lane] = v;
+      const u64 alive_m = __ballot(!dead);
+      if (lane == 0) wave_cnt[wv] = __popcll(alive_m);
       __syncthreads();
-      if (wv == 0) {
-        unsigned int dead = valid ? 0u : 1u;
+      int before = 0, ns = 0;
 #pragma unroll
-        for (int w = 0; w < NWAVE; ++w) dead |= vote[w][lane];
-        u64 alive = ~__ballot(dead != 0u);
-        u64 kbits = 0ull;
-        while (alive) {
-          const int i = __builtin_ctzll(alive);
-          kbits |= 1ull << i;
-          float4 kbx;
-          kbx.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, me.x), i));
-          kbx.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, me.y), i));
-          kbx.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, me.z), i));
-          kbx.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, me.w), i));
-          const bool hit = os2d_iou_gt(kbx, os2d_box_area(kbx), me, my_area, iou_thr);
-          alive &= ~(__ballot(hit) | ((2ull << i) - 1ull));
-        }
-        if ((kbits >> lane) & 1ull) {
-          const int slot = nk + __popcll(kbits & ((1ull << lane) - 1ull));
-          if (slot < KCAP) kbox[slot] = me;
-          kpos[slot] = (unsigned short)idx;
-        }
-        if (lane == 0) kept_count = nk + __popcll(kbits);
+      for (int w = 0; w < NWAVE; ++w) {
+        const int c = wave_cnt[w];
+        before += w < wv ? c : 0;
+        ns += c;
       }
+      if (!dead) surv[before + __popcll(alive_m & ((1ull << lane) - 1ull))] = (unsigned short)ci;
       __syncthreads();
+      for (int s0 = 0; s0 < ns; s0 += 64) {
+        const int nk = kept_count;
+        const bool valid = s0 + lane < ns;
+        const int cj = valid ? (int)surv[s0 + lane] : 0;
+        const int idx = w0 + cj;
+        const float4 cand = valid ? wbox[cj] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float cand_area = os2d_box_area(cand);
+        unsigned int v = 0u;
+        const int nk_lds = min(nk, KCAP);
+        for (int j = nk0 + wv; j < nk_lds; j += NWAVE) {                 // only the boxes kept since the batch started
+          const float4 kbx = kbox[j];
+          v |= os2d_iou_gt(kbx, os2d_box_area(kbx), cand, cand_area, iou_thr) ? 1u : 0u;
+        }
+        for (int j = max(nk0, KCAP) + wv; j < nk; j += NWAVE) {
+          const float4 kbx = bx[srt[kpos[j]]];
+          v |= os2d_iou_gt(kbx, os2d_box_area(kbx), cand, cand_area, iou_thr) ? 1u : 0u;
+        }
+        vote[wv][lane] = v;
+        __syncthreads();
+        if (wv == 0) {
+          unsigned int dd = valid ? 0u : 1u;
+#pragma unroll
+          for (int w = 0; w < NWAVE; ++w) dd |= vote[w][lane];
+          u64 alive = ~__ballot(dd != 0u);
+          u64 kbits = 0ull;
+          while (alive) {
+            const int i = __builtin_ctzll(alive);
+            kbits |= 1ull << i;
+            float4 kbx;
+            kbx.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cand.x), i));
+            kbx.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cand.y), i));
+            kbx.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cand.z), i));
+            kbx.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cand.w), i));
+            const bool hit = os2d_iou_gt(kbx, os2d_box_area(kbx), cand, cand_area, iou_thr);
+            alive &= ~(__ballot(hit) | ((2ull << i) - 1ull));
+          }
+          if ((kbits >> lane) & 1ull) {
+            const int slot = nk + __popcll(kbits & ((1ull << lane) - 1ull));
+            if (slot < KCAP) kbox[slot] = cand;
+            kpos[slot] = (unsigned short)idx;
+          }
+          if (lane == 0) kept_count = nk + __popcll(kbits);
+        }
+        __syncthreads();
+      }
     }
   }
 

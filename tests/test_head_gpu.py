@@ -533,8 +533,8 @@ def test_baseline_config_pyramid_level_sizes_match_oracle(H, W, device):
                                            scale=2.5 if precision != "f16x2" else 4.0)    # coordinates up to ~2000 px
 
 
-@pytest.mark.parametrize("H,W,C,B", [(100, 140, 64, 7), (157, 209, 32, 3), (64, 209, 32, 4), (200, 100, 32, 8)])
-def test_tiled_frequency_domain_route_matches_oracle_and_direct_kernel(H, W, C, B, device):
+@pytest.mark.parametrize("H,W,C,B,A", [(100, 140, 64, 7, 1), (157, 209, 32, 3, 1), (64, 209, 32, 4, 1), (200, 100, 32, 8, 1), (97, 130, 32, 5, 2)])
+def test_tiled_frequency_domain_route_matches_oracle_and_direct_kernel(H, W, C, B, A, device):
     """Maps beyond one in-LDS transform (up to the 209-column limit of the other kernels): the frequency-domain modes cut
     them into overlap-save tiles (os2d_fft_tiles).  Ragged tilings (tile sizes that do not divide the map), a one-axis
     tiling and the widest supported map, against the oracle and against the direct f16x3 kernel on the same inputs."""
@@ -547,7 +547,7 @@ def test_tiled_frequency_domain_route_matches_oracle_and_direct_kernel(H, W, C, 
     assert t4[0].value * t4[1].value > 1, "the case is meant to be tiled"
     P, inverse = 6, True
     state = synthetic.make_transform_net_state(P, seed=4)
-    fm = synthetic.make_feature_map(C, H, W, seed=H + W)
+    fm = synthetic.make_feature_map(C, H, W, seed=H + W, A=A)          # A = 2: two images per call (pair = image x class x tile)
     class_fms = synthetic.make_class_feature_maps(B, C, sizes=[(15, 15), (12, 18)], seed=77)
     creator = util.make_head_creator(P, inverse, state, device)
     ref = _oracle(fm, class_fms, state, inverse)

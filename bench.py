@@ -45,7 +45,9 @@ Arithmetic (``--precision``):
   f16x2            as f16x3, except that the dominant 7x7 layer takes its WEIGHTS as fp16 roundings only (two MFMAs per
                    product): scores within 1e-6 and box regression within 5e-5 of fp32 - inside the 1e-4 parity bound of
                    BASELINE.json, but no longer fp32-equivalent;
-  f32              v_mfma_f32_32x32x2_f32, exact fp32.
+  fft32            strictly fp32 and fast: fp32-MFMA correlation and 5x5 layers (as f32), the 7x7 layer in the frequency domain
+                   in fp32 (as fft) - no fp16 value anywhere;
+  f32              v_mfma_f32_32x32x2_f32, exact fp32 (the reference's direct arithmetic).
 The primary line is measured in the selected mode; the other modes are timed right after and reported under
 "other_precisions" so all are always on record.
 
@@ -81,14 +83,15 @@ sys.path.insert(0, REPO)
 C_FEAT, H_FM, W_FM = 1024, 60, 80          # ResNet50-C4 features of a 1280x960 input
 LEVEL_HW = [(30, 40), (38, 50), (48, 64), (60, 80), (72, 96), (84, 112), (96, 128)]   # 7 scales 0.5-1.6
 FLOP_PER_LOC = {"corr": 2 * 225 * 1024, "conv1": 2 * 128 * 225 * 49, "conv2": 2 * 64 * 128 * 25}
-PEAK = {"f32": 157.3e12, "f16x3": 2.5e15, "f16x2": 2.5e15, "fft": 157.3e12, "fftx3": 2.5e15}  # dense MFMA peaks (MI355X_MICROARCH.md): fp32-input MFMA; fp16/bf16 MFMA
+PEAK = {"f32": 157.3e12, "f16x3": 2.5e15, "f16x2": 2.5e15, "fft": 157.3e12, "fftx3": 2.5e15, "fft32": 157.3e12}  # dense MFMA peaks (MI355X_MICROARCH.md): fp32-input MFMA; fp16/bf16 MFMA
 STAGES = ("corr", "conv1", "conv2", "conv3", "sample")
-FFT_MODES = ("fft", "fftx3")
-PREC_ID = {"f32": 0, "f16x3": 1, "f16x2": 2, "fft": 3, "fftx3": 4}
+FFT_MODES = ("fft", "fftx3", "fft32")
+PREC_ID = {"f32": 0, "f16x3": 1, "f16x2": 2, "fft": 3, "fftx3": 4, "fft32": 5}
 DTYPE = {"f32": "f32",
          "f16x3": "f16x3 (fp32 operands split into fp16 hi+lo, 3 half MFMAs per product, fp32 accumulate)",
          "f16x2": "f16x2 (as f16x3; the 7x7 layer's weights enter as fp16 roundings only, 2 half MFMAs per product)",
          "fft": "fft (as f16x3; the 7x7 layer in the frequency domain in fp32: real FFT, complex GEMM per bin on the fp32 MFMA, inverse FFT)",
+         "fft32": "fft32 (strictly fp32: fp32-MFMA correlation and 5x5 layers as f32, the 7x7 layer in the frequency domain in fp32 as fft; no fp16 value anywhere)",
          "fftx3": "fftx3 (as fft; the per-bin complex GEMM on the fp16 MFMA with spectra split into fp16 hi+lo, 3 MFMAs per product, fp32 accumulate)"}
 DISTINCT_CLASS_MAPS = 64     # synthetic class maps are generated for 64 seeds and repeated (separate device copies)
 
@@ -102,7 +105,7 @@ def parse():
     ap.add_argument("--classes-total", type=int, default=None,
                     help="classes in total, block-sharded over the ranks (strong scaling); default 1024 at N>1")
     ap.add_argument("--variant", default="v2", choices=["v2", "v1"], help="v2: affine+inverse (P=6); v1: simplified (P=4)")
-    ap.add_argument("--precision", default=os.environ.get("OS2D_PRECISION", "fftx3"), choices=["f32", "f16x3", "f16x2", "fft", "fftx3"])
+    ap.add_argument("--precision", default=os.environ.get("OS2D_PRECISION", "fftx3"), choices=["f32", "f16x3", "f16x2", "fft", "fftx3", "fft32"])
     ap.add_argument("--pyramid", action="store_true",
                     help="BASELINE configs[4]: 7-scale pyramid (0.5-1.6) of the 1280x960 image, one HIP stream per level; "
                          "a pair then means one (image, class) over all 7 levels")
@@ -480,8 +483,8 @@ class Workload(object):
         if stage_ms is not None and precision in FFT_MODES and len(stage_ms) >= 8:
             return self.roofline_fft(stage_ms, precision)
         fell_back = precision in FFT_MODES and stage_ms is not None     # staged run without the sub-stage events: the class batch
-        if fell_back:                                               # is below FFT_MIN_PAIRS and the direct f16x3 kernel ran
-            precision = "f16x3"
+        if fell_back:                                               # is below FFT_MIN_PAIRS and the direct kernel ran
+            precision = "f32" if precision == "fft32" else "f16x3"
         peak = PEAK[precision]
         if stage_ms is not None:
             flops = FLOP_PER_LOC["conv1"] * H_FM * W_FM * B            # algorithmic FLOPs of ONE conv1 launch
@@ -644,7 +647,7 @@ def precision_deviation(w):
     with torch.no_grad():
         ref = [t.clone() for t in w.head(w.fm, precision="f32")]
         keep = {}
-        for p in ("f16x3", "f16x2", "fft", "fftx3"):
+        for p in ("f16x3", "f16x2", "fft", "fftx3", "fft32"):
             o = w.head(w.fm, precision=p)
             out[p] = {"cls": float((o[1] - ref[1]).abs().max()), "loc": float((o[0] - ref[0]).abs().max()),
                       "corners_px": float((o[3] - ref[3]).abs().max())}
@@ -741,7 +744,7 @@ def main():
     result["head_tflops_algorithmic"] = round(w.whole_head_flops_per_class() * value / 1e12, 3)
     if not args.no_other_precision:
         result["other_precisions"] = []
-        for other in ("fft", "fftx3", "f16x3", "f16x2", "f32"):
+        for other in ("fft", "fftx3", "f16x3", "f16x2", "fft32", "f32"):
             if other == args.precision:
                 continue
             dt2, stage2 = w.run(other, max(2, min(args.steps, 10)), 1)
@@ -811,12 +814,14 @@ def main():
             r["counters_source"] = ("LIVE: rocprofv3 PMC passes of this run over a 3-step child run of the same workload ({} launches of {}; "
                                     "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes)".format(k.get("launches"), kname))
     if "other_precisions" in result:
-        f32 = [o for o in result["other_precisions"] if o["precision"] == "f32"]
-        if f32:
-            result["f32_pairs_per_s"] = f32[0]["value"]       # the strictly-fp32 mode (v_mfma_f32_32x32x2_f32 everywhere), same run
+        by_mode = {o["precision"]: o["value"] for o in result["other_precisions"]}
+        if "f32" in by_mode:
+            result["f32_pairs_per_s"] = by_mode["f32"]        # strictly fp32, the reference's own arithmetic (direct kernels on v_mfma_f32_32x32x2_f32), same run
+        if "fft32" in by_mode:
+            result["fft32_pairs_per_s"] = by_mode["fft32"]    # strictly fp32 with the 7x7 layer in the frequency domain (no fp16 value anywhere)
     # the figures a reader looks for first go first: a truncated copy of the line still shows them
     front = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-             "dtype", "data", "f32_pairs_per_s", "stages_ms", "roofline", "roofline_corr", "cpu_baseline", "speedup_vs_cpu_baseline",
+             "dtype", "data", "f32_pairs_per_s", "fft32_pairs_per_s", "stages_ms", "roofline", "roofline_corr", "cpu_baseline", "speedup_vs_cpu_baseline",
              "config", "scaling_reference"]
     result = {**{k: result[k] for k in front if k in result}, **{k: v for k, v in result.items() if k not in front}}
     if rank == 0:

@@ -37,6 +37,10 @@ extern "C" {
                                /* (16.7x fewer multiply-adds; agrees with an fp64 convolution to 1e-7, closer than a direct fp32    */
                                /* convolution).  Maps larger than the in-LDS transform are cut into overlap-save tiles (os2d_fft_tiles) */
 
+#define OS2D_PRECISION_FFT32 5 /* strictly fp32 AND fast: fp32-MFMA correlation and 5x5 layers as F32, the 7x7 layer in the frequency  */
+                               /* domain as FFT (fp32 transforms, complex GEMM on the fp32 matrix cores, fp32 planes out); no fp16   */
+                               /* value anywhere.  w1..w3 / b1..b3 from os2d_pack_conv (w1 unused), wspec as for FFT                  */
+
 #define OS2D_PRECISION_FFTX3 4 /* as FFT, with the per-bin complex GEMM on the half-precision matrix cores: spectra split into fp16   */
                                /* hi + lo (three v_mfma_f32_32x32x16_f16 per product, the arithmetic of F16X3; scales chosen so that  */
                                /* no spectrum value can leave the fp16 range: |X| <= H*W by construction, the weight spectra are     */

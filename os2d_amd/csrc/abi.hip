@@ -212,7 +212,8 @@ int os2d_head_workspace_bytes_ex(int A, int B, int C, int H, int W, int P, int p
   }
   if (!head_args_ok(A, B, C, H, W, P)) return -1;
   int bins = 0, tiles[6] = {1, 1, 0, 0, 0, 0};
-  if ((precision == OS2D_PRECISION_FFT || precision == OS2D_PRECISION_FFTX3) && !os2d_fft_plan(H, W, nullptr, nullptr, &bins, tiles)) {
+  if ((precision == OS2D_PRECISION_FFT || precision == OS2D_PRECISION_FFTX3 || precision == OS2D_PRECISION_FFT32) &&
+      !os2d_fft_plan(H, W, nullptr, nullptr, &bins, tiles)) {
     os2d_set_error("os2d_head_workspace_bytes_ex: no transform plan for a %dx%d map", H, W);
     return -3;
   }
@@ -237,7 +238,7 @@ int os2d_corr(const float* fm, const float* qp, const float* sumsq, float* corr,
   if (!head_args_ok(A, B, C, H, W, 6)) return -1;
   int rc = os2d_launch_border_zero(rnorm, A * B * OS2D_KP, H, W, S(stream));
   if (rc) return rc;
-  return os2d_launch_corr(fm, qp, sumsq, corr, rnorm, A, B, C, H, W, 0, S(stream));
+  return os2d_launch_corr(fm, qp, sumsq, corr, rnorm, nullptr, A, B, C, H, W, 0, S(stream));
 }
 
 size_t os2d_corr_f16x3_workspace_bytes(int A, int C, int H, int W) {
@@ -352,12 +353,12 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     return -1;
   }
   if (precision != OS2D_PRECISION_F32 && precision != OS2D_PRECISION_F16X3 && precision != OS2D_PRECISION_F16X2 &&
-      precision != OS2D_PRECISION_FFT && precision != OS2D_PRECISION_FFTX3) {
+      precision != OS2D_PRECISION_FFT && precision != OS2D_PRECISION_FFTX3 && precision != OS2D_PRECISION_FFT32) {
     os2d_set_error("os2d_head_forward: unknown precision %d", precision);
     return -1;
   }
   int fft_bins = 0, tiles[6] = {1, 1, 0, 0, 0, 0};
-  if (precision == OS2D_PRECISION_FFT || precision == OS2D_PRECISION_FFTX3) {
+  if (precision == OS2D_PRECISION_FFT || precision == OS2D_PRECISION_FFTX3 || precision == OS2D_PRECISION_FFT32) {
     if (!wspec || !twQ || !twP) {
       os2d_set_error("os2d_head_forward: the FFT mode needs the weight spectra and the two twiddle tables");
       return -1;
@@ -368,7 +369,8 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     }
   }
   const int fft_T = tiles[0] * tiles[1];
-  if (precision != OS2D_PRECISION_F32 && !qs) {
+  const bool fp32_ops = precision == OS2D_PRECISION_F32 || precision == OS2D_PRECISION_FFT32;   // fp32 MFMA correlation / 5x5 layers
+  if (!fp32_ops && !qs) {
     os2d_set_error("os2d_head_forward: precision f16x3 / f16x2 needs the split class operand (os2d_class_split)");
     return -1;
   }
@@ -417,24 +419,25 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
   };
   int rc = os2d_launch_fm_sumsq(fm, sumsq, A, C, H * W, st);
   if (rc) return rc;
-  if (precision != OS2D_PRECISION_F32 && (rc = os2d_launch_split_fm(fm, sumsq, fsplit, A, C, H * W, st))) return rc;
+  if (!fp32_ops && (rc = os2d_launch_split_fm(fm, sumsq, fsplit, A, C, H * W, st))) return rc;
   for (int b0 = 0; b0 < B; b0 += Bc) {
     const int bc = (B - b0 < Bc) ? (B - b0) : Bc;
     const int NB = A * bc;
-    const bool f16 = precision != OS2D_PRECISION_F32;
+    const bool f16 = !fp32_ops;
     const int terms1 = precision == OS2D_PRECISION_F16X2 ? 2 : 3;  // 7x7 layer: weights as fp16 roundings only under f16x2
     mark(b0, 0);
     if (f16) {
       // the frequency-domain 7x7 layer takes corr + invn; the split / blocked copy of the normalised maps is not written
       if (!fft_bins && (rc = os2d_launch_border_zero_shb(rpad, NB, H, W, st))) return rc;
-    } else {
+    } else if (!fft_bins) {
       if ((rc = os2d_launch_border_zero(rpad, NB * OS2D_KP, H, W, st))) return rc;
     }
     if (f16) {
       const char* qsb = static_cast<const char*>(qs) + (size_t)b0 * os2d_corr_groups(C) * 2 * 256 * 16;
       if ((rc = os2d_launch_corr_f16x3(fsplit, qsb, corr, fft_bins ? nullptr : rpad, invn, A, bc, C, H, W, st))) return rc;
     } else {
-      if ((rc = os2d_launch_corr(fm, qp + (size_t)b0 * C * OS2D_QROWS, sumsq, corr, rpad, A, bc, C, H, W, 0, st)))
+      if ((rc = os2d_launch_corr(fm, qp + (size_t)b0 * C * OS2D_QROWS, sumsq, corr, fft_bins ? nullptr : rpad, invn, A, bc, C, H, W,
+                                 0, st)))
         return rc;
     }
     mark(b0, 1);
@@ -442,7 +445,11 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     if (fft_bins) {
       // the 7x7 layer in the frequency domain (fft.hip, spectral.hip): fp32 FFT of relu(corr) / norm -> one complex GEMM
       // per bin on the fp32 matrix cores -> inverse FFT + bias + ReLU + split into the activation buffer of the 5x5 layer
-      if ((rc = os2d_launch_border_zero_shb_planes(h1, NB * 16 * 2, H, W, st))) return rc;
+      if (f16) {
+        if ((rc = os2d_launch_border_zero_shb_planes(h1, NB * 16 * 2, H, W, st))) return rc;
+      } else if ((rc = os2d_launch_border_zero(h1, NB * 128, H, W, st))) {     // all-fp32 mode: fp32 planes for the fp32 5x5 kernel
+        return rc;
+      }
       mark(b0, 10);
       // the split-half GEMM writes its output spectra in quads of bins (include/os2d_hip.h, OS2D_SPECTRA_QUADS)
 #ifdef OS2D_DIAG_SPECTRA_ROWS
@@ -461,7 +468,7 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
         return rc;
       }
       mark(b0, 12);
-      if ((rc = os2d_launch_fft_inverse(yspec, b1, 128, h1, twQ, twP, NB, 128, H, W, status, layout, st))) return rc;
+      if ((rc = os2d_launch_fft_inverse(yspec, b1, 128, h1, twQ, twP, NB, 128, H, W, status, layout, f16 ? 0 : 1, st))) return rc;
     } else if (f16) {
       if ((rc = os2d_launch_conv_f16x3(1, rpad, w1, b1, status, h1, NB, P, H, W, terms1, st))) return rc;
     } else {
@@ -627,7 +634,7 @@ int os2d_fft_inverse_ex(const float* Y, const float* packed_b, void* out, const 
   }
   int rc = os2d_launch_border_zero_shb_planes(out, NB * (Cout / 8) * 2, H, W, S(stream));
   if (rc) return rc;
-  return os2d_launch_fft_inverse(Y, packed_b, 128, out, twQ, twP, NB, Cout, H, W, status, layout, S(stream));
+  return os2d_launch_fft_inverse(Y, packed_b, 128, out, twQ, twP, NB, Cout, H, W, status, layout, 0, S(stream));
 }
 
 int os2d_fft_inverse(const float* Y, const float* packed_b, void* out, const float* twQ, const float* twP, int NB, int Cout,

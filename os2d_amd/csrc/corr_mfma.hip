@@ -29,7 +29,8 @@ template <bool VEC4, bool SHB>
 __global__ __launch_bounds__(256, 2) void corr_mfma_kernel(const float* __restrict__ fm,     // [A][C][HW]
                                                            const float* __restrict__ qp,     // [B][C][256]
                                                            const float* __restrict__ sumsq,  // [A][HW]
-                                                           float* __restrict__ corr, float* __restrict__ rpad,
+                                                           float* __restrict__ corr, float* __restrict__ rpad /*or NULL*/,
+                                                           float* __restrict__ invn /*[A*B][HW] 1/(norm+eps), or NULL*/,
                                                            int B, int C, int H, int W, int PLANE) {
   __shared__ __attribute__((aligned(16))) float ldsA[2][KC * OS2D_QROWS];
   __shared__ __attribute__((aligned(16))) float ldsB[2][KC * NT];
@@ -177,6 +178,8 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_kernel(const float* __restri
     const int n = n0 + col;
     if (n >= HW) continue;
     const float inv_r = 1.0f / (sqrtf(red[0][col] + red[1][col]) + 1e-6f);  // head.py:650,597 (eps 1e-6)
+    if (invn != nullptr && wm == 0 && hi == 0) invn[(size_t)nb * HW + n] = inv_r;   // for the frequency-domain 7x7 layer
+    if (rpad == nullptr) continue;                                                   // ... which reads corr + invn only
     const int h = n / W, w = n - h * W;
     const size_t cell = (size_t)BASE + (size_t)h * Ws + w;
     if (!SHB) {
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_kernel(const float* __restri
 
 }  // namespace
 
-int os2d_launch_corr(const float* fm, const float* qp, const float* sumsq, float* corr, void* rnorm, int A, int B,
+int os2d_launch_corr(const float* fm, const float* qp, const float* sumsq, float* corr, void* rnorm, float* invn, int A, int B,
                      int C, int H, int W, int shb, hipStream_t stream) {
   const int HW = H * W;
   dim3 grid((HW + NT - 1) / NT, B, A);
@@ -226,7 +229,7 @@ int os2d_launch_corr(const float* fm, const float* qp, const float* sumsq, float
   float* rp = reinterpret_cast<float*>(rnorm);
   const int PL = os2d_plane(H, W);
 #define CORR_GO(V, S) \
-  hipLaunchKernelGGL((corr_mfma_kernel<V, S>), grid, dim3(256), 0, stream, fm, qp, sumsq, corr, rp, B, C, H, W, PL)
+  hipLaunchKernelGGL((corr_mfma_kernel<V, S>), grid, dim3(256), 0, stream, fm, qp, sumsq, corr, rp, invn, B, C, H, W, PL)
   if (vec4 && shb) CORR_GO(true, true);
   else if (vec4) CORR_GO(true, false);
   else if (shb) CORR_GO(false, true);

@@ -320,7 +320,8 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
                                                              int MTP, char* __restrict__ out,  // SHB [NB][Cout/8][2][PLANE] x 16 B
                                                              const f32x2* __restrict__ twQ, const f32x2* __restrict__ twP,
                                                              FftPlan pl, int Cout, int H, int W, int NBINS, int PLANE,
-                                                             int images, unsigned inv_v, int* __restrict__ status, int quad) {
+                                                             int images, unsigned inv_v, int* __restrict__ status, int quad,
+                                                             int out32 /* CPT == 0 only: out = fp32 planes [NB][Cout][PLANE] */) {
   // images = NB * T * Cout: image -> (pair' = nb * T + tile, output channel); RH = rows of the inverse that are needed.
   // quad == 0: Y[pair'][o][bin]; quad == 1 (what os2d_spectral_gemm_f16 writes): Y[bin / 4][pair'][o][bin % 4] - the GEMM
   // then stores 1 KB runs (32 lanes = 32 consecutive output channels x 32 bytes) and this kernel gathers 32-byte pieces
@@ -469,6 +470,15 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
           }
         }
       }
+    } else if (out32) {
+      // all-fp32 mode: the layer's output as fp32 zero-bordered planes (what the fp32 5x5 kernel reads), bias + ReLU only
+      float* plane = reinterpret_cast<float*>(out) + ((size_t)nb * Cout + o) * (size_t)PLANE + BASE;
+      for (int th = wv; th < TH_ && y0 + th < H; th += NWV)
+        for (int tw = lane; tw < TW_ && x0 + tw < W; tw += 64) {
+          const f32x2 z = R[((th + oy) >> 1) * QS + tw + ox];
+          const float t = (((th + oy) & 1) ? z[1] : z[0]) * norm + bias;
+          plane[(size_t)(y0 + th) * Ws + x0 + tw] = fmaxf(t, 0.f);
+        }
     } else {
       _Float16* hi = reinterpret_cast<_Float16*>(hi_unit) + slot;
       _Float16* lo = reinterpret_cast<_Float16*>(lo_unit) + slot;
@@ -692,7 +702,7 @@ int os2d_launch_fft_forward(const float* corr, const float* inv, float* X, const
 }
 
 int os2d_launch_fft_inverse(const float* Y, const float* bp, int MTP, void* out, const float* twQ, const float* twP, int NB,
-                            int Cout, int H, int W, int* status, int layout, hipStream_t stream) {
+                            int Cout, int H, int W, int* status, int layout, int out_fp32, hipStream_t stream) {
   FftPlan pl;
   size_t lds;
   if (!make_plan(H, W, &pl, &lds)) {
@@ -704,7 +714,7 @@ int os2d_launch_fft_inverse(const float* Y, const float* bp, int MTP, void* out,
 #define OS2D_FFT_GRP 2
 #endif
   constexpr int CPT = 10, GRP = OS2D_FFT_GRP;
-  const bool grouped = Cout % GRP == 0 && pl.TH * pl.TW <= CPT * FFT_THR && ept <= 10;
+  const bool grouped = !out_fp32 && Cout % GRP == 0 && pl.TH * pl.TW <= CPT * FFT_THR && ept <= 10;
 #define OS2D_INV_KERN(T_)                                                                        \
   (grouped ? (ept <= 6   ? fft_inverse_kernel<6, CPT, GRP, T_>                                   \
               : ept <= 8 ? fft_inverse_kernel<8, CPT, GRP, T_>                                   \
@@ -725,6 +735,6 @@ int os2d_launch_fft_inverse(const float* Y, const float* bp, int MTP, void* out,
   hipLaunchKernelGGL(kern, dim3(grid), dim3(FFT_THR), lds, stream, reinterpret_cast<const f32x2*>(Y), bp, MTP,
                      static_cast<char*>(out), reinterpret_cast<const f32x2*>(twQ), reinterpret_cast<const f32x2*>(twP), pl,
                      Cout, H, W, os2d_round_up(pl.P * pl.V, 8), os2d_plane(H, W), images,
-                     (unsigned)(((1ull << 32) + pl.V - 1) / pl.V), status, layout ? 1 : 0);
+                     (unsigned)(((1ull << 32) + pl.V - 1) / pl.V), status, layout ? 1 : 0, out_fp32 ? 1 : 0);
   return check("fft_inverse");
 }

@@ -120,7 +120,8 @@ int os2d_launch_class_prepare_batch(const float* const* srcs, const int* sizes, 
                                     float* qp, float* partial, hipStream_t stream);
 int os2d_launch_corr_normalize_shb(const float* corr, void* rshb, int NB, int H, int W, hipStream_t stream);
 // corr_mfma.hip (shb != 0: rnorm is written in the split-half blocked layout of conv_f16x3.hip)
-int os2d_launch_corr(const float* fm, const float* qp, const float* sumsq, float* corr, void* rnorm,
+int os2d_launch_corr(const float* fm, const float* qp, const float* sumsq, float* corr, void* rnorm /*or NULL*/,
+                     float* invn /*or NULL: 1 / (norm + eps) per (pair, location) for the frequency-domain 7x7 layer*/,
                      int A, int B, int C, int H, int W, int shb, hipStream_t stream);
 // conv_f16x3.hip
 int os2d_launch_conv3_f16x3(const void* in, const void* wp, const float* bp, void* out, int NB, int P, int H, int W,
@@ -151,7 +152,9 @@ int os2d_fft_plan(int H, int W, int* P, int* Q, int* nbins, int* tiles /* [6]: T
 int os2d_launch_fft_forward(const float* corr, const float* inv, float* X, const float* twQ, const float* twP, int NB, int C,
                             int H, int W, hipStream_t stream);
 int os2d_launch_fft_inverse(const float* Y, const float* bp, int MTP, void* out, const float* twQ, const float* twP, int NB,
-                            int Cout, int H, int W, int* status, int layout /* OS2D_SPECTRA_ROWS | OS2D_SPECTRA_QUADS */, hipStream_t stream);
+                            int Cout, int H, int W, int* status, int layout /* OS2D_SPECTRA_ROWS | OS2D_SPECTRA_QUADS */,
+                            int out_fp32 /* 1: out = fp32 zero-bordered planes [NB][Cout][PLANE] (all-fp32 mode), no scale / split */,
+                            hipStream_t stream);
 // spectral.hip
 size_t os2d_spectral_weight_floats(int C, int Cout, int NBINS);
 int os2d_launch_spectral_gemm(const float* wspec, const float* X, float* Y, int NB, int C, int Cout, int NBINS,

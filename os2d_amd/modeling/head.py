@@ -29,8 +29,9 @@ TEMPLATE = 15
 QROWS = 256
 FFT_MIN_PAIRS = 7       # precision "fft" / "fftx3": image x class pairs below which the direct 7x7 kernel is used instead
                         # (measured crossover at 60 x 80, tools/time_small_batches.py: 6 pairs 0.413 vs 0.416 ms, 8 pairs 0.46 vs 0.53)
-PRECISIONS = {"f32": 0, "f16x3": 1, "f16x2": 2, "fft": 3, "fftx3": 4}     # OS2D_PRECISION_* of include/os2d_hip.h
-FFT_MODES = ("fft", "fftx3")
+PRECISIONS = {"f32": 0, "f16x3": 1, "f16x2": 2, "fft": 3, "fftx3": 4, "fft32": 5}     # OS2D_PRECISION_* of include/os2d_hip.h
+FFT_MODES = ("fft", "fftx3", "fft32")
+FP32_MODES = ("f32", "fft32")           # no fp16 value anywhere: fp32-MFMA correlation and 5x5 layers
 DEFAULT_PRECISION = "fftx3"
 
 
@@ -42,7 +43,9 @@ def resolve_precision(precision=None):
     (as f16x3, but the 7x7 layer runs in the frequency domain in fp32: real FFT -> one complex GEMM per bin on the fp32
     matrix cores -> inverse FFT; fp32-equivalent, 16.7x fewer multiply-adds; maps that do not fit the in-LDS transform and
     small class batches fall back to f16x3), or "fftx3" (as fft, with the per-bin GEMM on the half-precision matrix cores:
-    spectra split into fp16 hi + lo, the arithmetic of f16x3).  Default from $OS2D_PRECISION, else DEFAULT_PRECISION."""
+    spectra split into fp16 hi + lo, the arithmetic of f16x3), or "fft32" (strictly fp32 and fast: the correlation and the 5x5
+    layers on the fp32 matrix cores as in "f32", the 7x7 layer in the frequency domain in fp32 as in "fft" - no fp16 value
+    anywhere; 2.6x the throughput of "f32").  Default from $OS2D_PRECISION, else DEFAULT_PRECISION."""
     return _resolve(precision)[0]
 
 
@@ -319,6 +322,8 @@ class TransformationNet(nn.Module):
         if precision in ("f16x2", "fft", "fftx3"):
             precision = "f16x3"        # same packed weights and scales (f16x2 skips the lo halves of layer 1; fft replaces
                                        # layer 1 by ``spectra`` and keeps its bias / output scales)
+        elif precision == "fft32":
+            precision = "f32"          # fp32 packing; layer 1's weights are replaced by ``spectra``, its folded bias is used
         key = (precision,) + self._state_key()
         dev = self.linear.weight.device
         cached = self._packed_cache.get(precision)
@@ -465,7 +470,7 @@ class TransformationNet(nn.Module):
         out = torch.empty(N, P, H, W, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             stream = _lib.current_stream(dev)
-            if precision == "f32":
+            if precision in FP32_MODES:      # (the frequency-domain modes differ from their families only inside the fused head)
                 plane = lib.os2d_plane_floats(H, W)
                 r = torch.empty(N * 226 * plane, dtype=torch.float32, device=dev)
                 h1 = torch.empty(N * 128 * plane, dtype=torch.float32, device=dev)
@@ -697,7 +702,7 @@ class Os2dHead(nn.Module):
         runner) call this first; the caches are event-tracked either way."""
         precision = resolve_precision(precision or self.precision)
         self.aligner.parameter_regressor.packed(precision)
-        if precision != "f32":
+        if precision not in FP32_MODES:
             self._split_class_operand()
         return self
 
@@ -763,7 +768,7 @@ class Os2dHead(nn.Module):
         regressor = self.aligner.parameter_regressor
         P = regressor.output_dim
         precision, pinned = _resolve(precision or self.precision)
-        if precision != "f32" and int(self._status_word()[0]) != 0:
+        if precision not in FP32_MODES and int(self._status_word()[0]) != 0:
             self._handle_range_flag()
             precision = "f32"
         regressor.check_ready()                  # device / eval-mode errors before any torch op can trip over them
@@ -775,7 +780,7 @@ class Os2dHead(nn.Module):
             pairs = A * B if route_pairs is None else int(route_pairs)
             spectra = regressor.spectra(H, W, split=precision == "fftx3") if (pinned or pairs >= FFT_MIN_PAIRS) else None
             if spectra is None:
-                precision = "f16x3"
+                precision = "f32" if precision == "fft32" else "f16x3"       # the direct kernels of the same arithmetic family
         self.last_precision = precision          # the arithmetic that actually ran (bench.py / tests)
         w1, b1, w2, b2, w3, b3 = regressor.packed(precision)
         if out is None:
@@ -793,17 +798,17 @@ class Os2dHead(nn.Module):
         _lib.check(lib.os2d_head_workspace_bytes_ex(A, 1, C, H, W, P, PRECISIONS[precision], ctypes.byref(one)), "os2d_head_workspace_bytes_ex")
         with torch.cuda.device(dev):     # hipFuncSetAttribute / launches act on the CURRENT device
             ws = get_workspace(dev, full.value, one.value)
-            status = self._status_word() if precision != "f32" else None
+            status = self._status_word() if precision not in FP32_MODES else None
             _lib.check(lib.os2d_head_forward_ex(
                 _lib.ptr(feature_maps), _lib.ptr(self._qp), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2),
                 _lib.ptr(w3), _lib.ptr(b3), A, B, C, H, W, P, 1 if self.aligner.use_inverse_geom_model else 0,
                 self._stride, self._rec_field, _lib.ptr(loc), _lib.ptr(cls), _lib.ptr(corners),
                 _lib.ptr(ws), ws.numel(), _lib.current_stream(dev), PRECISIONS[precision],
-                _lib.ptr(self._split_class_operand()) if precision != "f32" else None, stage_events, None,
+                _lib.ptr(self._split_class_operand()) if precision not in FP32_MODES else None, stage_events, None,
                 _lib.host_ptr(status), *([_lib.ptr(t) for t in spectra[:3]] if spectra is not None else [None, None, None])),
                 "os2d_head_forward_ex")
         strict = self.strict_range if strict_range is None else strict_range
-        if strict and precision != "f32":
+        if strict and precision not in FP32_MODES:
             torch.cuda.current_stream(dev).synchronize()
             if int(self._status[0]) != 0:
                 self._handle_range_flag()

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 TOL_CLS, TOL_LOC, TOL_CORNERS = util.TOL_CLS, util.TOL_LOC, util.TOL_CORNERS
 
 
-PRECISIONS = ["f32", "f16x3", "f16x2", "fft", "fftx3"]     # every arithmetic mode must meet the same tolerances
+PRECISIONS = ["f32", "f16x3", "f16x2", "fft", "fftx3", "fft32"]     # every arithmetic mode must meet the same tolerances
 
 
 @pytest.fixture(autouse=True)
@@ -121,7 +121,7 @@ def test_transformation_net_stage_kernels(name, precision, device):
     tol = 1e-5 if precision != "f16x2" else 1e-4       # f16x2 rounds the 7x7 weights to fp16
     assert util.maxdiff(p, fx["ref_params"]) < tol
     assert util.maxdiff(p, O.transform_net(fx["ref_corr"], fx["state"])) < tol
-    if precision != "f32":
+    if precision not in ("f32", "fft32"):
         assert int(net.last_status.item()) == 0
 
 

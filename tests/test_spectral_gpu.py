@@ -231,6 +231,36 @@ def test_weight_spectra_cache_is_keyed_by_transform_size_and_bounded(device, mon
     assert not torch.equal(e[0], a[0])
 
 
+def test_weight_spectra_miss_cost_is_bounded(device):
+    """a dataset fed at its own aspect ratios meets ~50 transform sizes (tools/bench_size_churn.py); every
+    new size costs one construction of the weight spectra (a 7-term DFT per axis as float64 matrix products + the fp16 split:
+    ~20 ms on the MI355X, 50 ms with the round-2 rfft2 of zero maps).  Bounds: a miss < 120 ms, a hit < 2 ms, and a miss
+    reproduces exactly what the first construction gave (the cache is not part of the result)."""
+    import time
+    from os2d_amd.modeling import head as head_mod
+    from os2d_amd.utils import synthetic
+    net = head_mod.TransformationNet(output_dim=6)
+    net.load_state_dict(synthetic.make_transform_net_state(6, seed=2))
+    net.to(device).eval()
+    net.spectra(30, 40, split=True)                      # warm-up of the float64 kernels / allocator
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    first = net.spectra(60, 80, split=True)
+    torch.cuda.synchronize()
+    miss = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    again = net.spectra(60, 80, split=True)
+    torch.cuda.synchronize()
+    hit = time.perf_counter() - t0
+    assert again[0].data_ptr() == first[0].data_ptr()
+    keep = first[0].clone()
+    net._spectra_cache.clear()
+    rebuilt = net.spectra(60, 80, split=True)
+    assert torch.equal(rebuilt[0], keep)
+    print("weight spectra for 64 x 84: miss {:.1f} ms, hit {:.3f} ms, {:.0f} MB".format(miss * 1e3, hit * 1e3, keep.numel() / 1e6))
+    assert miss < 0.120 and hit < 0.002
+
+
 @pytest.mark.parametrize("H,W,NB", [(11, 13, 5), (30, 40, 70)])
 def test_split_half_spectral_gemm_matches_float64(H, W, NB, device):
     """os2d_spectral_gemm_f16 (spectra split into fp16 hi + lo on the half-precision matrix cores) and os2d_spectral_gemm (fp32

@@ -267,6 +267,15 @@ int os2d_spectral_gemm(const float* wspec, const float* X, float* Y, int NB, int
  * X is [C, NB, nbins] as for os2d_spectral_gemm; Y is written in the OS2D_SPECTRA_QUADS layout ([nbins/4, NB, Cout, 4]
  * complex64): hand it to os2d_fft_inverse_ex(..., OS2D_SPECTRA_QUADS).                                                    */
 size_t os2d_spectral_weight16_bytes(int C, int nbins);
+/* Builds the weight spectra of the 7x7 layer on the device, once per transform size and parameter version (off the per-step
+ * path): wfold = the BatchNorm-folded filters [Cout,C,7,7] as DEVICE float64 (reference head.py:619-623; the fold is the
+ * caller's), centred on the origin of the P x Q grid; twP64 / twQ64 = DEVICE float64 tables [P][2] / [Q][2] of (cos, sin) of
+ * -2 pi m / n (exact values rounded once).  K[o][c][u][v] is a 7-term DFT per axis evaluated in float64.
+ *   split != 0  out = the layout of os2d_spectral_gemm_f16 (os2d_spectral_weight16_bytes(C, nbins) bytes, incl. the 128 row
+ *               scales); workspace = 1 KB of device memory (row maxima)
+ *   split == 0  out = the layout of os2d_spectral_gemm (os2d_spectral_weight_bytes(C, Cout, nbins) bytes)                  */
+int os2d_spectral_weights_build(const double* wfold, const double* twP64, const double* twQ64, int C, int Cout, int P, int Q,
+                                int nbins, int split, void* out, void* workspace, void* stream);
 float os2d_spectral_xscale(int H, int W);
 int os2d_spectral_gemm_f16(const void* w16, const float* X, float* Y, int NB, int C, int Cout, int nbins, float xscale,
                            void* stream);

@@ -40,6 +40,7 @@ SIGNATURES = {
     "os2d_spectral_gemm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "os2d_spectral_weight16_bytes": (_sz, [_i, _i]),
     "os2d_spectral_xscale": (_f, [_i, _i]),
+    "os2d_spectral_weights_build": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "os2d_spectral_gemm_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "os2d_debug_set_dump": (None, [_vp, _i, _vp, _sz]),
     "os2d_fft_sizes": (_i, [_i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)]),
@@ -146,7 +147,8 @@ def ptr(t):
     if t is None:
         return None
     import torch
-    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype in (torch.float32, torch.uint8, torch.int32, torch.int64) and t.is_contiguous()):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype in (torch.float32, torch.float64, torch.uint8, torch.int32, torch.int64)
+            and t.is_contiguous()):
         raise ValueError("expected a contiguous device tensor, got {}".format(
             (type(t).__name__, getattr(t, "device", None), getattr(t, "dtype", None))))
     return ctypes.c_void_p(t.data_ptr())

@@ -660,6 +660,19 @@ int os2d_spectral_gemm(const float* wspec, const float* X, float* Y, int NB, int
   return os2d_launch_spectral_gemm(wspec, X, Y, NB, C, Cout, nbins, S(stream));
 }
 
+int os2d_spectral_weights_build(const double* wfold, const double* twP64, const double* twQ64, int C, int Cout, int P, int Q,
+                                int nbins, int split, void* out, void* workspace, void* stream) {
+  if (!wfold || !twP64 || !twQ64 || !out || (split && !workspace) || C < 1 || Cout < 1 || Cout > 128 || nbins < 8 || (nbins & 7)) {
+    os2d_set_error("os2d_spectral_weights_build: bad arguments (C=%d Cout=%d nbins=%d)", C, Cout, nbins);
+    return -1;
+  }
+  if ((reinterpret_cast<uintptr_t>(out) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 7)) {
+    os2d_set_error("os2d_spectral_weights_build: out must be 16-byte, workspace 8-byte aligned");
+    return -1;
+  }
+  return os2d_launch_spectra_pack(wfold, twP64, twQ64, C, Cout, P, Q, nbins, split, out, workspace, S(stream));
+}
+
 size_t os2d_spectral_weight16_bytes(int C, int nbins) {
   if (C < 1 || nbins < 8 || (nbins & 7)) return 0;
   return os2d_spectral_weight16_size(C, nbins);

@@ -155,6 +155,9 @@ int os2d_launch_fft_inverse(const float* Y, const float* bp, int MTP, void* out,
                             int Cout, int H, int W, int* status, int layout /* OS2D_SPECTRA_ROWS | OS2D_SPECTRA_QUADS */,
                             int out_fp32 /* 1: out = fp32 zero-bordered planes [NB][Cout][PLANE] (all-fp32 mode), no scale / split */,
                             hipStream_t stream);
+// spectra_pack.hip
+int os2d_launch_spectra_pack(const double* wfold, const double* twP64, const double* twQ64, int C, int Cout, int P, int Q,
+                             int NBINS, int split, void* out, void* workspace, hipStream_t stream);
 // spectral.hip
 size_t os2d_spectral_weight_floats(int C, int Cout, int NBINS);
 int os2d_launch_spectral_gemm(const float* wspec, const float* X, float* Y, int NB, int C, int Cout, int NBINS,

@@ -169,7 +169,8 @@ def spectra_cache_cap_bytes():
 
 
 def split_rows_f16(T):
-    """fp16 hi + lo split of a float64 tensor whose leading dimension indexes rows that get their own power-of-two scale
+    """(float64 MODEL of what spectra_pack.hip does on the device; used by tests/test_range_plan.py.)
+    fp16 hi + lo split of a float64 tensor whose leading dimension indexes rows that get their own power-of-two scale
     (precision "fftx3": the weight spectra; one row per output channel): row r is multiplied by 2^wexp[r], the largest
     power of two that keeps its largest |entry| <= 32768 (< 65504: no overflow, also not through rounding), then
     hi = rn16(v), lo = rn16(v - hi): hi + lo carries 22 bits of v wherever |v| >= 2^-3 and an absolute 2^-25 below (fp16
@@ -393,50 +394,28 @@ class TransformationNet(nn.Module):
         for k in [k for k, c in self._spectra_cache.items() if c.key != key]:
             del self._spectra_cache[k]                           # a parameter changed: every cached size is stale
         with torch.cuda.device(dev), torch.no_grad():
-            (w1, _), _, _ = self._folded()                       # float64 [128,225,7,7]
-            V = Q // 2 + 1
-            G, KS = nbins // 8, (225 + 7) // 8
+            (w1, _), _, _ = self._folded()                       # float64 [128,225,7,7]: the BatchNorm fold
+            # the spectrum of a 7 x 7 filter is a 7-term DFT per axis; os2d_spectral_weights_build evaluates it in float64
+            # from exact twiddle tables and writes the packed layout of the GEMM directly (spectra_pack.hip: ~2 ms per
+            # transform size; round 2 took 50 ms through torch.fft.rfft2 of zero-padded maps, an intermediate version 20 ms
+            # through float64 matrix products - no vendor library is left under the head)
+            def table64(n):
+                m = torch.arange(n, dtype=torch.float64)
+                ang = m * (-2.0 * torch.pi / n)
+                return torch.stack([torch.cos(ang), torch.sin(ang)], 1).to(dev).contiguous()
             if split:
-                nunits = G * 2 * KS * 8 * 2 * 2 * 64
-                wbuf = torch.zeros(nunits * 16 + 128 * 4, dtype=torch.uint8, device=dev)
-                packed16 = wbuf[:nunits * 16].view(torch.float16).view(G, 2, KS, 8, 2, 2, 64, 8)
-                wscale = wbuf[nunits * 16:].view(torch.float32)
+                wspec = torch.empty(lib.os2d_spectral_weight16_bytes(225, nbins), dtype=torch.uint8, device=dev)
             else:
-                packed = torch.zeros(G, 2, 225, 8, 64, dtype=torch.complex64, device=dev)
-            # the spectrum of a 7 x 7 filter is a 7-term DFT per axis: K = Ep w Eq^T with Ep[u][t] = exp(-2 pi i u pos_t / P),
-            # pos_t = (3 - t) mod P (the filter centred on the origin), Eq likewise over the V = Q/2 + 1 kept columns - two
-            # small float64 / complex128 matrix products per (o, c) instead of a P x Q transform of a map that is 99 % zeros
-            # (round 2: torch.fft.rfft2 of [64, 225, P, Q] float64, ~50 ms per transform size; same values to 1e-14)
-            def dft(n, nout):
-                pos = (3 - torch.arange(7, device=dev)) % n
-                m = (torch.arange(nout, device=dev).view(-1, 1) * pos.view(1, -1)) % n     # exact integer phase index
-                ang = m.double() * (-2.0 * torch.pi / n)
-                return torch.complex(torch.cos(ang), torch.sin(ang))
-            Ep, EqT = dft(P, P), dft(Q, V).t().contiguous()
-            for half in range(2):                               # 64 output channels at a time bounds the float64 transient
-                wc = w1[64 * half:64 * half + 64].to(torch.complex128)              # [64,225,7,7]
-                K = torch.matmul(Ep, torch.matmul(wc, EqT)).reshape(64, 225, P * V)
-                del wc
-                if split:
-                    # row o scaled by the power of two that puts its largest |Kr|, |Ki| in (16384, 32768]; fp16 hi + lo of
-                    # (Kr, Ki); units of 4 channels x (re, im): [g][half][k-step][bin][channel group][hi|lo][o][8 halves]
-                    T = torch.zeros(64, KS * 8, nbins, 2, dtype=torch.float64, device=dev)
-                    T[:, :225, :P * V] = torch.view_as_real(K)
-                    del K
-                    hi, lo, wexp = split_rows_f16(T)
-                    del T
-                    wscale[64 * half:64 * half + 64] = torch.exp2(-wexp).float()
-                    for part, t in enumerate((hi, lo)):
-                        # [o][ks][grp][c4][g][bin][ri] -> [g][ks][bin][grp][o][c4][ri]
-                        packed16[:, half, :, :, :, part] = t.view(64, KS, 2, 4, G, 8, 2).permute(4, 1, 5, 2, 0, 3, 6).reshape(G, KS, 8, 2, 64, 8)
-                    del hi, lo
-                else:
-                    Kp = torch.zeros(64, 225, nbins, dtype=torch.complex64, device=dev)
-                    Kp[:, :, :P * V] = K.to(torch.complex64)
-                    del K
-                    packed[:, half] = Kp.view(64, 225, G, 8).permute(2, 1, 3, 0)      # [g][c][j][r]
-                    del Kp
-            wspec = wbuf if split else torch.view_as_real(packed).contiguous()
+                wspec = torch.empty(lib.os2d_spectral_weight_bytes(225, 128, nbins) // 4, dtype=torch.float32, device=dev)
+            wfold = w1.to(dev).contiguous()
+            tp64, tq64 = table64(P), table64(Q)
+            scratch = torch.empty(1024, dtype=torch.uint8, device=dev)
+            _lib.check(lib.os2d_spectral_weights_build(_lib.ptr(wfold), _lib.ptr(tp64), _lib.ptr(tq64), 225, 128, P, Q, nbins,
+                                                       1 if split else 0, _lib.ptr(wspec), _lib.ptr(scratch),
+                                                       _lib.current_stream(dev)), "os2d_spectral_weights_build")
+            cur = torch.cuda.current_stream(dev)
+            for t in (wfold, tp64, tq64, scratch):
+                t.record_stream(cur)
 
             def table(n):
                 m = torch.arange(n, dtype=torch.float64)

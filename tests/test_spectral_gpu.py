@@ -231,6 +231,49 @@ def test_weight_spectra_cache_is_keyed_by_transform_size_and_bounded(device, mon
     assert not torch.equal(e[0], a[0])
 
 
+@pytest.mark.parametrize("H,W", [(11, 13), (30, 40), (60, 80), (96, 128)])
+def test_device_built_weight_spectra_match_torch_fft(H, W, device):
+    """os2d_spectral_weights_build (spectra_pack.hip: a 7-term DFT per axis in float64, packed on the device) against the
+    definition - torch.fft.rfft2 in float64 of the BatchNorm-folded filters placed at ((3 - t) mod P, (3 - s) mod Q): the
+    complex64 layout of os2d_spectral_gemm to fp32 round-off, the split-fp16 layout of os2d_spectral_gemm_f16 (hi + lo times
+    the row scale) to 2^-21 of the row maximum, padding bins / channels exactly zero, row scales powers of two that put the
+    row maximum in (16384, 32768]."""
+    from os2d_amd.modeling import head as head_mod
+    from os2d_amd.utils import synthetic
+    net = head_mod.TransformationNet(output_dim=6)
+    net.load_state_dict(synthetic.make_transform_net_state(6, seed=11))
+    net.to(device).eval()
+    P, Q, nbins = fft_sizes(H, W)
+    V = Q // 2 + 1
+    (w1, _), _, _ = net._folded()
+    k = torch.zeros(128, 225, P, Q, dtype=torch.float64, device=device)
+    k[:, :, ((3 - torch.arange(7, device=device)) % P).view(-1, 1), ((3 - torch.arange(7, device=device)) % Q).view(1, -1)] = w1
+    K = torch.fft.rfft2(k).reshape(128, 225, P * V)                       # [o, c, bin]
+    del k
+    G = nbins // 8
+    # ---- complex64 layout [g][half][c][j][r]
+    w32 = net.spectra(H, W)[0].view(G, 2, 225, 8, 64, 2)
+    got = torch.view_as_complex(w32.double().contiguous()).permute(1, 4, 2, 0, 3).reshape(128, 225, nbins)      # [half*64+r, c, g*8+j]
+    scale = float(K.abs().max())
+    assert float((got[:, :, :P * V] - K).abs().max()) <= 2e-7 * scale
+    assert float(got[:, :, P * V:].abs().max()) == 0.0 if nbins > P * V else True
+    # ---- split-fp16 layout [g][half][ks][j][grp][hi|lo][o][c4, (re, im)] + 128 row scales
+    buf = net.spectra(H, W, split=True)[0]
+    KS = 29
+    nunits = G * 2 * KS * 8 * 2 * 2 * 64
+    units = buf[:nunits * 16].view(torch.float16).view(G, 2, KS, 8, 2, 2, 64, 4, 2).double()
+    wscale = buf[nunits * 16:].view(torch.float32).double()
+    val = units[:, :, :, :, :, 0] + units[:, :, :, :, :, 1]                  # hi + lo: [g, half, ks, j, grp, o, c4, ri]
+    val = val.permute(1, 5, 2, 4, 6, 0, 3, 7).reshape(128, KS * 8, nbins, 2)  # [half*64+o, ks*8+grp*4+c4, g*8+j, ri]
+    rec = torch.view_as_complex(val.contiguous()) * wscale.view(-1, 1, 1)
+    rowmax = torch.maximum(K.real.abs(), K.imag.abs()).flatten(1).amax(dim=1)
+    assert float(((rec[:, :225, :P * V] - K).abs() / rowmax.view(-1, 1, 1)).max()) <= 2.0 ** -21
+    assert float(rec[:, 225:].abs().max()) == 0.0 and (float(rec[:, :, P * V:].abs().max()) == 0.0 if nbins > P * V else True)
+    scaled = rowmax / wscale
+    assert bool(((scaled > 16384.0 * (1 - 1e-12)) & (scaled <= 32768.0)).all())
+    assert bool((torch.log2(wscale) == torch.log2(wscale).round()).all())
+
+
 def test_weight_spectra_miss_cost_is_bounded(device):
     """a dataset fed at its own aspect ratios meets ~50 transform sizes (tools/bench_size_churn.py); every
     new size costs one construction of the weight spectra (a 7-term DFT per axis as float64 matrix products + the fp16 split:

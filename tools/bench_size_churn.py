@@ -81,11 +81,13 @@ def main():
         for hw in lv:
             if hw not in feats:
                 feats[hw] = synthetic.make_feature_map(args.channels, hw[0], hw[1], seed=hw[0] * 1000 + hw[1]).to(dev)
-    misses = {"n": 0, "s": 0.0}
+    misses = {"n": 0, "s": 0.0, "sync_before": False}
     real = net.spectra.__func__
 
     def counting(self, H, W, split=False):
         before = len(self._spectra_cache), [id(v) for v in self._spectra_cache.values()]
+        if misses.get("sync_before"):
+            torch.cuda.synchronize()          # so that a miss is timed on its own, not together with the kernels queued before it
         t0 = time.perf_counter()
         r = real(self, H, W, split)
         after = [id(v) for v in self._spectra_cache.values()]
@@ -115,10 +117,22 @@ def main():
             res[label] = {"ms_per_image": round(dt / len(maps) * 1e3, 2), "head_calls": calls, "cache_misses": misses["n"],
                           "hit_rate": round(1.0 - misses["n"] / calls, 4), "ms_per_miss": round(misses["s"] / max(misses["n"], 1) * 1e3, 2),
                           "miss_ms_per_image": round(misses["s"] / len(maps) * 1e3, 2)}
+    # the cost of a miss without the pipeline drain: a third pass over an emptied cache with a synchronisation BEFORE every call
+    net._spectra_cache.clear()
+    misses["n"], misses["s"], misses["sync_before"] = 0, 0.0, True
+    with torch.no_grad():
+        for lv in maps:
+            for hw in lv:
+                head(feats[hw])
+    torch.cuda.synchronize()
+    isolated = {"cache_misses": misses["n"], "ms_per_miss": round(misses["s"] / max(misses["n"], 1) * 1e3, 2)}
     out = {"images": len(maps), "classes": args.classes, "levels_per_image": len(SCALES), "distinct_map_sizes": len(feats),
            "distinct_transform_sizes": len(tsizes), "cache_entries_at_end": len(net._spectra_cache),
            "cache_bytes_at_end": sum(c.nbytes() for c in net._spectra_cache.values()),
-           "cache_cap_bytes": head_mod.spectra_cache_cap_bytes(), "cold": res["cold"], "warm": res["warm"],
+           "cache_cap_bytes": head_mod.spectra_cache_cap_bytes(), "cold": res["cold"], "warm": res["warm"], "miss_isolated": isolated,
+           "miss_ms_derived": round((res["cold"]["ms_per_image"] - res["warm"]["ms_per_image"]) * len(maps) / max(res["cold"]["cache_misses"], 1), 2),
+           "note": "cold.ms_per_miss includes draining the kernels queued before the miss (the head is asynchronous); miss_isolated times a "
+                   "miss on its own, miss_ms_derived = (cold - warm) / misses",
            "aspect_ratios": "3:4, 4:3, 2:3, 3:2, 9:16, 16:9, 1:1, 4:5 with +-8 % jitter, resized to area target^2 like reference utils.py:32-37"}
     print(json.dumps(out))
 

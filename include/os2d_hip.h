@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define OS2D_ABI_VERSION 8
+#define OS2D_ABI_VERSION 9
 
 /* arithmetic of the two large TransformNet convolutions (everything else is fp32 in both modes) */
 #define OS2D_PRECISION_F32 0   /* v_mfma_f32_32x32x2_f32: exact fp32 (k-ordered fmaf chain)                            */
@@ -215,6 +215,27 @@ int os2d_detect_level(const float* loc, const float* cls, int B, int H, int W, i
                       float img_h, float scale_x, float scale_y, float score_threshold, float iou_threshold,
                       float* out_boxes, float* out_scores, int* out_index, int* out_count, void* stream);
 
+/* Box transform chains: what the reference hands to decode_pyramid as ``inverse_box_transforms`` - per level a TransformList
+ * of closures (os2d/structures/transforms.py:12-27, appended by transpose :32-52, resize :78-79 and crop :188-191 from
+ * os2d/data/dataloader.py:286-336, called at os2d/modeling/box_coder.py:499-503) - is a chain of at most OS2D_BOX_MAX_OPS
+ * axis-aligned box operations (os2d/structures/bounding_box.py:138-226), applied in order, each product / difference rounded
+ * on its own exactly like the reference's tensor expressions:
+ *   OS2D_BOX_OP_SCALE  BoxList.resize:                     x * ax, y * ay            (ax = target_w / image_w, ...)
+ *   OS2D_BOX_OP_HFLIP  BoxList.transpose(FLIP_LEFT_RIGHT): (x1, x2) = (ax - x2, ax - x1)   (ax = image width)
+ *   OS2D_BOX_OP_VFLIP  BoxList.transpose(FLIP_TOP_BOTTOM): (y1, y2) = (ay - y2, ay - y1)   (ay = image height)
+ *   OS2D_BOX_OP_SHIFT  BoxList.crop:                       x - ax, y - ay            (ax, ay = left, top of the crop box)
+ * op_kinds [op_count], op_args [op_count][2] = (ax, ay) are HOST arrays.  os2d_detect_level_ops = os2d_detect_level with such a
+ * chain instead of the two scale factors (op_count 0 = no mapping).                                                        */
+#define OS2D_BOX_OP_SCALE 1
+#define OS2D_BOX_OP_HFLIP 2
+#define OS2D_BOX_OP_VFLIP 3
+#define OS2D_BOX_OP_SHIFT 4
+#define OS2D_BOX_MAX_OPS 6
+int os2d_detect_level_ops(const float* loc, const float* cls, int B, int H, int W, int stride, int rec_field, float img_w,
+                          float img_h, int op_count, const int* op_kinds, const float* op_args, float score_threshold,
+                          float iou_threshold, float* out_boxes, float* out_scores, int* out_index, int* out_count,
+                          void* stream);
+
 /* ---- the frequency-domain form of the 7x7 TransformNet layer (reference head.py:619-623; DESIGN.md section 4, "fft"):
  * what os2d_head_forward_ex chains under OS2D_PRECISION_FFT, exported for callers and tests.  For every frequency bin the
  * layer is one complex matrix product
@@ -314,6 +335,17 @@ int os2d_detect_pyramid_merged(const float* const* loc, const float* const* cls,
                                const int* slot_rows, float* out_boxes, float* out_scores, int* out_index, float* out_default,
                                float* out_corners, int* out_count, int* unfinished, void* workspace, size_t workspace_bytes,
                                void* stream);
+
+/* Both of the above with a box transform chain per level (see OS2D_BOX_OP_*) instead of the scale table: op_counts HOST int [L],
+ * op_kinds HOST int [L][OS2D_BOX_MAX_OPS], op_args HOST float [L][OS2D_BOX_MAX_OPS][2]; the anchors and the transform corners
+ * go through the same chain (the corners as the two "boxes" (x0, y0, x1, y1), (x2, y2, x3, y3), like the reference's
+ * box_coder.py:493-503).  slot_rows NULL: every head row its own label (G, V ignored); otherwise as os2d_detect_pyramid_merged. */
+int os2d_detect_pyramid_ops(const float* const* loc, const float* const* cls, const float* const* corners, int B, int L,
+                            const int* hw, int stride, int rec_field, const float* img_wh, const int* op_counts,
+                            const int* op_kinds, const float* op_args, float score_threshold, float iou_threshold,
+                            int nms_max_batch, int passes, int G, int V, const int* slot_rows, float* out_boxes,
+                            float* out_scores, int* out_index, float* out_default, float* out_corners, int* out_count,
+                            int* unfinished, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

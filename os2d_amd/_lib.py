@@ -9,7 +9,7 @@ import os
 
 from .build import LIB_PATH
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _c_float_p = ctypes.c_void_p   # device pointers travel as raw addresses (tensor.data_ptr())
 _vp = ctypes.c_void_p
@@ -69,12 +69,15 @@ SIGNATURES = {
     "os2d_nms": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "os2d_detect_level_supported": (_i, [_i, _i]),
     "os2d_detect_level": (_i, [_vp, _vp] + [_i] * 5 + [_f] * 6 + [_vp] * 5),
+    "os2d_detect_level_ops": (_i, [_vp, _vp] + [_i] * 5 + [_f, _f, _i, _vp, _vp, _f, _f] + [_vp] * 5),
     "os2d_detect_pyramid_supported": (_i, [_i, _i, _i]),
     "os2d_detect_pyramid_workspace_bytes": (_i, [_i, _i, _i, ctypes.POINTER(_sz)]),
     "os2d_detect_pyramid": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                  _vp, _vp, _sz, _vp]),
     "os2d_detect_pyramid_merged": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _f, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp,
                                         _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "os2d_detect_pyramid_ops": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _vp, _vp, _vp,
+                                     _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
 

@@ -74,7 +74,7 @@ std::vector<DumpEntry> g_dumps;
 std::mutex g_dumps_mutex;               // ctypes releases the GIL: callers may race on the table
 bool dumps_active() {
   std::lock_guard<std::mutex> lock(g_dumps_mutex);
-  return dumps_active();
+  return !g_dumps.empty();
 }
 void dump_slot(void* stream, int slot, const void* src, size_t bytes) {
   std::lock_guard<std::mutex> lock(g_dumps_mutex);
@@ -312,8 +312,26 @@ int os2d_detect_level(const float* loc, const float* cls, int B, int H, int W, i
     os2d_set_error("os2d_detect_level: bad arguments");
     return -1;
   }
-  return os2d_launch_detect_level(loc, cls, B, H, W, stride, rec_field, img_w, img_h, scale_x, scale_y, score_threshold,
-                                  iou_threshold, out_boxes, out_scores, out_index, out_count, S(stream));
+  return os2d_launch_detect_level(loc, cls, B, H, W, stride, rec_field, img_w, img_h, os2d_box_ops_scale(scale_x, scale_y),
+                                  score_threshold, iou_threshold, out_boxes, out_scores, out_index, out_count, S(stream));
+}
+
+int os2d_detect_level_ops(const float* loc, const float* cls, int B, int H, int W, int stride, int rec_field, float img_w,
+                          float img_h, int op_count, const int* op_kinds, const float* op_args, float score_threshold,
+                          float iou_threshold, float* out_boxes, float* out_scores, int* out_index, int* out_count,
+                          void* stream) {
+  if (!loc || !cls || !out_boxes || !out_scores || !out_index || !out_count || B < 1 || H < 1 || W < 1 || stride < 1 ||
+      rec_field < 1) {
+    os2d_set_error("os2d_detect_level_ops: bad arguments");
+    return -1;
+  }
+  Os2dBoxOps ops;
+  if (!os2d_box_ops_from(op_kinds, op_args, op_count, &ops)) {
+    os2d_set_error("os2d_detect_level_ops: bad transform chain (at most %d ops of kind 1..4)", OS2D_BOX_MAX_OPS);
+    return -1;
+  }
+  return os2d_launch_detect_level(loc, cls, B, H, W, stride, rec_field, img_w, img_h, ops, score_threshold, iou_threshold,
+                                  out_boxes, out_scores, out_index, out_count, S(stream));
 }
 
 int os2d_nms_workspace_bytes(int NC, int N, size_t* bytes) {

@@ -28,7 +28,7 @@ constexpr int NTHR = 1024, NWAVE = NTHR / 64;
 __global__ __launch_bounds__(NTHR) void detect_level_kernel(const float* __restrict__ loc,  // [B][4][HW]
                                                            const float* __restrict__ cls,  // [B][HW]
                                                            int H, int W, float stride, float half_box, float img_w,
-                                                           float img_h, float rx, float ry, float score_thr,
+                                                           float img_h, Os2dBoxOps ops, float score_thr,
                                                            float iou_thr, int NP2, float4* out_boxes,
                                                            float* __restrict__ out_scores, int* __restrict__ out_index,
                                                            int* __restrict__ out_count) {
@@ -122,15 +122,10 @@ __global__ __launch_bounds__(NTHR) void detect_level_kernel(const float* __restr
   }
 #undef DET_SORT_CHUNK
 
-  // ---- 3. boxes in sorted order, mapped to the output image (BoxList.resize: x * ratio_w, y * ratio_h)
+  // ---- 3. boxes in sorted order, mapped to the output image (the level's chain of BoxList.resize / transpose / crop)
   for (int jx = tid; jx < n; jx += NTHR) {
     const int i = sidx[jx];
-    float4 b = os2d_decode_box(lc + i, HW, i, W, stride, half_box, img_w, img_h);
-    b.x *= rx;
-    b.y *= ry;
-    b.z *= rx;
-    b.w *= ry;
-    sbox[jx] = b;
+    sbox[jx] = os2d_apply_box_ops(os2d_decode_box(lc + i, HW, i, W, stride, half_box, img_w, img_h), ops);
   }
   __syncthreads();  // from here on the score keys are dead: their storage holds the kept boxes
 
@@ -213,7 +208,7 @@ size_t os2d_detect_level_lds_bytes(int H, int W) {
 }
 
 int os2d_launch_detect_level(const float* loc, const float* cls, int B, int H, int W, int stride, int rec_field,
-                             float img_w, float img_h, float scale_x, float scale_y, float score_thr, float iou_thr,
+                             float img_w, float img_h, const Os2dBoxOps& ops, float score_thr, float iou_thr,
                              float* out_boxes, float* out_scores, int* out_index, int* out_count, hipStream_t stream) {
   const size_t lds = os2d_detect_level_lds_bytes(H, W);
   if (lds == 0) {
@@ -228,7 +223,7 @@ int os2d_launch_detect_level(const float* loc, const float* cls, int B, int H, i
   }
   const float half_box = 0.5f * (float)(stride * (OS2D_T - 1) + rec_field);
   hipLaunchKernelGGL(detect_level_kernel, dim3(B), dim3(NTHR), lds, stream, loc, cls, H, W, (float)stride, half_box, img_w,
-                     img_h, scale_x, scale_y, score_thr, iou_thr, next_pow2(H * W), reinterpret_cast<float4*>(out_boxes),
+                     img_h, ops, score_thr, iou_thr, next_pow2(H * W), reinterpret_cast<float4*>(out_boxes),
                      out_scores, out_index, out_count);
   e = hipGetLastError();
   if (e != hipSuccess) {

@@ -46,7 +46,8 @@ struct LevelTable {
   const float* cls[MAX_LEVELS];  // [B][HW_l]
   const float* corners[MAX_LEVELS];  // [B][8][HW_l] or all NULL
   int H[MAX_LEVELS], W[MAX_LEVELS], off[MAX_LEVELS + 1];
-  float img_w[MAX_LEVELS], img_h[MAX_LEVELS], sx[MAX_LEVELS], sy[MAX_LEVELS];
+  float img_w[MAX_LEVELS], img_h[MAX_LEVELS];
+  Os2dBoxOps ops[MAX_LEVELS];    // level -> output image
   int L;
 };
 
@@ -76,10 +77,7 @@ __global__ __launch_bounds__(256) void pyr_decode_kernel(LevelTable T, int N, fl
   const float s = T.cls[l][(size_t)b * HW + n];
   const bool empty = (bx.w <= bx.y) || (bx.z <= bx.x);
   const bool valid = s > score_thr && !empty;   // false for NaN scores
-  bx.x *= T.sx[l];
-  bx.y *= T.sy[l];
-  bx.z *= T.sx[l];
-  bx.w *= T.sy[l];
+  bx = os2d_apply_box_ops(bx, T.ops[l]);
   boxes[(size_t)slot * N + g] = bx;
   scores[(size_t)slot * N + g] = s;
   keys[(size_t)slot * N + g] = valid ? score_key(s) : 0xffffffffu;   // a valid key is never 0xffffffff (that would be score -NaN)
@@ -445,13 +443,18 @@ __global__ __launch_bounds__(NTHR) void pyr_finalize_kernel(int passes, int N, i
     const int nloc = g1 - T.off[l], HWl = T.H[l] * T.W[l];
     const int hh = nloc / T.W[l], ww = nloc - hh * T.W[l];
     const float ecx = stride * ((float)ww + 0.5f), ecy = stride * ((float)hh + 0.5f);
-    out_default[(size_t)b * N + s] = make_float4((ecx - half_box) * T.sx[l], (ecy - half_box) * T.sy[l],
-                                                 (ecx + half_box) * T.sx[l], (ecy + half_box) * T.sy[l]);
+    out_default[(size_t)b * N + s] = os2d_apply_box_ops(make_float4(ecx - half_box, ecy - half_box, ecx + half_box, ecy + half_box), T.ops[l]);
     if (out_corners != nullptr) {
       const int row = slot_rows ? slot_rows[b * V + view] : b;
       const float* cp = T.corners[l] + (size_t)row * 8 * HWl + nloc;
+      // the reference maps the corners as two "boxes" (x0, y0, x1, y1), (x2, y2, x3, y3) through the same closures
+      // (box_coder.py:493-503): a flip therefore exchanges the x (or y) of the two points of a pair - reproduced as is
 #pragma unroll
-      for (int k = 0; k < 8; ++k) out_corners[((size_t)b * N + s) * 8 + k] = cp[(size_t)k * HWl] * ((k & 1) ? T.sy[l] : T.sx[l]);
+      for (int k = 0; k < 2; ++k) {
+        const float4 c4 = os2d_apply_box_ops(make_float4(cp[(size_t)(4 * k) * HWl], cp[(size_t)(4 * k + 1) * HWl],
+                                                         cp[(size_t)(4 * k + 2) * HWl], cp[(size_t)(4 * k + 3) * HWl]), T.ops[l]);
+        reinterpret_cast<float4*>(out_corners + ((size_t)b * N + s) * 8)[k] = c4;
+      }
     }
   }
   if (tid == 0) out_count[b] = total;
@@ -520,12 +523,12 @@ int os2d_detect_pyramid_workspace_bytes(int B, int N, int passes, size_t* bytes)
 // B head rows in loc / cls / corners; G labels of at most V rows each (slot_rows: DEVICE int [G * V], NULL = every row its
 // own label, G = B, V = 1); outputs are [G][V * N]
 static int detect_pyramid_impl(const float* const* loc, const float* const* cls, const float* const* corners, int B, int L,
-                               const int* hw, int stride, int rec_field, const float* img_wh, const float* scale_xy,
+                               const int* hw, int stride, int rec_field, const float* img_wh, const Os2dBoxOps* level_ops,
                                float score_threshold, float iou_threshold, int nms_max_batch, int passes, float* out_boxes,
                                float* out_scores, int* out_index, float* out_default, float* out_corners, int* out_count,
                                int* unfinished, void* workspace, size_t workspace_bytes, void* stream, int G, int V,
                                const int* slot_rows) {
-  if (!loc || !cls || !hw || !img_wh || !scale_xy || !out_boxes || !out_scores || !out_index || !out_default || !out_count ||
+  if (!loc || !cls || !hw || !img_wh || !level_ops || !out_boxes || !out_scores || !out_index || !out_default || !out_count ||
       !unfinished || !workspace || B < 1 || G < 1 || V < 1 || stride < 1 || rec_field < 1 || passes < 1 || passes > 16 ||
       ((corners != nullptr) != (out_corners != nullptr)) || (!slot_rows && (G != B || V != 1))) {
     os2d_set_error("os2d_detect_pyramid: bad arguments");
@@ -555,8 +558,7 @@ static int detect_pyramid_impl(const float* const* loc, const float* const* cls,
     N1 += hw[2 * l] * hw[2 * l + 1];
     T.img_w[l] = img_wh[2 * l];
     T.img_h[l] = img_wh[2 * l + 1];
-    T.sx[l] = scale_xy[2 * l];
-    T.sy[l] = scale_xy[2 * l + 1];
+    T.ops[l] = level_ops[l];
   }
   T.off[L] = N1;
   T.L = L;
@@ -618,12 +620,24 @@ static int detect_pyramid_impl(const float* const* loc, const float* const* cls,
   return check("pyr_finalize");
 }
 
+// level -> output image as plain per-axis scales (BoxList.resize): the one-op chains of the original entry points
+static bool ops_from_scales(const float* scale_xy, int L, Os2dBoxOps* ops) {
+  if (!scale_xy || L < 1 || L > MAX_LEVELS) {
+    os2d_set_error("os2d_detect_pyramid: bad scale table / level count");
+    return false;
+  }
+  for (int l = 0; l < L; ++l) ops[l] = os2d_box_ops_scale(scale_xy[2 * l], scale_xy[2 * l + 1]);
+  return true;
+}
+
 int os2d_detect_pyramid(const float* const* loc, const float* const* cls, const float* const* corners, int B, int L,
                         const int* hw, int stride, int rec_field, const float* img_wh, const float* scale_xy,
                         float score_threshold, float iou_threshold, int nms_max_batch, int passes, float* out_boxes,
                         float* out_scores, int* out_index, float* out_default, float* out_corners, int* out_count,
                         int* unfinished, void* workspace, size_t workspace_bytes, void* stream) {
-  return detect_pyramid_impl(loc, cls, corners, B, L, hw, stride, rec_field, img_wh, scale_xy, score_threshold, iou_threshold,
+  Os2dBoxOps ops[MAX_LEVELS];
+  if (!ops_from_scales(scale_xy, L, ops)) return -1;
+  return detect_pyramid_impl(loc, cls, corners, B, L, hw, stride, rec_field, img_wh, ops, score_threshold, iou_threshold,
                              nms_max_batch, passes, out_boxes, out_scores, out_index, out_default, out_corners, out_count,
                              unfinished, workspace, workspace_bytes, stream, B, 1, nullptr);
 }
@@ -638,7 +652,35 @@ int os2d_detect_pyramid_merged(const float* const* loc, const float* const* cls,
     os2d_set_error("os2d_detect_pyramid_merged: slot_rows is required");
     return -1;
   }
-  return detect_pyramid_impl(loc, cls, corners, B, L, hw, stride, rec_field, img_wh, scale_xy, score_threshold, iou_threshold,
+  Os2dBoxOps ops[MAX_LEVELS];
+  if (!ops_from_scales(scale_xy, L, ops)) return -1;
+  return detect_pyramid_impl(loc, cls, corners, B, L, hw, stride, rec_field, img_wh, ops, score_threshold, iou_threshold,
+                             nms_max_batch, passes, out_boxes, out_scores, out_index, out_default, out_corners, out_count,
+                             unfinished, workspace, workspace_bytes, stream, G, V, slot_rows);
+}
+
+int os2d_detect_pyramid_ops(const float* const* loc, const float* const* cls, const float* const* corners, int B, int L,
+                            const int* hw, int stride, int rec_field, const float* img_wh, const int* op_counts,
+                            const int* op_kinds, const float* op_args, float score_threshold, float iou_threshold,
+                            int nms_max_batch, int passes, int G, int V, const int* slot_rows, float* out_boxes,
+                            float* out_scores, int* out_index, float* out_default, float* out_corners, int* out_count,
+                            int* unfinished, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!op_counts || L < 1 || L > MAX_LEVELS) {
+    os2d_set_error("os2d_detect_pyramid_ops: bad op tables / level count");
+    return -1;
+  }
+  Os2dBoxOps ops[MAX_LEVELS];
+  for (int l = 0; l < L; ++l)
+    if (!os2d_box_ops_from(op_kinds ? op_kinds + (size_t)l * OS2D_BOX_MAX_OPS : nullptr,
+                           op_args ? op_args + (size_t)l * OS2D_BOX_MAX_OPS * 2 : nullptr, op_counts[l], &ops[l])) {
+      os2d_set_error("os2d_detect_pyramid_ops: bad transform chain of level %d (at most %d ops of kind 1..4)", l, OS2D_BOX_MAX_OPS);
+      return -1;
+    }
+  if (!slot_rows) {      // every head row its own label
+    G = B;
+    V = 1;
+  }
+  return detect_pyramid_impl(loc, cls, corners, B, L, hw, stride, rec_field, img_wh, ops, score_threshold, iou_threshold,
                              nms_max_batch, passes, out_boxes, out_scores, out_index, out_default, out_corners, out_count,
                              unfinished, workspace, workspace_bytes, stream, G, V, slot_rows);
 }

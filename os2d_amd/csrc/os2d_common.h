@@ -65,6 +65,74 @@ __device__ __forceinline__ float4 os2d_decode_box(const float* __restrict__ l, i
   return o;
 }
 
+// Chain of axis-aligned box transforms that maps a level's boxes into the output image: what the reference's per-level
+// ``TransformList`` of closures amounts to (os2d/structures/transforms.py:12-27, built by os2d/data/dataloader.py:286-336 from
+// BoxList.resize / transpose / crop, os2d/structures/bounding_box.py:138-226), applied op by op with the reference's
+// roundings - every product / difference rounded on its own (no contraction into fused multiply-adds), so the fused decode
+// equals the generic chain (which calls the closures on a BoxList) bit for bit.  Kinds: OS2D_BOX_OP_* of include/os2d_hip.h.
+#define OS2D_BOX_MAX_OPS 6
+struct Os2dBoxOps {
+  int n;
+  int kind[OS2D_BOX_MAX_OPS];
+  float ax[OS2D_BOX_MAX_OPS], ay[OS2D_BOX_MAX_OPS];
+};
+__device__ __forceinline__ float4 os2d_apply_box_ops(float4 b, const Os2dBoxOps& t) {
+#pragma clang fp contract(off)
+  for (int k = 0; k < t.n; ++k) {
+    const float ax = t.ax[k], ay = t.ay[k];
+    switch (t.kind[k]) {
+      case 1:   // SCALE: BoxList.resize
+        b.x = b.x * ax;
+        b.y = b.y * ay;
+        b.z = b.z * ax;
+        b.w = b.w * ay;
+        break;
+      case 2: { // HFLIP about the image width ax: (xmin, xmax) = (W - xmax, W - xmin)
+        const float lo = ax - b.z, hi = ax - b.x;
+        b.x = lo;
+        b.z = hi;
+        break;
+      }
+      case 3: { // VFLIP about the image height ay
+        const float lo = ay - b.w, hi = ay - b.y;
+        b.y = lo;
+        b.w = hi;
+        break;
+      }
+      case 4:   // SHIFT: BoxList.crop (x - left, y - top)
+        b.x = b.x - ax;
+        b.y = b.y - ay;
+        b.z = b.z - ax;
+        b.w = b.w - ay;
+        break;
+      default:
+        break;
+    }
+  }
+  return b;
+}
+static inline Os2dBoxOps os2d_box_ops_scale(float sx, float sy) {
+  Os2dBoxOps t = {};
+  t.n = 1;
+  t.kind[0] = 1;
+  t.ax[0] = sx;
+  t.ay[0] = sy;
+  return t;
+}
+// ops from the ABI arrays (kinds [nops], args [nops][2]); false on a bad chain
+static inline bool os2d_box_ops_from(const int* kinds, const float* args, int nops, Os2dBoxOps* t) {
+  *t = Os2dBoxOps{};
+  if (nops < 0 || nops > OS2D_BOX_MAX_OPS || (nops > 0 && (!kinds || !args))) return false;
+  t->n = nops;
+  for (int k = 0; k < nops; ++k) {
+    if (kinds[k] < 1 || kinds[k] > 4) return false;
+    t->kind[k] = kinds[k];
+    t->ax[k] = args[2 * k];
+    t->ay[k] = args[2 * k + 1];
+  }
+  return true;
+}
+
 // IoU(a, b) > thr with torchvision's arithmetic (inter / (area_a + area_b - inter) in fp32, reference
 // os2d/structures/bounding_box.py:367 -> torchvision.ops.nms).  The IEEE division (a dozen VALU instructions) is only
 // executed when some lane of the wave is within 1e-5 (relative) of the threshold - everywhere else comparing inter with
@@ -145,7 +213,7 @@ int os2d_launch_nms(const float* boxes, const int* counts, int NC, int N, float 
 // detect.hip
 size_t os2d_detect_level_lds_bytes(int H, int W);
 int os2d_launch_detect_level(const float* loc, const float* cls, int B, int H, int W, int stride, int rec_field,
-                             float img_w, float img_h, float scale_x, float scale_y, float score_thr, float iou_thr,
+                             float img_w, float img_h, const Os2dBoxOps& ops, float score_thr, float iou_thr,
                              float* out_boxes, float* out_scores, int* out_index, int* out_count, hipStream_t stream);
 // fft.hip
 int os2d_fft_plan(int H, int W, int* P, int* Q, int* nbins, int* tiles /* [6]: TY, TX, TH, TW, window rows, window columns */);

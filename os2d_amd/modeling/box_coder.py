@@ -15,9 +15,11 @@ import torch
 
 from .. import _lib
 from ..structures.feature_map import FeatureMapSize
-from ..structures.bounding_box import BoxList
+from ..structures.bounding_box import BoxList, FLIP_LEFT_RIGHT, FLIP_TOP_BOTTOM
 
 BOX_ENCODING_WEIGHTS = (10.0, 10.0, 5.0, 5.0)   # reference box_coder.py:13
+OP_SCALE, OP_HFLIP, OP_VFLIP, OP_SHIFT = 1, 2, 3, 4   # OS2D_BOX_OP_* of include/os2d_hip.h
+MAX_BOX_OPS = 6                                       # OS2D_BOX_MAX_OPS
 
 
 @lru_cache()
@@ -35,7 +37,8 @@ def create_strided_boxes_columnfirst(grid_size, box_size, box_stride):
 class ResizeBoxes(object):
     """``inverse_box_transforms`` entry that maps a level's boxes to ``target_size`` (what the reference's
     ``TransformList`` inverse amounts to for a resized image, box_coder.py:499-503): ``boxlist.resize(target_size)``.
-    Being a recognisable type (not a lambda) lets ``decode_pyramid`` hand the two scale factors to the fused kernel."""
+    (Any entry made of BoxList.resize / transpose / crop calls - this class, the reference's ``TransformList`` of lambdas -
+    reaches the fused decode kernels: ``trace_box_transform`` records the chain.)"""
 
     def __init__(self, target_size):
         self.target_size = target_size
@@ -45,6 +48,91 @@ class ResizeBoxes(object):
 
     def ratios(self, img_size):
         return float(self.target_size.w) / img_size.w, float(self.target_size.h) / img_size.h
+
+
+class _BoxTrace(object):
+    """Stand-in for a ``BoxList`` that RECORDS what an ``inverse_box_transforms`` entry does to it.  The reference hands
+    ``decode_pyramid`` one ``TransformList`` of closures per level (os2d/structures/transforms.py:12-27; the closures are
+    ``lambda boxes: boxes.resize(size)`` / ``boxes.transpose(FLIP_*)`` / ``boxes.crop(uncrop_xyxy)``, appended by
+    transforms.py:32-52, 78-79, 188-191 from os2d/data/dataloader.py:286-336) and calls it on BoxLists
+    (os2d/modeling/box_coder.py:499-503).  Called on this object instead, the same closures leave the exact sequence of
+    operations with their parameters - which the fused decode kernels then apply op by op with the reference's roundings
+    (a numerical probe could only recover the composite map, not where it rounds).  Anything else a closure might touch
+    (``bbox_xyxy``, fields, ...) is not defined here: the AttributeError sends the caller to the generic chain."""
+
+    def __init__(self, image_size, ops=()):
+        self.image_size = image_size
+        self.ops = tuple(ops)
+
+    def resize(self, target_size):                      # BoxList.resize, reference bounding_box.py:138-163
+        op = (OP_SCALE, float(target_size.w) / self.image_size.w, float(target_size.h) / self.image_size.h)
+        return _BoxTrace(target_size, self.ops + (op,))
+
+    def transpose(self, method):                        # reference bounding_box.py:165-200
+        if method == FLIP_LEFT_RIGHT:
+            op = (OP_HFLIP, float(self.image_size.w), 0.0)
+        elif method == FLIP_TOP_BOTTOM:
+            op = (OP_VFLIP, 0.0, float(self.image_size.h))
+        else:
+            raise NotImplementedError("Only FLIP_LEFT_RIGHT and FLIP_TOP_BOTTOM implemented")
+        return _BoxTrace(self.image_size, self.ops + (op,))
+
+    def crop(self, box):                                # reference bounding_box.py:202-226
+        size = FeatureMapSize(w=box[2] - box[0], h=box[3] - box[1])
+        return _BoxTrace(size, self.ops + ((OP_SHIFT, float(box[0]), float(box[1])),))
+
+
+def apply_box_ops(boxes, ops):
+    """The recorded chain on a [n,4] xyxy tensor with the arithmetic of the BoxList methods (one float32 rounding per
+    product / difference) - what os2d_apply_box_ops does on the device."""
+    x1, y1, x2, y2 = boxes.unbind(1)
+    for kind, ax, ay in ops:
+        if kind == OP_SCALE:
+            x1, y1, x2, y2 = x1 * ax, y1 * ay, x2 * ax, y2 * ay
+        elif kind == OP_HFLIP:
+            x1, x2 = ax - x2, ax - x1
+        elif kind == OP_VFLIP:
+            y1, y2 = ay - y2, ay - y1
+        else:
+            x1, y1, x2, y2 = x1 - ax, y1 - ay, x2 - ax, y2 - ay
+    return torch.stack([x1, y1, x2, y2], dim=1)
+
+
+_PROBE_BOXES = ((0.0, 0.0, 1.0, 1.0), (13.25, 7.5, 211.0, 95.75), (3.0, 250.5, 640.125, 479.0))
+
+
+def trace_box_transform(transform, img_size):
+    """-> (ops, output image size) of one ``inverse_box_transforms`` entry applied to boxes on an image of ``img_size``, or
+    None when the entry is not a chain of BoxList.resize / transpose / crop (then only the generic decode can run it).
+    ``None`` entries trace to the empty chain.  The recorded chain is checked against the entry itself on three probe boxes
+    (unit, generic, near the border): bit-equal boxes and the same output size, or it is not used."""
+    if transform is None:
+        return (), img_size
+    try:
+        traced = transform(_BoxTrace(img_size))
+        if not isinstance(traced, _BoxTrace) or len(traced.ops) > MAX_BOX_OPS:
+            return None
+        probe = torch.tensor(_PROBE_BOXES, dtype=torch.float32)
+        direct = transform(BoxList(probe.clone(), img_size))
+        if direct.image_size != traced.image_size or not torch.equal(direct.bbox_xyxy, apply_box_ops(probe, traced.ops)):
+            return None
+    except Exception:   # noqa: BLE001 - a closure that does anything else than the three BoxList operations
+        return None
+    return traced.ops, traced.image_size
+
+
+def _ops_tables(ops_per_level):
+    """ctypes tables (counts [L], kinds [L][MAX], args [L][MAX][2]) of os2d_detect_pyramid_ops."""
+    L = len(ops_per_level)
+    counts = (ctypes.c_int * L)(*[len(o) for o in ops_per_level])
+    kinds = (ctypes.c_int * (L * MAX_BOX_OPS))()
+    args = (ctypes.c_float * (L * MAX_BOX_OPS * 2))()
+    for l, ops in enumerate(ops_per_level):
+        for k, (kind, ax, ay) in enumerate(ops):
+            kinds[l * MAX_BOX_OPS + k] = kind
+            args[(l * MAX_BOX_OPS + k) * 2] = ax
+            args[(l * MAX_BOX_OPS + k) * 2 + 1] = ay
+    return counts, kinds, args
 
 
 class BoxGridGenerator(object):
@@ -212,9 +300,9 @@ class Os2dBoxCoder(object):
         if inverse_box_transforms is None:
             # the reference concatenates the levels of a label with cat_boxlist, which asserts one common image size
             # (bounding_box.py:390-437): levels of different sizes need transforms into a common frame
-            assert len({(s_.w, s_.h) for s_ in img_size_pyramid}) <= 1, \
-                "pyramid levels live on different image sizes ({}): pass inverse_box_transforms to map them to one image size " \
-                "before they are merged".format(sorted({(s_.w, s_.h) for s_ in img_size_pyramid}))
+            if len({(s_.w, s_.h) for s_ in img_size_pyramid}) > 1:     # (not an ``assert``: must survive ``python -O``)
+                raise ValueError("pyramid levels live on different image sizes ({}): pass inverse_box_transforms to map them to "
+                                 "one image size before they are merged".format(sorted({(s_.w, s_.h) for s_ in img_size_pyramid})))
         fused = self._decode_single_level_fused(loc_scores_pyramid, cls_scores_pyramid, img_size_pyramid, class_ids,
                                                 nms_score_threshold, nms_iou_threshold, inverse_box_transforms,
                                                 transform_corners_pyramid)
@@ -321,10 +409,11 @@ class Os2dBoxCoder(object):
         ids = [int(c) for c in class_ids]
         if len(set(ids)) != len(ids):
             return None
-        t = inverse[0] if inverse is not None else None
-        if t is not None and not isinstance(t, ResizeBoxes):
-            return None
         loc, cls, img_size = loc_pyr[0], cls_pyr[0], size_pyr[0]
+        traced = trace_box_transform(inverse[0] if inverse is not None else None, img_size)
+        if traced is None:
+            return None
+        ops, out_size = traced
         fm = self.get_feature_map_size(img_size)
         lib = _lib.load()
         if not lib.os2d_detect_level_supported(fm.h, fm.w):
@@ -336,18 +425,17 @@ class Os2dBoxCoder(object):
         loc = loc.contiguous()
         cls = cls.float().contiguous()
         assert tuple(loc.shape) == (B, 4, HW) and tuple(cls.shape) == (B, HW), "level tensors do not match class_ids / feature map"
-        rx, ry = t.ratios(img_size) if t is not None else (1.0, 1.0)
-        out_size = t.target_size if t is not None else img_size
+        counts_c, kinds_c, args_c = _ops_tables([ops])
         out_boxes = torch.empty(B, HW, 4, dtype=torch.float32, device=dev)
         out_scores = torch.empty(B, HW, dtype=torch.float32, device=dev)
         out_index = torch.empty(B, HW, dtype=torch.int32, device=dev)
         out_count = torch.empty(B, dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):     # hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device
-            _lib.check(lib.os2d_detect_level(_lib.ptr(loc), _lib.ptr(cls), B, fm.h, fm.w, self._stride, self._rec_field,
-                                             ctypes.c_float(img_size.w), ctypes.c_float(img_size.h), ctypes.c_float(rx),
-                                             ctypes.c_float(ry), ctypes.c_float(score_thr), ctypes.c_float(iou_thr),
-                                             _lib.ptr(out_boxes), _lib.ptr(out_scores), _lib.ptr(out_index),
-                                             _lib.ptr(out_count), _lib.current_stream(dev)), "os2d_detect_level")
+            _lib.check(lib.os2d_detect_level_ops(_lib.ptr(loc), _lib.ptr(cls), B, fm.h, fm.w, self._stride, self._rec_field,
+                                                 ctypes.c_float(img_size.w), ctypes.c_float(img_size.h), len(ops), kinds_c, args_c,
+                                                 ctypes.c_float(score_thr), ctypes.c_float(iou_thr),
+                                                 _lib.ptr(out_boxes), _lib.ptr(out_scores), _lib.ptr(out_index),
+                                                 _lib.ptr(out_count), _lib.current_stream(dev)), "os2d_detect_level_ops")
         # rows in the label order of the reference (iteration order of ``set(class_ids)``), survivors of a row by score
         rank = {l: k for k, l in enumerate(set(ids))}      # the reference iterates ``set(class_ids)`` (box_coder.py:483)
         order = sorted(range(B), key=lambda i: rank[ids[i]])
@@ -365,18 +453,32 @@ class Os2dBoxCoder(object):
         result.add_field("scores", out_scores.view(-1)[flat])
         result.add_field("labels", torch.tensor([ids[i] for i in order], dtype=torch.long, device=dev)[row])
         loc_idx = out_index.view(-1)[flat].long()
-        dflt = self._get_default_boxes(img_size).bbox_xyxy.to(dev)[loc_idx]
-        scale = None
-        if t is not None:
-            scale = torch.tensor([rx, ry, rx, ry], dtype=torch.float32, device=dev) if rx != ry else rx
-            dflt = dflt * scale
+        dflt = apply_box_ops(self._get_default_boxes(img_size).bbox_xyxy.to(dev)[loc_idx], ops)
         result.add_field("default_boxes", BoxList(dflt, out_size))
         if corners_pyr is not None:
             corners = corners_pyr[0][src_row, :, loc_idx]                                   # [n, 8]
-            if scale is not None:
-                corners = (corners.view(-1, 4) * scale).view(-1, 8)
-            result.add_field("transform_corners", corners)
+            # like the reference, the corners go through the level's transform as the two "boxes" (x0, y0, x1, y1), (x2, y2, x3, y3)
+            result.add_field("transform_corners", apply_box_ops(corners.reshape(-1, 4), ops).view(-1, 8))
         return result
+
+    def _slot_rows(self, ids, labels, V, dev):
+        """Device table [G][V] of the head rows of every label (-1: no such view), cached per (class ids, device): the rows of
+        an evaluation's class batch are the same for every image, and building the table is a blocking host-to-device copy
+        from pageable memory on the per-image path."""
+        cache = self.__dict__.setdefault("_slot_rows_cache", {})
+        key = (ids, V, str(dev))
+        table = cache.get(key)
+        if table is None:
+            rows_of = {}
+            for i, c in enumerate(ids):
+                rows_of.setdefault(c, []).append(i)
+            host = torch.tensor([(rows_of[l] + [-1] * V)[:V] for l in labels], dtype=torch.int32).pin_memory()
+            table = host.to(dev, non_blocking=True)
+            if len(cache) >= 16:
+                cache.pop(next(iter(cache)))
+            cache[key] = (table, host)         # the pinned source lives as long as the copy may be in flight
+            return table
+        return table[0]
 
     def _decode_pyramid_fused(self, loc_pyr, cls_pyr, size_pyr, class_ids, score_thr, iou_thr, inverse, corners_pyr):
         """Several levels and / or merged labels (class-image views: several head rows with one class id, reference
@@ -391,12 +493,11 @@ class Os2dBoxCoder(object):
         # (a single level with one row per label normally took os2d_detect_level before this is called; levels beyond that
         # kernel's LDS budget - more than ~5,900 locations, e.g. 72 x 96 - come here as a pyramid of one level)
         ts = list(inverse) if inverse is not None else [None] * len(loc_pyr)
-        if any(t is not None and not isinstance(t, ResizeBoxes) for t in ts) or len({t is None for t in ts}) != 1:
-            return None
-        if ts[0] is not None and len({(t.target_size.w, t.target_size.h) for t in ts}) != 1:
-            return None
-        if ts[0] is None and len({(s_.w, s_.h) for s_ in size_pyr}) != 1:
-            return None      # decode_pyramid asserts this before it gets here (reference cat_boxlist, bounding_box.py:390-437)
+        traced = [trace_box_transform(t, s_) for t, s_ in zip(ts, size_pyr)]
+        if any(t is None for t in traced):
+            return None      # an entry that is not a chain of BoxList.resize / transpose / crop: generic path
+        if len({(sz.w, sz.h) for _, sz in traced}) != 1:
+            return None      # levels that end on different image sizes: the generic path fails like the reference's cat_boxlist
         lib = _lib.load()
         L = len(loc_pyr)
         fms = [self.get_feature_map_size(s) for s in size_pyr]
@@ -420,8 +521,8 @@ class Os2dBoxCoder(object):
             assert tuple(loc.shape) == (B, 4, hw) and tuple(cls.shape) == (B, hw), "level tensors do not match class_ids / feature map"
             locs.append(loc)
             clss.append(cls)
-        ratios = [t.ratios(s) if t is not None else (1.0, 1.0) for t, s in zip(ts, size_pyr)]
-        out_size = ts[0].target_size if ts[0] is not None else size_pyr[0]
+        out_size = traced[0][1]
+        c_counts, c_kinds, c_args = _ops_tables([ops for ops, _ in traced])
         passes = int(self.fused_pyramid_passes)
         nbytes = ctypes.c_size_t()
         _lib.check(lib.os2d_detect_pyramid_workspace_bytes(G, N, passes, ctypes.byref(nbytes)), "os2d_detect_pyramid_workspace_bytes")
@@ -441,27 +542,16 @@ class Os2dBoxCoder(object):
             out_corners = torch.empty(G, N, 8, dtype=torch.float32, device=dev)
         c_hw = (ctypes.c_int * (2 * L))(*[v for fm in fms for v in (fm.h, fm.w)])
         c_img = (ctypes.c_float * (2 * L))(*[float(v) for s_ in size_pyr for v in (s_.w, s_.h)])
-        c_scale = (ctypes.c_float * (2 * L))(*[float(v) for r in ratios for v in r])
         identity = not merged and labels == ids          # one row per label, already in the reference's label order
         with torch.cuda.device(dev):
-            if identity:
-                _lib.check(lib.os2d_detect_pyramid(c_loc, c_cls, c_cor, B, L, c_hw, self._stride, self._rec_field, c_img, c_scale,
-                                                   ctypes.c_float(score_thr), ctypes.c_float(iou_thr), int(self.nms_max_batch),
-                                                   passes, _lib.ptr(out_boxes), _lib.ptr(out_scores), _lib.ptr(out_index),
+            slot_rows = None if identity else self._slot_rows(tuple(ids), tuple(labels), V, dev)
+            _lib.check(lib.os2d_detect_pyramid_ops(c_loc, c_cls, c_cor, B, L, c_hw, self._stride, self._rec_field, c_img,
+                                                   c_counts, c_kinds, c_args, ctypes.c_float(score_thr), ctypes.c_float(iou_thr),
+                                                   int(self.nms_max_batch), passes, G, V, _lib.ptr(slot_rows),
+                                                   _lib.ptr(out_boxes), _lib.ptr(out_scores), _lib.ptr(out_index),
                                                    _lib.ptr(out_default), _lib.ptr(out_corners), _lib.ptr(out_count),
                                                    _lib.ptr(unfinished), _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
-                           "os2d_detect_pyramid")
-            else:
-                table = [(rows_of[l] + [-1] * V)[:V] for l in labels]
-                slot_rows = torch.tensor(table, dtype=torch.int32).to(dev)
-                _lib.check(lib.os2d_detect_pyramid_merged(c_loc, c_cls, c_cor, B, L, c_hw, self._stride, self._rec_field, c_img,
-                                                          c_scale, ctypes.c_float(score_thr), ctypes.c_float(iou_thr),
-                                                          int(self.nms_max_batch), passes, G, V, _lib.ptr(slot_rows),
-                                                          _lib.ptr(out_boxes), _lib.ptr(out_scores), _lib.ptr(out_index),
-                                                          _lib.ptr(out_default), _lib.ptr(out_corners), _lib.ptr(out_count),
-                                                          _lib.ptr(unfinished), _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
-                           "os2d_detect_pyramid_merged")
-                slot_rows.record_stream(torch.cuda.current_stream(dev))
+                       "os2d_detect_pyramid_ops")
         mask = torch.arange(N, device=dev).unsqueeze(0) < out_count.unsqueeze(1)
         row, pos = mask.nonzero(as_tuple=True)                   # the one host synchronisation: sizes the result
         if int(unfinished.item()) != 0:

@@ -3,6 +3,12 @@
 xyxy storage, image size, named per-box fields, indexing, resize, clipping and the empty-box mask."""
 import torch
 
+from .feature_map import FeatureMapSize
+
+# flip methods of ``BoxList.transpose`` (values of PIL.Image.FLIP_LEFT_RIGHT / FLIP_TOP_BOTTOM, reference bounding_box.py:11-12)
+FLIP_LEFT_RIGHT = 0
+FLIP_TOP_BOTTOM = 1
+
 
 class BoxList(object):
     def __init__(self, bbox, image_size, mode="xyxy"):
@@ -63,6 +69,30 @@ class BoxList(object):
             scaled = self.bbox_xyxy * torch.tensor([rw, rh, rw, rh], dtype=torch.float32, device=self.bbox_xyxy.device)
         out = BoxList(scaled, target_size)
         out.extra_fields = dict(self.extra_fields)
+        return out
+
+    def transpose(self, method):
+        """reference bounding_box.py:165-200: horizontal / vertical flip inside the image."""
+        if method not in (FLIP_LEFT_RIGHT, FLIP_TOP_BOTTOM):
+            raise NotImplementedError("Only FLIP_LEFT_RIGHT and FLIP_TOP_BOTTOM implemented")
+        x1, y1, x2, y2 = self.bbox_xyxy.unbind(1)
+        if method == FLIP_LEFT_RIGHT:
+            x1, x2 = self.image_size.w - x2, self.image_size.w - x1
+        else:
+            y1, y2 = self.image_size.h - y2, self.image_size.h - y1
+        out = BoxList(torch.stack([x1, y1, x2, y2], dim=1), self.image_size)
+        for k, v in self.extra_fields.items():
+            out.add_field(k, v if isinstance(v, torch.Tensor) else v.transpose(method))
+        return out
+
+    def crop(self, box):
+        """reference bounding_box.py:202-226: coordinates relative to the (left, upper, right, lower) region ``box``; the
+        result lives on an image of the region's size and is NOT clipped to it."""
+        x1, y1, x2, y2 = self.bbox_xyxy.unbind(1)
+        out = BoxList(torch.stack([x1 - box[0], y1 - box[1], x2 - box[0], y2 - box[1]], dim=1),
+                      FeatureMapSize(w=box[2] - box[0], h=box[3] - box[1]))
+        for k, v in self.extra_fields.items():
+            out.add_field(k, v if isinstance(v, torch.Tensor) else v.crop(box))
         return out
 
     def clip_to_image(self, remove_empty=True):

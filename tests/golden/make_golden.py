@@ -401,6 +401,83 @@ def make_model_fixture():
     np.savez_compressed(os.path.join(HERE, "model_forward.npz"), **arrays)
 
 
+def make_decode_transforms_fixture():
+    """decode_pyramid with the inverse box transforms the reference's OWN dataloader code builds (os2d/data/dataloader.py:
+    286-336): image -> hflip + vflip (transforms.py:32-52) -> mined crop (:84-191) -> resize to the augmentation size (:55-81) ->
+    one more resize per pyramid level on a deep copy of the list.  The TransformList of a level then undoes, in order:
+    pyramid resize, augmentation resize, crop ("uncrop"), vertical flip, horizontal flip.  The fixture stores that chain as
+    data (kind + parameters per step, in the order the inverse applies them) and what the reference's decode_pyramid returns."""
+    import copy
+    from PIL import Image
+    from os2d.modeling.box_coder import Os2dBoxCoder, BoxGridGenerator
+    from os2d.structures import transforms as T
+    from os2d.structures.bounding_box import BoxList
+    from os2d.structures.feature_map import FeatureMapSize
+
+    gen = BoxGridGenerator(box_size=FeatureMapSize(w=240, h=240), box_stride=FeatureMapSize(w=16, h=16))
+
+    def fm_size(img_size):
+        f = lambda s: -(-(-(-(-(-(-(-s // 2)) // 2)) // 2)) // 2)
+        return FeatureMapSize(w=f(img_size.w), h=f(img_size.h))
+
+    coder = Os2dBoxCoder(0.5, 0.1, 0.5, 0.1, gen, fm_size, do_nms_across_classes=False)
+    rs = np.random.RandomState(91)
+    orig = Image.new("RGB", (500, 380))
+    orig_size = FeatureMapSize(img=orig)
+    boxes = BoxList(torch.tensor([[40.0, 30.0, 200.0, 180.0], [250.0, 100.0, 470.0, 350.0]]), orig_size, mode="xyxy")
+    tl = T.TransformList()
+    img, boxes = T.transpose(orig, hflip=True, vflip=True, boxes=boxes, transform_list=tl)
+    crop_xyxy = (37, 21, 421, 341)
+    crop_pos = BoxList(torch.tensor([[float(v) for v in crop_xyxy]]), FeatureMapSize(img=img), mode="xyxy")
+    img, boxes, _, _ = T.crop(img, crop_position=crop_pos, boxes=boxes, transform_list=tl)
+    crop_size = FeatureMapSize(img=img)
+    aug_size = FeatureMapSize(w=320, h=272)
+    img, boxes = T.resize(img, target_size=aug_size, boxes=boxes, transform_list=tl)
+    level_sizes = [FeatureMapSize(w=208, h=176), FeatureMapSize(w=320, h=272), FeatureMapSize(w=400, h=340)]
+    inverse, spec = [], []
+    uncrop = (-crop_xyxy[0], -crop_xyxy[1], -crop_xyxy[0] + orig_size.w, -crop_xyxy[1] + orig_size.h)
+    for p_size in level_sizes:
+        tl_l = copy.deepcopy(tl)
+        T.resize(img, target_size=p_size, boxes=boxes, transform_list=tl_l)
+        inverse.append(tl_l)
+        # kind 1 = resize to (w, h); 4 = crop (left, top, right, bottom); 3 = FLIP_TOP_BOTTOM; 2 = FLIP_LEFT_RIGHT
+        spec.append([[1, aug_size.w, aug_size.h, 0, 0], [1, crop_size.w, crop_size.h, 0, 0], [4] + list(uncrop),
+                     [3, 0, 0, 0, 0], [2, 0, 0, 0, 0]])
+    n_cls = 3
+    arrays = dict(n_levels=np.int64(len(level_sizes)), n_classes=np.int64(n_cls),
+                  img_sizes=np.array([[s.w, s.h] for s in level_sizes], dtype=np.int64),
+                  orig_size=np.array([orig_size.w, orig_size.h], dtype=np.int64), chain=np.array(spec, dtype=np.float64))
+    locs, clss, corners = [], [], []
+    for i, s_ in enumerate(level_sizes):
+        f = fm_size(s_)
+        n = f.w * f.h
+        locs.append(torch.from_numpy((rs.standard_normal((n_cls, 4, n)) * np.array([2.0, 2.0, 1.5, 1.5])[None, :, None]).astype(np.float32)))
+        clss.append(torch.from_numpy(rs.uniform(-1, 1, size=(n_cls, n)).astype(np.float32)))
+        corners.append(torch.from_numpy(rs.uniform(0, 300, size=(n_cls, 8, n)).astype(np.float32)))
+        arrays["loc_{}".format(i)], arrays["cls_{}".format(i)], arrays["corners_{}".format(i)] = \
+            locs[-1].numpy(), clss[-1].numpy(), corners[-1].numpy()
+    # the chain on plain boxes (what every step does to coordinates and to the image size)
+    probe = torch.tensor([[0.0, 0.0, 1.0, 1.0], [13.25, 7.5, 211.0, 95.75], [3.0, 150.5, 200.125, 170.0]])
+    for i, s_ in enumerate(level_sizes):
+        out = inverse[i](BoxList(probe.clone(), s_, mode="xyxy"))
+        assert out.image_size == orig_size
+        arrays["probe_out_{}".format(i)] = out.bbox_xyxy.numpy()
+    arrays["probe"] = probe.numpy()
+    for thr_name, score_thr in (("t0", 0.0), ("tinf", float("-inf"))):
+        res = coder.decode_pyramid([l.clone() for l in locs], [c.clone() for c in clss], level_sizes,
+                                   class_ids=list(range(n_cls)), nms_score_threshold=score_thr, nms_iou_threshold=0.3,
+                                   inverse_box_transforms=inverse, transform_corners_pyramid=[k.clone() for k in corners])
+        order = torch.argsort(res.get_field("labels") * 10 - res.get_field("scores"), stable=True)
+        arrays["ref_{}_default_boxes".format(thr_name)] = res.get_field("default_boxes").bbox_xyxy[order].numpy()
+        arrays["ref_{}_corners".format(thr_name)] = res.get_field("transform_corners")[order].numpy()
+        arrays["ref_{}_boxes".format(thr_name)] = res.bbox_xyxy[order].numpy()
+        arrays["ref_{}_scores".format(thr_name)] = res.get_field("scores")[order].numpy()
+        arrays["ref_{}_labels".format(thr_name)] = res.get_field("labels")[order].numpy()
+        assert res.image_size == orig_size
+        print("decode with dataloader transforms {}: {} detections".format(thr_name, len(order)))
+    np.savez_compressed(os.path.join(HERE, "decode_transforms.npz"), **arrays)
+
+
 def make_chunked_nms_fixture():
     """The reference's memory-bounded NMS (bounding_box.py:343-374: lists longer than nms_max_batch are NMS-ed in
     chunks of that size, survivors concatenated chunk by chunk in score order, repeated until one chunk is left or
@@ -439,6 +516,7 @@ def main():
     make_extreme_fixtures()
     make_decode_fixture()
     make_chunked_nms_fixture()
+    make_decode_transforms_fixture()
     make_model_fixture()
 
 

@@ -452,7 +452,7 @@ def test_levels_of_different_image_sizes_need_transforms(device):
     for fused in (True, False):
         coder = _coder()
         coder.use_fused_level_kernel = fused
-        with pytest.raises(AssertionError, match="image size"):
+        with pytest.raises(ValueError, match="image size"):
             coder.decode_pyramid(locs, clss, sizes, [0, 1], nms_score_threshold=0.0)
 
 
@@ -470,3 +470,68 @@ def test_single_level_beyond_the_level_kernel_takes_the_pyramid_path(device):
     generic = coder.decode_pyramid(locs, clss, sizes, ids, nms_score_threshold=0.0, transform_corners_pyramid=corners)
     _assert_same_detections(fused, generic)
     assert len(fused) > 0
+
+
+# ------------------------------------------------------------------------- the reference's closure lists on the device path
+def test_dataloader_style_transforms_take_the_fused_path_and_match_the_reference(device):
+    """VERDICT r3 item 3 / SURVEY 8(b): ``inverse_box_transforms`` as the reference's dataloader builds them - one list of
+    closures per level (flips, mined crop, two resizes; os2d/data/dataloader.py:286-336) - now reach the fused decode
+    (os2d_detect_pyramid_ops): the device path runs, matches what the reference's decode_pyramid returned for the same
+    closures (fixture), and equals the generic chain - which calls the closures on BoxLists - bit for bit, incl. anchors and
+    transform corners (which the reference maps as pairs of points, so a flip exchanges their x / y)."""
+    from os2d_amd.structures.feature_map import FeatureMapSize
+    d = np.load(util.GOLDEN + "/decode_transforms.npz")
+    L = int(d["n_levels"])
+    sizes = [FeatureMapSize(w=int(w), h=int(h)) for w, h in d["img_sizes"]]
+    locs = [torch.from_numpy(d["loc_%d" % i]).to(device) for i in range(L)]
+    clss = [torch.from_numpy(d["cls_%d" % i]).to(device) for i in range(L)]
+    corners = [torch.from_numpy(d["corners_%d" % i]).to(device) for i in range(L)]
+    orig = FeatureMapSize(w=int(d["orig_size"][0]), h=int(d["orig_size"][1]))
+    inverse = [util.dataloader_style_inverse(d["chain"][i]) for i in range(L)]
+    ids = list(range(int(d["n_classes"])))
+    coder = _coder()
+    assert coder._decode_pyramid_fused(locs, clss, sizes, ids, 0.0, 0.3, inverse, corners) is not None, "device path not taken"
+    for name, thr in (("t0", 0.0), ("tinf", float("-inf"))):
+        coder.use_fused_level_kernel = True
+        res = coder.decode_pyramid(locs, clss, sizes, class_ids=ids, nms_score_threshold=thr, nms_iou_threshold=0.3,
+                                   inverse_box_transforms=inverse, transform_corners_pyramid=corners)
+        assert res.image_size == orig and len(res) == len(d["ref_%s_scores" % name]), name
+        assert torch.equal(res.get_field("labels").cpu(), torch.from_numpy(d["ref_%s_labels" % name]))
+        assert torch.equal(res.get_field("scores").cpu(), torch.from_numpy(d["ref_%s_scores" % name]))
+        assert util.maxdiff(res.bbox_xyxy, torch.from_numpy(d["ref_%s_boxes" % name])) < 1e-3
+        assert util.maxdiff(res.get_field("default_boxes").bbox_xyxy, torch.from_numpy(d["ref_%s_default_boxes" % name])) < 1e-3
+        assert util.maxdiff(res.get_field("transform_corners"), torch.from_numpy(d["ref_%s_corners" % name])) < 1e-3
+        coder.use_fused_level_kernel = False
+        generic = coder.decode_pyramid(locs, clss, sizes, class_ids=ids, nms_score_threshold=thr, nms_iou_threshold=0.3,
+                                       inverse_box_transforms=inverse, transform_corners_pyramid=corners)
+        _assert_same_detections(res, generic)
+    # one level alone: the single-level kernel (os2d_detect_level_ops) with the same chain; merged labels: 2 views per label
+    coder.use_fused_level_kernel = True
+    assert coder._decode_single_level_fused(locs[:1], clss[:1], sizes[:1], ids, 0.0, 0.3, inverse[:1], corners[:1]) is not None
+    fused1 = coder.decode_pyramid(locs[:1], clss[:1], sizes[:1], ids, nms_score_threshold=0.0, inverse_box_transforms=inverse[:1],
+                                  transform_corners_pyramid=corners[:1])
+    merged_ids = [7, 2, 7]
+    assert coder._decode_pyramid_fused(locs, clss, sizes, merged_ids, 0.0, 0.3, inverse, corners) is not None
+    fused_m = coder.decode_pyramid(locs, clss, sizes, merged_ids, nms_score_threshold=0.0, inverse_box_transforms=inverse,
+                                   transform_corners_pyramid=corners)
+    coder.use_fused_level_kernel = False
+    _assert_same_detections(fused1, coder.decode_pyramid(locs[:1], clss[:1], sizes[:1], ids, nms_score_threshold=0.0,
+                                                         inverse_box_transforms=inverse[:1], transform_corners_pyramid=corners[:1]))
+    _assert_same_detections(fused_m, coder.decode_pyramid(locs, clss, sizes, merged_ids, nms_score_threshold=0.0,
+                                                          inverse_box_transforms=inverse, transform_corners_pyramid=corners))
+    assert len(fused1) > 0 and len(fused_m) > 0
+
+
+def test_untraceable_transform_falls_back_to_the_generic_chain(device):
+    """An entry that does anything else than BoxList.resize / transpose / crop cannot be handed to the kernels: the decode
+    then runs the closures on BoxLists (generic chain) and still returns the right thing."""
+    from os2d_amd.structures.bounding_box import BoxList
+    from os2d_amd.structures.feature_map import FeatureMapSize
+    levels = [(9, 12), (9, 12)]
+    sizes, locs, clss, corners = _pyramid_inputs(levels, 2, 31, device)
+    shift = [lambda b: BoxList(b.bbox_xyxy + 2.0, b.image_size) for _ in levels]
+    coder = _coder()
+    assert coder._decode_pyramid_fused(locs, clss, sizes, [0, 1], 0.0, 0.3, shift, None) is None
+    res = coder.decode_pyramid(locs, clss, sizes, [0, 1], nms_score_threshold=0.0, inverse_box_transforms=shift)
+    plain = coder.decode_pyramid(locs, clss, sizes, [0, 1], nms_score_threshold=0.0)
+    assert len(res) == len(plain) and torch.equal(res.bbox_xyxy, plain.bbox_xyxy + 2.0)

@@ -142,3 +142,38 @@ def test_bench_refuses_to_run_without_a_device():
     out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--steps", "1"], cwd=repo, capture_output=True,
                          text=True, timeout=300)
     assert out.returncode != 0 and "HIP device" in (out.stderr + out.stdout)
+
+
+def test_dataloader_style_inverse_transforms_are_traced_exactly():
+    """the reference hands decode_pyramid a TransformList of closures per level.  On the fixture the
+    reference's own dataloader functions produced (flips + mined crop + two resizes, tests/golden/make_golden.py::
+    make_decode_transforms_fixture): (i) this repo's BoxList runs the closures to the reference's coordinates bit for bit,
+    (ii) ``trace_box_transform`` recovers the chain of 5 operations, and (iii) applying the recorded chain reproduces the
+    closures' result bit for bit - so the fused decode kernels can replace the closures."""
+    import numpy as np
+    import util
+    from os2d_amd.modeling.box_coder import OP_HFLIP, OP_SCALE, OP_SHIFT, OP_VFLIP, ResizeBoxes, apply_box_ops, trace_box_transform
+    d = np.load(util.GOLDEN + "/decode_transforms.npz")
+    orig = FeatureMapSize(w=int(d["orig_size"][0]), h=int(d["orig_size"][1]))
+    probe = torch.from_numpy(d["probe"])
+    for l in range(int(d["n_levels"])):
+        size = FeatureMapSize(w=int(d["img_sizes"][l][0]), h=int(d["img_sizes"][l][1]))
+        t = util.dataloader_style_inverse(d["chain"][l])
+        out = t(BoxList(probe.clone(), size))
+        assert out.image_size == orig
+        assert torch.equal(out.bbox_xyxy, torch.from_numpy(d["probe_out_%d" % l]))
+        ops, out_size = trace_box_transform(t, size)
+        assert out_size == orig and [o[0] for o in ops] == [OP_SCALE, OP_SCALE, OP_SHIFT, OP_VFLIP, OP_HFLIP]
+        assert torch.equal(apply_box_ops(probe, ops), torch.from_numpy(d["probe_out_%d" % l]))
+    # identity / ResizeBoxes / plain lambdas trace too; anything else than the three BoxList operations does not
+    size = FeatureMapSize(w=320, h=272)
+    assert trace_box_transform(None, size) == ((), size)
+    ops, out_size = trace_box_transform(ResizeBoxes(orig), size)
+    assert out_size == orig and ops == ((OP_SCALE, 500.0 / 320, 380.0 / 272),)
+    assert trace_box_transform(lambda b: b.resize(orig), size)[0] == ops
+    assert trace_box_transform(lambda b: BoxList(b.bbox_xyxy + 1.0, b.image_size), size) is None      # touches coordinates
+    assert trace_box_transform(lambda b: b.resize(orig).clip_to_image(), size) is None                # an untraced method
+    long_chain = util.InverseTransformList()
+    for _ in range(7):
+        long_chain.append(lambda b: b.resize(orig))
+    assert trace_box_transform(long_chain, size) is None                                               # more than 6 operations

@@ -97,3 +97,40 @@ def adversarial_transform_net_state(P, seed, lo1=-3.0, hi1=6.0, lo2=-3.0, hi2=3.
         st[bn + ".bias"] = st[bn + ".bias"] * s
         st[nxt] = st[nxt] / s.view(1, -1, 1, 1)
     return st
+
+
+class InverseTransformList(object):
+    """A per-level inverse box transform shaped like the one the reference's dataloader hands to decode_pyramid (reference
+    os2d/structures/transforms.py:12-27: closures appended in augmentation order, applied last-appended first)."""
+
+    def __init__(self):
+        self.steps = []
+
+    def append(self, fn):
+        self.steps.append(fn)
+
+    def __call__(self, boxes):
+        for fn in self.steps[::-1]:
+            boxes = fn(boxes)
+        return boxes
+
+
+def dataloader_style_inverse(chain):
+    """``chain`` [n,5] of tests/golden/decode_transforms.npz - the steps in the order the inverse applies them (kind 1: resize
+    to (w, h); 4: crop (left, top, right, bottom); 2 / 3: horizontal / vertical flip) - as a list of lambdas calling
+    BoxList.resize / crop / transpose, exactly what reference transforms.py:32-52, 78-79, 188-191 append."""
+    from os2d_amd.structures.bounding_box import FLIP_LEFT_RIGHT, FLIP_TOP_BOTTOM
+    from os2d_amd.structures.feature_map import FeatureMapSize
+    t = InverseTransformList()
+    for kind, a, b, c, d in list(chain)[::-1]:          # appended in augmentation order = reverse of the inverse's order
+        kind = int(kind)
+        if kind == 1:
+            size = FeatureMapSize(w=int(a), h=int(b))
+            t.append(lambda boxes, size=size: boxes.resize(size))
+        elif kind == 4:
+            region = (int(a), int(b), int(c), int(d))
+            t.append(lambda boxes, region=region: boxes.crop(region))
+        else:
+            method = FLIP_LEFT_RIGHT if kind == 2 else FLIP_TOP_BOTTOM
+            t.append(lambda boxes, method=method: boxes.transpose(method))
+    return t

@@ -110,19 +110,28 @@ def release_workspaces():
 
 
 _STATUS_WORDS = {}
+STATUS_SLOTS = 1024
 
 
 def device_status_word(device):
-    """The sticky range-status word of the split-fp16 kernels: ONE int32 in mapped pinned host memory per device, allocated
-    once and kept for the life of the process.  Kernels in flight store to it through a raw pointer (only when an activation
-    leaves the fp16 range), so it must never go back to the host allocator while any kernel of any head may still run -
-    a per-head tensor (round 2) could be garbage-collected with its head while that head's kernels were still queued
-    (ADVICE r2).  Every head of the device shares the word: whichever call starts next sees a raised flag."""
+    """A sticky range-status word of the split-fp16 kernels for ONE head: an int32 in mapped pinned host memory.  The words
+    of a device live in one array that is allocated once and kept for the life of the process: kernels in flight store to a
+    word through a raw pointer (only when an activation leaves the fp16 range), so the memory must never go back to the host
+    allocator while any kernel of any head may still run - a per-head tensor (round 2) could be garbage-collected with its
+    head while that head's kernels were still queued.  Every head takes the next slot of the array (round 3 shared
+    ONE word between all heads of a device: a flag raised by head A's kernels could be consumed and cleared by head B, which
+    then ran a needless fp32 pass while A never recomputed - ADVICE r3); beyond ``STATUS_SLOTS`` heads per device and process
+    the slots are shared round-robin, with exactly that (harmless, conservative) cross-talk between the heads of one slot."""
     index = device.index if device.index is not None else torch.cuda.current_device()
-    word = _STATUS_WORDS.get(index)
-    if word is None:
-        word = _STATUS_WORDS[index] = torch.zeros(1, dtype=torch.int32).pin_memory()
-    return word
+    entry = _STATUS_WORDS.get(index)
+    if entry is None:
+        entry = _STATUS_WORDS[index] = [torch.zeros(STATUS_SLOTS, dtype=torch.int32).pin_memory(), 0]
+    words, taken = entry
+    entry[1] = taken + 1
+    slot = taken % STATUS_SLOTS
+    if taken >= STATUS_SLOTS:
+        words[slot] = 0      # a recycled slot starts clean (its previous owner's late flag, if any, is dropped)
+    return words[slot:slot + 1]
 
 
 class _StreamOrdered(object):
@@ -698,12 +707,12 @@ class Os2dHead(nn.Module):
         return int(self._status_word()[0])
 
     def _handle_range_flag(self):
-        """A previous split-fp16 call on this device overflowed (non-finite input: nothing else gets past the range plan).
+        """A previous split-fp16 call of THIS head overflowed (non-finite input: nothing else gets past the range plan).
         The flag is cleared and the call that noticed it runs in exact fp32; later calls return to the configured arithmetic
         (round 2 switched the head to fp32 for good: one NaN image made every later image 5.7x slower)."""
         self._status[0] = 0
         logging.getLogger("OS2D").warning(
-            "OS2D head: a split-fp16 activation left the fp16 range in an earlier call on this device (non-finite input); "
+            "OS2D head: a split-fp16 activation left the fp16 range in an earlier call of this head (non-finite input); "
             "this call runs in precision='f32'")
 
     @classmethod

@@ -132,6 +132,8 @@ class ClassShardedHead(object):
         self.reuse_buffers = int(reuse_buffers)
         self._rings = {}            # (A, H, W, device) -> [list of _GatherBuffers, next slot]
         self.copies_last_call = None    # how many result tensors the last forward had to re-copy after the gather (tests)
+        self.wait_events = None         # a list: every wait for asynchronous gathers appends (before, after) timing events recorded
+                                        # on the waiting stream - how long that stream stood still for the collective (bench.py)
 
     def prepare(self, precision=None):
         """Build the local head's cached operands on the current stream (see ``Os2dHead.prepare``)."""
@@ -206,8 +208,15 @@ class ClassShardedHead(object):
 
         def finish(_keep=(buf, out, sent)):
             if async_gather:
+                timed = self.wait_events is not None and dev.type == "cuda"
+                if timed:
+                    before, after = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    before.record()
                 for w in works:
                     w.wait()
+                if timed:
+                    after.record()
+                    self.wait_events.append((before, after))
             r = self._assemble(buf.recv, A, H, W)
             return (None, r[0], r[0], None) if scores_only else (r[0], r[1], r[1], r[2])
         return finish if async_gather else finish()

@@ -50,3 +50,10 @@ def test_bench_distributed_path_runs_on_one_rank(extra, device):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["classes_total"] == 16
+    # what makes a first real N > 1 run diagnosable: per-rank class counts, the collective timeout, a
+    # standalone all-gather timing and - where the step gathers asynchronously - how long it actually waited for it
+    assert d["config"]["classes_per_gpu"] == [16] and d["config"]["dist_timeout_s"] > 0
+    probe = d["allgather_probe"]
+    assert probe["bytes_per_rank"] == 32 << 20 and probe["ms"] > 0 and probe["algbw_gbps"] > 0
+    if "--pyramid" not in extra:
+        assert d["gather_wait_ms"] >= 0.0

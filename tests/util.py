@@ -66,11 +66,20 @@ def assert_close(got, ref, atol, rtol=0.0, what=""):
         what, float((got - ref).abs().max()), atol, rtol, float(excess.max()))
 
 
-def assert_head_outputs_close(name, loc, cls, corners, ref_loc, ref_cls, ref_corners, scale=1.0):
-    """The one place the head tolerances live; ``scale`` loosens all of them together (e.g. 2.5 for 1400-px coordinates)."""
-    assert_close(cls, ref_cls, CLS_TOL_OVERRIDE.get(name, TOL_CLS) * scale, 0.0, name + " cls")
-    assert_close(loc, ref_loc, TOL_LOC * scale, RTOL_LOC * scale, name + " loc")
-    assert_close(corners, ref_corners, TOL_CORNERS * scale, RTOL_CORNERS * scale, name + " corners")
+# the fp32-equivalent modes at BASELINE.json's full size, pinned at <= 3x what is measured there (scores
+# 2.4e-7, loc 1e-5): a regression of the default arithmetic by a factor of a few fails, long before north_star's 1e-4
+PIN_CLS, PIN_LOC = 1e-6, 3e-5
+FP32_EQUIVALENT = ("f32", "fft32", "fft", "fftx3", "f16x3")
+
+
+def assert_head_outputs_close(name, loc, cls, corners, ref_loc, ref_cls, ref_corners, scale=1.0, corners_scale=1.0, pin=False):
+    """The one place the head tolerances live.  ``corners_scale`` loosens the CORNER tolerance only (pixel coordinates: 2.5
+    for levels whose coordinates reach 1400 - 2000 px, where one fp32 ulp is 1.2e-4 px); ``scale`` loosens all three and is
+    for the opt-in reduced-precision mode (f16x2) only; ``pin``: scores and loc at the full-size pins above instead."""
+    tol_cls, tol_loc = (PIN_CLS, PIN_LOC) if pin else (CLS_TOL_OVERRIDE.get(name, TOL_CLS) * scale, TOL_LOC * scale)
+    assert_close(cls, ref_cls, tol_cls, 0.0, name + " cls")
+    assert_close(loc, ref_loc, tol_loc, RTOL_LOC * scale, name + " loc")
+    assert_close(corners, ref_corners, TOL_CORNERS * scale * corners_scale, RTOL_CORNERS * scale, name + " corners")
 
 
 def adversarial_transform_net_state(P, seed, lo1=-3.0, hi1=6.0, lo2=-3.0, hi2=3.0):

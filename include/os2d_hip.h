@@ -231,6 +231,7 @@ int os2d_detect_level(const float* loc, const float* cls, int B, int H, int W, i
 #define OS2D_BOX_OP_VFLIP 3
 #define OS2D_BOX_OP_SHIFT 4
 #define OS2D_BOX_MAX_OPS 6
+#define OS2D_BOX_MAX_DEFAULT_OPS 12
 int os2d_detect_level_ops(const float* loc, const float* cls, int B, int H, int W, int stride, int rec_field, float img_w,
                           float img_h, int op_count, const int* op_kinds, const float* op_args, float score_threshold,
                           float iou_threshold, float* out_boxes, float* out_scores, int* out_index, int* out_count,
@@ -337,12 +338,17 @@ int os2d_detect_pyramid_merged(const float* const* loc, const float* const* cls,
                                void* stream);
 
 /* Both of the above with a box transform chain per level (see OS2D_BOX_OP_*) instead of the scale table: op_counts HOST int [L],
- * op_kinds HOST int [L][OS2D_BOX_MAX_OPS], op_args HOST float [L][OS2D_BOX_MAX_OPS][2]; the anchors and the transform corners
- * go through the same chain (the corners as the two "boxes" (x0, y0, x1, y1), (x2, y2, x3, y3), like the reference's
- * box_coder.py:493-503).  slot_rows NULL: every head row its own label (G, V ignored); otherwise as os2d_detect_pyramid_merged. */
+ * op_kinds HOST int [L][OS2D_BOX_MAX_OPS], op_args HOST float [L][OS2D_BOX_MAX_OPS][2]; the transform corners go through the
+ * same chain (as the two "boxes" (x0, y0, x1, y1), (x2, y2, x3, y3), like the reference's box_coder.py:439-446).  The anchors
+ * (out_default) have a chain of their own, default_op_* with OS2D_BOX_MAX_DEFAULT_OPS entries per level: in the reference the
+ * anchors ride along as a BoxList field of the boxes - BoxList.transpose / crop transform such fields as well, resize does not
+ * (bounding_box.py:162,196-199,222-225) - and the level's transform is applied to the field once more afterwards
+ * (box_coder.py:515-516); for a resize-only chain (the evaluation's) the two chains are equal.
+ * slot_rows NULL: every head row its own label (G, V ignored); otherwise as os2d_detect_pyramid_merged.                      */
 int os2d_detect_pyramid_ops(const float* const* loc, const float* const* cls, const float* const* corners, int B, int L,
                             const int* hw, int stride, int rec_field, const float* img_wh, const int* op_counts,
-                            const int* op_kinds, const float* op_args, float score_threshold, float iou_threshold,
+                            const int* op_kinds, const float* op_args, const int* default_op_counts,
+                            const int* default_op_kinds, const float* default_op_args, float score_threshold, float iou_threshold,
                             int nms_max_batch, int passes, int G, int V, const int* slot_rows, float* out_boxes,
                             float* out_scores, int* out_index, float* out_default, float* out_corners, int* out_count,
                             int* unfinished, void* workspace, size_t workspace_bytes, void* stream);

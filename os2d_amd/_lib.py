@@ -76,7 +76,7 @@ SIGNATURES = {
                                  _vp, _vp, _sz, _vp]),
     "os2d_detect_pyramid_merged": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _f, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp,
                                         _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "os2d_detect_pyramid_ops": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _vp, _vp, _vp,
+    "os2d_detect_pyramid_ops": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _vp, _vp, _vp,
                                      _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 

@@ -312,7 +312,7 @@ int os2d_detect_level(const float* loc, const float* cls, int B, int H, int W, i
     os2d_set_error("os2d_detect_level: bad arguments");
     return -1;
   }
-  return os2d_launch_detect_level(loc, cls, B, H, W, stride, rec_field, img_w, img_h, os2d_box_ops_scale(scale_x, scale_y),
+  return os2d_launch_detect_level(loc, cls, B, H, W, stride, rec_field, img_w, img_h, os2d_box_ops_scale<OS2D_BOX_MAX_OPS>(scale_x, scale_y),
                                   score_threshold, iou_threshold, out_boxes, out_scores, out_index, out_count, S(stream));
 }
 

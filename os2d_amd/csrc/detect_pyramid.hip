@@ -41,6 +41,10 @@ constexpr int MAX_LEVELS = OS2D_PYRAMID_MAX_LEVELS;
 constexpr int MAX_CHUNKS = 64;      // chunks per class and pass that the count tables hold
 constexpr int KCAP = 2048;          // kept boxes cached in LDS (32 KB); later ones are re-read through the id lists
 
+struct DefaultOpsTable {        // per level: the chain the anchors ("default_boxes") go through (os2d_common.h)
+  Os2dDefaultBoxOps ops[OS2D_PYRAMID_MAX_LEVELS];
+};
+
 struct LevelTable {
   const float* loc[MAX_LEVELS];  // [B][4][HW_l]
   const float* cls[MAX_LEVELS];  // [B][HW_l]
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(NTHR) void pyr_finalize_kernel(int passes, int N, i
                                                            int* __restrict__ unfinished, LevelTable T, float stride,
                                                            float half_box, float4* __restrict__ out_default,
                                                            float* __restrict__ out_corners, int N1 /*candidates per head row*/,
-                                                           int V, const int* __restrict__ slot_rows) {
+                                                           int V, const int* __restrict__ slot_rows, DefaultOpsTable D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned int* skey = reinterpret_cast<unsigned int*>(smem);                        // [NP2]
   unsigned short* spos = reinterpret_cast<unsigned short*>(smem + (size_t)NP2 * 4);  // [NP2]
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(NTHR) void pyr_finalize_kernel(int passes, int N, i
     const int nloc = g1 - T.off[l], HWl = T.H[l] * T.W[l];
     const int hh = nloc / T.W[l], ww = nloc - hh * T.W[l];
     const float ecx = stride * ((float)ww + 0.5f), ecy = stride * ((float)hh + 0.5f);
-    out_default[(size_t)b * N + s] = os2d_apply_box_ops(make_float4(ecx - half_box, ecy - half_box, ecx + half_box, ecy + half_box), T.ops[l]);
+    out_default[(size_t)b * N + s] = os2d_apply_box_ops(make_float4(ecx - half_box, ecy - half_box, ecx + half_box, ecy + half_box), D.ops[l]);
     if (out_corners != nullptr) {
       const int row = slot_rows ? slot_rows[b * V + view] : b;
       const float* cp = T.corners[l] + (size_t)row * 8 * HWl + nloc;
@@ -524,7 +528,7 @@ int os2d_detect_pyramid_workspace_bytes(int B, int N, int passes, size_t* bytes)
 // own label, G = B, V = 1); outputs are [G][V * N]
 static int detect_pyramid_impl(const float* const* loc, const float* const* cls, const float* const* corners, int B, int L,
                                const int* hw, int stride, int rec_field, const float* img_wh, const Os2dBoxOps* level_ops,
-                               float score_threshold, float iou_threshold, int nms_max_batch, int passes, float* out_boxes,
+                               const Os2dDefaultBoxOps* default_ops, float score_threshold, float iou_threshold, int nms_max_batch, int passes, float* out_boxes,
                                float* out_scores, int* out_index, float* out_default, float* out_corners, int* out_count,
                                int* unfinished, void* workspace, size_t workspace_bytes, void* stream, int G, int V,
                                const int* slot_rows) {
@@ -535,6 +539,7 @@ static int detect_pyramid_impl(const float* const* loc, const float* const* cls,
     return -1;
   }
   LevelTable T;
+  DefaultOpsTable D;
   int N1 = 0;
   if (L < 1 || L > MAX_LEVELS) {
     os2d_set_error("os2d_detect_pyramid: %d levels (at most %d)", L, MAX_LEVELS);
@@ -559,6 +564,7 @@ static int detect_pyramid_impl(const float* const* loc, const float* const* cls,
     T.img_w[l] = img_wh[2 * l];
     T.img_h[l] = img_wh[2 * l + 1];
     T.ops[l] = level_ops[l];
+    D.ops[l] = default_ops[l];
   }
   T.off[L] = N1;
   T.L = L;
@@ -616,17 +622,20 @@ static int detect_pyramid_impl(const float* const* loc, const float* const* cls,
   hipLaunchKernelGGL(pyr_finalize_kernel, dim3(G), dim3(NTHR), (size_t)16384 * 6, st, passes, N, M, 16384, boxes, scores, keys,
                      ids[0], ids[1], counts, final_pass, reinterpret_cast<float4*>(out_boxes), out_scores, out_index, out_count,
                      unfinished, T, (float)stride, half_box, reinterpret_cast<float4*>(out_default), out_corners, N1, V,
-                     slot_rows);
+                     slot_rows, D);
   return check("pyr_finalize");
 }
 
 // level -> output image as plain per-axis scales (BoxList.resize): the one-op chains of the original entry points
-static bool ops_from_scales(const float* scale_xy, int L, Os2dBoxOps* ops) {
+static bool ops_from_scales(const float* scale_xy, int L, Os2dBoxOps* ops, Os2dDefaultBoxOps* dops) {
   if (!scale_xy || L < 1 || L > MAX_LEVELS) {
     os2d_set_error("os2d_detect_pyramid: bad scale table / level count");
     return false;
   }
-  for (int l = 0; l < L; ++l) ops[l] = os2d_box_ops_scale(scale_xy[2 * l], scale_xy[2 * l + 1]);
+  for (int l = 0; l < L; ++l) {
+    ops[l] = os2d_box_ops_scale<OS2D_BOX_MAX_OPS>(scale_xy[2 * l], scale_xy[2 * l + 1]);
+    dops[l] = os2d_box_ops_scale<OS2D_BOX_MAX_DEFAULT_OPS>(scale_xy[2 * l], scale_xy[2 * l + 1]);
+  }
   return true;
 }
 
@@ -636,8 +645,9 @@ int os2d_detect_pyramid(const float* const* loc, const float* const* cls, const 
                         float* out_scores, int* out_index, float* out_default, float* out_corners, int* out_count,
                         int* unfinished, void* workspace, size_t workspace_bytes, void* stream) {
   Os2dBoxOps ops[MAX_LEVELS];
-  if (!ops_from_scales(scale_xy, L, ops)) return -1;
-  return detect_pyramid_impl(loc, cls, corners, B, L, hw, stride, rec_field, img_wh, ops, score_threshold, iou_threshold,
+  Os2dDefaultBoxOps dops[MAX_LEVELS];
+  if (!ops_from_scales(scale_xy, L, ops, dops)) return -1;
+  return detect_pyramid_impl(loc, cls, corners, B, L, hw, stride, rec_field, img_wh, ops, dops, score_threshold, iou_threshold,
                              nms_max_batch, passes, out_boxes, out_scores, out_index, out_default, out_corners, out_count,
                              unfinished, workspace, workspace_bytes, stream, B, 1, nullptr);
 }
@@ -653,34 +663,41 @@ int os2d_detect_pyramid_merged(const float* const* loc, const float* const* cls,
     return -1;
   }
   Os2dBoxOps ops[MAX_LEVELS];
-  if (!ops_from_scales(scale_xy, L, ops)) return -1;
-  return detect_pyramid_impl(loc, cls, corners, B, L, hw, stride, rec_field, img_wh, ops, score_threshold, iou_threshold,
+  Os2dDefaultBoxOps dops[MAX_LEVELS];
+  if (!ops_from_scales(scale_xy, L, ops, dops)) return -1;
+  return detect_pyramid_impl(loc, cls, corners, B, L, hw, stride, rec_field, img_wh, ops, dops, score_threshold, iou_threshold,
                              nms_max_batch, passes, out_boxes, out_scores, out_index, out_default, out_corners, out_count,
                              unfinished, workspace, workspace_bytes, stream, G, V, slot_rows);
 }
 
 int os2d_detect_pyramid_ops(const float* const* loc, const float* const* cls, const float* const* corners, int B, int L,
                             const int* hw, int stride, int rec_field, const float* img_wh, const int* op_counts,
-                            const int* op_kinds, const float* op_args, float score_threshold, float iou_threshold,
+                            const int* op_kinds, const float* op_args, const int* default_op_counts,
+                            const int* default_op_kinds, const float* default_op_args, float score_threshold, float iou_threshold,
                             int nms_max_batch, int passes, int G, int V, const int* slot_rows, float* out_boxes,
                             float* out_scores, int* out_index, float* out_default, float* out_corners, int* out_count,
                             int* unfinished, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!op_counts || L < 1 || L > MAX_LEVELS) {
+  if (!op_counts || !default_op_counts || L < 1 || L > MAX_LEVELS) {
     os2d_set_error("os2d_detect_pyramid_ops: bad op tables / level count");
     return -1;
   }
   Os2dBoxOps ops[MAX_LEVELS];
+  Os2dDefaultBoxOps dops[MAX_LEVELS];
   for (int l = 0; l < L; ++l)
     if (!os2d_box_ops_from(op_kinds ? op_kinds + (size_t)l * OS2D_BOX_MAX_OPS : nullptr,
-                           op_args ? op_args + (size_t)l * OS2D_BOX_MAX_OPS * 2 : nullptr, op_counts[l], &ops[l])) {
-      os2d_set_error("os2d_detect_pyramid_ops: bad transform chain of level %d (at most %d ops of kind 1..4)", l, OS2D_BOX_MAX_OPS);
+                           op_args ? op_args + (size_t)l * OS2D_BOX_MAX_OPS * 2 : nullptr, op_counts[l], &ops[l]) ||
+        !os2d_box_ops_from(default_op_kinds ? default_op_kinds + (size_t)l * OS2D_BOX_MAX_DEFAULT_OPS : nullptr,
+                           default_op_args ? default_op_args + (size_t)l * OS2D_BOX_MAX_DEFAULT_OPS * 2 : nullptr,
+                           default_op_counts[l], &dops[l])) {
+      os2d_set_error("os2d_detect_pyramid_ops: bad transform chain of level %d (at most %d / %d ops of kind 1..4)", l,
+                     OS2D_BOX_MAX_OPS, OS2D_BOX_MAX_DEFAULT_OPS);
       return -1;
     }
   if (!slot_rows) {      // every head row its own label
     G = B;
     V = 1;
   }
-  return detect_pyramid_impl(loc, cls, corners, B, L, hw, stride, rec_field, img_wh, ops, score_threshold, iou_threshold,
+  return detect_pyramid_impl(loc, cls, corners, B, L, hw, stride, rec_field, img_wh, ops, dops, score_threshold, iou_threshold,
                              nms_max_batch, passes, out_boxes, out_scores, out_index, out_default, out_corners, out_count,
                              unfinished, workspace, workspace_bytes, stream, G, V, slot_rows);
 }

@@ -71,12 +71,20 @@ __device__ __forceinline__ float4 os2d_decode_box(const float* __restrict__ l, i
 // roundings - every product / difference rounded on its own (no contraction into fused multiply-adds), so the fused decode
 // equals the generic chain (which calls the closures on a BoxList) bit for bit.  Kinds: OS2D_BOX_OP_* of include/os2d_hip.h.
 #define OS2D_BOX_MAX_OPS 6
-struct Os2dBoxOps {
+#define OS2D_BOX_MAX_DEFAULT_OPS 12
+template <int N>
+struct Os2dBoxOpsN {
   int n;
-  int kind[OS2D_BOX_MAX_OPS];
-  float ax[OS2D_BOX_MAX_OPS], ay[OS2D_BOX_MAX_OPS];
+  unsigned char kind[N];
+  float ax[N], ay[N];
 };
-__device__ __forceinline__ float4 os2d_apply_box_ops(float4 b, const Os2dBoxOps& t) {
+typedef Os2dBoxOpsN<OS2D_BOX_MAX_OPS> Os2dBoxOps;
+// the anchors ("default_boxes") go through a chain of their own: in the reference they ride along as a BoxList FIELD of the
+// boxes - BoxList.transpose / crop also transform such fields, resize does not (bounding_box.py:162,196-199,222-225) - and the
+// level's transform is then applied to the field once more (box_coder.py:515-516); the caller records that whole sequence
+typedef Os2dBoxOpsN<OS2D_BOX_MAX_DEFAULT_OPS> Os2dDefaultBoxOps;
+template <int N>
+__device__ __forceinline__ float4 os2d_apply_box_ops(float4 b, const Os2dBoxOpsN<N>& t) {
 #pragma clang fp contract(off)
   for (int k = 0; k < t.n; ++k) {
     const float ax = t.ax[k], ay = t.ay[k];
@@ -111,8 +119,9 @@ __device__ __forceinline__ float4 os2d_apply_box_ops(float4 b, const Os2dBoxOps&
   }
   return b;
 }
-static inline Os2dBoxOps os2d_box_ops_scale(float sx, float sy) {
-  Os2dBoxOps t = {};
+template <int N>
+static inline Os2dBoxOpsN<N> os2d_box_ops_scale(float sx, float sy) {
+  Os2dBoxOpsN<N> t = {};
   t.n = 1;
   t.kind[0] = 1;
   t.ax[0] = sx;
@@ -120,13 +129,14 @@ static inline Os2dBoxOps os2d_box_ops_scale(float sx, float sy) {
   return t;
 }
 // ops from the ABI arrays (kinds [nops], args [nops][2]); false on a bad chain
-static inline bool os2d_box_ops_from(const int* kinds, const float* args, int nops, Os2dBoxOps* t) {
-  *t = Os2dBoxOps{};
-  if (nops < 0 || nops > OS2D_BOX_MAX_OPS || (nops > 0 && (!kinds || !args))) return false;
+template <int N>
+static inline bool os2d_box_ops_from(const int* kinds, const float* args, int nops, Os2dBoxOpsN<N>* t) {
+  *t = Os2dBoxOpsN<N>{};
+  if (nops < 0 || nops > N || (nops > 0 && (!kinds || !args))) return false;
   t->n = nops;
   for (int k = 0; k < nops; ++k) {
     if (kinds[k] < 1 || kinds[k] > 4) return false;
-    t->kind[k] = kinds[k];
+    t->kind[k] = (unsigned char)kinds[k];
     t->ax[k] = args[2 * k];
     t->ay[k] = args[2 * k + 1];
   }

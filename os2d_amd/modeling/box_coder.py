@@ -20,6 +20,7 @@ from ..structures.bounding_box import BoxList, FLIP_LEFT_RIGHT, FLIP_TOP_BOTTOM
 BOX_ENCODING_WEIGHTS = (10.0, 10.0, 5.0, 5.0)   # reference box_coder.py:13
 OP_SCALE, OP_HFLIP, OP_VFLIP, OP_SHIFT = 1, 2, 3, 4   # OS2D_BOX_OP_* of include/os2d_hip.h
 MAX_BOX_OPS = 6                                       # OS2D_BOX_MAX_OPS
+MAX_DEFAULT_BOX_OPS = 12                              # OS2D_BOX_MAX_DEFAULT_OPS
 
 
 @lru_cache()
@@ -60,13 +61,23 @@ class _BoxTrace(object):
     (a numerical probe could only recover the composite map, not where it rounds).  Anything else a closure might touch
     (``bbox_xyxy``, fields, ...) is not defined here: the AttributeError sends the caller to the generic chain."""
 
-    def __init__(self, image_size, ops=()):
+    def __init__(self, image_size, ops=(), fields=None):
         self.image_size = image_size
         self.ops = tuple(ops)
+        self.extra_fields = dict(fields or {})     # name -> _BoxTrace (BoxList-valued fields: "default_boxes")
+
+    def add_field(self, field, field_data):
+        self.extra_fields[field] = field_data
+
+    def get_field(self, field):
+        return self.extra_fields[field]
+
+    def has_field(self, field):
+        return field in self.extra_fields
 
     def resize(self, target_size):                      # BoxList.resize, reference bounding_box.py:138-163
         op = (OP_SCALE, float(target_size.w) / self.image_size.w, float(target_size.h) / self.image_size.h)
-        return _BoxTrace(target_size, self.ops + (op,))
+        return _BoxTrace(target_size, self.ops + (op,), self.extra_fields)          # fields are copied AS THEY ARE (:162)
 
     def transpose(self, method):                        # reference bounding_box.py:165-200
         if method == FLIP_LEFT_RIGHT:
@@ -75,11 +86,13 @@ class _BoxTrace(object):
             op = (OP_VFLIP, 0.0, float(self.image_size.h))
         else:
             raise NotImplementedError("Only FLIP_LEFT_RIGHT and FLIP_TOP_BOTTOM implemented")
-        return _BoxTrace(self.image_size, self.ops + (op,))
+        # BoxList-valued fields are flipped too, each inside ITS OWN image (:196-199)
+        return _BoxTrace(self.image_size, self.ops + (op,), {k: v.transpose(method) for k, v in self.extra_fields.items()})
 
     def crop(self, box):                                # reference bounding_box.py:202-226
         size = FeatureMapSize(w=box[2] - box[0], h=box[3] - box[1])
-        return _BoxTrace(size, self.ops + ((OP_SHIFT, float(box[0]), float(box[1])),))
+        return _BoxTrace(size, self.ops + ((OP_SHIFT, float(box[0]), float(box[1])),),
+                         {k: v.crop(box) for k, v in self.extra_fields.items()})
 
 
 def apply_box_ops(boxes, ops):
@@ -101,37 +114,59 @@ def apply_box_ops(boxes, ops):
 _PROBE_BOXES = ((0.0, 0.0, 1.0, 1.0), (13.25, 7.5, 211.0, 95.75), (3.0, 250.5, 640.125, 479.0))
 
 
+def transform_level_boxes(transform, boxes, default_boxes, corners, img_size):
+    """What reference box_coder.py:509-521 does with a level's ``inverse_box_transforms`` entry, on plain tensors:
+    boxes [n,4] -> transform(boxes); the anchors ride along as the BoxList FIELD "default_boxes" (BoxList.transpose / crop
+    transform BoxList-valued fields as well, each inside its own image; resize copies them as they are) and the transform is
+    applied to that field once more afterwards; the corners [m,4] go through as boxes of their own.  For a resize-only chain
+    (the evaluation's) all three see the same map; with flips / crops the anchors see them twice - reproduced as is, so that
+    a caller of the reference gets the reference's numbers.  Returns (boxes, default_boxes, corners or None, output size)."""
+    bl = BoxList(boxes, img_size)
+    bl.add_field("default_boxes", BoxList(default_boxes, img_size))
+    out = transform(bl)
+    dflt = transform(out.get_field("default_boxes"))
+    cor = transform(BoxList(corners, img_size)).bbox_xyxy if corners is not None else None
+    return out.bbox_xyxy, dflt.bbox_xyxy, cor, out.image_size
+
+
 def trace_box_transform(transform, img_size):
-    """-> (ops, output image size) of one ``inverse_box_transforms`` entry applied to boxes on an image of ``img_size``, or
-    None when the entry is not a chain of BoxList.resize / transpose / crop (then only the generic decode can run it).
-    ``None`` entries trace to the empty chain.  The recorded chain is checked against the entry itself on three probe boxes
-    (unit, generic, near the border): bit-equal boxes and the same output size, or it is not used."""
+    """-> (box ops, anchor ops, output image size) of one ``inverse_box_transforms`` entry applied to a level on an image of
+    ``img_size`` (see ``transform_level_boxes`` for why the anchors have a chain of their own), or None when the entry is not a
+    chain of BoxList.resize / transpose / crop - then only the generic decode can run it.  ``None`` entries trace to empty
+    chains.  The recorded chains are checked against the entry itself on three probe boxes (unit, generic, near the border):
+    bit-equal coordinates and the same output size, or they are not used."""
     if transform is None:
-        return (), img_size
+        return (), (), img_size
     try:
-        traced = transform(_BoxTrace(img_size))
+        root = _BoxTrace(img_size)
+        root.add_field("default_boxes", _BoxTrace(img_size))
+        traced = transform(root)
         if not isinstance(traced, _BoxTrace) or len(traced.ops) > MAX_BOX_OPS:
             return None
+        anchors = transform(traced.get_field("default_boxes"))
+        if not isinstance(anchors, _BoxTrace) or len(anchors.ops) > MAX_DEFAULT_BOX_OPS:
+            return None
         probe = torch.tensor(_PROBE_BOXES, dtype=torch.float32)
-        direct = transform(BoxList(probe.clone(), img_size))
-        if direct.image_size != traced.image_size or not torch.equal(direct.bbox_xyxy, apply_box_ops(probe, traced.ops)):
+        b, d, c, size = transform_level_boxes(transform, probe.clone(), probe.clone() + 0.5, probe.clone(), img_size)
+        if size != traced.image_size or not (torch.equal(b, apply_box_ops(probe, traced.ops)) and torch.equal(c, b)
+                                             and torch.equal(d, apply_box_ops(probe + 0.5, anchors.ops))):
             return None
     except Exception:   # noqa: BLE001 - a closure that does anything else than the three BoxList operations
         return None
-    return traced.ops, traced.image_size
+    return traced.ops, anchors.ops, traced.image_size
 
 
-def _ops_tables(ops_per_level):
-    """ctypes tables (counts [L], kinds [L][MAX], args [L][MAX][2]) of os2d_detect_pyramid_ops."""
+def _ops_tables(ops_per_level, width=MAX_BOX_OPS):
+    """ctypes tables (counts [L], kinds [L][width], args [L][width][2]) of os2d_detect_level_ops / os2d_detect_pyramid_ops."""
     L = len(ops_per_level)
     counts = (ctypes.c_int * L)(*[len(o) for o in ops_per_level])
-    kinds = (ctypes.c_int * (L * MAX_BOX_OPS))()
-    args = (ctypes.c_float * (L * MAX_BOX_OPS * 2))()
+    kinds = (ctypes.c_int * (L * width))()
+    args = (ctypes.c_float * (L * width * 2))()
     for l, ops in enumerate(ops_per_level):
         for k, (kind, ax, ay) in enumerate(ops):
-            kinds[l * MAX_BOX_OPS + k] = kind
-            args[(l * MAX_BOX_OPS + k) * 2] = ax
-            args[(l * MAX_BOX_OPS + k) * 2 + 1] = ay
+            kinds[l * width + k] = kind
+            args[(l * width + k) * 2] = ax
+            args[(l * width + k) * 2 + 1] = ay
     return counts, kinds, args
 
 
@@ -325,11 +360,8 @@ class Os2dBoxCoder(object):
             if transform_corners_pyramid is not None:
                 corners = transform_corners_pyramid[lvl].transpose(1, 2).reshape(num_classes * HW * 2, 4)
             if inverse_box_transforms is not None:
-                t = inverse_box_transforms[lvl]
-                boxes = t(BoxList(boxes.reshape(-1, 4), img_size)).bbox_xyxy.reshape(num_classes, HW, 4)
-                dflt = t(BoxList(dflt, img_size)).bbox_xyxy
-                if corners is not None:
-                    corners = t(BoxList(corners, img_size)).bbox_xyxy
+                boxes, dflt, corners, _ = transform_level_boxes(inverse_box_transforms[lvl], boxes.reshape(-1, 4), dflt, corners, img_size)
+                boxes = boxes.reshape(num_classes, HW, 4)
             boxes_l.append(boxes)
             scores_l.append(cls)
             valid_l.append(valid)
@@ -413,7 +445,7 @@ class Os2dBoxCoder(object):
         traced = trace_box_transform(inverse[0] if inverse is not None else None, img_size)
         if traced is None:
             return None
-        ops, out_size = traced
+        ops, default_ops, out_size = traced
         fm = self.get_feature_map_size(img_size)
         lib = _lib.load()
         if not lib.os2d_detect_level_supported(fm.h, fm.w):
@@ -453,7 +485,7 @@ class Os2dBoxCoder(object):
         result.add_field("scores", out_scores.view(-1)[flat])
         result.add_field("labels", torch.tensor([ids[i] for i in order], dtype=torch.long, device=dev)[row])
         loc_idx = out_index.view(-1)[flat].long()
-        dflt = apply_box_ops(self._get_default_boxes(img_size).bbox_xyxy.to(dev)[loc_idx], ops)
+        dflt = apply_box_ops(self._get_default_boxes(img_size).bbox_xyxy.to(dev)[loc_idx], default_ops)
         result.add_field("default_boxes", BoxList(dflt, out_size))
         if corners_pyr is not None:
             corners = corners_pyr[0][src_row, :, loc_idx]                                   # [n, 8]
@@ -496,7 +528,7 @@ class Os2dBoxCoder(object):
         traced = [trace_box_transform(t, s_) for t, s_ in zip(ts, size_pyr)]
         if any(t is None for t in traced):
             return None      # an entry that is not a chain of BoxList.resize / transpose / crop: generic path
-        if len({(sz.w, sz.h) for _, sz in traced}) != 1:
+        if len({(sz.w, sz.h) for _, _, sz in traced}) != 1:
             return None      # levels that end on different image sizes: the generic path fails like the reference's cat_boxlist
         lib = _lib.load()
         L = len(loc_pyr)
@@ -521,8 +553,9 @@ class Os2dBoxCoder(object):
             assert tuple(loc.shape) == (B, 4, hw) and tuple(cls.shape) == (B, hw), "level tensors do not match class_ids / feature map"
             locs.append(loc)
             clss.append(cls)
-        out_size = traced[0][1]
-        c_counts, c_kinds, c_args = _ops_tables([ops for ops, _ in traced])
+        out_size = traced[0][2]
+        c_counts, c_kinds, c_args = _ops_tables([t_[0] for t_ in traced])
+        d_counts, d_kinds, d_args = _ops_tables([t_[1] for t_ in traced], MAX_DEFAULT_BOX_OPS)
         passes = int(self.fused_pyramid_passes)
         nbytes = ctypes.c_size_t()
         _lib.check(lib.os2d_detect_pyramid_workspace_bytes(G, N, passes, ctypes.byref(nbytes)), "os2d_detect_pyramid_workspace_bytes")
@@ -546,7 +579,8 @@ class Os2dBoxCoder(object):
         with torch.cuda.device(dev):
             slot_rows = None if identity else self._slot_rows(tuple(ids), tuple(labels), V, dev)
             _lib.check(lib.os2d_detect_pyramid_ops(c_loc, c_cls, c_cor, B, L, c_hw, self._stride, self._rec_field, c_img,
-                                                   c_counts, c_kinds, c_args, ctypes.c_float(score_thr), ctypes.c_float(iou_thr),
+                                                   c_counts, c_kinds, c_args, d_counts, d_kinds, d_args,
+                                                   ctypes.c_float(score_thr), ctypes.c_float(iou_thr),
                                                    int(self.nms_max_batch), passes, G, V, _lib.ptr(slot_rows),
                                                    _lib.ptr(out_boxes), _lib.ptr(out_scores), _lib.ptr(out_index),
                                                    _lib.ptr(out_default), _lib.ptr(out_corners), _lib.ptr(out_count),

@@ -459,9 +459,14 @@ def make_decode_transforms_fixture():
     # the chain on plain boxes (what every step does to coordinates and to the image size)
     probe = torch.tensor([[0.0, 0.0, 1.0, 1.0], [13.25, 7.5, 211.0, 95.75], [3.0, 150.5, 200.125, 170.0]])
     for i, s_ in enumerate(level_sizes):
-        out = inverse[i](BoxList(probe.clone(), s_, mode="xyxy"))
+        bl = BoxList(probe.clone(), s_, mode="xyxy")
+        # the anchors as decode_pyramid carries them: a BoxList FIELD of the boxes (transposed / cropped with them, not resized:
+        # bounding_box.py:162,196-199,222-225), then the transform once more on the field (box_coder.py:515-516)
+        bl.add_field("default_boxes", BoxList(probe.clone() + 0.5, s_, mode="xyxy"))
+        out = inverse[i](bl)
         assert out.image_size == orig_size
         arrays["probe_out_{}".format(i)] = out.bbox_xyxy.numpy()
+        arrays["probe_default_out_{}".format(i)] = inverse[i](out.get_field("default_boxes")).bbox_xyxy.numpy()
     arrays["probe"] = probe.numpy()
     for thr_name, score_thr in (("t0", 0.0), ("tinf", float("-inf"))):
         res = coder.decode_pyramid([l.clone() for l in locs], [c.clone() for c in clss], level_sizes,

@@ -169,7 +169,9 @@ def test_fused_level_kernel_fallbacks(device):
     loc = torch.zeros(2, 4, 11 * 13, device=device)
     cls = torch.rand(2, 11 * 13, device=device)
     assert coder._decode_single_level_fused([loc], [cls], [size], [4, 4], 0.0, 0.3, None, None) is None
-    assert coder._decode_single_level_fused([loc], [cls], [size], [1, 2], 0.0, 0.3, [lambda b: b], None) is None
+    from os2d_amd.structures.bounding_box import BoxList
+    assert coder._decode_single_level_fused([loc], [cls], [size], [1, 2], 0.0, 0.3, [lambda b: BoxList(b.bbox_xyxy * 2.0, b.image_size)], None) is None
+    assert coder._decode_single_level_fused([loc], [cls], [size], [1, 2], 0.0, 0.3, [lambda b: b], None) is not None   # an identity traces to the empty chain
     assert coder._decode_single_level_fused([loc, loc], [cls, cls], [size, size], [1, 2], 0.0, 0.3, None, None) is None
     assert coder._decode_single_level_fused([loc], [cls], [size], [1, 2], 0.0, 0.3, None, None) is not None
 

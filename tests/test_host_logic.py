@@ -162,14 +162,22 @@ def test_dataloader_style_inverse_transforms_are_traced_exactly():
         out = t(BoxList(probe.clone(), size))
         assert out.image_size == orig
         assert torch.equal(out.bbox_xyxy, torch.from_numpy(d["probe_out_%d" % l]))
-        ops, out_size = trace_box_transform(t, size)
+        ops, anchor_ops, out_size = trace_box_transform(t, size)
         assert out_size == orig and [o[0] for o in ops] == [OP_SCALE, OP_SCALE, OP_SHIFT, OP_VFLIP, OP_HFLIP]
         assert torch.equal(apply_box_ops(probe, ops), torch.from_numpy(d["probe_out_%d" % l]))
+        # the anchors: as a BoxList field of the boxes they are cropped / flipped (not resized) WITH the boxes, then the whole
+        # transform is applied to them again (the reference's behaviour, reproduced): 3 + 5 operations
+        assert [o[0] for o in anchor_ops] == [OP_SHIFT, OP_VFLIP, OP_HFLIP, OP_SCALE, OP_SCALE, OP_SHIFT, OP_VFLIP, OP_HFLIP]
+        assert torch.equal(apply_box_ops(probe + 0.5, anchor_ops), torch.from_numpy(d["probe_default_out_%d" % l]))
+        from os2d_amd.modeling.box_coder import transform_level_boxes
+        b, dflt, c, sz = transform_level_boxes(t, probe.clone(), probe.clone() + 0.5, probe.clone(), size)
+        assert sz == orig and torch.equal(b, torch.from_numpy(d["probe_out_%d" % l])) and torch.equal(c, b)
+        assert torch.equal(dflt, torch.from_numpy(d["probe_default_out_%d" % l]))
     # identity / ResizeBoxes / plain lambdas trace too; anything else than the three BoxList operations does not
     size = FeatureMapSize(w=320, h=272)
-    assert trace_box_transform(None, size) == ((), size)
-    ops, out_size = trace_box_transform(ResizeBoxes(orig), size)
-    assert out_size == orig and ops == ((OP_SCALE, 500.0 / 320, 380.0 / 272),)
+    assert trace_box_transform(None, size) == ((), (), size)
+    ops, anchor_ops, out_size = trace_box_transform(ResizeBoxes(orig), size)
+    assert out_size == orig and ops == ((OP_SCALE, 500.0 / 320, 380.0 / 272),) and anchor_ops == ops     # resize-only: one chain
     assert trace_box_transform(lambda b: b.resize(orig), size)[0] == ops
     assert trace_box_transform(lambda b: BoxList(b.bbox_xyxy + 1.0, b.image_size), size) is None      # touches coordinates
     assert trace_box_transform(lambda b: b.resize(orig).clip_to_image(), size) is None                # an untraced method

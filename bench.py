@@ -174,6 +174,7 @@ PMC_KERNELS = {"spectral_gemm_f16_kernel": "%spectral_gemm_f16_kernel%", "spectr
                "corr_f16x3_kernel": "%corr_f16x3_kernel%", "conv_f16x3_kernel<5>": "%conv_f16x3_kernelILi5%",
                "conv_f16x3_kernel<7>": "%conv_f16x3_kernelILi7%", "fft_forward_kernel": "%fft_forward_kernel%",
                "fft_inverse_kernel": "%fft_inverse_kernel%", "sample_decode_kernel": "%sample_decode_kernel%",
+               "dft_forward_kernel": "%dft_forward_kernel%", "dft_inverse_kernel": "%dft_inverse_kernel%",
                "conv3_f16x3_kernel": "%conv3_f16x3_kernel%"}
 
 
@@ -574,10 +575,16 @@ class Workload(object):
         for h, w in levels:
             pP, pQ, nb = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
             per_loc = FLOP_PER_LOC["corr"] + FLOP_PER_LOC["conv2"] + 2 * self.P * 64 * 25
-            if self.lib.os2d_fft_sizes(h, w, ctypes.byref(pP), ctypes.byref(pQ), ctypes.byref(nb)) == 0:
-                t4 = [ctypes.c_int() for _ in range(4)]       # maps beyond one in-LDS transform: TY x TX overlap-save tiles
+            t6 = (ctypes.c_int * 6)()       # TY, TX, ...: maps beyond one transform are cut into TY x TX overlap-save tiles
+            if precision == "fftx3":
+                ok = self.lib.os2d_dft_sizes(h, w, ctypes.byref(pP), ctypes.byref(pQ), ctypes.byref(nb), t6) == 0
+            else:
+                ok = self.lib.os2d_fft_sizes(h, w, ctypes.byref(pP), ctypes.byref(pQ), ctypes.byref(nb)) == 0
+                t4 = [ctypes.c_int() for _ in range(4)]
                 self.lib.os2d_fft_tiles(h, w, *[ctypes.byref(t) for t in t4])
-                f32 += 8 * 128 * 225 * B * t4[0].value * t4[1].value * pP.value * (pQ.value // 2 + 1)
+                t6[0], t6[1] = t4[0].value, t4[1].value
+            if ok:
+                f32 += 8 * 128 * 225 * B * t6[0] * t6[1] * pP.value * (pQ.value // 2 + 1)
             else:
                 per_loc += FLOP_PER_LOC["conv1"]
             f16 += per_loc * h * w * B
@@ -594,13 +601,22 @@ class Workload(object):
                 "peak_is": "FLOP-weighted harmonic blend of the fp16 (2500) and fp32 (157.3) dense MFMA peaks for this mix",
                 "avg_launch_ms": round(seconds * 1e3, 4), "timing": "wall clock of the timed steps, this run"}
 
+    def transform_size(self, precision):
+        """(P, Q, nbins) as ctypes ints of the 60 x 80 map's transform: the matrix-product transforms of "fftx3" take P = 64,
+        Q = 84 too, but other maps differ from the FFT-friendly sizes of "fft" / "fft32"."""
+        pP, pQ, nb = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        if precision == "fftx3":
+            self.lib.os2d_dft_sizes(H_FM, W_FM, ctypes.byref(pP), ctypes.byref(pQ), ctypes.byref(nb), None)
+        else:
+            self.lib.os2d_fft_sizes(H_FM, W_FM, ctypes.byref(pP), ctypes.byref(pQ), ctypes.byref(nb))
+        return pP, pQ, nb
+
     def roofline_fft(self, stage_ms, precision="fft"):
         """fft mode: the spectral GEMM (dominant kernel of the step).  Per bin Y[128 x pairs] = K[128 x 225] X[225 x pairs]
         in complex fp32 = 8 real FLOPs per complex multiply-add, all of them issued as v_mfma_f32_32x32x2_f32 with
         k = {re, im}; bins = P * (Q/2 + 1) of the P x Q transform of the map.  Algorithmic HBM bytes: the weight spectra,
         the input spectra and the output spectra once each (8 B per complex value)."""
-        pP, pQ, nb = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-        self.lib.os2d_fft_sizes(H_FM, W_FM, ctypes.byref(pP), ctypes.byref(pQ), ctypes.byref(nb))
+        pP, pQ, nb = self.transform_size(precision)
         bins, pairs = pP.value * (pQ.value // 2 + 1), self.B_local
         fwd, gemm, inv = stage_ms[5] * 1e-3, stage_ms[6] * 1e-3, stage_ms[7] * 1e-3
         flops = 8 * 128 * 225 * pairs * bins
@@ -673,16 +689,17 @@ class Workload(object):
         out["corr"]["pmc_kernel"] = "corr_f16x3_kernel" if f16 else "corr_mfma_kernel"
         plane = int(self.lib.os2d_plane_floats(H_FM, W_FM))
         if fft:
-            pP, pQ, nb = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-            self.lib.os2d_fft_sizes(H_FM, W_FM, ctypes.byref(pP), ctypes.byref(pQ), ctypes.byref(nb))
+            pP, pQ, nb = self.transform_size(precision)
             bins = nb.value
+            mm = precision == "fftx3"      # the transforms as matrix products on the half-precision matrix cores (dft_mfma.hip)
             out["spectral_gemm"] = self.roofline_fft(stage_ms, precision)
             out["spectral_gemm"]["pmc_kernel"] = "spectral_gemm_f16_kernel" if precision == "fftx3" else "spectral_gemm_kernel"
             out["fft_forward"] = hbm("forward transform of the 7x7 layer's input (relu + normalisation folded into the load): reads corr + inverse "
                                      "norms, writes the input spectra", "fft_forward_kernel",
                                      B * (225 * HW * 4 + HW * 4 + 225 * bins * 8), stage_ms[5])
             out["fft_inverse"] = hbm("inverse transform + bias / ReLU / fp16 split epilogue: reads the output spectra, writes the 5x5 layer's "
-                                     "activations", "fft_inverse_kernel", B * 128 * (bins * 8 + HW * 4), stage_ms[7])
+                                     "activations" + (" (matrix products, v_mfma_f32_32x32x16_f16 x3)" if mm else " (in-LDS FFT)"),
+                                     "dft_inverse_kernel" if mm else "fft_inverse_kernel", B * 128 * (bins * 8 + HW * 4), stage_ms[7])
         else:
             r = self.roofline(precision, stage_ms[:5], None)
             r["pmc_kernel"] = "conv_f16x3_kernel<7>"

@@ -126,8 +126,12 @@ int os2d_class_split(const float* qp, void* qs, int B, int C, void* stream);
  *   status        NULL, or a device-visible int (device memory or mapped pinned host memory) that receives sticky
  *                 status bits (plain system-scope stores, never cleared by the library): OS2D_STATUS_F16_RANGE when a split-fp16 activation left the
  *                 fp16 range (only possible with non-finite inputs) - the caller then re-runs in OS2D_PRECISION_F32;
- *   wspec, twQ, twP  OS2D_PRECISION_FFT only (NULL otherwise): weight spectra of the 7x7 layer for THIS map size in the layout of
- *                 os2d_spectral_gemm and the two twiddle tables of os2d_fft_forward (w1 / b1..b3 / w2 / w3 as for F16X3).      */
+ *   wspec, twQ, twP  the frequency-domain precisions only (NULL otherwise; w1 / b1..b3 / w2 / w3 as for F16X3, FFT32: as for F32):
+ *                 OS2D_PRECISION_FFT / _FFT32: the weight spectra of the 7x7 layer for THIS map's transform size in the layout of
+ *                 os2d_spectral_gemm and the two twiddle tables of os2d_fft_forward;
+ *                 OS2D_PRECISION_FFTX3: wspec = the split weight spectra of os2d_spectral_weights_build_dft for the transform size
+ *                 of os2d_dft_sizes(H, W), twQ = the operand matrices of os2d_dft_matrices_build for it, twP = NULL.
+ * Width: maps up to 316 columns; beyond 209 (the direct 7x7 kernels' limit) only the frequency-domain precisions run.        */
 #define OS2D_STATUS_F16_RANGE 1
 int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const float* b1, const void* w2,
                          const float* b2, const void* w3, const float* b3, int A, int B, int C, int H, int W, int P,
@@ -301,6 +305,40 @@ int os2d_spectral_weights_build(const double* wfold, const double* twP64, const 
 float os2d_spectral_xscale(int H, int W);
 int os2d_spectral_gemm_f16(const void* w16, const float* X, float* Y, int NB, int C, int Cout, int nbins, float xscale,
                            void* stream);
+
+/* ---- the same layer with the TRANSFORMS as matrix products on the half-precision matrix cores (round 4; what
+ * os2d_head_forward_ex chains under OS2D_PRECISION_FFTX3; dft_mfma.hip): per image the row transform is x . FqT, the column
+ * transform Fp2 . R (complex as real 2 x 2 blocks), the inverse E2 . Y and T^T . Gq with the Hermitian weights folded into Gq -
+ * every operand split into fp16 hi + lo, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulation (the arithmetic of the
+ * per-bin GEMM above); four images (4 channels of one pair / 4 output channels) per work-group iteration.  Any transform size
+ * with P % 4 == 0, P <= 64, even Q <= 94 will do (no factorisation constraint): P = H + 3 rounded up to 4, Q = W + 3 rounded up
+ * to 2 for a map that fits, overlap-save tiles otherwise (any map width up to the head's own limit).
+ *   os2d_dft_sizes           P, Q, nbins (multiple of 8) and tiles[6] = TY, TX, tile_h, tile_w, window rows, window columns
+ *                            (tiles may be NULL); BIN ORDER: bin = v * P + u (u fastest: a quad of 4 bins never straddles v)
+ *   os2d_dft_channel_stride  Cpad: channel stride of the input spectra (225 -> 232 = the GEMM's k-steps of 8)
+ *   os2d_dft_matrices_build  the four constant operand matrices of a (P, Q) transform from float64 tables (cos, sin of
+ *                            -2 pi m / n as for os2d_spectral_weights_build), os2d_dft_matrices_bytes(P, Q) bytes; they depend
+ *                            on (P, Q) only
+ *   os2d_dft_forward         relu(corr [NB,C,H*W]) * inv_norm [NB,H*W] -> X [nbins/4, NB*T, Cpad, 4] complex64 (quads of bins x
+ *                            channels: 128-byte runs per work-group iteration, 256-byte runs per k-step of the GEMM)
+ *   os2d_spectral_weights_build_dft   the split weight spectra of os2d_spectral_gemm_f16 in that bin order
+ *   os2d_spectral_gemm_f16_quads      the per-bin GEMM reading X in that layout (xscale: os2d_dft_xscale(H, W)); Y as before,
+ *                            [nbins/4, NB*T, Cout, 4]
+ *   os2d_dft_inverse         Y -> the layer's activations (bias, ReLU, channel scale, fp16 hi | lo) in the split-half blocked
+ *                            buffer, as os2d_fft_inverse                                                                   */
+int os2d_dft_sizes(int H, int W, int* P, int* Q, int* nbins, int* tiles);
+int os2d_dft_channel_stride(int C);
+size_t os2d_dft_matrices_bytes(int P, int Q);
+int os2d_dft_matrices_build(const double* twP64, const double* twQ64, int P, int Q, void* out, void* stream);
+int os2d_dft_forward(const float* corr, const float* inv_norm, float* X, const void* matrices, int NB, int C, int H, int W,
+                     void* stream);
+int os2d_dft_inverse(const float* Y, const float* packed_b, void* out, const void* matrices, int NB, int Cout, int H, int W,
+                     int* status, void* stream);
+int os2d_spectral_weights_build_dft(const double* wfold, const double* twP64, const double* twQ64, int C, int Cout, int P, int Q,
+                                    int nbins, void* out, void* workspace, void* stream);
+int os2d_spectral_gemm_f16_quads(const void* w16, const float* X, float* Y, int NB, int C, int Cout, int nbins, float xscale,
+                                 void* stream);
+float os2d_dft_xscale(int H, int W);
 
 /* ---- detection over a whole image pyramid: reference os2d/modeling/box_coder.py:448-536 per label for L levels, incl. the
  * reference's memory-bounded NMS (os2d/structures/bounding_box.py:343-374: lists longer than nms_max_batch are NMS-ed in

@@ -48,6 +48,15 @@ SIGNATURES = {
     "os2d_fft_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "os2d_fft_inverse": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "os2d_fft_inverse_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "os2d_dft_sizes": (_i, [_i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "os2d_dft_channel_stride": (_i, [_i]),
+    "os2d_dft_matrices_bytes": (_sz, [_i, _i]),
+    "os2d_dft_matrices_build": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "os2d_dft_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "os2d_dft_inverse": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "os2d_spectral_weights_build_dft": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "os2d_spectral_gemm_f16_quads": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "os2d_dft_xscale": (_f, [_i, _i]),
     "os2d_class_split": (_i, [_vp, _vp, _i, _i, _vp]),
     "os2d_class_split_bytes": (_sz, [_i, _i]),
     "os2d_head_forward_ex": (_i, [_vp] * 8 + [_i] * 9 + [_vp, _vp, _vp, _vp, _sz, _vp, _i, _vp,

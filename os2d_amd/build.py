@@ -19,7 +19,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libos2d_hip.so")
 BUILD_DIR = os.path.join(HERE, "csrc", "build")
 VARIANT_DIR = os.path.join(HERE, "..", "tools", "diag_libs")
-SOURCES = ["abi.hip", "prep.hip", "corr_mfma.hip", "conv_mfma.hip", "conv_f16x3.hip", "conv3_f16x3.hip", "corr_f16x3.hip", "sample_decode.hip", "nms.hip", "detect.hip", "detect_pyramid.hip", "spectral.hip", "spectral_f16.hip", "spectra_pack.hip", "fft.hip"]
+SOURCES = ["abi.hip", "prep.hip", "corr_mfma.hip", "conv_mfma.hip", "conv_f16x3.hip", "conv3_f16x3.hip", "corr_f16x3.hip", "sample_decode.hip", "nms.hip", "detect.hip", "detect_pyramid.hip", "spectral.hip", "spectral_f16.hip", "spectra_pack.hip", "fft.hip", "dft_mfma.hip"]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 # No packed-FP32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) in the translation units listed in

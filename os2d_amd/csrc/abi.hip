@@ -32,7 +32,7 @@ int os2d_conv1_steps_padded() { return 25; }
 struct Carve {
   size_t sumsq, fs, corr, rpad, h1, h2, params, invn, xspec, yspec, total;
 };
-Carve carve(int A, int Bc, int C, int H, int W, int P, int fft_bins = 0, int fft_tiles = 1) {
+Carve carve(int A, int Bc, int C, int H, int W, int P, int fft_bins = 0, int fft_tiles = 1, int xspec_channels = OS2D_K) {
   const size_t HW = (size_t)H * W, PL = os2d_plane(H, W), NB = (size_t)A * Bc;
   Carve c;
   size_t off = 0;
@@ -52,7 +52,7 @@ Carve carve(int A, int Bc, int C, int H, int W, int P, int fft_bins = 0, int fft
   c.invn = c.xspec = c.yspec = 0;
   if (fft_bins > 0) {  // frequency-domain 7x7 layer: inverse norms, input / output spectra (complex64)
     c.invn = take(NB * HW);
-    c.xspec = take(NB * fft_tiles * OS2D_K * (size_t)fft_bins * 2);     // a tile of a tiled map is one more "pair" (fft.hip)
+    c.xspec = take(NB * fft_tiles * xspec_channels * (size_t)fft_bins * 2);     // a tile of a tiled map is one more "pair" (fft.hip)
     c.yspec = take(NB * fft_tiles * 128 * (size_t)fft_bins * 2);
   }
   c.total = off;
@@ -94,8 +94,24 @@ bool head_args_ok(int A, int B, int C, int H, int W, int P) {
     return false;
   }
   if (W > OS2D_MAX_W) {
-    os2d_set_error("feature map width %d > %d: the 7x7 kernels keep 3 halo rows of the input in LDS (images wider than %d px "
+    os2d_set_error("feature map width %d > %d: the 5x5 kernels keep 2 halo rows of their input in LDS (images wider than %d px "
                    "at stride 16 are not supported)", W, OS2D_MAX_W, OS2D_MAX_W * 16);
+    return false;
+  }
+  return true;
+}
+bool is_freq(int precision) {
+  return precision == OS2D_PRECISION_FFT || precision == OS2D_PRECISION_FFTX3 || precision == OS2D_PRECISION_FFT32;
+}
+// transform plan of the frequency-domain 7x7 layer: the matrix-product transforms (dft_mfma.hip) under FFTX3, the in-LDS FFTs
+// (fft.hip) under FFT / FFT32
+int freq_plan(int precision, int H, int W, int* P, int* Q, int* bins, int* tiles) {
+  return precision == OS2D_PRECISION_FFTX3 ? os2d_dft_plan(H, W, P, Q, bins, tiles) : os2d_fft_plan(H, W, P, Q, bins, tiles);
+}
+bool direct7_width_ok(int W) {
+  if (W > OS2D_MAX_W_DIRECT7) {
+    os2d_set_error("feature map width %d > %d: the direct 7x7 kernels keep 3 halo rows of their input in LDS - wider maps need a "
+                   "frequency-domain precision (fftx3 / fft / fft32), which tiles any width up to %d", W, OS2D_MAX_W_DIRECT7, OS2D_MAX_W);
     return false;
   }
   return true;
@@ -212,12 +228,11 @@ int os2d_head_workspace_bytes_ex(int A, int B, int C, int H, int W, int P, int p
   }
   if (!head_args_ok(A, B, C, H, W, P)) return -1;
   int bins = 0, tiles[6] = {1, 1, 0, 0, 0, 0};
-  if ((precision == OS2D_PRECISION_FFT || precision == OS2D_PRECISION_FFTX3 || precision == OS2D_PRECISION_FFT32) &&
-      !os2d_fft_plan(H, W, nullptr, nullptr, &bins, tiles)) {
+  if (is_freq(precision) && !freq_plan(precision, H, W, nullptr, nullptr, &bins, tiles)) {
     os2d_set_error("os2d_head_workspace_bytes_ex: no transform plan for a %dx%d map", H, W);
     return -3;
   }
-  *bytes = carve(A, B, C, H, W, P, bins, tiles[0] * tiles[1]).total;
+  *bytes = carve(A, B, C, H, W, P, bins, tiles[0] * tiles[1], precision == OS2D_PRECISION_FFTX3 ? OS2D_XSPEC_CPAD : OS2D_K).total;
   return 0;
 }
 
@@ -376,17 +391,21 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     return -1;
   }
   int fft_bins = 0, tiles[6] = {1, 1, 0, 0, 0, 0};
-  if (precision == OS2D_PRECISION_FFT || precision == OS2D_PRECISION_FFTX3 || precision == OS2D_PRECISION_FFT32) {
-    if (!wspec || !twQ || !twP) {
-      os2d_set_error("os2d_head_forward: the FFT mode needs the weight spectra and the two twiddle tables");
+  const bool dft = precision == OS2D_PRECISION_FFTX3;           // transforms as matrix products (dft_mfma.hip): twQ = the matrices
+  if (is_freq(precision)) {
+    if (!wspec || !twQ || (!dft && !twP)) {
+      os2d_set_error("os2d_head_forward: the frequency-domain modes need the weight spectra and the transform tables "
+                     "(fft / fft32: twQ, twP; fftx3: the matrices of os2d_dft_matrices_build as twQ)");
       return -1;
     }
-    if (!os2d_fft_plan(H, W, nullptr, nullptr, &fft_bins, tiles)) {
+    if (!freq_plan(precision, H, W, nullptr, nullptr, &fft_bins, tiles)) {
       os2d_set_error("os2d_head_forward: no transform plan for a %dx%d map", H, W);
       return -3;
     }
+  } else if (!direct7_width_ok(W)) {
+    return -1;
   }
-  const int fft_T = tiles[0] * tiles[1];
+  const int fft_T = tiles[0] * tiles[1], xch = dft ? OS2D_XSPEC_CPAD : OS2D_K;
   const bool fp32_ops = precision == OS2D_PRECISION_F32 || precision == OS2D_PRECISION_FFT32;   // fp32 MFMA correlation / 5x5 layers
   if (!fp32_ops && !qs) {
     os2d_set_error("os2d_head_forward: precision f16x3 / f16x2 needs the split class operand (os2d_class_split)");
@@ -402,14 +421,14 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     return -1;
   }
   // largest class chunk that fits the workspace (footprint is affine in Bc)
-  const size_t one = carve(A, 1, C, H, W, P, fft_bins, fft_T).total;
+  const size_t one = carve(A, 1, C, H, W, P, fft_bins, fft_T, xch).total;
   if (workspace_bytes < one) {
     os2d_set_error("os2d_head_forward: workspace too small (%zu B, need >= %zu B for one class)", workspace_bytes, one);
     return -2;
   }
   int Bc = B;
-  while (Bc > 1 && carve(A, Bc, C, H, W, P, fft_bins, fft_T).total > workspace_bytes) {
-    const size_t two = carve(A, 2, C, H, W, P, fft_bins, fft_T).total;
+  while (Bc > 1 && carve(A, Bc, C, H, W, P, fft_bins, fft_T, xch).total > workspace_bytes) {
+    const size_t two = carve(A, 2, C, H, W, P, fft_bins, fft_T, xch).total;
     const size_t per = two - one;
     int guess = per ? (int)((workspace_bytes - one) / per) + 1 : 1;
     if (guess >= Bc) guess = Bc - 1;
@@ -418,7 +437,7 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
   }
   hipStream_t st = S(stream);
   char* ws = static_cast<char*>(workspace);
-  const Carve c = carve(A, Bc, C, H, W, P, fft_bins, fft_T);
+  const Carve c = carve(A, Bc, C, H, W, P, fft_bins, fft_T, xch);
   float* invn = fft_bins ? reinterpret_cast<float*>(ws + c.invn) : nullptr;
   float* xspec = fft_bins ? reinterpret_cast<float*>(ws + c.xspec) : nullptr;
   float* yspec = fft_bins ? reinterpret_cast<float*>(ws + c.yspec) : nullptr;
@@ -475,18 +494,24 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
 #else
       const int layout = precision == OS2D_PRECISION_FFTX3 ? OS2D_SPECTRA_QUADS : OS2D_SPECTRA_ROWS;
 #endif
-      if ((rc = os2d_launch_fft_forward(corr, invn, xspec, twQ, twP, NB, OS2D_K, H, W, st))) return rc;
-      mark(b0, 11);
-      if (precision == OS2D_PRECISION_FFTX3) {
-        // |X| <= number of samples of a window (every sample of the normalised maps is <= 1): tiles[4] x tiles[5]
+      if (dft) {
+        // the transforms as matrix products on the half-precision matrix cores, spectra in quads of bins on both sides of the
+        // per-bin GEMM (dft_mfma.hip); |X| <= number of samples of a window (every sample of the normalised maps is <= 1)
+        const void* mats = twQ;
+        if ((rc = os2d_launch_dft_forward(corr, invn, xspec, mats, NB, OS2D_K, xch, H, W, st))) return rc;
+        mark(b0, 11);
         if ((rc = os2d_launch_spectral_gemm_f16(wspec, xspec, yspec, NB * fft_T, OS2D_K, 128, fft_bins,
-                                                os2d_spectral_xscale_for(tiles[4], tiles[5]), st)))
+                                                os2d_spectral_xscale_for(tiles[4], tiles[5]), 1, xch, st)))
           return rc;
-      } else if ((rc = os2d_launch_spectral_gemm(wspec, xspec, yspec, NB * fft_T, OS2D_K, 128, fft_bins, st))) {
-        return rc;
+        mark(b0, 12);
+        if ((rc = os2d_launch_dft_inverse(yspec, b1, 128, h1, mats, NB, 128, H, W, status, st))) return rc;
+      } else {
+        if ((rc = os2d_launch_fft_forward(corr, invn, xspec, twQ, twP, NB, OS2D_K, H, W, st))) return rc;
+        mark(b0, 11);
+        if ((rc = os2d_launch_spectral_gemm(wspec, xspec, yspec, NB * fft_T, OS2D_K, 128, fft_bins, st))) return rc;
+        mark(b0, 12);
+        if ((rc = os2d_launch_fft_inverse(yspec, b1, 128, h1, twQ, twP, NB, 128, H, W, status, layout, f16 ? 0 : 1, st))) return rc;
       }
-      mark(b0, 12);
-      if ((rc = os2d_launch_fft_inverse(yspec, b1, 128, h1, twQ, twP, NB, 128, H, W, status, layout, f16 ? 0 : 1, st))) return rc;
     } else if (f16) {
       if ((rc = os2d_launch_conv_f16x3(1, rpad, w1, b1, status, h1, NB, P, H, W, terms1, st))) return rc;
     } else {
@@ -598,8 +623,8 @@ int os2d_transform_conv_f16x3(int layer, const void* in, const void* packed_w, c
     os2d_set_error("os2d_transform_conv_f16x3: bad arguments (layer=%d NB=%d P=%d terms=%d)", layer, NB, P, terms);
     return -1;
   }
-  if (W > OS2D_MAX_W) {
-    os2d_set_error("os2d_transform_conv_f16x3: feature map width %d > %d", W, OS2D_MAX_W);
+  if (W > (layer == 1 ? OS2D_MAX_W_DIRECT7 : OS2D_MAX_W)) {
+    os2d_set_error("os2d_transform_conv_f16x3: feature map width %d > %d", W, layer == 1 ? OS2D_MAX_W_DIRECT7 : OS2D_MAX_W);
     return -1;
   }
   return os2d_launch_conv_f16x3(layer, in, packed_w, packed_b, status, out, NB, P, H, W, terms, S(stream));
@@ -688,7 +713,7 @@ int os2d_spectral_weights_build(const double* wfold, const double* twP64, const 
     os2d_set_error("os2d_spectral_weights_build: out must be 16-byte, workspace 8-byte aligned");
     return -1;
   }
-  return os2d_launch_spectra_pack(wfold, twP64, twQ64, C, Cout, P, Q, nbins, split, out, workspace, S(stream));
+  return os2d_launch_spectra_pack(wfold, twP64, twQ64, C, Cout, P, Q, nbins, split, 0, out, workspace, S(stream));
 }
 
 size_t os2d_spectral_weight16_bytes(int C, int nbins) {
@@ -713,7 +738,87 @@ int os2d_spectral_gemm_f16(const void* w16, const float* X, float* Y, int NB, in
     os2d_set_error("os2d_spectral_gemm_f16: buffers must be 16-byte aligned");
     return -1;
   }
-  return os2d_launch_spectral_gemm_f16(w16, X, Y, NB, C, Cout, nbins, xscale, S(stream));
+  return os2d_launch_spectral_gemm_f16(w16, X, Y, NB, C, Cout, nbins, xscale, 0, 0, S(stream));
+}
+
+/* ---- the transforms of the frequency-domain 7x7 layer as matrix products (dft_mfma.hip; OS2D_PRECISION_FFTX3) */
+int os2d_dft_sizes(int H, int W, int* P, int* Q, int* nbins, int* tiles) {
+  if (!P || !Q || !nbins) {
+    os2d_set_error("os2d_dft_sizes: null output");
+    return -1;
+  }
+  if (!os2d_dft_plan(H, W, P, Q, nbins, tiles)) {
+    os2d_set_error("os2d_dft_sizes: no transform plan for a %dx%d map", H, W);
+    return -3;
+  }
+  return 0;
+}
+
+int os2d_dft_channel_stride(int C) { return C == OS2D_K ? OS2D_XSPEC_CPAD : (C + 7) / 8 * 8; }
+
+size_t os2d_dft_matrices_bytes(int P, int Q) {
+  if (P < 4 || (P & 3) || Q < 2 || (Q & 1)) return 0;
+  return os2d_dft_matrices_size(P, Q);
+}
+
+int os2d_dft_matrices_build(const double* twP64, const double* twQ64, int P, int Q, void* out, void* stream) {
+  if (!twP64 || !twQ64 || !out || (reinterpret_cast<uintptr_t>(out) & 15)) {
+    os2d_set_error("os2d_dft_matrices_build: bad arguments (out must be 16-byte aligned)");
+    return -1;
+  }
+  return os2d_launch_dft_matrices(twP64, twQ64, P, Q, out, S(stream));
+}
+
+int os2d_dft_forward(const float* corr, const float* inv_norm, float* X, const void* matrices, int NB, int C, int H, int W,
+                     void* stream) {
+  if (!corr || !inv_norm || !X || !matrices || NB < 1 || C < 1 || H < 1 || W < 1) {
+    os2d_set_error("os2d_dft_forward: bad arguments");
+    return -1;
+  }
+  return os2d_launch_dft_forward(corr, inv_norm, X, matrices, NB, C, os2d_dft_channel_stride(C), H, W, S(stream));
+}
+
+int os2d_dft_inverse(const float* Y, const float* packed_b, void* out, const void* matrices, int NB, int Cout, int H, int W,
+                     int* status, void* stream) {
+  if (!Y || !packed_b || !out || !matrices || NB < 1 || Cout != 128 || H < 1 || W < 1) {
+    os2d_set_error("os2d_dft_inverse: bad arguments (Cout must be 128: the 7x7 layer)");
+    return -1;
+  }
+  int rc = os2d_launch_border_zero_shb_planes(out, NB * (Cout / 8) * 2, H, W, S(stream));
+  if (rc) return rc;
+  return os2d_launch_dft_inverse(Y, packed_b, 128, out, matrices, NB, Cout, H, W, status, S(stream));
+}
+
+int os2d_spectral_weights_build_dft(const double* wfold, const double* twP64, const double* twQ64, int C, int Cout, int P, int Q,
+                                    int nbins, void* out, void* workspace, void* stream) {
+  if (!wfold || !twP64 || !twQ64 || !out || !workspace || C < 1 || Cout < 1 || Cout > 128 || nbins < 8 || (nbins & 7) || (P & 3)) {
+    os2d_set_error("os2d_spectral_weights_build_dft: bad arguments (C=%d Cout=%d P=%d nbins=%d)", C, Cout, P, nbins);
+    return -1;
+  }
+  if ((reinterpret_cast<uintptr_t>(out) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 7)) {
+    os2d_set_error("os2d_spectral_weights_build_dft: out must be 16-byte, workspace 8-byte aligned");
+    return -1;
+  }
+  return os2d_launch_spectra_pack(wfold, twP64, twQ64, C, Cout, P, Q, nbins, 1, 1, out, workspace, S(stream));
+}
+
+int os2d_spectral_gemm_f16_quads(const void* w16, const float* X, float* Y, int NB, int C, int Cout, int nbins, float xscale,
+                                 void* stream) {
+  if (!w16 || !X || !Y || NB < 1 || C < 1 || Cout < 1 || Cout > 128 || nbins < 8 || (nbins & 7) || !(xscale > 0.f)) {
+    os2d_set_error("os2d_spectral_gemm_f16_quads: bad arguments (NB=%d C=%d Cout=%d nbins=%d)", NB, C, Cout, nbins);
+    return -1;
+  }
+  if ((reinterpret_cast<uintptr_t>(w16) | reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) & 15) {
+    os2d_set_error("os2d_spectral_gemm_f16_quads: buffers must be 16-byte aligned");
+    return -1;
+  }
+  return os2d_launch_spectral_gemm_f16(w16, X, Y, NB, C, Cout, nbins, xscale, 1, os2d_dft_channel_stride(C), S(stream));
+}
+
+float os2d_dft_xscale(int H, int W) {
+  int t[6];
+  if (H < 1 || W < 1 || !os2d_dft_plan(H, W, nullptr, nullptr, nullptr, t)) return 0.f;
+  return os2d_spectral_xscale_for(t[4], t[5]);
 }
 
 int os2d_alignment_grids(const float* params, int NB, int H, int W, int P, int inverse, float* theta, float* grids,

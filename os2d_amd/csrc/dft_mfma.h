@@ -1,0 +1,838 @@
+// The two transforms of the frequency-domain 7x7 TransformNet layer (reference os2d/modeling/head.py:619-623, 650) as DENSE
+// MATRIX PRODUCTS on the half-precision matrix cores of gfx950 - precision "fftx3", round 4.  Included by dft_mfma.hip (device
+// build) and by tests/host/dft_mfma_check.cpp (host build on the SPMD emulator, tests/host/spmd_emu.h): the includer provides
+// the hardware hooks DFT_* below, everything else is the same source.
+//
+// Why matrix products.  Rounds 2 - 3 transformed one image (pair, channel) at a time with register FFTs in LDS: ~10 work-group
+// barriers per image and phases of a few hundred active lanes each - the kernels ran at 2.3 / 1.8 TB/s, bound by that serial
+// chain, with the matrix cores idle.  A 64 x 84 transform is small enough that the O(N^2) form costs less
+// TIME than the O(N log N) one once it runs on v_mfma_f32_32x32x16_f16 (2.5 PFLOP/s): per image 2 x 3.1 MFLOP, three
+// half-precision products per fp32-equivalent product (operands split into fp16 hi + lo, fp32 accumulation: the arithmetic of
+// f16x3 / of the split-half spectral GEMM), ~2,300 matrix cycles per image and CU against ~3,000 cycles of HBM time - and a
+// work-group iteration is 4 images behind 6 barriers.
+//
+//   forward   x[h][w] = relu(corr[nb][c][h][w]) * inv_norm[nb][h][w]   (head.py:650 folded into the load), zero-padded
+//     step 1  R^T[(img, h)][(v, re|im)] = x[(img, h)][w] . FqT[w][(v, re|im)]            rows of the map -> half spectrum in v
+//     step 2  X[(u, re|im)][(img, v)]   = Fp2[(u, re|im)][(re|im, h)] . R[(re|im, h)][(img, v)]   columns: complex as real 2 x 2
+//   inverse   Y[(re|im, u)][(img, v)]
+//     step A  T[(h, re|im)][(img, v)]   = E2[(h, re|im)][(re|im, u)] . Y[(re|im, u)][(img, v)]
+//     step B  y[(h, img)][w]            = T^T[(h, img)][(v, re|im)] . Gq[(v, re|im)][w]   Hermitian half spectrum -> real rows
+//   + the layer's epilogue (1 / (P Q), bias, ReLU, the channel's power-of-two scale, fp16 hi | lo split into the activation
+//   buffer of the 5x5 layer), as in fft.hip.
+// G = 4 images per work-group iteration: 4 consecutive channels of one pair (forward) / 4 consecutive output channels (inverse).
+// That makes the spectra layouts of BOTH sides of the per-bin GEMM "quads x channels": X [bins/4][pair'][Cpad][4] and
+// Y [bins/4][pair'][Cout][4] complex64 with bin = v * P + u (u fastest, P % 4 == 0: a quad never straddles v) - the forward
+// kernel writes 128-byte runs (4 channels x 4 bins), the GEMM reads 256-byte runs per (pair, k-step of 8 channels) instead of
+// 32-byte pieces 22 KB apart, its Y stores stay 1 KB runs, and the inverse kernel reads 128-byte runs.
+//
+// Operand format.  Every matrix operand lives in "units" of 16 bytes = 8 halves = 8 consecutive k of one row / column, hi and
+// lo parts in separate units: arrays [k / 8][hi | lo][row or column].  A fragment of the instruction is then ONE 16-byte read
+// per lane, 32 consecutive units per half-wave (conflict-free), lanes 32 - 63 take the next k group.  The constant matrices
+// (FqT, Fp2, E2, Gq: functions of (P, Q) only) are built once per transform size by dft_matrices_kernel from float64 tables.
+//
+// Scales (all powers of two; exact): x * 2^15 (x <= 1), DFT matrices * 2^14 (Gq: 2^13, its entries reach 2), the row
+// spectrum R * 2^8 (|R| <= window width <= 96), forward output X = acc * 2^-22; inverse: every image's spectrum is scaled by
+// its own power of two that puts its largest |component| into [2^13, 2^14) (the dynamic range of Y is far larger than that of
+// the rigorous bound), T * 2^-(14 + ceil(log2 P) + 1), output = acc * 2^(ceil(log2 P) + 1 - 13) / (scale * P * Q).
+#pragma once
+
+#ifndef DFT_DEV
+#error "the includer defines DFT_DEV, DFT_TID, DFT_BID, DFT_GRID, DFT_LDS, DFT_BARRIER, DFT_MFMA, DFT_SHFL_XOR, DFT_BALLOT, DFT_RAISE, DFT_UNIFORM"
+#endif
+
+#ifndef DFT_HD
+#define DFT_HD static inline      /* host + device helpers (the device build says __host__ __device__) */
+#endif
+
+namespace os2d_dft {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+constexpr int DFT_THR = 512, DFT_WAVES = 8;
+constexpr int DFT_G = 4;            // images per work-group iteration
+constexpr int DFT_MAXP = 64;        // transform rows (P <= 64: the 2P rows of step 2 / step A are at most four 32-row tiles)
+constexpr int DFT_MAXV = 48;        // half-spectrum columns (2V <= 96: three 32-column tiles; Q <= 94)
+constexpr int DFT_MAXWK = 96;       // window columns rounded up to 16
+constexpr int DFT_KREG = 8;         // k-steps of the register-resident operand (2 * Pp / 16 <= 8)
+
+struct DftPlan {
+  int H, W;                        // map
+  int P, Q, V, NBINS;              // transform size, V = Q/2 + 1; bins = v * P + u padded to a multiple of 8
+  int T, TY, TX, TH, TW;           // overlap-save tiles (T = TY * TX = 1: the whole map in one transform)
+  int oy, ox;                      // 3 along a tiled axis (window starts 3 cells before the tile; outputs sit at offset 3), else 0
+  int LH, LW;                      // rows / columns of the window a tile loads (TH + 6 | H, TW + 6 | W)
+  int RH;                          // rows of the inverse that are needed (oy + TH | H)
+  int Pp;                          // P rounded up to 8: rows of a window in the operand arrays (k of step 2 / step A = 2 * Pp)
+  int Wk;                          // LW rounded up to 16: k of step 1
+  int N1;                          // 2 V rounded up to 32: columns of step 1
+  int M2;                          // 2 P rounded up to 32: rows of step 2
+  int Mx;                          // G * Pp rounded up to 32: rows of step 1 = (img, h)
+  int N2;                          // G * V rounded up to 32: columns of step 2 / step A = (img, v)
+  int MA;                          // 2 * RH rounded up to 32: rows of step A = (h, re | im)
+  int MB;                          // G * (MA / 2) : rows of step B = (h, img)
+  int KB;                          // 2 V rounded up to 16: k of step B
+  int NBo;                         // columns of step B that are needed (ox + TW | W) rounded up to 32
+  int eT;                          // ceil(log2 P) + 1
+  int fast;                        // 1: W % 4 == 0 and untiled (16-byte loads of the correlation rows)
+  unsigned inv_cg, inv_t, inv_tx, inv_c4, inv_v, inv_pq, inv_og, inv_kg;   // ceil(2^32 / d) (0 where d == 1)
+  // LDS (bytes)
+  int lds_const, lds_union, lds_total;
+};
+
+DFT_HD int dft_round_up(int x, int m) { return (x + m - 1) / m * m; }
+DFT_HD unsigned dft_magic(unsigned d) { return d > 1 ? (unsigned)(((1ull << 32) + d - 1) / d) : 0u; }
+
+// sizes of the constant operand arrays of a (P, Q) transform, in 16-byte units: they depend on P and Q only, so every map
+// (and every tiling) that uses the transform shares them
+DFT_HD int dft_units_fqt(int P, int Q) { return (dft_round_up(Q, 16) / 8) * 2 * dft_round_up(Q + 2, 32); }
+DFT_HD int dft_units_fp2(int P, int Q) { return (2 * dft_round_up(P, 8) / 8) * 2 * dft_round_up(2 * P, 32); }
+DFT_HD int dft_units_e2(int P, int Q) { return (2 * dft_round_up(P, 8) / 8) * 2 * dft_round_up(2 * P, 32); }
+DFT_HD int dft_units_gq(int P, int Q) { return (dft_round_up(Q + 2, 16) / 8) * 2 * dft_round_up(Q, 32); }
+DFT_HD size_t dft_matrices_units(int P, int Q) {
+  return (size_t)dft_units_fqt(P, Q) + dft_units_fp2(P, Q) + dft_units_e2(P, Q) + dft_units_gq(P, Q);
+}
+
+// plan of ONE transform: window LH x LW -> P x Q, RH rows of the inverse needed, NBo output columns needed
+static inline bool dft_plan_transform(int LH, int LW, int RH, int ncols, int minP, int minQ, DftPlan* pl) {
+  pl->P = dft_round_up(minP, 4);
+  pl->Q = dft_round_up(minQ, 2);
+  pl->V = pl->Q / 2 + 1;
+  pl->NBINS = dft_round_up(pl->P * pl->V, 8);
+  pl->LH = LH;
+  pl->LW = LW;
+  pl->RH = RH;
+  pl->Pp = dft_round_up(pl->P, 8);
+  pl->Wk = dft_round_up(LW, 16);
+  pl->N1 = dft_round_up(2 * pl->V, 32);
+  pl->M2 = dft_round_up(2 * pl->P, 32);
+  pl->Mx = dft_round_up(DFT_G * pl->Pp, 32);
+  pl->N2 = dft_round_up(DFT_G * pl->V, 32);
+  pl->MA = dft_round_up(2 * RH, 32);
+  pl->MB = DFT_G * (pl->MA / 2);
+  pl->KB = dft_round_up(2 * pl->V, 16);
+  pl->NBo = dft_round_up(ncols, 32);
+  int e = 0;
+  while ((1 << e) < pl->P) ++e;
+  pl->eT = e + 1;
+  if (pl->P > DFT_MAXP || pl->V > DFT_MAXV || pl->Wk > DFT_MAXWK || LH > pl->P || LW > pl->Q || RH > pl->P) return false;
+  // LDS: constants FqT | Gq are resident (whichever kernel runs takes its own: the larger decides the common figure);
+  // the union region holds, one after the other, x | R2 | X staging (forward) and Y2 | Tt (inverse)
+  const int fqt = (pl->Wk / 8) * 2 * pl->N1 * 16, gq = (pl->KB / 8) * 2 * pl->NBo * 16;
+  const int x = (pl->Wk / 8) * 2 * (pl->Mx + 1) * 16, r2 = (2 * pl->Pp / 8) * 2 * (pl->N2 + 1) * 16;
+  const int xs = pl->V * (pl->P * 8 * DFT_G + 16);
+  const int y2 = r2, tt = (pl->KB / 8) * 2 * (pl->MB + 1) * 16;
+  int u = x;
+  if (r2 > u) u = r2;
+  if (xs > u) u = xs;
+  if (y2 > u) u = y2;
+  if (tt > u) u = tt;
+  pl->lds_const = fqt > gq ? fqt : gq;
+  pl->lds_union = dft_round_up(u, 256);
+  pl->lds_total = pl->lds_const + pl->lds_union + 1024;      // + per-image maxima / scales
+  return pl->lds_total <= 160 * 1024;
+}
+
+static inline void dft_set_tiles(DftPlan* pl, int H, int W, int TY, int TX, int TH, int TW) {
+  pl->H = H;
+  pl->W = W;
+  pl->TY = TY;
+  pl->TX = TX;
+  pl->T = TY * TX;
+  pl->TH = TH;
+  pl->TW = TW;
+  pl->oy = TY > 1 ? 3 : 0;
+  pl->ox = TX > 1 ? 3 : 0;
+  pl->fast = (pl->T == 1 && (W & 3) == 0) ? 1 : 0;
+  pl->inv_t = dft_magic((unsigned)pl->T);
+  pl->inv_tx = dft_magic((unsigned)TX);
+  pl->inv_c4 = dft_magic((unsigned)(pl->Wk / 4));
+  pl->inv_v = dft_magic((unsigned)pl->V);
+  pl->inv_pq = dft_magic((unsigned)(pl->P / 4 * DFT_G * 2));
+  pl->inv_kg = dft_magic((unsigned)(pl->Pp / 8));
+}
+
+// The whole map in one transform when it fits (P >= H + 3, Q >= W + 3: the zero padding is the halo), otherwise the tiling
+// with the fewest bins in total; an axis is either untiled or cut into >= 2 tiles of ceil(n / k) outputs whose window is 6
+// longer.  Any P % 4 == 0 and even Q will do (the transforms are matrix products: no factorisation constraint).
+static inline bool dft_make_plan(int H, int W, DftPlan* out) {
+  bool found = false;
+  long best = 0;
+  for (int TY = 1; TY <= 32; ++TY)
+    for (int TX = 1; TX <= 32; ++TX) {
+      const int TH = (H + TY - 1) / TY, TW = (W + TX - 1) / TX;
+      if ((TY > 1 && (TY - 1) * TH >= H) || (TX > 1 && (TX - 1) * TW >= W)) continue;     // an empty last tile
+      DftPlan c = {};
+      const int LH = TY > 1 ? TH + 6 : H, LW = TX > 1 ? TW + 6 : W;
+      if (!dft_plan_transform(LH, LW, TY > 1 ? TH + 3 : H, TX > 1 ? TW + 3 : W, TY > 1 ? TH + 6 : H + 3, TX > 1 ? TW + 6 : W + 3, &c))
+        continue;
+      dft_set_tiles(&c, H, W, TY, TX, TH, TW);
+      const long cost = (long)c.T * c.NBINS;
+      if (!found || cost < best) {
+        found = true;
+        best = cost;
+        *out = c;
+      }
+    }
+  return found;
+}
+
+// ---------------------------------------------------------------------------------------------------- device helpers
+DFT_DEV int dft_div(int x, unsigned magic) { return magic ? (int)(((unsigned long long)(unsigned)x * magic) >> 32) : x; }
+
+// fp16 hi + lo of four values: two 8-byte halves-of-a-unit
+DFT_DEV void dft_split4(float a, float b, float c, float d, u32x2v* hi, u32x2v* lo) {
+  const _Float16 ha = (_Float16)a, hb = (_Float16)b, hc = (_Float16)c, hd = (_Float16)d;
+  const _Float16 la = (_Float16)(a - (float)ha), lb = (_Float16)(b - (float)hb), lc = (_Float16)(c - (float)hc),
+                 ld = (_Float16)(d - (float)hd);
+  u32x2v h, l;
+  h[0] = (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+  h[1] = (unsigned)__builtin_bit_cast(unsigned short, hc) | ((unsigned)__builtin_bit_cast(unsigned short, hd) << 16);
+  l[0] = (unsigned)__builtin_bit_cast(unsigned short, la) | ((unsigned)__builtin_bit_cast(unsigned short, lb) << 16);
+  l[1] = (unsigned)__builtin_bit_cast(unsigned short, lc) | ((unsigned)__builtin_bit_cast(unsigned short, ld) << 16);
+  *hi = h;
+  *lo = l;
+}
+
+DFT_DEV half8 dft_frag(const u32x4v* p) { return __builtin_bit_cast(half8, *p); }
+
+// one split product step: acc += A_hi B_lo + A_lo B_hi + A_hi B_hi (fp32 accumulation; the dropped lo x lo term is 2^-22 relative)
+DFT_DEV f32x16v dft_mma3(half8 ah, half8 al, half8 bh, half8 bl, f32x16v acc) {
+  acc = DFT_MFMA(ah, bl, acc);
+  acc = DFT_MFMA(al, bh, acc);
+  acc = DFT_MFMA(ah, bh, acc);
+  return acc;
+}
+
+// acc[j] += A . B[tile j] for this wave's NT column tiles, the row operand A resident in REGISTERS (its k-steps as fragment
+// arrays): per k-step all B fragments are requested first, then the 3 NT matrix instructions run as they arrive.  NT is a
+// template parameter so that the loop body has no branches (the per-tile "is it mine" test would otherwise sit between every
+// fragment read and its matrix instructions and keep the compiler from moving the reads up).
+template <int NT>
+DFT_DEV void dft_product_rega(f32x16v* acc, const half8* ah, const half8* al, int ksn, const u32x4v* B, int bstride, int nt0, int ntstep,
+                              int l31, int hw) {
+#pragma unroll
+  for (int ks = 0; ks < DFT_KREG; ++ks) {
+    if (ks < ksn) {
+      half8 bh[NT], bl[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        bh[j] = dft_frag(B + (size_t)((2 * ks + hw) * 2 + 0) * bstride + (nt0 + ntstep * j) * 32 + l31);
+        bl[j] = dft_frag(B + (size_t)((2 * ks + hw) * 2 + 1) * bstride + (nt0 + ntstep * j) * 32 + l31);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = dft_mma3(ah[ks], al[ks], bh[j], bl[j], acc[j]);
+    }
+  }
+}
+
+// acc[j] += A[row tile mt_j] . B[column tile nt_j], both operands in LDS, tiles t = t0 + 8 j of a grid of mtn row tiles;
+// SHARE: all NT tiles have the same row tile (mtn == 8): its A fragment is read once per k-step
+template <int NT, bool SHARE>
+DFT_DEV void dft_product_lds(f32x16v* acc, int ksn, const u32x4v* A, int astride, const u32x4v* B, int bstride, int t0, int mtn, int l31,
+                             int hw) {
+  int tm[NT], tn[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int t = t0 + DFT_WAVES * j;
+    tn[j] = t / mtn;
+    tm[j] = t - tn[j] * mtn;
+  }
+  for (int ks = 0; ks < ksn; ++ks) {
+    half8 ah[SHARE ? 1 : NT], al[SHARE ? 1 : NT], bh[NT], bl[NT];
+#pragma unroll
+    for (int j = 0; j < (SHARE ? 1 : NT); ++j) {
+      ah[j] = dft_frag(A + (size_t)((2 * ks + hw) * 2 + 0) * astride + tm[j] * 32 + l31);
+      al[j] = dft_frag(A + (size_t)((2 * ks + hw) * 2 + 1) * astride + tm[j] * 32 + l31);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      bh[j] = dft_frag(B + (size_t)((2 * ks + hw) * 2 + 0) * bstride + tn[j] * 32 + l31);
+      bl[j] = dft_frag(B + (size_t)((2 * ks + hw) * 2 + 1) * bstride + tn[j] * 32 + l31);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = dft_mma3(ah[SHARE ? 0 : j], al[SHARE ? 0 : j], bh[j], bl[j], acc[j]);
+  }
+}
+
+DFT_DEV void dft_product_lds_any(f32x16v* acc, int ntiles, int ksn, const u32x4v* A, int astride, const u32x4v* B, int bstride, int t0,
+                                 int mtn, int l31, int hw) {
+  const bool share = mtn == DFT_WAVES;
+  if (ntiles == 3) {
+    if (share) dft_product_lds<3, true>(acc, ksn, A, astride, B, bstride, t0, mtn, l31, hw);
+    else dft_product_lds<3, false>(acc, ksn, A, astride, B, bstride, t0, mtn, l31, hw);
+  } else if (ntiles == 2) {
+    if (share) dft_product_lds<2, true>(acc, ksn, A, astride, B, bstride, t0, mtn, l31, hw);
+    else dft_product_lds<2, false>(acc, ksn, A, astride, B, bstride, t0, mtn, l31, hw);
+  } else if (ntiles == 1) {
+    dft_product_lds<1, true>(acc, ksn, A, astride, B, bstride, t0, mtn, l31, hw);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- constant matrices
+// thread per unit; tw tables: double [n][2] = (cos, sin) of -2 pi m / n.  Layouts (units of 8 halves along k):
+//   FqT [k = w / 8][hi|lo][n = 2 v + ri < N1]         value(w, n) = E_Q[v w].{re, im}                     * 2^14
+//   Fp2 [k = (ri * Pp + h) / 8][hi|lo][m = 2 u + ro]  value = ro == 0 ? (ri == 0 ? cos : sin) : (ri == 0 ? -sin : cos) of 2 pi u h / P
+//   E2  [k = (ri * Pp + u) / 8][hi|lo][m = 2 h + ro]  value = ro == 0 ? (ri == 0 ? cos : -sin) : (ri == 0 ? sin : cos)
+//   Gq  [k = (2 v + ri) / 8][hi|lo][n = w]            value = a_v * E_Q[v w].{re, im}, a_0 = a_{Q/2} = 1, else 2   * 2^13
+DFT_DEV void dft_matrix_unit(int which, int unit, int P, int Q, const double* twP, const double* twQ, u32x4v* out) {
+  const int V = Q / 2 + 1, Pp = dft_round_up(P, 8);
+  int cols, kidx, hl, col;
+  double vals[8];
+  if (which == 0) cols = dft_round_up(2 * V, 32);
+  else if (which == 1 || which == 2) cols = dft_round_up(2 * P, 32);
+  else cols = dft_round_up(Q, 32);
+  col = unit % cols;
+  hl = (unit / cols) & 1;
+  kidx = unit / (2 * cols);
+  for (int t = 0; t < 8; ++t) {
+    const int k = kidx * 8 + t;
+    double x = 0.0;
+    if (which == 0) {                  // FqT: k = w, col = 2 v + ri
+      const int v = col >> 1, ri = col & 1;
+      if (k < Q && v < V) x = twQ[2 * (int)(((long long)v * k) % Q) + ri] * 16384.0;
+    } else if (which == 1) {           // Fp2: k = ri * Pp + h, col (row of the product) = 2 u + ro
+      const int ri = k / Pp, h = k - ri * Pp, u = col >> 1, ro = col & 1;
+      if (h < P && u < P && ri < 2) {
+        const int a = (int)(((long long)u * h) % P);
+        const double c = twP[2 * a], s = -twP[2 * a + 1];          // cos, sin of +2 pi u h / P
+        x = (ro == 0 ? (ri == 0 ? c : s) : (ri == 0 ? -s : c)) * 16384.0;
+      }
+    } else if (which == 2) {           // E2: k = ri * Pp + u, col = 2 h + ro
+      const int ri = k / Pp, u = k - ri * Pp, h = col >> 1, ro = col & 1;
+      if (u < P && h < P && ri < 2) {
+        const int a = (int)(((long long)u * h) % P);
+        const double c = twP[2 * a], s = -twP[2 * a + 1];
+        x = (ro == 0 ? (ri == 0 ? c : -s) : (ri == 0 ? s : c)) * 16384.0;
+      }
+    } else {                           // Gq: k = 2 v + ri, col = w
+      const int v = k >> 1, ri = k & 1;
+      if (v < V && col < Q) {
+        const double a = (v == 0 || 2 * v == Q) ? 1.0 : 2.0;
+        x = a * twQ[2 * (int)(((long long)v * col) % Q) + ri] * 8192.0;
+      }
+    }
+    vals[t] = x;
+  }
+  unsigned w[4];
+  for (int t = 0; t < 4; ++t) {
+    unsigned short b[2];
+    for (int e = 0; e < 2; ++e) {
+      const double x = vals[2 * t + e];
+      const _Float16 h = (_Float16)x;
+      const _Float16 r = hl == 0 ? h : (_Float16)(x - (double)h);
+      b[e] = __builtin_bit_cast(unsigned short, r);
+    }
+    w[t] = (unsigned)b[0] | ((unsigned)b[1] << 16);
+  }
+  u32x4v o;
+  o[0] = w[0];
+  o[1] = w[1];
+  o[2] = w[2];
+  o[3] = w[3];
+  *out = o;
+}
+
+// ---------------------------------------------------------------------------------------------------- forward transform
+// iteration it -> (pair' = it / CG, channel group cg = it % CG), pair' = nb * T + tile; channels 4 cg .. 4 cg + 3
+template <bool TILED, bool FAST>
+DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
+                              const float* invn,      // [NB][H * W]
+                              float* X,               // [NBINS / 4][NBT][Cpad][4][2]
+                              const u32x4v* FqT, const u32x4v* Fp2, const DftPlan& pl, int C, int Cpad, int NBT, int iters) {
+  unsigned char* smem = DFT_LDS;
+  const int tid = DFT_TID, lane = tid & 63, l31 = lane & 31, hw = lane >> 5;
+  const int wv = DFT_UNIFORM(tid >> 6);      // wave-uniform (a scalar register): the tile ownership below is real branching, not exec masks
+  const int P = pl.P, V = pl.V, Pp = pl.Pp, Wk = pl.Wk, N1 = pl.N1, Mx = pl.Mx, N2 = pl.N2, LH = pl.LH, LW = pl.LW, W = pl.W, H = pl.H;
+  const int MxS = Mx + 1, N2S = N2 + 1;
+  const int CG = (C + DFT_G - 1) / DFT_G, HW = H * W;
+  u32x4v* ldsF = reinterpret_cast<u32x4v*>(smem);                                   // FqT [Wk / 8][2][N1]
+  u32x4v* ldsU = reinterpret_cast<u32x4v*>(smem + pl.lds_const);                    // x | R2 | X staging
+  unsigned char* ldsUb = smem + pl.lds_const;
+  const int nF = (Wk / 8) * 2 * N1;
+  for (int i = tid; i < nF; i += DFT_THR) ldsF[i] = FqT[i];
+
+  // the wave's tiles.  step 1: (row tile of x, column tile of FqT), round robin - with 8 row tiles a wave keeps ONE row tile
+  // and its A fragment serves all column tiles; step 2: row tile wv & 3 of Fp2 in REGISTERS, column tiles (wv >> 2) + 2 j
+  const int mt1n = Mx / 32, nt1n = N1 / 32, nt2n = N2 / 32, mt2n = pl.M2 / 32;
+  const int ks1n = Wk / 16, ks2n = 2 * Pp / 16;
+  const int mt2 = wv & 3;
+  half8 fp2h[DFT_KREG], fp2l[DFT_KREG];
+#pragma unroll
+  for (int ks = 0; ks < DFT_KREG; ++ks) {
+    const int kc = ks < ks2n ? ks : 0, mc = mt2 < mt2n ? mt2 : 0;
+    fp2h[ks] = dft_frag(Fp2 + ((size_t)((2 * kc + hw) * 2 + 0)) * pl.M2 + mc * 32 + l31);
+    fp2l[ks] = dft_frag(Fp2 + ((size_t)((2 * kc + hw) * 2 + 1)) * pl.M2 + mc * 32 + l31);
+  }
+
+  // ---- register prefetch of the next iteration's window: position slot s of a thread = (row r, 4 columns c4) of the window,
+  // all G images; raw values only (any arithmetic here would make the compiler wait for each load where it is issued)
+  constexpr int NSLOT = 3;                                     // ceil(Pp * Wk / 4 / 512) <= 64 * 24 / 512
+  const int npos = Pp * (Wk / 4);
+  f32x4v pc[NSLOT][DFT_G], pn[NSLOT];
+#define DFT_FWD_ITER(IT)                                                                                     \
+  const int pr_ = dft_div((IT), pl.inv_cg), cg_ = (IT)-pr_ * CG;                                             \
+  const int nb_ = TILED ? dft_div(pr_, pl.inv_t) : pr_, tile_ = TILED ? pr_ - nb_ * pl.T : 0;               \
+  const int ty_ = TILED ? dft_div(tile_, pl.inv_tx) : 0, tx_ = TILED ? tile_ - ty_ * pl.TX : 0;             \
+  const int Y0 = TILED ? ty_ * pl.TH - pl.oy : 0, X0 = TILED ? tx_ * pl.TW - pl.ox : 0;                     \
+  const int c0_ = cg_ * DFT_G;
+#define DFT_FWD_POS(TID, S)                                                                                  \
+  const int i_ = (TID) + (S)*DFT_THR;                                                                        \
+  const int r_ = dft_div(i_, pl.inv_c4), c4_ = i_ - r_ * (Wk / 4);                                          \
+  const int y_ = Y0 + r_, x_ = X0 + 4 * c4_;
+  // (a macro, not a lambda: register arrays captured by a closure end up in scratch memory with this compiler)
+#define DFT_FWD_PREFETCH(IT, TID)                                                                            \
+  {                                                                                                          \
+    DFT_FWD_ITER(IT)                                                                                         \
+    _Pragma("unroll") for (int s = 0; s < NSLOT; ++s) {                                                      \
+      DFT_FWD_POS(TID, s)                                                                                    \
+      if (FAST) {                                                                                            \
+        const bool ok = i_ < npos && r_ < LH && 4 * c4_ < LW;                                                \
+        const int off = ok ? y_ * W + x_ : 0;                                                                \
+        pn[s] = *reinterpret_cast<const f32x4v*>(invn + (size_t)nb_ * HW + off);                             \
+        _Pragma("unroll") for (int g = 0; g < DFT_G; ++g) {                                                  \
+          const int c = c0_ + g < C ? c0_ + g : C - 1;                                                       \
+          pc[s][g] = *reinterpret_cast<const f32x4v*>(corr + ((size_t)nb_ * C + c) * HW + off);              \
+        }                                                                                                    \
+      } else {                                                                                               \
+        const bool rok = i_ < npos && r_ < LH && y_ >= 0 && y_ < H;                                          \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                      \
+          const bool ok = rok && 4 * c4_ + e < LW && x_ + e >= 0 && x_ + e < W;                              \
+          const int off = ok ? y_ * W + x_ + e : 0;                                                          \
+          pn[s][e] = invn[(size_t)nb_ * HW + off];                                                           \
+          _Pragma("unroll") for (int g = 0; g < DFT_G; ++g) {                                                \
+            const int c = c0_ + g < C ? c0_ + g : C - 1;                                                     \
+            pc[s][g][e] = corr[((size_t)nb_ * C + c) * HW + off];                                            \
+          }                                                                                                  \
+        }                                                                                                    \
+      }                                                                                                      \
+    }                                                                                                        \
+  }
+  // XCD-aware order (work-group L runs on XCD L % 8): every XCD takes a contiguous range of iterations, so work-groups whose
+  // outputs share cache lines / 16-byte units (neighbouring channel groups) run on ONE XCD at about the same time
+  const int first = (DFT_GRID & 7) == 0 ? (DFT_BID & 7) * (DFT_GRID >> 3) + (DFT_BID >> 3) : DFT_BID;
+  if (first < iters) DFT_FWD_PREFETCH(first, tid)
+  DFT_BARRIER();     // FqT is in LDS
+
+  for (int it = first; it < iters; it += DFT_GRID) {
+    int tl = tid;
+#ifndef OS2D_HOST_EMU
+    asm volatile("" : "+v"(tl));       // per-iteration addresses are recomputed, not hoisted (register pressure)
+#endif
+    DFT_FWD_ITER(it)
+    // ---- W: x = relu(corr) * inv_norm * 2^15 as fp16 hi | lo units [w / 8][hi|lo][m = img * Pp + r]; zero outside the window
+    {
+#pragma unroll
+      for (int s = 0; s < NSLOT; ++s) {
+        DFT_FWD_POS(tl, s)
+        if (i_ < npos) {
+          bool ok[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            ok[e] = FAST ? (r_ < LH && 4 * c4_ < LW) : (r_ < LH && y_ >= 0 && y_ < H && 4 * c4_ + e < LW && x_ + e >= 0 && x_ + e < W);
+#pragma unroll
+          for (int g = 0; g < DFT_G; ++g) {
+            const bool cok = c0_ + g < C;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float a = pc[s][g][e], n = pn[s][e];
+              v[e] = (ok[e] && cok) ? fmaxf(a, 0.f) * n * 32768.0f : 0.f;
+            }
+            u32x2v hi, lo;
+            dft_split4(v[0], v[1], v[2], v[3], &hi, &lo);
+            const int m = g * Pp + r_;
+            unsigned char* dst = ldsUb + ((size_t)((c4_ >> 1) * 2) * MxS + m) * 16 + (c4_ & 1) * 8;
+            *reinterpret_cast<u32x2v*>(dst) = hi;
+            *reinterpret_cast<u32x2v*>(dst + (size_t)MxS * 16) = lo;
+          }
+        }
+      }
+      // rows G * Pp .. Mx of the last row tile (only when G * Pp is not a multiple of 32): zeros
+      for (int i = tid; i < (Mx - DFT_G * Pp) * (Wk / 8) * 2; i += DFT_THR) {
+        const int m = DFT_G * Pp + i % (Mx - DFT_G * Pp), kh = i / (Mx - DFT_G * Pp);
+        ldsU[(size_t)kh * MxS + m] = u32x4v{0u, 0u, 0u, 0u};
+      }
+    }
+    DFT_BARRIER();
+
+    // ---- step 1: R^T = x . FqT; this wave's tiles t = wv + 8 j of the mt1n x nt1n grid
+    f32x16v acc[3];
+    int tm[3], tn[3];
+    int nt1w = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int t = wv + DFT_WAVES * j;
+      const bool mine = t < mt1n * nt1n;
+      tn[j] = mine ? t / mt1n : 0;
+      tm[j] = mine ? t - tn[j] * mt1n : -1;
+      nt1w += mine ? 1 : 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    }
+    dft_product_lds_any(acc, nt1w, ks1n, ldsU, MxS, ldsF, N1, wv, mt1n, l31, hw);
+    DFT_BARRIER();      // every wave is done reading x: the region becomes R2
+
+    // ---- R: R * 2^8 as units [k = (ri * Pp + h) / 8][hi|lo][n2 = img * V + v]; this lane owns column n = 2 v + ri of its
+    // tiles and, per accumulator run, 4 consecutive h of one image: half a unit
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (tm[j] < 0) continue;
+      const int n = tn[j] * 32 + l31, v = n >> 1, ri = n & 1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m0 = tm[j] * 32 + 8 * q + 4 * hw;
+        const int img = m0 / Pp, h0 = m0 - img * Pp;
+        if (v < V && img < DFT_G) {
+          u32x2v hi, lo;
+          const float sc = 1.0f / 2097152.0f;      // 2^-21 = 2^8 / (2^15 * 2^14)
+          dft_split4(acc[j][4 * q] * sc, acc[j][4 * q + 1] * sc, acc[j][4 * q + 2] * sc, acc[j][4 * q + 3] * sc, &hi, &lo);
+          const int kg = ri * (Pp / 8) + (h0 >> 3);
+          unsigned char* dst = ldsUb + ((size_t)(kg * 2) * N2S + img * V + v) * 16 + (h0 & 4) * 2;
+          *reinterpret_cast<u32x2v*>(dst) = hi;
+          *reinterpret_cast<u32x2v*>(dst + (size_t)N2S * 16) = lo;
+        }
+      }
+    }
+    DFT_BARRIER();
+    // the next window's loads are issued here - the accumulators of step 1 are dead, the values are needed a whole step 2 +
+    // store phase later - so that their registers do not overlap the first product's
+    if (it + DFT_GRID < iters) DFT_FWD_PREFETCH(it + DFT_GRID, tl)
+
+    // ---- step 2: X = Fp2 . R2 (Fp2 fragments in registers); this wave's column tiles (wv >> 2) + 2 j of row tile wv & 3
+    f32x16v xc[3];
+    int un[3];
+    int nt2w = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int nt = (wv >> 2) + 2 * j;
+      const bool mine = nt < nt2n && mt2 < mt2n;
+      un[j] = mine ? nt : -1;
+      nt2w += mine ? 1 : 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xc[j][r] = 0.f;
+    }
+    if (nt2w == 3) dft_product_rega<3>(xc, fp2h, fp2l, ks2n, ldsU, N2S, wv >> 2, 2, l31, hw);
+    else if (nt2w == 2) dft_product_rega<2>(xc, fp2h, fp2l, ks2n, ldsU, N2S, wv >> 2, 2, l31, hw);
+    else if (nt2w == 1) dft_product_rega<1>(xc, fp2h, fp2l, ks2n, ldsU, N2S, wv >> 2, 2, l31, hw);
+    DFT_BARRIER();      // every wave is done reading R2: the region becomes the staging buffer of X
+
+    // ---- XS: X = acc * 2^-22 staged as [v][u / 4][img][u % 4][re|im] (+16 bytes per v: consecutive lanes = consecutive v land
+    // in different banks); a lane owns (img, v) and per accumulator run two consecutive u
+    const int XS = P * 8 * DFT_G + 16;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (un[j] < 0) continue;
+      const int n2 = un[j] * 32 + l31;
+      const int img = dft_div(n2, pl.inv_v), v = n2 - img * V;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int u0 = (mt2 * 32 + 8 * q + 4 * hw) >> 1;
+        if (img < DFT_G && u0 < P) {
+          const float sc = 1.0f / 4194304.0f;      // 2^-22 = 1 / (2^8 * 2^14)
+          f32x4v o;
+          o[0] = xc[j][4 * q] * sc;
+          o[1] = xc[j][4 * q + 1] * sc;
+          o[2] = xc[j][4 * q + 2] * sc;
+          o[3] = xc[j][4 * q + 3] * sc;
+          *reinterpret_cast<f32x4v*>(ldsUb + (size_t)v * XS + (u0 >> 2) * (DFT_G * 32) + img * 32 + (u0 & 3) * 8) = o;
+        }
+      }
+    }
+    DFT_BARRIER();
+
+    // ---- ST: 16-byte pieces, 8 per quad of bins = the 128 contiguous bytes of the 4 channels; then the padding bins
+    {
+      const int per_v = (P / 4) * (DFT_G * 2), npieces = V * per_v;
+      float* dstbase = X + ((size_t)pr_ * Cpad + c0_) * 8;
+      const size_t qstride = (size_t)NBT * Cpad * 8;             // floats between consecutive quads of bins
+      for (int i = tl; i < npieces; i += DFT_THR) {
+        const int v = dft_div(i, pl.inv_pq), rem = i - v * per_v;
+        const int uq = rem >> 3, jj = rem & 7;
+        const f32x4v val = *reinterpret_cast<const f32x4v*>(ldsUb + (size_t)v * XS + uq * (DFT_G * 32) + jj * 16);
+        *reinterpret_cast<f32x4v*>(dstbase + (size_t)(v * (P / 4) + uq) * qstride + jj * 4) = val;
+      }
+      const int qpad0 = (P * V) / 4, qpad1 = pl.NBINS / 4;
+      for (int i = tl; i < (qpad1 - qpad0) * 8; i += DFT_THR)
+        *reinterpret_cast<f32x4v*>(dstbase + (size_t)(qpad0 + (i >> 3)) * qstride + (i & 7) * 4) = f32x4v{0.f, 0.f, 0.f, 0.f};
+    }
+    DFT_BARRIER();      // the staging buffer is free: the next window may be written
+  }
+#undef DFT_FWD_ITER
+#undef DFT_FWD_POS
+#undef DFT_FWD_PREFETCH
+}
+
+// ---------------------------------------------------------------------------------------------------- inverse transform
+// iteration it -> (pair' = it / OG, output channel group og = it % OG): output channels 4 og .. 4 og + 3 of pair' = nb * T + tile
+template <bool TILED>
+DFT_DEV void dft_inverse_body(const float* Y,        // [NBINS / 4][NBT][Cout][4][2]
+                              const float* bp,       // [3][MTP]: bias | - | 2^out_exp
+                              int MTP, unsigned char* out,   // SHB [NB][Cout / 8][2][PLANE] x 16 B
+                              const u32x4v* E2, const u32x4v* Gq, const DftPlan& pl, int Cout, int NBT, int PLANE, int Ws,
+                              int BASE, int iters, int* bad_flag) {
+  unsigned char* smem = DFT_LDS;
+  const int tid = DFT_TID, lane = tid & 63, l31 = lane & 31, hw = lane >> 5;
+  const int wv = DFT_UNIFORM(tid >> 6);
+  const int P = pl.P, V = pl.V, Pp = pl.Pp, N2 = pl.N2, MB = pl.MB, KB = pl.KB, NBo = pl.NBo, H = pl.H, W = pl.W;
+  const int N2S = N2 + 1, MBS = MB + 1;
+  const int OG = Cout / DFT_G;
+  u32x4v* ldsG = reinterpret_cast<u32x4v*>(smem);                                   // Gq [KB / 8][2][NBo]
+  u32x4v* ldsU = reinterpret_cast<u32x4v*>(smem + pl.lds_const);                    // Y2 | Tt
+  unsigned char* ldsUb = smem + pl.lds_const;
+  float* smaxw = reinterpret_cast<float*>(smem + pl.lds_const + pl.lds_union);      // [8 waves][G]: |Y| maxima
+  const int nG = (KB / 8) * 2 * NBo, NQ = dft_round_up(pl.Q, 32);     // the Gq array has round_up(Q, 32) columns, NBo of them are needed
+  for (int i = tid; i < nG; i += DFT_THR) {
+    const int kh = i / NBo, n = i - kh * NBo;
+    ldsG[i] = Gq[(size_t)kh * NQ + n];
+  }
+
+  const int mtAn = pl.MA / 32, ntAn = N2 / 32, ksAn = 2 * Pp / 16;
+  const int mtBn = MB / 32, ntBn = NBo / 32, ksBn = KB / 16;
+  const int mtA = wv & 3;
+  half8 e2h[DFT_KREG], e2l[DFT_KREG];
+  const int MAfull = dft_round_up(2 * P, 32);                    // row count of the E2 array
+#pragma unroll
+  for (int ks = 0; ks < DFT_KREG; ++ks) {
+    const int kc = ks < ksAn ? ks : 0, mc = mtA < mtAn ? mtA : 0;
+    e2h[ks] = dft_frag(E2 + ((size_t)((2 * kc + hw) * 2 + 0)) * MAfull + mc * 32 + l31);
+    e2l[ks] = dft_frag(E2 + ((size_t)((2 * kc + hw) * 2 + 1)) * MAfull + mc * 32 + l31);
+  }
+
+  // ---- register prefetch: item = (img, v, octet of u) -> the two quads of bins u0 .. u0 + 7 of column v: 2 x 32 bytes
+  constexpr int NITEM = 3;                                      // ceil(G * V * Pp / 8 / 512) <= 4 * 48 * 8 / 512
+  const int uoct = Pp / 8, nitem = DFT_G * V * uoct;
+  f32x4v py[NITEM][4];
+  const size_t qstride = (size_t)NBT * Cout * 8;
+#define DFT_INV_PREFETCH(IT, TID)                                                           \
+  {                                                                                         \
+    const int pr_ = dft_div((IT), pl.inv_og), og_ = (IT)-pr_ * OG;                          \
+    const float* src_ = Y + ((size_t)pr_ * Cout + og_ * DFT_G) * 8;                         \
+    _Pragma("unroll") for (int s = 0; s < NITEM; ++s) {                                     \
+      const int e_ = (TID) + s * DFT_THR;                                                   \
+      const int ec_ = e_ < nitem ? e_ : 0;                                                  \
+      const int pimg_ = ec_ & (DFT_G - 1), prest_ = ec_ >> 2;                               \
+      const int pv_ = dft_div(prest_, pl.inv_kg), puo_ = prest_ - pv_ * (Pp / 8);           \
+      const int q0_ = pv_ * (P / 4) + 2 * puo_;                                             \
+      const bool ptwo_ = 8 * puo_ + 4 < P;                                                  \
+      const float* p0_ = src_ + (size_t)q0_ * qstride + pimg_ * 8;                          \
+      const float* p1_ = src_ + (size_t)(ptwo_ ? q0_ + 1 : q0_) * qstride + pimg_ * 8;      \
+      py[s][0] = *reinterpret_cast<const f32x4v*>(p0_);                                     \
+      py[s][1] = *reinterpret_cast<const f32x4v*>(p0_ + 4);                                 \
+      py[s][2] = *reinterpret_cast<const f32x4v*>(p1_);                                     \
+      py[s][3] = *reinterpret_cast<const f32x4v*>(p1_ + 4);                                 \
+    }                                                                                       \
+  }
+#define DFT_INV_ITEM(E)                                                                     \
+  const int img_ = (E) & (DFT_G - 1), rest_ = (E) >> 2;                                     \
+  const int v_ = dft_div(rest_, pl.inv_kg), uo_ = rest_ - v_ * uoct;                        \
+  const bool two_ = 8 * uo_ + 4 < P;
+  bool bad = false;
+  const int first = (DFT_GRID & 7) == 0 ? (DFT_BID & 7) * (DFT_GRID >> 3) + (DFT_BID >> 3) : DFT_BID;     // XCD-aware (see the forward kernel)
+  if (first < iters) DFT_INV_PREFETCH(first, tid)
+  DFT_BARRIER();
+
+  for (int it = first; it < iters; it += DFT_GRID) {
+    int tl = tid;
+#ifndef OS2D_HOST_EMU
+    asm volatile("" : "+v"(tl));
+#endif
+    const int pr = dft_div(it, pl.inv_og), og = it - pr * OG;
+    const int nb = TILED ? dft_div(pr, pl.inv_t) : pr, tile = TILED ? pr - nb * pl.T : 0;
+    const int ty = TILED ? dft_div(tile, pl.inv_tx) : 0, tx = TILED ? tile - ty * pl.TX : 0;
+    const int y0 = TILED ? ty * pl.TH : 0, x0 = TILED ? tx * pl.TW : 0, oy = TILED ? pl.oy : 0, ox = TILED ? pl.ox : 0;
+    const int TH_ = TILED ? pl.TH : H, TW_ = TILED ? pl.TW : W;
+    const int o0 = og * DFT_G;
+
+    // ---- M: the largest |component| of every image (this thread's items all belong to image tid % 4)
+    {
+      float m = 0.f;
+#pragma unroll
+      for (int s = 0; s < NITEM; ++s)
+        if (tl + s * DFT_THR < nitem) {
+          DFT_INV_ITEM(tl + s * DFT_THR)
+          (void)img_;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (k < 2 || two_) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(py[s][k][e]));
+            }
+        }
+      m = fmaxf(m, DFT_SHFL_XOR(m, 4));
+      m = fmaxf(m, DFT_SHFL_XOR(m, 8));
+      m = fmaxf(m, DFT_SHFL_XOR(m, 16));
+      m = fmaxf(m, DFT_SHFL_XOR(m, 32));
+      if (lane < DFT_G) smaxw[wv * DFT_G + lane] = m;
+    }
+    DFT_BARRIER();
+    float simg = 1.f, cinv[DFT_G];
+    {
+      // scale of an image: 2^(13 - E), E = floor(log2(max)): the largest component lands in [2^13, 2^14)
+#pragma unroll
+      for (int g = 0; g < DFT_G; ++g) {
+        float m = 0.f;
+#pragma unroll
+        for (int w = 0; w < DFT_WAVES; ++w) m = fmaxf(m, smaxw[w * DFT_G + g]);
+        int E = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu) - 127;
+        if (!(m > 0.f) || E < -100) E = -100;
+        if (E > 100) E = 100;
+        const float s = __builtin_bit_cast(float, (unsigned)(13 - E + 127) << 23);
+        const float sinv = __builtin_bit_cast(float, (unsigned)(E - 13 + 127) << 23);
+        if (g == (tl & (DFT_G - 1))) simg = s;
+        // output = acc * 2^(eT - 13) / (scale * P * Q)
+        cinv[g] = sinv * __builtin_bit_cast(float, (unsigned)(pl.eT - 13 + 127) << 23) / (float)(P * pl.Q);
+      }
+    }
+    // ---- WY: units [k = (ri * Pp + u) / 8][hi|lo][n = img * V + v]: this item's 8 u of column (img, v), re and im
+#pragma unroll
+    for (int s = 0; s < NITEM; ++s) {
+      const int e = tl + s * DFT_THR;
+      if (e < nitem) {
+        DFT_INV_ITEM(e)
+        const int img = img_, v = v_, uo = uo_;
+        const bool two = two_;
+        float re[8], im[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bool ok = k < 2 || two;
+          re[2 * k] = ok ? py[s][k][0] * simg : 0.f;
+          im[2 * k] = ok ? py[s][k][1] * simg : 0.f;
+          re[2 * k + 1] = ok ? py[s][k][2] * simg : 0.f;
+          im[2 * k + 1] = ok ? py[s][k][3] * simg : 0.f;
+        }
+        u32x2v h0, l0, h1, l1;
+        u32x4v t;
+        const size_t n = (size_t)img * V + v;
+        dft_split4(re[0], re[1], re[2], re[3], &h0, &l0);
+        dft_split4(re[4], re[5], re[6], re[7], &h1, &l1);
+        t[0] = h0[0], t[1] = h0[1], t[2] = h1[0], t[3] = h1[1];
+        ldsU[(size_t)((uo)*2 + 0) * N2S + n] = t;
+        t[0] = l0[0], t[1] = l0[1], t[2] = l1[0], t[3] = l1[1];
+        ldsU[(size_t)((uo)*2 + 1) * N2S + n] = t;
+        dft_split4(im[0], im[1], im[2], im[3], &h0, &l0);
+        dft_split4(im[4], im[5], im[6], im[7], &h1, &l1);
+        t[0] = h0[0], t[1] = h0[1], t[2] = h1[0], t[3] = h1[1];
+        ldsU[(size_t)((uoct + uo) * 2 + 0) * N2S + n] = t;
+        t[0] = l0[0], t[1] = l0[1], t[2] = l1[0], t[3] = l1[1];
+        ldsU[(size_t)((uoct + uo) * 2 + 1) * N2S + n] = t;
+      }
+    }
+    DFT_BARRIER();
+    if (it + DFT_GRID < iters) DFT_INV_PREFETCH(it + DFT_GRID, tl)
+
+    // ---- step A: T = E2 . Y2 (E2 fragments in registers)
+    f32x16v ta[3];
+    int an[3];
+    int ntaw = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int nt = (wv >> 2) + 2 * j;
+      const bool mine = nt < ntAn && mtA < mtAn;
+      an[j] = mine ? nt : -1;
+      ntaw += mine ? 1 : 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ta[j][r] = 0.f;
+    }
+    if (ntaw == 3) dft_product_rega<3>(ta, e2h, e2l, ksAn, ldsU, N2S, wv >> 2, 2, l31, hw);
+    else if (ntaw == 2) dft_product_rega<2>(ta, e2h, e2l, ksAn, ldsU, N2S, wv >> 2, 2, l31, hw);
+    else if (ntaw == 1) dft_product_rega<1>(ta, e2h, e2l, ksAn, ldsU, N2S, wv >> 2, 2, l31, hw);
+    DFT_BARRIER();      // every wave is done reading Y2: the region becomes Tt
+
+    // ---- WT: T * 2^-(14 + eT) as units [k = (2 v + ri) / 8][hi|lo][m = h * G + img]; a lane owns (img, v) and per accumulator
+    // run (re, im) of two consecutive h: 4 bytes of a unit each.  The k beyond 2 V of the last units are zeroed (Gq has zero
+    // rows there, but 0 * NaN-patterned garbage is NaN).
+    {
+      const float sc = __builtin_bit_cast(float, (unsigned)(127 - 14 - pl.eT) << 23);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        if (an[j] < 0) continue;
+        const int n = an[j] * 32 + l31;
+        const int img = dft_div(n, pl.inv_v), v = n - img * V;
+        if (img >= DFT_G) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int h0 = (mtA * 32 + 8 * q + 4 * hw) >> 1;
+          u32x2v hi, lo;
+          dft_split4(ta[j][4 * q] * sc, ta[j][4 * q + 1] * sc, ta[j][4 * q + 2] * sc, ta[j][4 * q + 3] * sc, &hi, &lo);
+          unsigned char* d0 = ldsUb + ((size_t)((v >> 2) * 2) * MBS + (size_t)h0 * DFT_G + img) * 16 + (v & 3) * 4;
+          *reinterpret_cast<unsigned*>(d0) = hi[0];
+          *reinterpret_cast<unsigned*>(d0 + (size_t)MBS * 16) = lo[0];
+          *reinterpret_cast<unsigned*>(d0 + DFT_G * 16) = hi[1];
+          *reinterpret_cast<unsigned*>(d0 + DFT_G * 16 + (size_t)MBS * 16) = lo[1];
+        }
+      }
+      const int vpad = KB / 2 - V;       // v slots V .. KB / 2 - 1
+      for (int i = tl; i < vpad * MB * 2; i += DFT_THR) {
+        const int m = i % MB, rest = i / MB, hl = rest & 1, v = V + (rest >> 1);
+        *reinterpret_cast<unsigned*>(ldsUb + ((size_t)((v >> 2) * 2 + hl) * MBS + m) * 16 + (v & 3) * 4) = 0u;
+      }
+    }
+    DFT_BARRIER();
+
+    // ---- step B: y = Tt . Gq; this wave's tiles t = wv + 8 j of the mtBn x ntBn grid
+    f32x16v yc[3];
+    int bm[3], bn[3];
+    int ntbw = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int t = wv + DFT_WAVES * j;
+      const bool mine = t < mtBn * ntBn;
+      bn[j] = mine ? t / mtBn : 0;
+      bm[j] = mine ? t - bn[j] * mtBn : -1;
+      ntbw += mine ? 1 : 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) yc[j][r] = 0.f;
+    }
+    dft_product_lds_any(yc, ntbw, ksBn, ldsU, MBS, ldsG, NBo, wv, mtBn, l31, hw);
+
+    // ---- epilogue: a lane owns window column w and, per accumulator run, the 4 channels of one row: + bias, ReLU, channel
+    // scale, fp16 hi | lo -> 8 + 8 bytes of the two 16-byte units of the cell (the other half of a unit comes from the
+    // work-group of the neighbouring channel group)
+    {
+      float bias[DFT_G], osc[DFT_G];
+#pragma unroll
+      for (int g = 0; g < DFT_G; ++g) {
+        bias[g] = bp[o0 + g];
+        osc[g] = bp[2 * MTP + o0 + g];
+      }
+      const int grp = o0 >> 3, slot = o0 & 7;
+      unsigned char* hi_unit = out + (((size_t)nb * ((Cout + 7) >> 3) + grp) * 2 + 0) * (size_t)PLANE * 16 + slot * 2;
+      unsigned char* lo_unit = out + (((size_t)nb * ((Cout + 7) >> 3) + grp) * 2 + 1) * (size_t)PLANE * 16 + slot * 2;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        if (bm[j] < 0) continue;
+        const int wwin = bn[j] * 32 + l31, tw = wwin - ox;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int hwin = (bm[j] * 32 + 8 * q + 4 * hw) >> 2, th = hwin - oy;
+          const int h = y0 + th, w = x0 + tw;
+          if (th >= 0 && th < TH_ && tw >= 0 && tw < TW_ && h < H && w < W) {
+            float t[DFT_G];
+#pragma unroll
+            for (int g = 0; g < DFT_G; ++g) {
+              t[g] = fmaxf(yc[j][4 * q + g] * cinv[g] + bias[g], 0.f) * osc[g];
+              if (!(fabsf(t[g]) <= 65504.f)) bad = true;
+            }
+            u32x2v hi, lo;
+            dft_split4(t[0], t[1], t[2], t[3], &hi, &lo);
+            const size_t off = ((size_t)BASE + (size_t)h * Ws + w) * 16;
+            *reinterpret_cast<u32x2v*>(hi_unit + off) = hi;
+            *reinterpret_cast<u32x2v*>(lo_unit + off) = lo;
+          }
+        }
+      }
+    }
+    DFT_BARRIER();      // every wave is done reading Tt (and the maxima): the next spectra may be written
+  }
+  if (bad_flag != nullptr && DFT_BALLOT(bad) != 0ull) {
+    if ((tid & 63) == 0) DFT_RAISE(bad_flag);
+  }
+#undef DFT_INV_ITEM
+#undef DFT_INV_PREFETCH
+}
+
+}  // namespace os2d_dft

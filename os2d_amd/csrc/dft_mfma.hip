@@ -1,0 +1,152 @@
+// Device build of dft_mfma.h (the transforms of the frequency-domain 7x7 layer as matrix products on v_mfma_f32_32x32x16_f16,
+// precision "fftx3"): hardware hooks, kernel entry points, the constant-matrix builder and the launchers.  The kernel bodies
+// live in the header so that tests/host/dft_mfma_check.cpp can run the same source on the CPU (tests/host/spmd_emu.h).
+#include "os2d_common.h"
+
+extern __shared__ __attribute__((aligned(16))) unsigned char os2d_dft_smem[];
+
+#define DFT_DEV __device__ __forceinline__
+#define DFT_HD __host__ __device__ static inline
+#define DFT_TID ((int)threadIdx.x)
+#define DFT_BID ((int)blockIdx.x)
+#define DFT_GRID ((int)gridDim.x)
+#define DFT_LDS os2d_dft_smem
+// barrier for data exchanged through LDS only: leaves this wave's global loads (the next iteration's prefetch) and stores in
+// flight (see fft.hip: __syncthreads() would wait for them at every barrier)
+#define DFT_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define DFT_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define DFT_SHFL_XOR(v, m) __shfl_xor(v, m, 64)
+#define DFT_BALLOT(p) __builtin_amdgcn_ballot_w64(p)
+#define DFT_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#define DFT_RAISE(p) __hip_atomic_store(p, OS2D_STATUS_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+#include "dft_mfma.h"
+
+namespace {
+
+using namespace os2d_dft;
+
+template <bool TILED, bool FAST>
+__global__ __launch_bounds__(DFT_THR, 1) void dft_forward_kernel(const float* __restrict__ corr, const float* __restrict__ invn,
+                                                                 float* __restrict__ X, const u32x4v* __restrict__ FqT,
+                                                                 const u32x4v* __restrict__ Fp2, DftPlan pl, int C, int Cpad, int NBT,
+                                                                 int iters) {
+  dft_forward_body<TILED, FAST>(corr, invn, X, FqT, Fp2, pl, C, Cpad, NBT, iters);
+}
+
+template <bool TILED>
+__global__ __launch_bounds__(DFT_THR, 1) void dft_inverse_kernel(const float* __restrict__ Y, const float* __restrict__ bp, int MTP,
+                                                                 unsigned char* __restrict__ out, const u32x4v* __restrict__ E2,
+                                                                 const u32x4v* __restrict__ Gq, DftPlan pl, int Cout, int NBT, int PLANE,
+                                                                 int Ws, int BASE, int iters, int* status) {
+  dft_inverse_body<TILED>(Y, bp, MTP, out, E2, Gq, pl, Cout, NBT, PLANE, Ws, BASE, iters, status);
+}
+
+// FqT | Fp2 | E2 | Gq of a (P, Q) transform, one thread per 16-byte unit
+__global__ __launch_bounds__(256) void dft_matrices_kernel(const double* __restrict__ twP, const double* __restrict__ twQ, int P, int Q,
+                                                           u32x4v* __restrict__ out) {
+  const int n0 = dft_units_fqt(P, Q), n1 = n0 + dft_units_fp2(P, Q), n2 = n1 + dft_units_e2(P, Q), n3 = n2 + dft_units_gq(P, Q);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n3) return;
+  const int which = i < n0 ? 0 : i < n1 ? 1 : i < n2 ? 2 : 3;
+  const int base = which == 0 ? 0 : which == 1 ? n0 : which == 2 ? n1 : n2;
+  dft_matrix_unit(which, i - base, P, Q, twP, twQ, out + i);
+}
+
+int dft_check(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    os2d_set_error("%s launch: %s", what, hipGetErrorString(e));
+    return -4;
+  }
+  return 0;
+}
+
+int dft_grid(int iters) {
+  int g = iters < 256 ? iters : 256;            // one work-group per CU (126 - 137 KB of LDS)
+  return (g + 7) / 8 * 8;                       // multiple of 8: XCD-aware iteration order
+}
+
+}  // namespace
+
+// plan of an H x W map for the matrix-product transforms: P, Q, padded number of bins (multiple of 8; bin = v * P + u) and
+// tiles[6] (optional) = TY, TX, TH, TW, window rows, window columns.  0 if the map has no plan.
+int os2d_dft_plan(int H, int W, int* P, int* Q, int* nbins, int* tiles) {
+  DftPlan pl;
+  if (H < 1 || W < 1 || !dft_make_plan(H, W, &pl)) return 0;
+  if (P) *P = pl.P;
+  if (Q) *Q = pl.Q;
+  if (nbins) *nbins = pl.NBINS;
+  if (tiles) {
+    tiles[0] = pl.TY;
+    tiles[1] = pl.TX;
+    tiles[2] = pl.TH;
+    tiles[3] = pl.TW;
+    tiles[4] = pl.LH;
+    tiles[5] = pl.LW;
+  }
+  return 1;
+}
+
+size_t os2d_dft_matrices_size(int P, int Q) { return dft_matrices_units(P, Q) * 16; }
+
+int os2d_launch_dft_matrices(const double* twP64, const double* twQ64, int P, int Q, void* out, hipStream_t stream) {
+  if (P < 4 || (P & 3) || P > DFT_MAXP || Q < 2 || (Q & 1) || Q / 2 + 1 > DFT_MAXV) {
+    os2d_set_error("dft_matrices: transform %d x %d is outside the kernels' range (P %% 4 == 0, P <= %d, Q even, Q/2 + 1 <= %d)", P, Q,
+                   DFT_MAXP, DFT_MAXV);
+    return -3;
+  }
+  const int n = (int)dft_matrices_units(P, Q);
+  hipLaunchKernelGGL(dft_matrices_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, twP64, twQ64, P, Q, static_cast<u32x4v*>(out));
+  return dft_check("dft_matrices");
+}
+
+int os2d_launch_dft_forward(const float* corr, const float* inv, float* X, const void* matrices, int NB, int C, int Cpad, int H, int W,
+                            hipStream_t stream) {
+  DftPlan pl;
+  if (!dft_make_plan(H, W, &pl)) {
+    os2d_set_error("dft_forward: no transform plan for a %dx%d map", H, W);
+    return -3;
+  }
+  if (Cpad < dft_round_up(C, DFT_G)) {
+    os2d_set_error("dft_forward: channel stride %d < %d", Cpad, dft_round_up(C, DFT_G));
+    return -1;
+  }
+  const int CG = (C + DFT_G - 1) / DFT_G, NBT = NB * pl.T, iters = NBT * CG;
+  pl.inv_cg = dft_magic((unsigned)CG);
+  const u32x4v* FqT = static_cast<const u32x4v*>(matrices);
+  const u32x4v* Fp2 = FqT + dft_units_fqt(pl.P, pl.Q);
+  auto kern = pl.T > 1 ? dft_forward_kernel<true, false> : (pl.fast ? dft_forward_kernel<false, true> : dft_forward_kernel<false, false>);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds_total);
+  if (e != hipSuccess) {
+    os2d_set_error("hipFuncSetAttribute(dft_forward): %s", hipGetErrorString(e));
+    return -4;
+  }
+  hipLaunchKernelGGL(kern, dim3(dft_grid(iters)), dim3(DFT_THR), pl.lds_total, stream, corr, inv, X, FqT, Fp2, pl, C, Cpad, NBT, iters);
+  return dft_check("dft_forward");
+}
+
+int os2d_launch_dft_inverse(const float* Y, const float* bp, int MTP, void* out, const void* matrices, int NB, int Cout, int H, int W,
+                            int* status, hipStream_t stream) {
+  DftPlan pl;
+  if (!dft_make_plan(H, W, &pl)) {
+    os2d_set_error("dft_inverse: no transform plan for a %dx%d map", H, W);
+    return -3;
+  }
+  if (Cout % 8) {
+    os2d_set_error("dft_inverse: Cout %d must be a multiple of 8", Cout);
+    return -1;
+  }
+  const int OG = Cout / DFT_G, NBT = NB * pl.T, iters = NBT * OG;
+  pl.inv_og = dft_magic((unsigned)OG);
+  const u32x4v* E2 = static_cast<const u32x4v*>(matrices) + dft_units_fqt(pl.P, pl.Q) + dft_units_fp2(pl.P, pl.Q);
+  const u32x4v* Gq = E2 + dft_units_e2(pl.P, pl.Q);
+  auto kern = pl.T > 1 ? dft_inverse_kernel<true> : dft_inverse_kernel<false>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds_total);
+  if (e != hipSuccess) {
+    os2d_set_error("hipFuncSetAttribute(dft_inverse): %s", hipGetErrorString(e));
+    return -4;
+  }
+  hipLaunchKernelGGL(kern, dim3(dft_grid(iters)), dim3(DFT_THR), pl.lds_total, stream, Y, bp, MTP, static_cast<unsigned char*>(out), E2, Gq,
+                     pl, Cout, NBT, os2d_plane(H, W), os2d_ws(W), os2d_base(W), iters, status);
+  return dft_check("dft_inverse");
+}

@@ -20,7 +20,10 @@
 #define OS2D_K 225           // T*T correlation channels
 #define OS2D_KP 226          // padded to an even channel count (MFMA 32x32x2 consumes channel pairs)
 #define OS2D_QROWS 256       // correlation GEMM M tile: 225 rows padded with zeros
-#define OS2D_MAX_W 209       // widest feature map: 256 + 2*(3*(W+3)+3) slab units must fit the conv 7x7 prefetch (<= 1536)
+#define OS2D_MAX_W_DIRECT7 209   // widest map of the DIRECT 7x7 kernels: 256 + 2*(3*(W+3)+3) slab units must fit their prefetch (<= 1536)
+#define OS2D_MAX_W 316       // widest feature map of the head: the 5x5 kernels' slabs, 256 + 2*(2*(W+3)+2) <= 1536 (5056-px images at
+                             // stride 16); beyond OS2D_MAX_W_DIRECT7 the 7x7 layer runs in the frequency domain (tiled) whatever the batch
+#define OS2D_XSPEC_CPAD 232  // channel stride of the input spectra of the matrix-product transforms: 225 rounded up to the GEMM's k-steps of 8
 #define OS2D_G 29            // 8-channel groups of the 225 correlation channels (f16x3 path)
 #define OS2D_RNORM_EXP 12    // the relu+L2-normalised correlation (|x| <= 1) is stored as fp16 hi|lo of x * 2^12
 #define OS2D_STATUS_F16_RANGE 1  // sticky status bit: a split-fp16 activation left the fp16 range (non-finite input)
@@ -235,7 +238,8 @@ int os2d_launch_fft_inverse(const float* Y, const float* bp, int MTP, void* out,
                             hipStream_t stream);
 // spectra_pack.hip
 int os2d_launch_spectra_pack(const double* wfold, const double* twP64, const double* twQ64, int C, int Cout, int P, int Q,
-                             int NBINS, int split, void* out, void* workspace, hipStream_t stream);
+                             int NBINS, int split, int u_fastest /* bin = v * P + u (dft_mfma.hip) instead of u * V + v */,
+                             void* out, void* workspace, hipStream_t stream);
 // spectral.hip
 size_t os2d_spectral_weight_floats(int C, int Cout, int NBINS);
 int os2d_launch_spectral_gemm(const float* wspec, const float* X, float* Y, int NB, int C, int Cout, int NBINS,
@@ -244,7 +248,16 @@ int os2d_launch_spectral_gemm(const float* wspec, const float* X, float* Y, int 
 size_t os2d_spectral_weight16_size(int C, int NBINS);
 float os2d_spectral_xscale_for(int H, int W);
 int os2d_launch_spectral_gemm_f16(const void* w16, const float* X, float* Y, int NB, int C, int Cout, int NBINS, float xscale,
+                                  int x_quads /* 1: X [NBINS/4][NB][Cpad][4] (dft_mfma.hip), 0: X [C][NB][NBINS] */, int Cpad,
                                   hipStream_t stream);
+// dft_mfma.hip: the transforms of the frequency-domain 7x7 layer as matrix products on the half-precision matrix cores
+int os2d_dft_plan(int H, int W, int* P, int* Q, int* nbins, int* tiles /* [6]: TY, TX, TH, TW, window rows, window columns */);
+size_t os2d_dft_matrices_size(int P, int Q);
+int os2d_launch_dft_matrices(const double* twP64, const double* twQ64, int P, int Q, void* out, hipStream_t stream);
+int os2d_launch_dft_forward(const float* corr, const float* inv, float* X, const void* matrices, int NB, int C, int Cpad, int H, int W,
+                            hipStream_t stream);
+int os2d_launch_dft_inverse(const float* Y, const float* bp, int MTP, void* out, const void* matrices, int NB, int Cout, int H, int W,
+                            int* status, hipStream_t stream);
 // corr_f16x3.hip
 int os2d_corr_groups(int C);  // 8-channel groups of the split correlation operands, padded to whole K chunks
 int os2d_launch_split_fm(const float* fm, const float* sumsq, void* fs, int A, int C, int HW, hipStream_t stream);

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(SP_THR) void spectra_pack_kernel(const double* __re
                                                               const double* __restrict__ twP, const double* __restrict__ twQ,
                                                               int C, int Cout, int P, int Q, int NBINS, int bins_per_block,
                                                               unsigned long long* __restrict__ amax, void* __restrict__ out,
-                                                              float* __restrict__ wscale) {
+                                                              float* __restrict__ wscale, int ufast) {
+  // ufast: bin = v * P + u (the bin order of the matrix-product transforms, dft_mfma.hip) instead of u * V + v
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cd* tP = reinterpret_cast<cd*>(smem);
   cd* tQ = tP + P;
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(SP_THR) void spectra_pack_kernel(const double* __re
   if (MODE == 0) {
     double m = 0.0;
     for (int bin = bin0; bin < min(bin1, P * V); ++bin) {
-      const int u = bin / V, v = bin - u * V;
+      const int u = ufast ? bin % P : bin / V, v = ufast ? bin / P : bin - u * V;
       const cd k = sp_value(w, tP, tQ, u, v, P, Q);
       m = fmax(m, fmax(fabs(k.re), fabs(k.im)));
     }
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(SP_THR) void spectra_pack_kernel(const double* __re
   for (int bin = bin0; bin < bin1; ++bin) {
     cd k{0.0, 0.0};
     if (bin < P * V) {
-      const int u = bin / V, v = bin - u * V;
+      const int u = ufast ? bin % P : bin / V, v = ufast ? bin / P : bin - u * V;
       k = sp_value(w, tP, tQ, u, v, P, Q);
     }
     const int g = bin >> 3, j = bin & 7;
@@ -141,7 +142,7 @@ int sp_check(const char* what) {
 // split != 0: out = the split-fp16 layout of os2d_spectral_weight16_bytes (incl. the 128 trailing row scales), workspace =
 // 128 x 8 bytes (row maxima); split == 0: out = the complex64 layout of os2d_spectral_weight_bytes
 int os2d_launch_spectra_pack(const double* wfold, const double* twP64, const double* twQ64, int C, int Cout, int P, int Q,
-                             int NBINS, int split, void* out, void* workspace, hipStream_t stream) {
+                             int NBINS, int split, int u_fastest, void* out, void* workspace, hipStream_t stream) {
   const int V = Q / 2 + 1, KSTEPS = (C + 7) / 8;
   if (P * V > NBINS || (NBINS & 7) || Cout > 128 || P < 1 || Q < 2 || (Q & 1)) {
     os2d_set_error("spectra_pack: bad sizes (P=%d Q=%d NBINS=%d Cout=%d)", P, Q, NBINS, Cout);
@@ -158,15 +159,15 @@ int os2d_launch_spectra_pack(const double* wfold, const double* twP64, const dou
       return -4;
     }
     hipLaunchKernelGGL(spectra_pack_kernel<0>, grid, dim3(SP_THR), lds, stream, wfold, twP64, twQ64, C, Cout, P, Q, NBINS, per, amax,
-                       nullptr, nullptr);
+                       nullptr, nullptr, u_fastest);
     int rc = sp_check("spectra_pack (row maxima)");
     if (rc) return rc;
     float* wscale = reinterpret_cast<float*>(static_cast<char*>(out) + (size_t)(NBINS / 8) * 2 * KSTEPS * 8 * 256 * 16);
     hipLaunchKernelGGL(spectra_pack_kernel<1>, grid, dim3(SP_THR), lds, stream, wfold, twP64, twQ64, C, Cout, P, Q, NBINS, per, amax,
-                       out, wscale);
+                       out, wscale, u_fastest);
     return sp_check("spectra_pack (split)");
   }
   hipLaunchKernelGGL(spectra_pack_kernel<2>, grid, dim3(SP_THR), lds, stream, wfold, twP64, twQ64, C, Cout, P, Q, NBINS, per, nullptr,
-                     out, nullptr);
+                     out, nullptr, u_fastest);
   return sp_check("spectra_pack (complex64)");
 }

@@ -65,11 +65,16 @@ __device__ __forceinline__ f32x16 sh_keep(half8 x, half8 y, f32x16 acc) {
 // barrier for data exchanged through LDS that leaves the wave's global loads in flight (see fft.hip)
 __device__ __forceinline__ void sh_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// XQ: the input spectra in quads of bins too - X [NBINS/4][NB][Cpad][4] (what the matrix-product forward transform of
+// dft_mfma.hip writes, 4 channels x 4 bins = 128 contiguous bytes per work-group iteration): a k-step of 8 channels of one pair
+// is ONE 256-byte run, 8 lanes of a wave walk it in two 16-byte loads each - instead of the 32-byte pieces 22 KB apart of the
+// row layout X [C][NB][NBINS] (round 3: 2.5 of the kernel's 5.6 ms at 1024 pairs were spent on those).
+template <bool XQ>
 __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x4* w16,            // [G][2][KS][8][2][2][64] units
                                                                       const float* __restrict__ wscale,  // [128] 2^-wexp[o]
-                                                                      const f32x2* __restrict__ X,       // [C][NB][NBINS]
+                                                                      const f32x2* __restrict__ X,       // [C][NB][NBINS] | quads
                                                                       f32x2* __restrict__ Y,             // [NBINS/4][NB][Cout][4]
-                                                                      int NB, int C, int Cout, int NBINS, int G, float xscale,
+                                                                      int NB, int C, int Cpad, int Cout, int NBINS, int G, float xscale,
                                                                       int nunits) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* ldsW = reinterpret_cast<u32x4*>(smem);                 // [SH_WRING][SH_WSTAGE]
@@ -118,10 +123,15 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
   // spectra of k-step s: this thread owns pair xn, bins 2 xj / 2 xj + 1 and TWO channels (xg * 4 + wh * 2 + {0, 1}).  A wave
   // covers 16 pairs x (2 bin pairs x 2 channel groups): with one pair per lane a load instruction would touch 64 rows 5 MB
   // apart and spend its time in address translation, not in the memory system
-  const int xn = wq * 16 + (lane & 15), xj = (lane >> 4) & 1, xg = lane >> 5;
+  // (XQ: a wave covers 8 pairs x the 8 sixteen-byte pieces (channel pair, bin pair) of a k-step's 256-byte run; the thread's
+  // second load is the neighbouring channel, 32 bytes on: wh = which channel pair of the group comes from the LANE then)
+  const int xn = XQ ? wv * 8 + (lane >> 3) : wq * 16 + (lane & 15);
+  const int xj = XQ ? (lane & 1) : (lane >> 4) & 1, xg = XQ ? (lane >> 2) & 1 : lane >> 5;
+  const int xwh = XQ ? (lane >> 1) & 1 : wh;
   const bool xn_ok = nb0 + xn < NB;
-  const f32x2* xrow = X + (size_t)min(nb0 + xn, NB - 1) * NBINS + bin0 + 2 * xj;
-  const size_t xcs = (size_t)NB * NBINS;      // channel stride of X [C][NB][NBINS]
+  const f32x2* xrow = XQ ? X + (((size_t)(bin0 >> 2) * NB + min(nb0 + xn, NB - 1)) * Cpad) * 4 + 2 * xj
+                         : X + (size_t)min(nb0 + xn, NB - 1) * NBINS + bin0 + 2 * xj;
+  const size_t xcs = XQ ? 4 : (size_t)NB * NBINS;      // channel stride: 4 bins | X [C][NB][NBINS]
   u32x4 pfa[2], pfb[2];     // two k-steps of spectra in flight (even / odd k-steps)
 #ifdef OS2D_DIAG_SH_NOX      /* diagnostic: no global loads of the spectra */
 #define SH_LOAD_X(S, pfx)                                                                                           \
@@ -132,7 +142,7 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
 #define SH_LOAD_X(S, pfx)                                                                                           \
   {                                                                                                                 \
     _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                              \
-      const int c_ = min((S)*SH_KC + xg * 4 + wh * 2 + i_, C - 1);                                                  \
+      const int c_ = min((S)*SH_KC + xg * 4 + xwh * 2 + i_, C - 1);                                                 \
       pfx[i_] = *reinterpret_cast<const u32x4*>(xrow + (size_t)c_ * xcs);                                           \
     }                                                                                                               \
   }
@@ -153,13 +163,13 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
     _Pragma("unroll") for (int b2_ = 0; b2_ < 2; ++b2_) {                                                           \
       half4 h_, l_;                                                                                                 \
       _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                            \
-        const bool ok_ = xn_ok && (S)*SH_KC + xg * 4 + wh * 2 + i_ < C;                                             \
+        const bool ok_ = xn_ok && (S)*SH_KC + xg * 4 + xwh * 2 + i_ < C;                                            \
         _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_) {                                                          \
           const unsigned raw_ = pfx[i_][2 * b2_ + p_];   /* (scalar copy first: see the ext-vector note in corr_f16x3.hip) */ \
           SH_SPLIT_VALUE                                                                                            \
         }                                                                                                           \
       }                                                                                                             \
-      char* dst_ = reinterpret_cast<char*>(ldsX + ((S)&1) * SH_STAGE + (((2 * xj + b2_) * 2 + xg) * 2) * 64 + xn) + wh * 8; \
+      char* dst_ = reinterpret_cast<char*>(ldsX + ((S)&1) * SH_STAGE + (((2 * xj + b2_) * 2 + xg) * 2) * 64 + xn) + xwh * 8; \
       *reinterpret_cast<half4*>(dst_) = h_;              /* channels 2 wh, 2 wh + 1 of the unit (re, im each) */      \
       *reinterpret_cast<half4*>(dst_ + 64 * 16) = l_;                                                               \
     }                                                                                                               \
@@ -273,15 +283,19 @@ float os2d_spectral_xscale_for(int H, int W) {
 }
 
 int os2d_launch_spectral_gemm_f16(const void* w16, const float* X, float* Y, int NB, int C, int Cout, int NBINS, float xscale,
-                                  hipStream_t stream) {
+                                  int x_quads, int Cpad, hipStream_t stream) {
   if (NBINS % SH_BINS || Cout > 2 * SH_OH) {
     os2d_set_error("spectral_gemm_f16: NBINS %d must be a multiple of %d and Cout %d <= %d", NBINS, SH_BINS, Cout, 2 * SH_OH);
     return -3;
   }
   const int G = NBINS / SH_BINS, nbt = (NB + SH_NB - 1) / SH_NB;
   const size_t lds = (size_t)(SH_WRING * SH_WSTAGE + 2 * SH_STAGE) * 16;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spectral_gemm_f16_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (x_quads && Cpad < C) {
+    os2d_set_error("spectral_gemm_f16: channel stride %d < C %d", Cpad, C);
+    return -1;
+  }
+  auto kern = x_quads ? spectral_gemm_f16_kernel<true> : spectral_gemm_f16_kernel<false>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) {
     os2d_set_error("hipFuncSetAttribute(spectral_gemm_f16): %s", hipGetErrorString(e));
     return -4;
@@ -290,8 +304,8 @@ int os2d_launch_spectral_gemm_f16(const void* w16, const float* X, float* Y, int
   const size_t KS = (size_t)(C + SH_KC - 1) / SH_KC;
   const float* wscale = reinterpret_cast<const float*>(static_cast<const char*>(w16) + (size_t)G * 2 * KS * SH_BINS * 256 * 16);
   dim3 grid((unsigned)((units + 7) / 8 * 8));
-  hipLaunchKernelGGL(spectral_gemm_f16_kernel, grid, dim3(SH_THR), lds, stream, static_cast<const u32x4*>(w16), wscale,
-                     reinterpret_cast<const f32x2*>(X), reinterpret_cast<f32x2*>(Y), NB, C, Cout, NBINS, G, xscale, (int)units);
+  hipLaunchKernelGGL(kern, grid, dim3(SH_THR), lds, stream, static_cast<const u32x4*>(w16), wscale,
+                     reinterpret_cast<const f32x2*>(X), reinterpret_cast<f32x2*>(Y), NB, C, Cpad, Cout, NBINS, G, xscale, (int)units);
   e = hipGetLastError();
   if (e != hipSuccess) {
     os2d_set_error("spectral_gemm_f16 launch: %s", hipGetErrorString(e));

@@ -27,6 +27,7 @@ from .box_coder import BoxGridGenerator
 
 TEMPLATE = 15
 QROWS = 256
+MAX_W_DIRECT7 = 209     # OS2D_MAX_W_DIRECT7: widest map of the direct 7x7 kernels; beyond it the layer runs in the frequency domain
 FFT_MIN_PAIRS = 7       # precision "fft" / "fftx3": image x class pairs below which the direct 7x7 kernel is used instead
                         # (measured crossover at 60 x 80, tools/time_small_batches.py: 6 pairs 0.413 vs 0.416 ms, 8 pairs 0.46 vs 0.53)
 PRECISIONS = {"f32": 0, "f16x3": 1, "f16x2": 2, "fft": 3, "fftx3": 4, "fft32": 5}     # OS2D_PRECISION_* of include/os2d_hip.h
@@ -377,20 +378,27 @@ class TransformationNet(nn.Module):
         return result
 
     def spectra(self, H, W, split=False):
-        """Frequency-domain form of the 7x7 layer for an H x W map (precision "fft"; ``split``: "fftx3", the weight spectra
-        pre-split into fp16 hi + lo with per-row power-of-two scales for os2d_spectral_gemm_f16): (wspec, twQ, twP, nbins); None only
-        when the library has no transform plan for the map (every map up to the 209-column limit has one: maps beyond one
-        in-LDS transform are cut into overlap-save tiles, os2d_fft_tiles, and P x Q is then a tile's size).  The BatchNorm-folded 7x7 filters are centred on the origin of the
-        P x Q grid (tap (t, s) at ((3 - t) mod P, (3 - s) mod Q): the circular convolution then IS the zero-padded
-        correlation of head.py:619 for the first H x W samples), transformed once in float64 (a 7-term DFT per axis) and
-        packed for os2d_spectral_gemm; the twiddle tables are exact float64 values rounded once.  Cached per TRANSFORM size (P, Q) -
-        sizes are products of 2s and 3s, so the many map sizes of a dataset share a few tens of them - until a parameter
-        changes, least recently used first out above ``spectra_cache_cap_bytes()`` (722 MB for 60 x 80; event-tracked like
-        ``packed``)."""
+        """Frequency-domain form of the 7x7 layer for an H x W map: (wspec, tables A, tables B, nbins), cached per TRANSFORM
+        size (P, Q) - which the many map sizes of a dataset share - until a parameter changes, least recently used first out
+        above ``spectra_cache_cap_bytes()`` (event-tracked like ``packed``).  None only when the library has no transform
+        plan for the map.
+          ``split`` False (precision "fft" / "fft32"): wspec = complex64 weight spectra for os2d_spectral_gemm, tables = the two
+            twiddle tables (twQ, twP) of the in-LDS FFTs (fft.hip; sizes 2^a 3^b or 42 / 84, maps beyond one in-LDS transform
+            are cut into overlap-save tiles, os2d_fft_tiles);
+          ``split`` True (precision "fftx3"): wspec = the weight spectra pre-split into fp16 hi + lo with per-row power-of-two
+            scales (os2d_spectral_gemm_f16) in the bin order of the matrix-product transforms (os2d_dft_sizes: any P % 4 == 0,
+            even Q; tiles beyond 64 x 94), tables A = the four operand matrices of os2d_dft_matrices_build, tables B = None.
+        The BatchNorm-folded 7x7 filters are centred on the origin of the P x Q grid (tap (t, s) at ((3 - t) mod P, (3 - s) mod
+        Q): the circular convolution then IS the zero-padded correlation of head.py:619 for the first H x W samples) and
+        transformed once in float64 on the device (a 7-term DFT per axis, spectra_pack.hip) from exact float64 tables."""
         lib = _lib.load()
         self.check_ready()
         cP, cQ, cN = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-        if lib.os2d_fft_sizes(int(H), int(W), ctypes.byref(cP), ctypes.byref(cQ), ctypes.byref(cN)) != 0:
+        if split:
+            rc = lib.os2d_dft_sizes(int(H), int(W), ctypes.byref(cP), ctypes.byref(cQ), ctypes.byref(cN), None)
+        else:
+            rc = lib.os2d_fft_sizes(int(H), int(W), ctypes.byref(cP), ctypes.byref(cQ), ctypes.byref(cN))
+        if rc != 0:
             return None
         P, Q, nbins = cP.value, cQ.value, cN.value
         dev = self.linear.weight.device
@@ -404,33 +412,37 @@ class TransformationNet(nn.Module):
             del self._spectra_cache[k]                           # a parameter changed: every cached size is stale
         with torch.cuda.device(dev), torch.no_grad():
             (w1, _), _, _ = self._folded()                       # float64 [128,225,7,7]: the BatchNorm fold
-            # the spectrum of a 7 x 7 filter is a 7-term DFT per axis; os2d_spectral_weights_build evaluates it in float64
-            # from exact twiddle tables and writes the packed layout of the GEMM directly (spectra_pack.hip: ~2 ms per
-            # transform size; round 2 took 50 ms through torch.fft.rfft2 of zero-padded maps, an intermediate version 20 ms
-            # through float64 matrix products - no vendor library is left under the head)
+
             def table64(n):
                 m = torch.arange(n, dtype=torch.float64)
                 ang = m * (-2.0 * torch.pi / n)
                 return torch.stack([torch.cos(ang), torch.sin(ang)], 1).to(dev).contiguous()
-            if split:
-                wspec = torch.empty(lib.os2d_spectral_weight16_bytes(225, nbins), dtype=torch.uint8, device=dev)
-            else:
-                wspec = torch.empty(lib.os2d_spectral_weight_bytes(225, 128, nbins) // 4, dtype=torch.float32, device=dev)
             wfold = w1.to(dev).contiguous()
             tp64, tq64 = table64(P), table64(Q)
             scratch = torch.empty(1024, dtype=torch.uint8, device=dev)
-            _lib.check(lib.os2d_spectral_weights_build(_lib.ptr(wfold), _lib.ptr(tp64), _lib.ptr(tq64), 225, 128, P, Q, nbins,
-                                                       1 if split else 0, _lib.ptr(wspec), _lib.ptr(scratch),
-                                                       _lib.current_stream(dev)), "os2d_spectral_weights_build")
+            stream = _lib.current_stream(dev)
+            if split:
+                wspec = torch.empty(lib.os2d_spectral_weight16_bytes(225, nbins), dtype=torch.uint8, device=dev)
+                _lib.check(lib.os2d_spectral_weights_build_dft(_lib.ptr(wfold), _lib.ptr(tp64), _lib.ptr(tq64), 225, 128, P, Q, nbins,
+                                                               _lib.ptr(wspec), _lib.ptr(scratch), stream),
+                           "os2d_spectral_weights_build_dft")
+                mats = torch.empty(lib.os2d_dft_matrices_bytes(P, Q), dtype=torch.uint8, device=dev)
+                _lib.check(lib.os2d_dft_matrices_build(_lib.ptr(tp64), _lib.ptr(tq64), P, Q, _lib.ptr(mats), stream),
+                           "os2d_dft_matrices_build")
+                result = (wspec, mats, None, nbins)
+            else:
+                wspec = torch.empty(lib.os2d_spectral_weight_bytes(225, 128, nbins) // 4, dtype=torch.float32, device=dev)
+                _lib.check(lib.os2d_spectral_weights_build(_lib.ptr(wfold), _lib.ptr(tp64), _lib.ptr(tq64), 225, 128, P, Q, nbins,
+                                                           0, _lib.ptr(wspec), _lib.ptr(scratch), stream), "os2d_spectral_weights_build")
+
+                def table(n):
+                    m = torch.arange(n, dtype=torch.float64)
+                    ang = -2.0 * torch.pi * m / n
+                    return torch.stack([torch.cos(ang), torch.sin(ang)], 1).float().to(dev).contiguous()
+                result = (wspec, table(Q), table(P), nbins)
             cur = torch.cuda.current_stream(dev)
             for t in (wfold, tp64, tq64, scratch):
                 t.record_stream(cur)
-
-            def table(n):
-                m = torch.arange(n, dtype=torch.float64)
-                ang = -2.0 * torch.pi * m / n
-                return torch.stack([torch.cos(ang), torch.sin(ang)], 1).float().to(dev).contiguous()
-            result = (wspec, table(Q), table(P), nbins)
             entry = _StreamOrdered(key, result, dev)
             cap, used = spectra_cache_cap_bytes(), entry.nbytes()
             for k in list(self._spectra_cache):                  # oldest first
@@ -761,6 +773,11 @@ class Os2dHead(nn.Module):
             precision = "f32"
         regressor.check_ready()                  # device / eval-mode errors before any torch op can trip over them
         spectra = None
+        if W > MAX_W_DIRECT7:
+            # wider than the direct 7x7 kernels take (the reference has no width limit, head.py:619): the layer runs in the
+            # frequency domain - tiled to any width - whatever the class batch, in the arithmetic family that was asked for
+            precision = {"f32": "fft32", "f16x3": "fftx3", "f16x2": "fftx3"}.get(precision, precision)
+            pinned = True
         if precision in FFT_MODES:
             # the frequency-domain 7x7 layer pays off from 7 pairs on (it streams 0.65 GB of weight spectra per call);
             # below that the direct f16x3 kernel does the layer.  The decision is made on ``route_pairs`` when given

@@ -32,6 +32,14 @@ def _fft_sizes(H, W):
     return P.value, Q.value, nb.value
 
 
+def _dft_sizes(H, W):
+    """Transform size of the matrix-product transforms (precision "fftx3"): P % 4 == 0, even Q, bins = v * P + u."""
+    lib = _lib.load()
+    P, Q, nb = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _lib.check(lib.os2d_dft_sizes(H, W, ctypes.byref(P), ctypes.byref(Q), ctypes.byref(nb), None), "os2d_dft_sizes")
+    return P.value, Q.value, nb.value
+
+
 class Harness:
     def __init__(self, device, H=48, W=64, NB=64):
         self.lib = lib = _lib.load()
@@ -81,17 +89,41 @@ class Harness:
                 return [torch.zeros(C, NB, nbins, 2, device=dev), torch.zeros(NB * shb, dtype=torch.uint8, device=dev)]
             keep = (tq, tp, corr, inv, Yin, bp)
         elif kind == "gemm16":
+            # the split-half GEMM as the head runs it: spectra in quads of bins x channels on both sides (dft_mfma.hip's layouts)
             w16 = self.net.spectra(H, W, split=True)[0]
-            xs = lib.os2d_spectral_xscale(H, W)
-            X = [(torch.rand(225, NB, nbins, 2, generator=g) * 40.0 - 20.0).to(dev) for _ in range(NF)]
+            nb2 = _dft_sizes(H, W)[2]
+            xs = lib.os2d_dft_xscale(H, W)
+            cpad = lib.os2d_dft_channel_stride(225)
+            X = [(torch.rand(nb2 // 4, NB, cpad, 4, 2, generator=g) * 40.0 - 20.0).to(dev) for _ in range(NF)]
 
             def run(i, out, st):
-                _lib.check(lib.os2d_spectral_gemm_f16(_lib.ptr(w16), _lib.ptr(X[i]), _lib.ptr(out[0]), NB, 225, 128, nbins, xs,
-                                                      ctypes.c_void_p(st.cuda_stream)), "gemm16")
+                _lib.check(lib.os2d_spectral_gemm_f16_quads(_lib.ptr(w16), _lib.ptr(X[i]), _lib.ptr(out[0]), NB, 225, 128, nb2, xs,
+                                                            ctypes.c_void_p(st.cuda_stream)), "gemm16")
 
             def outputs(i):
-                return [torch.zeros(NB, 128, nbins, 2, device=dev)]
+                return [torch.zeros(nb2 // 4, NB, 128, 4, 2, device=dev)]
             keep = (w16, X)
+        elif kind == "dft":
+            # the matrix-product transforms (half-precision MFMA + VALU splits, hand-made LDS-only barriers)
+            C, Cout = 225, 128
+            nb2 = _dft_sizes(H, W)[2]
+            cpad = lib.os2d_dft_channel_stride(C)
+            mats = self.net.spectra(H, W, split=True)[1]
+            corr = [torch.randn(NB, C, H * W, generator=g).to(dev) for _ in range(NF)]
+            inv = [(torch.rand(NB, H * W, generator=g) * 0.2 + 0.05).to(dev) for _ in range(NF)]
+            Yin = [torch.randn(nb2 // 4, NB, Cout, 4, 2, generator=g).to(dev) for _ in range(NF)]
+            bp = torch.ones(3 * 128, device=dev)
+            shb = lib.os2d_shb_bytes(Cout, H, W)
+
+            def run(i, out, st):
+                s = ctypes.c_void_p(st.cuda_stream)
+                _lib.check(lib.os2d_dft_forward(_lib.ptr(corr[i]), _lib.ptr(inv[i]), _lib.ptr(out[0]), _lib.ptr(mats), NB, C, H, W, s), "dft fwd")
+                _lib.check(lib.os2d_dft_inverse(_lib.ptr(Yin[i]), _lib.ptr(bp), _lib.ptr(out[1]), _lib.ptr(mats), NB, Cout, H, W,
+                                                _lib.ptr(self.status), s), "dft inv")
+
+            def outputs(i):
+                return [torch.zeros(nb2 // 4, NB, cpad, 4, 2, device=dev), torch.zeros(NB * shb, dtype=torch.uint8, device=dev)]
+            keep = (mats, corr, inv, Yin, bp)
         elif kind == "corr":
             Cf = 1024
             fm = [synthetic.make_feature_map(Cf, H, W, seed=10 + i).to(dev) for i in range(NF)]

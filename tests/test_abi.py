@@ -52,8 +52,10 @@ def test_library_loads_and_reports_abi(lib_path):
     assert lib.os2d_head_workspace_bytes(1, 1, 1023, 60, 80, 6, ctypes.byref(n)) == -1
     assert b"C%4" in lib.os2d_last_error() or b"C" in lib.os2d_last_error()
     assert lib.os2d_head_workspace_bytes(1, 1, 1024, 60, 80, 5, ctypes.byref(n)) == -1
-    assert lib.os2d_head_workspace_bytes(1, 1, 1024, 60, 209, 6, ctypes.byref(n)) == 0
-    assert lib.os2d_head_workspace_bytes(1, 1, 1024, 60, 210, 6, ctypes.byref(n)) == -1 and b"width" in lib.os2d_last_error()
+    # widest map: 316 columns (the 5x5 kernels' slabs); the direct 7x7 kernels stop at 209, beyond that the head runs the layer in
+    # the frequency domain (tiled) whatever the batch
+    assert lib.os2d_head_workspace_bytes(1, 1, 1024, 60, 316, 6, ctypes.byref(n)) == 0
+    assert lib.os2d_head_workspace_bytes(1, 1, 1024, 60, 317, 6, ctypes.byref(n)) == -1 and b"width" in lib.os2d_last_error()
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
@@ -111,7 +113,7 @@ def test_every_included_header_is_part_of_the_build_stamp(tmp_path, monkeypatch)
 def test_fft_plan_host_logic():
     """os2d_fft_sizes / os2d_fft_tiles are host code: transform sizes of the frequency-domain 7x7 layer for the pyramid
     levels of BASELINE.json configs[4] (the 96 x 128 level is cut into overlap-save tiles), the invariants every plan must
-    satisfy for every map the head accepts (width <= 209), and the fp16 scale of the input spectra."""
+    satisfy for every map (the in-LDS FFTs serve precisions "fft" / "fft32"), and the fp16 scale of the input spectra."""
     import ctypes
     from os2d_amd import _lib
     lib = _lib.load()
@@ -148,3 +150,32 @@ def test_fft_plan_host_logic():
                 assert m == 1 or n in (42, 84)
     # |X| <= samples of one window: 60 x 80 -> 2^3 * 4800 <= 65504; a 96 x 128 map's window is a 54 x 70 tile + halo -> 2^4
     assert lib.os2d_spectral_xscale(60, 80) == 8.0 and lib.os2d_spectral_xscale(96, 128) == 16.0
+
+
+def test_dft_plan_host_logic():
+    """os2d_dft_sizes (precision "fftx3": the transforms as matrix products, dft_mfma.hip) is host code: any P % 4 == 0 <= 64
+    and even Q <= 94 is a transform size, so maps that fit take the smallest one (fewer bins than the FFT-friendly sizes),
+    larger maps are cut into overlap-save tiles - every map up to the head's width limit has a plan."""
+    import ctypes
+    from os2d_amd import _lib
+    lib = _lib.load()
+
+    def plan(h, w):
+        P, Q, nb = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        t = (ctypes.c_int * 6)()
+        rc = lib.os2d_dft_sizes(h, w, ctypes.byref(P), ctypes.byref(Q), ctypes.byref(nb), t)
+        return (rc, P.value, Q.value, nb.value) + tuple(t)
+
+    assert plan(60, 80) == (0, 64, 84, 2752, 1, 1, 60, 80, 60, 80)
+    assert plan(30, 40)[:4] == (0, 36, 44, 828 + 4) and plan(48, 64)[:4] == (0, 52, 68, 52 * 35 + 4)
+    assert plan(96, 128)[4:8] == (2, 2, 48, 64) and plan(96, 128)[1:3] == (56, 70)
+    for h in list(range(1, 100, 7)) + [120, 157, 300]:
+        for w in list(range(1, 130, 9)) + [150, 209, 260, 316]:
+            rc, P, Q, nb, ty, tx, th, tw, lh, lw = plan(h, w)
+            assert rc == 0, (h, w)
+            assert ty >= 1 and tx >= 1 and ty * th >= h and tx * tw >= w and (ty - 1) * th < h and (tx - 1) * tw < w
+            assert (lh, lw) == (th + 6 if ty > 1 else h, tw + 6 if tx > 1 else w)
+            assert P >= (th + 6 if ty > 1 else h + 3) and Q >= (tw + 6 if tx > 1 else w + 3)
+            assert P % 4 == 0 and P <= 64 and Q % 2 == 0 and Q <= 94 and nb % 8 == 0 and nb >= P * (Q // 2 + 1)
+    assert lib.os2d_dft_channel_stride(225) == 232 and lib.os2d_dft_matrices_bytes(64, 84) > 0
+    assert lib.os2d_dft_xscale(60, 80) == 8.0

@@ -1,0 +1,164 @@
+"""GPU: the transforms of the frequency-domain 7x7 layer as matrix products on the half-precision matrix cores
+(os2d_amd/csrc/dft_mfma.h, precision "fftx3") against torch.fft in float64 - the same checks tests/test_spectral_gpu.py runs
+for the in-LDS FFTs of the fp32 modes: untiled and tiled maps (ragged tiles), widths that are not a multiple of 4, maps wider
+than the direct 7x7 kernels take, the spectra layouts of both sides of the per-bin GEMM (quads of bins x channels,
+bin = v * P + u).  The kernel source itself also runs on the CPU emulator (tests/test_dft_mfma_host.py)."""
+import numpy as np
+import pytest
+import torch
+
+from os2d_amd import _lib
+from test_spectral_gpu import dft_sizes
+
+pytestmark = pytest.mark.gpu
+
+
+def table64(n, device):
+    m = torch.arange(n, dtype=torch.float64)
+    ang = m * (-2.0 * np.pi / n)
+    return torch.stack([torch.cos(ang), torch.sin(ang)], 1).to(device).contiguous()
+
+
+def matrices(P, Q, device):
+    lib = _lib.load()
+    tp, tq = table64(P, device), table64(Q, device)
+    out = torch.empty(lib.os2d_dft_matrices_bytes(P, Q), dtype=torch.uint8, device=device)
+    _lib.check(lib.os2d_dft_matrices_build(_lib.ptr(tp), _lib.ptr(tq), P, Q, _lib.ptr(out), _lib.current_stream(device)), "os2d_dft_matrices_build")
+    torch.cuda.synchronize()
+    return out
+
+
+def windows(H, W):
+    P, Q, nbins, (TY, TX, TH, TW, LH, LW) = dft_sizes(H, W)
+    oy, ox = (3 if TY > 1 else 0), (3 if TX > 1 else 0)
+    return [(ty * TH, tx * TW, oy, ox) for ty in range(TY) for tx in range(TX)], (P, Q, nbins, TY, TX, TH, TW, LH, LW)
+
+
+PYRAMID_LEVELS = [(30, 40), (38, 50), (48, 64), (60, 80), (72, 96), (84, 112), (96, 128)]
+OTHER_MAPS = [(11, 13), (9, 16), (2, 5), (1, 1), (61, 91), (64, 260), (157, 209), (200, 100), (97, 129), (33, 316)]
+
+
+def test_plans_of_the_pyramid_levels():
+    """Any P % 4 == 0 and even Q will do for a matrix-product transform: the levels that fit take P = H + 3 -> 4, Q = W + 3 -> 2
+    (fewer bins than the FFT-friendly sizes of fft.hip), larger ones are cut into overlap-save tiles of at most 58 x 88 outputs."""
+    got = {hw: dft_sizes(*hw) for hw in PYRAMID_LEVELS}
+    assert got[(60, 80)][:3] == (64, 84, 2752) and got[(60, 80)][3][:2] == (1, 1)
+    assert got[(30, 40)][:2] == (36, 44) and got[(48, 64)][:2] == (52, 68)
+    for hw, (P, Q, nbins, (TY, TX, TH, TW, LH, LW)) in got.items():
+        assert P % 4 == 0 and Q % 2 == 0 and nbins % 8 == 0 and nbins >= P * (Q // 2 + 1) and P <= 64 and Q <= 94
+        assert P >= (TH + 6 if TY > 1 else hw[0] + 3) and Q >= (TW + 6 if TX > 1 else hw[1] + 3)
+        assert TY * TH >= hw[0] and TX * TW >= hw[1]
+    assert got[(96, 128)][3][:2] == (2, 2)
+
+
+@pytest.mark.parametrize("H,W,NB,C", [(60, 80, 2, 9), (60, 80, 1, 225)] + [(h, w, 1, 5) for h, w in PYRAMID_LEVELS if (h, w) != (60, 80)] +
+                         [(h, w, 2, 3) for h, w in OTHER_MAPS])
+def test_dft_forward_matches_torch_fft(H, W, NB, C, device):
+    lib = _lib.load()
+    wins, (P, Q, nbins, TY, TX, TH, TW, LH, LW) = windows(H, W)
+    T, V = TY * TX, Q // 2 + 1
+    cpad = lib.os2d_dft_channel_stride(C)
+    g = torch.Generator().manual_seed(H * 100 + W)
+    corr = (torch.rand(NB, C, H, W, generator=g) - 0.3).to(device)
+    inv = (0.4 + torch.rand(NB, H, W, generator=g)).to(device)             # relu(corr) * inv <= 0.7 * 1.4 < 1, like the normalised maps
+    X = torch.full((nbins // 4, NB * T, cpad, 4, 2), float("nan"), device=device)
+    mats = matrices(P, Q, device)
+    _lib.check(lib.os2d_dft_forward(_lib.ptr(corr), _lib.ptr(inv), _lib.ptr(X), _lib.ptr(mats), NB, C, H, W, _lib.current_stream(device)),
+               "os2d_dft_forward")
+    x = (corr.clamp(min=0) * inv.unsqueeze(1)).double()
+    rows = X.permute(1, 2, 0, 3, 4).reshape(NB * T, cpad, nbins, 2)          # [pair', c, bin]
+    got = torch.view_as_complex(rows[:, :C, :P * V].contiguous()).to(torch.complex128).view(NB, T, C, V, P)
+    for t, (y0, x0, oy, ox) in enumerate(wins):
+        big = torch.zeros(NB, C, H + 2 * LH + 6, W + 2 * LW + 6, dtype=torch.float64, device=device)
+        big[:, :, LH:LH + H, LW:LW + W] = x
+        win = big[:, :, LH + y0 - oy:LH + y0 - oy + LH, LW + x0 - ox:LW + x0 - ox + LW]
+        ref = torch.fft.rfft2(win, s=(P, Q)).transpose(2, 3)                  # [NB, C, V, P]: bin = v * P + u
+        scale = float(ref.abs().max())
+        assert float((got[:, t] - ref).abs().max()) <= 2e-6 * max(scale, 1e-30), ("tile", t)
+    if nbins > P * V:
+        assert float(rows[:, :C, P * V:].abs().max()) == 0.0
+    # the channels between C and the next multiple of 4 belong to the last work-group iteration: zeros, not garbage
+    c4 = (C + 3) // 4 * 4
+    if c4 > C:
+        assert float(rows[:, C:c4].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("H,W,NB", [(60, 80, 2)] + [(h, w, 1) for h, w in PYRAMID_LEVELS if (h, w) != (60, 80)] + [(h, w, 2) for h, w in OTHER_MAPS])
+def test_dft_inverse_matches_torch_fft_and_epilogue(H, W, NB, device):
+    """Inverse transform + the layer epilogue (bias, ReLU, per-channel power-of-two scale, fp16 hi|lo split into the split-half
+    blocked buffer with zero borders) against torch.fft; every tile's spectrum holds its part of the map at offset (3, 3) along
+    the tiled axes and arbitrary content elsewhere; output channels with very different magnitudes (every image of an
+    iteration is scaled by its own power of two)."""
+    lib = _lib.load()
+    wins, (P, Q, nbins, TY, TX, TH, TW, LH, LW) = windows(H, W)
+    T, V, Cout = TY * TX, Q // 2 + 1, 128
+    g = torch.Generator().manual_seed(H + W)
+    mag = torch.exp2(torch.randint(-12, 9, (Cout,), generator=g).double())            # 2^-12 .. 2^8 between channels
+    y_true = torch.randn(NB, Cout, H, W, generator=g).double() * 0.3 * mag.view(1, -1, 1, 1)
+    Y = torch.zeros(NB, T, Cout, nbins, 2)
+    fmax = torch.zeros(Cout, dtype=torch.float64)
+    for t, (y0, x0, oy, ox) in enumerate(wins):
+        full = torch.randn(NB, Cout, P, Q, generator=g).double() * mag.view(1, -1, 1, 1)
+        th, tw = min(TH, H - y0), min(TW, W - x0)
+        full[:, :, oy:oy + th, ox:ox + tw] = y_true[:, :, y0:y0 + th, x0:x0 + tw]
+        fmax = torch.maximum(fmax, full.abs().amax(dim=(0, 2, 3)))
+        Yc = torch.fft.rfft2(full).transpose(2, 3)                                    # [NB, Cout, V, P]
+        Y[:, t, :, :P * V] = torch.view_as_real(Yc.reshape(NB, Cout, P * V).to(torch.complex64))
+    bias = torch.randn(Cout, generator=g).double() * 0.1 * mag
+    oexp = torch.floor(torch.log2(1024.0 / mag))                                      # activations ~2^8 .. 2^10: both halves normal
+    bp = torch.zeros(3 * 128)
+    bp[:Cout] = bias.float()
+    bp[256:256 + Cout] = torch.exp2(oexp).float()
+    Yq = Y.view(NB * T, Cout, nbins // 4, 4, 2).permute(2, 0, 1, 3, 4).contiguous().to(device)      # [nbins/4, NBT, Cout, 4]
+    shb_bytes = lib.os2d_shb_bytes(Cout, H, W)
+    out = torch.full((NB * shb_bytes,), 0x5A, dtype=torch.uint8, device=device)
+    status = torch.zeros(1, dtype=torch.int32, device=device)
+    mats, bpd = matrices(P, Q, device), bp.to(device)
+    _lib.check(lib.os2d_dft_inverse(_lib.ptr(Yq), _lib.ptr(bpd), _lib.ptr(out), _lib.ptr(mats), NB, Cout, H, W, _lib.ptr(status),
+                                    _lib.current_stream(device)), "os2d_dft_inverse")
+    plane = lib.os2d_plane_floats(H, W)
+    Ws, base = W + 3, (3 * (W + 3) + 3 + 3) // 4 * 4
+    units = out.view(torch.float16).view(NB, Cout // 8, 2, plane, 8).double().cpu()
+    val = (units[:, :, 0] + units[:, :, 1]).permute(0, 1, 3, 2).reshape(NB, Cout, plane)          # [NB,Cout,PLANE] scaled values
+    got = val[:, :, base:base + H * Ws].reshape(NB, Cout, H, Ws)[..., :W] / torch.exp2(oexp).view(1, -1, 1, 1)
+    ref = torch.relu(y_true + bias.view(1, -1, 1, 1))
+    err = ((got - ref).abs() / fmax.view(1, -1, 1, 1)).max()
+    assert float(err) < 2e-6, float(err)
+    border = val.clone()
+    border[:, :, base:base + H * Ws].view(NB, Cout, H, Ws)[..., :W] = 0
+    assert float(border.abs().max()) == 0.0
+    assert int(status.item()) == 0
+
+
+def test_dft_transforms_full_size_timing(device):
+    """BASELINE.json configs[1] size (64 pairs x 225 / 128 images of 60 x 80): the two launches the head makes, timed."""
+    import time
+    lib = _lib.load()
+    H, W, NB = 60, 80, 64
+    P, Q, nbins, _ = dft_sizes(H, W)
+    cpad = lib.os2d_dft_channel_stride(225)
+    mats = matrices(P, Q, device)
+    corr = torch.rand(NB, 225, H, W, device=device)
+    inv = torch.rand(NB, H, W, device=device) * 0.1
+    X = torch.empty(nbins // 4, NB, cpad, 4, 2, device=device)
+    Yq = torch.randn(nbins // 4, NB, 128, 4, 2, device=device)
+    bp = torch.ones(3 * 128, device=device)
+    out = torch.zeros(NB * lib.os2d_shb_bytes(128, H, W), dtype=torch.uint8, device=device)
+    status = torch.zeros(1, dtype=torch.int32, device=device)
+    st = _lib.current_stream(device)
+
+    def fwd():
+        _lib.check(lib.os2d_dft_forward(_lib.ptr(corr), _lib.ptr(inv), _lib.ptr(X), _lib.ptr(mats), NB, 225, H, W, st), "fwd")
+
+    def invt():
+        _lib.check(lib.os2d_dft_inverse(_lib.ptr(Yq), _lib.ptr(bp), _lib.ptr(out), _lib.ptr(mats), NB, 128, H, W, _lib.ptr(status), st), "inv")
+    for name, fn, nbytes in (("forward", fwd, NB * 225 * (H * W * 4 + nbins * 8)), ("inverse", invt, NB * 128 * (nbins * 8 + H * W * 4))):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 10 * 1e3
+        print("dft {} 64 pairs 60x80: {:.3f} ms = {:.2f} TB/s algorithmic".format(name, ms, nbytes / ms / 1e9))
+        assert ms < 2.0

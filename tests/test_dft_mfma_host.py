@@ -1,0 +1,26 @@
+"""CPU: the kernel source of the matrix-product transforms (os2d_amd/csrc/dft_mfma.h - forward, inverse, plans and the
+constant-matrix builder) compiled for the host and run on the SPMD emulator of tests/host/spmd_emu.h (work items = threads,
+LDS = a buffer, v_mfma_f32_32x32x16_f16 = an operand exchange inside the wave) against float64 DFTs: the LDS layouts, fragment
+addressing, tile ownership, window / tile arithmetic and the power-of-two scale bookkeeping are checked without a GPU."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_dft_mfma_kernels_on_the_host_emulator(tmp_path):
+    cxx = shutil.which("clang++") or "/opt/rocm/lib/llvm/bin/clang++"      # ext_vector_type + _Float16: clang
+    if not os.path.exists(cxx) and shutil.which(cxx) is None:
+        pytest.skip("no clang++")
+    exe = str(tmp_path / "dft_mfma_check")
+    subprocess.run([cxx, "-std=c++17", "-O1", "-pthread", "-Wno-psabi", "-I", os.path.join(REPO, "os2d_amd", "csrc"),
+                    "-I", os.path.join(REPO, "tests", "host"), os.path.join(REPO, "tests", "host", "dft_mfma_check.cpp"), "-o", exe],
+                   check=True, timeout=300)
+    # small untiled (W % 4 != 0, partial channel group), fast path with several work-groups, a tiled map with ragged tiles, a
+    # level of the pyramid with P % 8 == 4
+    out = subprocess.run([exe, "11", "13", "5", "1", "20", "24", "4", "2", "70", "100", "5", "1", "30", "43", "6", "2"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-3000:] + out.stderr[-2000:]

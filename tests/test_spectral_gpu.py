@@ -257,7 +257,18 @@ def test_device_built_weight_spectra_match_torch_fft(H, W, device):
     scale = float(K.abs().max())
     assert float((got[:, :, :P * V] - K).abs().max()) <= 2e-7 * scale
     assert float(got[:, :, P * V:].abs().max()) == 0.0 if nbins > P * V else True
-    # ---- split-fp16 layout [g][half][ks][j][grp][hi|lo][o][c4, (re, im)] + 128 row scales
+    # ---- split-fp16 layout [g][half][ks][j][grp][hi|lo][o][c4, (re, im)] + 128 row scales, for the transform size and the bin
+    # order (bin = v * P + u) of the matrix-product transforms (os2d_dft_sizes)
+    import ctypes
+    cP, cQ, cN = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _lib.check(_lib.load().os2d_dft_sizes(H, W, ctypes.byref(cP), ctypes.byref(cQ), ctypes.byref(cN), None), "os2d_dft_sizes")
+    P, Q, nbins = cP.value, cQ.value, cN.value
+    V, G = Q // 2 + 1, nbins // 8
+    assert P % 4 == 0 and Q % 2 == 0 and nbins % 8 == 0
+    k = torch.zeros(128, 225, P, Q, dtype=torch.float64, device=device)
+    k[:, :, ((3 - torch.arange(7, device=device)) % P).view(-1, 1), ((3 - torch.arange(7, device=device)) % Q).view(1, -1)] = w1
+    K = torch.fft.rfft2(k).permute(0, 1, 3, 2).reshape(128, 225, V * P)   # [o, c, bin = v * P + u]
+    del k
     buf = net.spectra(H, W, split=True)[0]
     KS = 29
     nunits = G * 2 * KS * 8 * 2 * 2 * 64
@@ -304,47 +315,71 @@ def test_weight_spectra_miss_cost_is_bounded(device):
     assert miss < 0.120 and hit < 0.002
 
 
+def dft_sizes(H, W):
+    """(P, Q, nbins, (TY, TX, TH, TW, window rows, window columns)) of the matrix-product transforms (precision "fftx3")."""
+    import ctypes
+    lib = _lib.load()
+    P, Q, nb = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    t = (ctypes.c_int * 6)()
+    _lib.check(lib.os2d_dft_sizes(H, W, ctypes.byref(P), ctypes.byref(Q), ctypes.byref(nb), t), "os2d_dft_sizes")
+    return P.value, Q.value, nb.value, tuple(t)
+
+
 @pytest.mark.parametrize("H,W,NB", [(11, 13, 5), (30, 40, 70)])
 def test_split_half_spectral_gemm_matches_float64(H, W, NB, device):
-    """os2d_spectral_gemm_f16 (spectra split into fp16 hi + lo on the half-precision matrix cores) and os2d_spectral_gemm (fp32
-    matrix cores) against a float64 product, with the weight spectra as TransformationNet.spectra packs them."""
+    """os2d_spectral_gemm (fp32 matrix cores) and os2d_spectral_gemm_f16 (spectra split into fp16 hi + lo on the half-precision
+    matrix cores; input spectra in rows [C, NB, nbins] or - os2d_spectral_gemm_f16_quads, what the head runs - in quads of
+    bins x channels [nbins/4, NB, Cpad, 4]) against a float64 product, with the weight spectra as TransformationNet.spectra
+    packs them: the fp32 ones for the sizes / bin order of the in-LDS FFTs, the split ones for those of the matrix-product
+    transforms (bin = v * P + u)."""
     from os2d_amd.modeling import head as head_mod
     from os2d_amd.utils import synthetic
     lib = _lib.load()
     net = head_mod.TransformationNet(output_dim=6)
     net.load_state_dict(synthetic.make_transform_net_state(6, seed=3))
     net.to(device).eval()
-    P, Q, nbins = fft_sizes(H, W)
-    V = Q // 2 + 1
-    w32 = net.spectra(H, W)[0]
-    w16 = net.spectra(H, W, split=True)[0]
-    assert w16.numel() == lib.os2d_spectral_weight16_bytes(225, nbins)
-    # input spectra of maps with samples in [0, 1] (what the layer sees), a few channels forced to the extremes of the range
+    # input maps with samples in [0, 1] (what the layer sees), a few channels forced to the extremes of the range
     g = torch.Generator().manual_seed(H + W)
     x = torch.rand(NB, 225, H, W, generator=g, dtype=torch.float64)
     x[:, 0] = 1.0                       # DC bin = H * W: the largest value the scale must hold
     x[:, 1] *= 1e-6                     # tiny channel: its lo halves are subnormal
-    Xc = torch.fft.rfft2(x, s=(P, Q)).reshape(NB, 225, P * V)
-    X = torch.zeros(NB, 225, nbins, 2)
-    X[:, :, :P * V] = torch.view_as_real(Xc.to(torch.complex64))
-    Xd = X.permute(1, 0, 2, 3).contiguous().to(device)              # channel-major
-    # reference from the fp32 spectra actually uploaded (isolates the kernels' arithmetic from the packing)
     (w1, _), _, _ = net._folded()
-    k = torch.zeros(128, 225, P, Q, dtype=torch.float64)
-    k[:, :, ((3 - torch.arange(7)) % P).view(-1, 1), ((3 - torch.arange(7)) % Q).view(1, -1)] = w1.cpu()
-    K = torch.fft.rfft2(k).reshape(128, 225, P * V)
-    ref = torch.einsum("ocb,ncb->nob", K, torch.view_as_complex(X[:, :, :P * V].double().contiguous()))
-    scale = float(ref.abs().max())
     st = _lib.current_stream(device)
-    for name in ("f32", "f16"):
-        Y = torch.full((NB, 128, nbins, 2), float("nan"), device=device)
+    for name in ("f32", "f16 rows", "f16 quads"):
         if name == "f32":
+            P, Q, nbins = fft_sizes(H, W)
+        else:
+            P, Q, nbins, _ = dft_sizes(H, W)
+        V = Q // 2 + 1
+        k = torch.zeros(128, 225, P, Q, dtype=torch.float64)
+        k[:, :, ((3 - torch.arange(7)) % P).view(-1, 1), ((3 - torch.arange(7)) % Q).view(1, -1)] = w1.cpu()
+        K, Xc = torch.fft.rfft2(k), torch.fft.rfft2(x, s=(P, Q))                          # [.., P, V]
+        if name != "f32":
+            K, Xc = K.transpose(2, 3), Xc.transpose(2, 3)                               # bin = v * P + u
+        K, Xc = K.reshape(128, 225, P * V), Xc.reshape(NB, 225, P * V)
+        X = torch.zeros(NB, 225, nbins, 2)
+        X[:, :, :P * V] = torch.view_as_real(Xc.to(torch.complex64))
+        ref = torch.einsum("ocb,ncb->nob", K, torch.view_as_complex(X[:, :, :P * V].double().contiguous()))
+        scale = float(ref.abs().max())
+        Xd = X.permute(1, 0, 2, 3).contiguous().to(device)              # channel-major rows
+        if name == "f32":
+            w32 = net.spectra(H, W)[0]
+            Y = torch.full((NB, 128, nbins, 2), float("nan"), device=device)
             _lib.check(lib.os2d_spectral_gemm(_lib.ptr(w32), _lib.ptr(Xd), _lib.ptr(Y), NB, 225, 128, nbins, st), "gemm")
         else:
-            xs = lib.os2d_spectral_xscale(H, W)
+            w16 = net.spectra(H, W, split=True)[0]
+            assert w16.numel() == lib.os2d_spectral_weight16_bytes(225, nbins)
+            xs = lib.os2d_dft_xscale(H, W)
             assert xs * H * W <= 65504 < 2 * xs * H * W
             Yq = torch.full((nbins // 4, NB, 128, 4, 2), float("nan"), device=device)      # written in quads of bins (OS2D_SPECTRA_QUADS)
-            _lib.check(lib.os2d_spectral_gemm_f16(_lib.ptr(w16), _lib.ptr(Xd), _lib.ptr(Yq), NB, 225, 128, nbins, xs, st), "gemm16")
+            if name == "f16 rows":
+                _lib.check(lib.os2d_spectral_gemm_f16(_lib.ptr(w16), _lib.ptr(Xd), _lib.ptr(Yq), NB, 225, 128, nbins, xs, st), "gemm16")
+            else:
+                cpad = lib.os2d_dft_channel_stride(225)
+                Xq = torch.full((nbins // 4, NB, cpad, 4, 2), float("nan"))                # pad channels: never read as numbers
+                Xq[:, :, :225] = X.view(NB, 225, nbins // 4, 4, 2).permute(2, 0, 1, 3, 4)
+                Xq = Xq.to(device)
+                _lib.check(lib.os2d_spectral_gemm_f16_quads(_lib.ptr(w16), _lib.ptr(Xq), _lib.ptr(Yq), NB, 225, 128, nbins, xs, st), "gemm16 quads")
             Y = y_quads_to_rows(Yq, NB, 128, nbins)
         got = torch.view_as_complex(Y.cpu()[:, :, :P * V].contiguous()).to(torch.complex128)
         err = float((got - ref).abs().max())
@@ -382,7 +417,7 @@ def test_quad_layout_of_the_inverse_transform_equals_the_row_layout(H, W, NB, de
     assert torch.equal(out_q, out_r)
 
 
-@pytest.mark.parametrize("kind", ["fft", "gemm16", "corr", "sample"])
+@pytest.mark.parametrize("kind", ["fft", "dft", "gemm16", "corr", "sample"])
 def test_kernels_are_stable_next_to_mfma_kernels(kind, device):
     """Regression test of the packed-FP32 finding: a victim kernel on four streams while the direct
     7x7 kernel (half-precision MFMA at full rate) runs on three others must return exactly the bytes it returns alone.

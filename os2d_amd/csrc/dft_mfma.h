@@ -155,30 +155,62 @@ static inline void dft_set_tiles(DftPlan* pl, int H, int W, int TY, int TX, int 
   pl->inv_kg = dft_magic((unsigned)(pl->Pp / 8));
 }
 
+// Transform sizes.  The weight spectra of the per-bin GEMM cost 0.24 MB per bin and transform size (654 MB for 64 x 84), and a
+// dataset fed at its own aspect ratios and 7 pyramid scales meets hundreds of map sizes (reference os2d/data/dataloader.py:326,
+// os2d/config.py:194).  Since every map can be cut into overlap-save tiles, the planner may restrict itself to a handful of
+// CANONICAL sizes and pay in bins instead of in resident spectra (35.6 GB cached for 52 FFT-friendly sizes):
+//   policy 1 (default)  the six sizes below - the exact transforms of the 7-scale pyramid of a 1280 x 960 image (levels 30x40 ..
+//                       60x80 whole, 72x96 / 84x112 / 96x128 as 2 x 2 tiles): 10,220 bins = 2.4 GB of weight spectra in total
+//   policy 0            any P % 4 == 0, even Q: the smallest transform per map (fewest bins; one set of spectra per size)
+// $OS2D_DFT_SIZES = canonical | exact selects it for the process (read once).
+struct DftSize {
+  int P, Q;
+};
+static const DftSize DFT_CANONICAL[6] = {{36, 46}, {44, 54}, {48, 62}, {52, 68}, {56, 70}, {64, 84}};
+
 // The whole map in one transform when it fits (P >= H + 3, Q >= W + 3: the zero padding is the halo), otherwise the tiling
 // with the fewest bins in total; an axis is either untiled or cut into >= 2 tiles of ceil(n / k) outputs whose window is 6
-// longer.  Any P % 4 == 0 and even Q will do (the transforms are matrix products: no factorisation constraint).
-static inline bool dft_make_plan(int H, int W, DftPlan* out) {
+// longer.
+static inline bool dft_make_plan_policy(int H, int W, int canonical, DftPlan* out) {
   bool found = false;
   long best = 0;
-  for (int TY = 1; TY <= 32; ++TY)
-    for (int TX = 1; TX <= 32; ++TX) {
+  for (int TY = 1; TY <= 48; ++TY)
+    for (int TX = 1; TX <= 48; ++TX) {
       const int TH = (H + TY - 1) / TY, TW = (W + TX - 1) / TX;
       if ((TY > 1 && (TY - 1) * TH >= H) || (TX > 1 && (TX - 1) * TW >= W)) continue;     // an empty last tile
-      DftPlan c = {};
       const int LH = TY > 1 ? TH + 6 : H, LW = TX > 1 ? TW + 6 : W;
-      if (!dft_plan_transform(LH, LW, TY > 1 ? TH + 3 : H, TX > 1 ? TW + 3 : W, TY > 1 ? TH + 6 : H + 3, TX > 1 ? TW + 6 : W + 3, &c))
-        continue;
-      dft_set_tiles(&c, H, W, TY, TX, TH, TW);
-      const long cost = (long)c.T * c.NBINS;
-      if (!found || cost < best) {
-        found = true;
-        best = cost;
-        *out = c;
+      const int minP = TY > 1 ? TH + 6 : H + 3, minQ = TX > 1 ? TW + 6 : W + 3;
+      if (minP > DFT_MAXP || minQ > 2 * (DFT_MAXV - 1)) continue;
+      for (int k = 0; k < (canonical ? 6 : 1); ++k) {
+        if (canonical && (DFT_CANONICAL[k].P < minP || DFT_CANONICAL[k].Q < minQ)) continue;
+        DftPlan c = {};
+        if (!dft_plan_transform(LH, LW, TY > 1 ? TH + 3 : H, TX > 1 ? TW + 3 : W, canonical ? DFT_CANONICAL[k].P : minP,
+                                canonical ? DFT_CANONICAL[k].Q : minQ, &c))
+          continue;
+        dft_set_tiles(&c, H, W, TY, TX, TH, TW);
+        const long cost = (long)c.T * c.NBINS;
+        if (!found || cost < best) {
+          found = true;
+          best = cost;
+          *out = c;
+        }
       }
     }
   return found;
 }
+
+#ifndef OS2D_HOST_EMU
+static inline int dft_size_policy() {
+  static const int policy = [] {
+    const char* e = getenv("OS2D_DFT_SIZES");
+    return (e && (e[0] == 'e' || e[0] == '0')) ? 0 : 1;
+  }();
+  return policy;
+}
+#else
+static inline int dft_size_policy() { return emu_dft_policy; }
+#endif
+static inline bool dft_make_plan(int H, int W, DftPlan* out) { return dft_make_plan_policy(H, W, dft_size_policy(), out); }
 
 // ---------------------------------------------------------------------------------------------------- device helpers
 DFT_DEV int dft_div(int x, unsigned magic) { return magic ? (int)(((unsigned long long)(unsigned)x * magic) >> 32) : x; }

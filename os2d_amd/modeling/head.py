@@ -164,18 +164,67 @@ class _StreamOrdered(object):
 
 
 def spectra_cache_cap_bytes():
-    """Upper bound for the cached weight spectra of the frequency-domain modes over all transform sizes (least recently used
-    sizes are dropped first; 654 MB for the 64 x 84 transform of a 60 x 80 map).  $OS2D_FFT_CACHE_BYTES; default: a quarter of
-    the device's memory, at most 64 GiB - a dataset fed at its own aspect ratios at 7 pyramid scales (reference
-    os2d/data/dataloader.py:326) meets ~50 transform sizes = ~30 GB (tools/bench_size_churn.py), which an MI355X keeps resident
-    in its 288 GB; with a smaller cap than the working set an LRU cache misses on EVERY call of a cyclic access pattern."""
+    """Upper bound for the cached weight spectra of the frequency-domain modes on ONE DEVICE - over all transform sizes and all
+    TransformationNets of the process (least recently used entries are dropped first; 654 MB for the 64 x 84 transform of a
+    60 x 80 map).  $OS2D_FFT_CACHE_BYTES; default: an eighth of the device's memory, at most 8 GiB.  Round 3 needed 64 GiB per
+    net: one set of spectra per FFT-friendly transform size, 52 sizes = 35.6 GB for a dataset fed at its own aspect ratios
+    and 7 pyramid scales (reference os2d/data/dataloader.py:326; tools/bench_size_churn.py).  The default precision now plans
+    every map on six canonical transform sizes (overlap-save tiles; os2d_amd/csrc/dft_mfma.h): 2.4 GB in total, whatever the
+    dataset - a cap below the working set would make an LRU cache miss on EVERY call of a cyclic access pattern."""
     env = os.environ.get("OS2D_FFT_CACHE_BYTES")
     if env:
         return int(env)
     total = 64 << 30
     if torch.cuda.is_available():
         total = torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory
-    return int(min(64 << 30, total // 4))
+    return int(min(8 << 30, total // 8))
+
+
+class _SpectraStore(object):
+    """The cached weight spectra of one device, shared by every TransformationNet of the process (a per-net cap let N
+    nets pin N times the cap, invisibly to the caching allocator's out-of-memory retry).  Entries are keyed by (net id, slot),
+    least recently used first; a net that goes away takes its entries with it."""
+    _stores = {}
+
+    @classmethod
+    def of(cls, device):
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        store = cls._stores.get(index)
+        if store is None:
+            store = cls._stores[index] = cls()
+        return store
+
+    def __init__(self):
+        self.entries = collections.OrderedDict()
+
+    def get(self, net_id, slot, key):
+        entry = self.entries.get((net_id, slot))
+        if entry is None or entry.key != key:
+            return None
+        self.entries.move_to_end((net_id, slot))
+        return entry
+
+    def drop_stale(self, net_id, key):
+        for k in [k for k, e in self.entries.items() if k[0] == net_id and e.key != key]:
+            del self.entries[k]
+
+    def drop_net(self, net_id):
+        for k in [k for k in self.entries if k[0] == net_id]:
+            del self.entries[k]
+
+    def put(self, net_id, slot, entry):
+        cap, used = spectra_cache_cap_bytes(), entry.nbytes()
+        for k in list(self.entries):                          # oldest first, whichever net it belongs to
+            if used + sum(e.nbytes() for e in self.entries.values()) <= cap:
+                break
+            del self.entries[k]
+        self.entries[(net_id, slot)] = entry
+
+    def slots_of(self, net_id):
+        return [k[1] for k in self.entries if k[0] == net_id]
+
+    def nbytes(self):
+        return sum(e.nbytes() for e in self.entries.values())
 
 
 def split_rows_f16(T):
@@ -207,6 +256,33 @@ def _require_device_f32(t, name):
 
 
 # --------------------------------------------------------------------------------------------- TransformNet
+class _SpectraView(object):
+    """dict-like access to ONE net's entries of a device store (tests / tools: len, in, clear, values)."""
+
+    def __init__(self, store, net_id):
+        self.store, self.net_id = store, net_id
+
+    def __len__(self):
+        return len(self.store.slots_of(self.net_id))
+
+    def __contains__(self, slot):
+        return (self.net_id, slot) in self.store.entries
+
+    def __iter__(self):
+        return iter(self.store.slots_of(self.net_id))
+
+    def values(self):
+        return [e for k, e in self.store.entries.items() if k[0] == self.net_id]
+
+    def clear(self):
+        self.store.drop_net(self.net_id)
+
+
+def _drop_spectra_of(net_id):
+    for store in _SpectraStore._stores.values():
+        store.drop_net(net_id)
+
+
 class TransformationNet(nn.Module):
     """Parameter container with the reference's layout (head.py:604-646): ``conv`` = Sequential(Conv 225->128 k7,
     BatchNorm, ReLU, Conv 128->64 k5, BatchNorm, ReLU) and ``linear`` = Conv 64->output_dim k5, the latter
@@ -243,7 +319,9 @@ class TransformationNet(nn.Module):
                 self.linear.bias[2] = 1
         self.output_dim = output_dim
         self._packed_cache = {}
-        self._spectra_cache = collections.OrderedDict()     # (P, Q) -> _StreamOrdered, least recently used first
+        import weakref
+        self._net_id = id(self)
+        weakref.finalize(self, _drop_spectra_of, self._net_id)
         if use_cuda:
             self.conv.cuda()
             self.linear.cuda()
@@ -404,12 +482,11 @@ class TransformationNet(nn.Module):
         dev = self.linear.weight.device
         key = self._state_key()
         slot = (P, Q, bool(split))
-        cached = self._spectra_cache.get(slot)
-        if cached is not None and cached.key == key:
-            self._spectra_cache.move_to_end(slot)
+        store = _SpectraStore.of(dev)
+        cached = store.get(self._net_id, slot, key)
+        if cached is not None:
             return cached.get(dev)
-        for k in [k for k, c in self._spectra_cache.items() if c.key != key]:
-            del self._spectra_cache[k]                           # a parameter changed: every cached size is stale
+        store.drop_stale(self._net_id, key)                      # a parameter changed: every cached size of this net is stale
         with torch.cuda.device(dev), torch.no_grad():
             (w1, _), _, _ = self._folded()                       # float64 [128,225,7,7]: the BatchNorm fold
 
@@ -443,14 +520,17 @@ class TransformationNet(nn.Module):
             cur = torch.cuda.current_stream(dev)
             for t in (wfold, tp64, tq64, scratch):
                 t.record_stream(cur)
-            entry = _StreamOrdered(key, result, dev)
-            cap, used = spectra_cache_cap_bytes(), entry.nbytes()
-            for k in list(self._spectra_cache):                  # oldest first
-                if used + sum(c.nbytes() for c in self._spectra_cache.values()) <= cap:
-                    break
-                del self._spectra_cache[k]
-            self._spectra_cache[slot] = entry
+            store.put(self._net_id, slot, _StreamOrdered(key, result, dev))
         return result
+
+    @property
+    def _spectra_cache(self):
+        """{slot: entry} view of this net's cached weight spectra (the store itself is per device, shared by all nets)."""
+        dev = self.linear.weight.device
+        if dev.type != "cuda":
+            return {}
+        store = _SpectraStore.of(dev)
+        return _SpectraView(store, self._net_id)
 
     def forward(self, corr_maps, precision="f32"):
         """corr_maps [N,225,H,W] -> transform parameters [N,P,H,W] (reference head.py:648-655): input normalisation + the

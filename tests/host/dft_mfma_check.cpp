@@ -9,6 +9,7 @@
 #include "spmd_emu.h"
 
 #define OS2D_HOST_EMU 1
+static int emu_dft_policy = 0;      // 0: smallest transform per map, 1: the canonical sizes
 #define DFT_DEV static inline
 #define DFT_TID emu::tid()
 #define DFT_BID emu::bid()
@@ -218,6 +219,11 @@ static int check_case(int H, int W, int C, int NB, int grid) {
 
 int main(int argc, char** argv) {
   int rc = 0;
+  if (argc >= 2 && argv[1][0] == 'c') {      // "canonical" as the first argument: plan on the six canonical transform sizes
+    emu_dft_policy = 1;
+    --argc;
+    ++argv;
+  }
   if (argc >= 5) {
     for (int i = 1; i + 3 < argc; i += 4) rc |= check_case(std::atoi(argv[i]), std::atoi(argv[i + 1]), std::atoi(argv[i + 2]), std::atoi(argv[i + 3]), 2);
   } else {

@@ -153,9 +153,10 @@ def test_fft_plan_host_logic():
 
 
 def test_dft_plan_host_logic():
-    """os2d_dft_sizes (precision "fftx3": the transforms as matrix products, dft_mfma.hip) is host code: any P % 4 == 0 <= 64
-    and even Q <= 94 is a transform size, so maps that fit take the smallest one (fewer bins than the FFT-friendly sizes),
-    larger maps are cut into overlap-save tiles - every map up to the head's width limit has a plan."""
+    """os2d_dft_sizes (precision "fftx3": the transforms as matrix products, dft_mfma.hip) is host code.  Any P % 4 == 0 <= 64
+    and even Q <= 94 could be a transform size; the default policy plans every map on SIX canonical sizes - the exact transforms
+    of the 7-scale pyramid of a 1280 x 960 image - through overlap-save tiles, so that the weight spectra of a whole dataset are
+    2.4 GB, not one 0.2 - 0.7 GB set per map shape; every map up to the head's width limit has a plan."""
     import ctypes
     from os2d_amd import _lib
     lib = _lib.load()
@@ -166,9 +167,12 @@ def test_dft_plan_host_logic():
         rc = lib.os2d_dft_sizes(h, w, ctypes.byref(P), ctypes.byref(Q), ctypes.byref(nb), t)
         return (rc, P.value, Q.value, nb.value) + tuple(t)
 
+    canonical = {(36, 46), (44, 54), (48, 62), (52, 68), (56, 70), (64, 84)}
     assert plan(60, 80) == (0, 64, 84, 2752, 1, 1, 60, 80, 60, 80)
-    assert plan(30, 40)[:4] == (0, 36, 44, 828 + 4) and plan(48, 64)[:4] == (0, 52, 68, 52 * 35 + 4)
-    assert plan(96, 128)[4:8] == (2, 2, 48, 64) and plan(96, 128)[1:3] == (56, 70)
+    assert plan(30, 40)[:4] == (0, 36, 46, 864) and plan(38, 50)[:4] == (0, 44, 54, 1232) and plan(48, 64)[:4] == (0, 52, 68, 52 * 35 + 4)
+    assert plan(72, 96)[1:8] == (44, 54, 1232, 2, 2, 36, 48) and plan(84, 112)[1:8] == (48, 62, 1536, 2, 2, 42, 56)
+    assert plan(96, 128)[1:8] == (56, 70, 2016, 2, 2, 48, 64)
+    assert sum(p * (q // 2 + 1) for p, q in canonical) * 128 * 232 * 8 < 2.5e9          # all six sets of weight spectra
     for h in list(range(1, 100, 7)) + [120, 157, 300]:
         for w in list(range(1, 130, 9)) + [150, 209, 260, 316]:
             rc, P, Q, nb, ty, tx, th, tw, lh, lw = plan(h, w)
@@ -176,6 +180,6 @@ def test_dft_plan_host_logic():
             assert ty >= 1 and tx >= 1 and ty * th >= h and tx * tw >= w and (ty - 1) * th < h and (tx - 1) * tw < w
             assert (lh, lw) == (th + 6 if ty > 1 else h, tw + 6 if tx > 1 else w)
             assert P >= (th + 6 if ty > 1 else h + 3) and Q >= (tw + 6 if tx > 1 else w + 3)
-            assert P % 4 == 0 and P <= 64 and Q % 2 == 0 and Q <= 94 and nb % 8 == 0 and nb >= P * (Q // 2 + 1)
+            assert (P, Q) in canonical and nb % 8 == 0 and nb >= P * (Q // 2 + 1)
     assert lib.os2d_dft_channel_stride(225) == 232 and lib.os2d_dft_matrices_bytes(64, 84) > 0
     assert lib.os2d_dft_xscale(60, 80) == 8.0

@@ -39,16 +39,15 @@ OTHER_MAPS = [(11, 13), (9, 16), (2, 5), (1, 1), (61, 91), (64, 260), (157, 209)
 
 
 def test_plans_of_the_pyramid_levels():
-    """Any P % 4 == 0 and even Q will do for a matrix-product transform: the levels that fit take P = H + 3 -> 4, Q = W + 3 -> 2
-    (fewer bins than the FFT-friendly sizes of fft.hip), larger ones are cut into overlap-save tiles of at most 58 x 88 outputs."""
+    """The default policy plans every map on six canonical transform sizes: the levels of the 7-scale pyramid of a 1280 x 960
+    image take their exact transforms (the four smaller ones whole, the three larger ones as 2 x 2 overlap-save tiles)."""
     got = {hw: dft_sizes(*hw) for hw in PYRAMID_LEVELS}
-    assert got[(60, 80)][:3] == (64, 84, 2752) and got[(60, 80)][3][:2] == (1, 1)
-    assert got[(30, 40)][:2] == (36, 44) and got[(48, 64)][:2] == (52, 68)
+    assert [got[hw][:2] for hw in PYRAMID_LEVELS] == [(36, 46), (44, 54), (52, 68), (64, 84), (44, 54), (48, 62), (56, 70)]
+    assert got[(60, 80)][2] == 2752 and [got[hw][3][:2] for hw in PYRAMID_LEVELS] == [(1, 1)] * 4 + [(2, 2)] * 3
     for hw, (P, Q, nbins, (TY, TX, TH, TW, LH, LW)) in got.items():
         assert P % 4 == 0 and Q % 2 == 0 and nbins % 8 == 0 and nbins >= P * (Q // 2 + 1) and P <= 64 and Q <= 94
         assert P >= (TH + 6 if TY > 1 else hw[0] + 3) and Q >= (TW + 6 if TX > 1 else hw[1] + 3)
         assert TY * TH >= hw[0] and TX * TW >= hw[1]
-    assert got[(96, 128)][3][:2] == (2, 2)
 
 
 @pytest.mark.parametrize("H,W,NB,C", [(60, 80, 2, 9), (60, 80, 1, 225)] + [(h, w, 1, 5) for h, w in PYRAMID_LEVELS if (h, w) != (60, 80)] +

@@ -24,3 +24,7 @@ def test_dft_mfma_kernels_on_the_host_emulator(tmp_path):
     out = subprocess.run([exe, "11", "13", "5", "1", "20", "24", "4", "2", "70", "100", "5", "1", "30", "43", "6", "2"],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-3000:] + out.stderr[-2000:]
+    # the same kernels planned on the canonical transform sizes (the default policy): a map much smaller than its transform, and
+    # a map that needs tiles although its smallest transform would fit
+    out = subprocess.run([exe, "canonical", "11", "13", "5", "1", "50", "70", "4", "1"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-3000:] + out.stderr[-2000:]

@@ -73,7 +73,7 @@ def main():
     for lv in maps:
         for h, w in lv:
             p, q, nb = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-            lib.os2d_fft_sizes(h, w, ctypes.byref(p), ctypes.byref(q), ctypes.byref(nb))
+            lib.os2d_dft_sizes(h, w, ctypes.byref(p), ctypes.byref(q), ctypes.byref(nb), None)    # the default precision's planner
             tsizes.add((p.value, q.value))
     # features per distinct map size (the content does not matter for the timing)
     feats = {}
@@ -129,7 +129,8 @@ def main():
     out = {"images": len(maps), "classes": args.classes, "levels_per_image": len(SCALES), "distinct_map_sizes": len(feats),
            "distinct_transform_sizes": len(tsizes), "cache_entries_at_end": len(net._spectra_cache),
            "cache_bytes_at_end": sum(c.nbytes() for c in net._spectra_cache.values()),
-           "cache_cap_bytes": head_mod.spectra_cache_cap_bytes(), "cold": res["cold"], "warm": res["warm"], "miss_isolated": isolated,
+           "cache_cap_bytes": head_mod.spectra_cache_cap_bytes(), "size_policy": os.environ.get("OS2D_DFT_SIZES", "canonical"),
+           "transform_sizes": sorted(tsizes), "cold": res["cold"], "warm": res["warm"], "miss_isolated": isolated,
            "miss_ms_derived": round((res["cold"]["ms_per_image"] - res["warm"]["ms_per_image"]) * len(maps) / max(res["cold"]["cache_misses"], 1), 2),
            "note": "cold.ms_per_miss includes draining the kernels queued before the miss (the head is asynchronous); miss_isolated times a "
                    "miss on its own, miss_ms_derived = (cold - warm) / misses",

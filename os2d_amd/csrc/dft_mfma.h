@@ -43,6 +43,11 @@
 #ifndef DFT_HD
 #define DFT_HD static inline      /* host + device helpers (the device build says __host__ __device__) */
 #endif
+#ifndef DFT_STAMP
+#define DFT_STAMP(K)              /* diagnostic builds (-DOS2D_DIAG_DFT_STAMPS): time since the previous stamp -> phase K */
+#define DFT_STAMP_BEGIN()
+#define DFT_STAMP_END(BASE)
+#endif
 
 namespace os2d_dft {
 
@@ -449,6 +454,7 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
   if (first < iters) DFT_FWD_PREFETCH(first, tid)
   DFT_BARRIER();     // FqT is in LDS
 
+  DFT_STAMP_BEGIN()
   for (int it = first; it < iters; it += DFT_GRID) {
     int tl = tid;
 #ifndef OS2D_HOST_EMU
@@ -490,6 +496,7 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
       }
     }
     DFT_BARRIER();
+    DFT_STAMP(0)
 
     // ---- step 1: R^T = x . FqT; this wave's tiles t = wv + 8 j of the mt1n x nt1n grid
     f32x16v acc[3];
@@ -507,6 +514,7 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
     }
     dft_product_lds_any(acc, nt1w, ks1n, ldsU, MxS, ldsF, N1, wv, mt1n, l31, hw);
     DFT_BARRIER();      // every wave is done reading x: the region becomes R2
+    DFT_STAMP(1)
 
     // ---- R: R * 2^8 as units [k = (ri * Pp + h) / 8][hi|lo][n2 = img * V + v]; this lane owns column n = 2 v + ri of its
     // tiles and, per accumulator run, 4 consecutive h of one image: half a unit
@@ -530,6 +538,7 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
       }
     }
     DFT_BARRIER();
+    DFT_STAMP(2)
     // the next window's loads are issued here - the accumulators of step 1 are dead, the values are needed a whole step 2 +
     // store phase later - so that their registers do not overlap the first product's
     if (it + DFT_GRID < iters) DFT_FWD_PREFETCH(it + DFT_GRID, tl)
@@ -551,6 +560,7 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
     else if (nt2w == 2) dft_product_rega<2>(xc, fp2h, fp2l, ks2n, ldsU, N2S, wv >> 2, 2, l31, hw);
     else if (nt2w == 1) dft_product_rega<1>(xc, fp2h, fp2l, ks2n, ldsU, N2S, wv >> 2, 2, l31, hw);
     DFT_BARRIER();      // every wave is done reading R2: the region becomes the staging buffer of X
+    DFT_STAMP(3)
 
     // ---- XS: X = acc * 2^-22 staged as [v][u / 4][img][u % 4][re|im] (+16 bytes per v: consecutive lanes = consecutive v land
     // in different banks); a lane owns (img, v) and per accumulator run two consecutive u
@@ -575,6 +585,7 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
       }
     }
     DFT_BARRIER();
+    DFT_STAMP(4)
 
     // ---- ST: 16-byte pieces, 8 per quad of bins = the 128 contiguous bytes of the 4 channels; then the padding bins
     {
@@ -592,7 +603,9 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
         *reinterpret_cast<f32x4v*>(dstbase + (size_t)(qpad0 + (i >> 3)) * qstride + (i & 7) * 4) = f32x4v{0.f, 0.f, 0.f, 0.f};
     }
     DFT_BARRIER();      // the staging buffer is free: the next window may be written
+    DFT_STAMP(5)
   }
+  DFT_STAMP_END(0)
 #undef DFT_FWD_ITER
 #undef DFT_FWD_POS
 #undef DFT_FWD_PREFETCH
@@ -667,6 +680,7 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBINS / 4][NBT][Cout][4
   if (first < iters) DFT_INV_PREFETCH(first, tid)
   DFT_BARRIER();
 
+  DFT_STAMP_BEGIN()
   for (int it = first; it < iters; it += DFT_GRID) {
     int tl = tid;
 #ifndef OS2D_HOST_EMU
@@ -701,6 +715,7 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBINS / 4][NBT][Cout][4
       if (lane < DFT_G) smaxw[wv * DFT_G + lane] = m;
     }
     DFT_BARRIER();
+    DFT_STAMP(0)
     float simg = 1.f, cinv[DFT_G];
     {
       // scale of an image: 2^(13 - E), E = floor(log2(max)): the largest component lands in [2^13, 2^14)
@@ -754,6 +769,7 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBINS / 4][NBT][Cout][4
       }
     }
     DFT_BARRIER();
+    DFT_STAMP(1)
     if (it + DFT_GRID < iters) DFT_INV_PREFETCH(it + DFT_GRID, tl)
 
     // ---- step A: T = E2 . Y2 (E2 fragments in registers)
@@ -773,6 +789,7 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBINS / 4][NBT][Cout][4
     else if (ntaw == 2) dft_product_rega<2>(ta, e2h, e2l, ksAn, ldsU, N2S, wv >> 2, 2, l31, hw);
     else if (ntaw == 1) dft_product_rega<1>(ta, e2h, e2l, ksAn, ldsU, N2S, wv >> 2, 2, l31, hw);
     DFT_BARRIER();      // every wave is done reading Y2: the region becomes Tt
+    DFT_STAMP(2)
 
     // ---- WT: T * 2^-(14 + eT) as units [k = (2 v + ri) / 8][hi|lo][m = h * G + img]; a lane owns (img, v) and per accumulator
     // run (re, im) of two consecutive h: 4 bytes of a unit each.  The k beyond 2 V of the last units are zeroed (Gq has zero
@@ -804,6 +821,7 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBINS / 4][NBT][Cout][4
       }
     }
     DFT_BARRIER();
+    DFT_STAMP(3)
 
     // ---- step B: y = Tt . Gq; this wave's tiles t = wv + 8 j of the mtBn x ntBn grid
     f32x16v yc[3];
@@ -820,6 +838,7 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBINS / 4][NBT][Cout][4
       for (int r = 0; r < 16; ++r) yc[j][r] = 0.f;
     }
     dft_product_lds_any(yc, ntbw, ksBn, ldsU, MBS, ldsG, NBo, wv, mtBn, l31, hw);
+    DFT_STAMP(4)
 
     // ---- epilogue: a lane owns window column w and, per accumulator run, the 4 channels of one row: + bias, ReLU, channel
     // scale, fp16 hi | lo -> 8 + 8 bytes of the two 16-byte units of the cell (the other half of a unit comes from the
@@ -859,7 +878,9 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBINS / 4][NBT][Cout][4
       }
     }
     DFT_BARRIER();      // every wave is done reading Tt (and the maxima): the next spectra may be written
+    DFT_STAMP(5)
   }
+  DFT_STAMP_END(8)
   if (bad_flag != nullptr && DFT_BALLOT(bad) != 0ull) {
     if ((tid & 63) == 0) DFT_RAISE(bad_flag);
   }

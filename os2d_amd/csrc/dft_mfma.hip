@@ -19,6 +19,25 @@ extern __shared__ __attribute__((aligned(16))) unsigned char os2d_dft_smem[];
 #define DFT_BALLOT(p) __builtin_amdgcn_ballot_w64(p)
 #define DFT_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #define DFT_RAISE(p) __hip_atomic_store(p, OS2D_STATUS_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+#ifdef OS2D_DIAG_DFT_STAMPS
+// diagnostic build: thread 0 of every work-group accumulates the wall-clock ticks (100 MHz) between the phase barriers; the sums
+// over all work-groups land in os2d_dft_stamps[0..5] (forward: W | step 1 | R | step 2 | XS | ST) and [8..13] (inverse: max |
+// WY | step A | WT | step B | epilogue), [6] / [14] count iterations.  Read with os2d_debug_dft_stamps (tools/time_dft_phases.py).
+__device__ unsigned long long os2d_dft_stamps[16];
+#define DFT_STAMP_BEGIN() unsigned long long st_acc_[6] = {0, 0, 0, 0, 0, 0}, st_n_ = 0, st_last_ = wall_clock64();
+#define DFT_STAMP(K)                                   \
+  {                                                    \
+    const unsigned long long t_ = wall_clock64();      \
+    st_acc_[K] += t_ - st_last_;                       \
+    st_last_ = t_;                                     \
+    if ((K) == 5) ++st_n_;                             \
+  }
+#define DFT_STAMP_END(BASE)                                                                   \
+  if (threadIdx.x == 0) {                                                                     \
+    for (int k_ = 0; k_ < 6; ++k_) atomicAdd(&os2d_dft_stamps[(BASE) + k_], st_acc_[k_]);     \
+    atomicAdd(&os2d_dft_stamps[(BASE) + 6], st_n_);                                           \
+  }
+#endif
 #include "dft_mfma.h"
 
 namespace {
@@ -149,4 +168,20 @@ int os2d_launch_dft_inverse(const float* Y, const float* bp, int MTP, void* out,
   hipLaunchKernelGGL(kern, dim3(dft_grid(iters)), dim3(DFT_THR), pl.lds_total, stream, Y, bp, MTP, static_cast<unsigned char*>(out), E2, Gq,
                      pl, Cout, NBT, os2d_plane(H, W), os2d_ws(W), os2d_base(W), iters, status);
   return dft_check("dft_inverse");
+}
+
+// diagnostic builds only (-DOS2D_DIAG_DFT_STAMPS): copy the 16 phase counters to the host and optionally reset them
+extern "C" int os2d_debug_dft_stamps(unsigned long long* out16, int reset) {
+#ifdef OS2D_DIAG_DFT_STAMPS
+  if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(os2d_dft_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return -4;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(os2d_dft_stamps), z, sizeof(z)) != hipSuccess) return -4;
+  }
+  return 0;
+#else
+  (void)out16, (void)reset;
+  os2d_set_error("os2d_debug_dft_stamps: this library was built without -DOS2D_DIAG_DFT_STAMPS");
+  return -1;
+#endif
 }

@@ -531,7 +531,12 @@ def test_untraceable_transform_falls_back_to_the_generic_chain(device):
     from os2d_amd.structures.feature_map import FeatureMapSize
     levels = [(9, 12), (9, 12)]
     sizes, locs, clss, corners = _pyramid_inputs(levels, 2, 31, device)
-    shift = [lambda b: BoxList(b.bbox_xyxy + 2.0, b.image_size) for _ in levels]
+    def shift2(b):        # not one of the three BoxList operations; keeps the fields like they do (the reference reads them back)
+        out = BoxList(b.bbox_xyxy + 2.0, b.image_size)
+        for k in b.fields():
+            out.add_field(k, b.get_field(k))
+        return out
+    shift = [shift2 for _ in levels]
     coder = _coder()
     assert coder._decode_pyramid_fused(locs, clss, sizes, [0, 1], 0.0, 0.3, shift, None) is None
     res = coder.decode_pyramid(locs, clss, sizes, [0, 1], nms_score_threshold=0.0, inverse_box_transforms=shift)

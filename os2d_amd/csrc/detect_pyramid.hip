@@ -40,15 +40,6 @@ constexpr int NTHR = 1024, NWAVE = NTHR / 64;
 constexpr int MAX_LEVELS = OS2D_PYRAMID_MAX_LEVELS;
 constexpr int MAX_CHUNKS = 64;      // chunks per class and pass that the count tables hold
 constexpr int KCAP = 2048;          // kept boxes cached in LDS (32 KB); later ones are re-read through the id lists
-constexpr int GRID = 16, GRID_CELLS = GRID * GRID;   // cells of the spatial grid over the kept boxes (pyr_chunk_nms_kernel)
-constexpr int PRUNE_MIN = 48;       // kept boxes from which the grid pays for itself
-
-// monotone map float -> unsigned (ascending), for min / max with integer atomics
-__device__ __forceinline__ unsigned int ord_key(float f) {
-  const unsigned int u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float ord_val(unsigned int k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
 struct DefaultOpsTable {        // per level: the chain the anchors ("default_boxes") go through (os2d_common.h)
   Os2dDefaultBoxOps ops[OS2D_PYRAMID_MAX_LEVELS];
@@ -156,10 +147,6 @@ __global__ __launch_bounds__(NTHR) void pyr_chunk_nms_kernel(int pass, int N, in
   __shared__ int kept_count;
   __shared__ unsigned short surv[NTHR];   // positions (inside the window) of a batch's survivors, in sorted order
   __shared__ int wave_cnt[NWAVE];
-  // spatial pruning of the kept list (round 4): the kept boxes re-bucketed by the grid cell of their top-left corner
-  __shared__ int chist[GRID_CELLS], cfill[GRID_CELLS];
-  __shared__ unsigned short cstart[GRID_CELLS + 1];
-  __shared__ unsigned int gstat[6];        // ordered-uint keys: min x1 | max x1 | min y1 | max y1 | max width | max height of the kept boxes
 
   const int ch = blockIdx.x, b = blockIdx.y, B = gridDim.y;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -294,86 +281,9 @@ __global__ __launch_bounds__(NTHR) void pyr_chunk_nms_kernel(int pass, int N, in
       const float my_area = os2d_box_area(me);
       bool dead = !in_batch;
       const int nk0_lds = min(nk0, KCAP);
-      // Round 4: a candidate can only be suppressed by kept boxes that INTERSECT it (IoU > threshold >= 0),
-      // so the kept list is re-bucketed per batch by the grid cell of each box's top-left corner (counting sort into the dead
-      // storage of the sort positions) and a candidate walks only the cells [cell(x1 - widest kept box), cell(x2)] x [cell(y1 -
-      // tallest), cell(y2)]: the cell map is monotone, so no intersecting box is skipped and every decision is the one the
-      // full scan makes - at 240-px boxes on a 1280 x 960 image ~1/6 of the pair tests (20 G per image were the 4.0 of the
-      // 7.0 ms of 64 labels x 8 views x 7 levels).  Per-lane walks: the IoU arithmetic (~25 VALU operations) dominates a
-      // test, not the 16-byte LDS read, so divergent reads cost little.
-      const int KC = min(KCAP, NP2full >> 3);                 // boxes the re-bucketed copy holds (the sort positions' storage)
-      const int nkc = min(nk0_lds, KC);
-      const bool pruned = nkc >= PRUNE_MIN && iou_thr >= 0.f;
-      if (pruned) {
-        float4* kc = reinterpret_cast<float4*>(spos);
-        if (tid < 6) gstat[tid] = (tid == 0 || tid == 2) ? 0xffffffffu : 0u;
-        for (int i = tid; i < GRID_CELLS; i += NTHR) chist[i] = cfill[i] = 0;
-        __syncthreads();
-        {   // extent of the top-left corners, largest width / height: wave reductions, one atomic per wave
-          float x1lo = 3.0e38f, x1hi = -3.0e38f, y1lo = 3.0e38f, y1hi = -3.0e38f, wmax = 0.f, hmax = 0.f;
-          for (int j = tid; j < nkc; j += NTHR) {
-            const float4 k = kbox[j];
-            x1lo = fminf(x1lo, k.x), x1hi = fmaxf(x1hi, k.x), y1lo = fminf(y1lo, k.y), y1hi = fmaxf(y1hi, k.y);
-            wmax = fmaxf(wmax, k.z - k.x), hmax = fmaxf(hmax, k.w - k.y);
-          }
-#pragma unroll
-          for (int m = 1; m < 64; m <<= 1) {
-            x1lo = fminf(x1lo, __shfl_xor(x1lo, m, 64)), x1hi = fmaxf(x1hi, __shfl_xor(x1hi, m, 64));
-            y1lo = fminf(y1lo, __shfl_xor(y1lo, m, 64)), y1hi = fmaxf(y1hi, __shfl_xor(y1hi, m, 64));
-            wmax = fmaxf(wmax, __shfl_xor(wmax, m, 64)), hmax = fmaxf(hmax, __shfl_xor(hmax, m, 64));
-          }
-          if (lane == 0) {
-            atomicMin(&gstat[0], ord_key(x1lo)), atomicMax(&gstat[1], ord_key(x1hi));
-            atomicMin(&gstat[2], ord_key(y1lo)), atomicMax(&gstat[3], ord_key(y1hi));
-            atomicMax(&gstat[4], ord_key(wmax)), atomicMax(&gstat[5], ord_key(hmax));
-          }
-        }
-        __syncthreads();
-        const float gx0 = ord_val(gstat[0]), gy0 = ord_val(gstat[2]);
-        const float gsx = (float)GRID / fmaxf(ord_val(gstat[1]) - gx0, 1e-3f), gsy = (float)GRID / fmaxf(ord_val(gstat[3]) - gy0, 1e-3f);
-        // monotone cell maps (the same for the kept boxes and for the candidates' ranges); NaN-free: all boxes are finite
-#define PYR_CELLX(X) min(GRID - 1, max(0, (int)floorf(((X)-gx0) * gsx)))
-#define PYR_CELLY(Y) min(GRID - 1, max(0, (int)floorf(((Y)-gy0) * gsy)))
-        for (int j = tid; j < nkc; j += NTHR) {
-          const float4 k = kbox[j];
-          atomicAdd(&chist[PYR_CELLY(k.y) * GRID + PYR_CELLX(k.x)], 1);
-        }
-        __syncthreads();
-        if (tid <= GRID_CELLS) {
-          int sfx = 0;
-          for (int i = 0; i < tid; ++i) sfx += chist[i];
-          cstart[tid] = (unsigned short)sfx;
-        }
-        __syncthreads();
-        for (int j = tid; j < nkc; j += NTHR) {
-          const float4 k = kbox[j];
-          const int c = PYR_CELLY(k.y) * GRID + PYR_CELLX(k.x);
-          kc[cstart[c] + atomicAdd(&cfill[c], 1)] = k;          // order inside a cell is irrelevant: the tests are OR-ed
-        }
-        __syncthreads();
-        if (!dead) {
-          // margins: the widest / tallest kept box (+ a little: the widths are rounded differences)
-          const float mw = ord_val(gstat[4]) * 1.0001f + 1e-3f, mh = ord_val(gstat[5]) * 1.0001f + 1e-3f;
-          const int cx0 = PYR_CELLX(me.x - mw), cx1 = PYR_CELLX(me.z), cy0 = PYR_CELLY(me.y - mh), cy1 = PYR_CELLY(me.w);
-          for (int cy = cy0; cy <= cy1 && !dead; ++cy) {
-            const int e = cstart[cy * GRID + cx1 + 1];
-            for (int j = cstart[cy * GRID + cx0]; j < e; ++j) {
-              const float4 kbx = kc[j];
-              dead |= os2d_iou_gt(kbx, os2d_box_area(kbx), me, my_area, iou_thr);
-            }
-          }
-        }
-#undef PYR_CELLX
-#undef PYR_CELLY
-        for (int j = nkc; j < nk0_lds; ++j) {                    // kept boxes beyond the re-bucketed copy (small chunk sizes only)
-          const float4 kbx = kbox[j];
-          dead |= os2d_iou_gt(kbx, os2d_box_area(kbx), me, my_area, iou_thr);
-        }
-      } else {
-        for (int j = 0; j < nk0_lds; ++j) {
-          const float4 kbx = kbox[j];
-          dead |= os2d_iou_gt(kbx, os2d_box_area(kbx), me, my_area, iou_thr);
-        }
+      for (int j = 0; j < nk0_lds; ++j) {
+        const float4 kbx = kbox[j];
+        dead |= os2d_iou_gt(kbx, os2d_box_area(kbx), me, my_area, iou_thr);
       }
       for (int j = KCAP; j < nk0; ++j) {
         const float4 kbx = bx[srt[kpos[j]]];

@@ -43,6 +43,9 @@
 #ifndef DFT_HD
 #define DFT_HD static inline      /* host + device helpers (the device build says __host__ __device__) */
 #endif
+#ifndef DFT_SCHED_FENCE
+#define DFT_SCHED_FENCE()         /* device build: __builtin_amdgcn_sched_barrier(0) - the scheduler moves nothing across it */
+#endif
 #ifndef DFT_STAMP
 #define DFT_STAMP(K)              /* diagnostic builds (-DOS2D_DIAG_DFT_STAMPS): time since the previous stamp -> phase K */
 #define DFT_STAMP_BEGIN()
@@ -83,7 +86,7 @@ struct DftPlan {
   int NBo;                         // columns of step B that are needed (ox + TW | W) rounded up to 32
   int eT;                          // ceil(log2 P) + 1
   int fast;                        // 1: W % 4 == 0 and untiled (16-byte loads of the correlation rows)
-  unsigned inv_cg, inv_t, inv_tx, inv_c4, inv_v, inv_pq, inv_og, inv_kg;   // ceil(2^32 / d) (0 where d == 1)
+  unsigned inv_cg, inv_t, inv_tx, inv_c4, inv_v, inv_pq, inv_og, inv_kg, inv_pp;   // ceil(2^32 / d) (0 where d == 1)
   // LDS (bytes)
   int lds_const, lds_union, lds_total;
 };
@@ -158,6 +161,7 @@ static inline void dft_set_tiles(DftPlan* pl, int H, int W, int TY, int TX, int 
   pl->inv_v = dft_magic((unsigned)pl->V);
   pl->inv_pq = dft_magic((unsigned)(pl->P / 4 * DFT_G * 2));
   pl->inv_kg = dft_magic((unsigned)(pl->Pp / 8));
+  pl->inv_pp = dft_magic((unsigned)pl->Pp);
 }
 
 // Transform sizes.  The weight spectra of the per-bin GEMM cost 0.24 MB per bin and transform size (654 MB for 64 x 84), and a
@@ -245,32 +249,35 @@ DFT_DEV f32x16v dft_mma3(half8 ah, half8 al, half8 bh, half8 bl, f32x16v acc) {
 }
 
 // acc[j] += A . B[tile j] for this wave's NT column tiles, the row operand A resident in REGISTERS (its k-steps as fragment
-// arrays): per k-step all B fragments are requested first, then the 3 NT matrix instructions run as they arrive.  NT is a
-// template parameter so that the loop body has no branches (the per-tile "is it mine" test would otherwise sit between every
-// fragment read and its matrix instructions and keep the compiler from moving the reads up).
+// arrays).  NT and the number of k-steps KS are template parameters: the body is straight-line code - no "is this tile mine" /
+// "is this k-step live" branch between a fragment read and its matrix instructions - and the B fragments of k-step ks + 1 are
+// requested before the matrix instructions of k-step ks (round 4, first version: a uniform branch per k-step and tile made
+// every scheduling region one read-wait-multiply sequence; measured 5.1 us for 2.2 us of matrix time).
 template <int NT>
 DFT_DEV void dft_product_rega(f32x16v* acc, const half8* ah, const half8* al, int ksn, const u32x4v* B, int bstride, int nt0, int ntstep,
                               int l31, int hw) {
+  // one column tile after the other (A is in registers: no fragment is read twice); the k loop is unrolled over the register
+  // arrays with a wave-uniform guard per k-step
 #pragma unroll
-  for (int ks = 0; ks < DFT_KREG; ++ks) {
-    if (ks < ksn) {
-      half8 bh[NT], bl[NT];
+  for (int j = 0; j < NT; ++j) {
+    const u32x4v* Bj = B + (size_t)(hw * 2) * bstride + (nt0 + ntstep * j) * 32 + l31;
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        bh[j] = dft_frag(B + (size_t)((2 * ks + hw) * 2 + 0) * bstride + (nt0 + ntstep * j) * 32 + l31);
-        bl[j] = dft_frag(B + (size_t)((2 * ks + hw) * 2 + 1) * bstride + (nt0 + ntstep * j) * 32 + l31);
+    for (int ks = 0; ks < DFT_KREG; ++ks) {
+      if (ks < ksn) {
+        const half8 bh = dft_frag(Bj + (size_t)(4 * ks) * bstride), bl = dft_frag(Bj + (size_t)(4 * ks + 1) * bstride);
+        acc[j] = dft_mma3(ah[ks], al[ks], bh, bl, acc[j]);
       }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[j] = dft_mma3(ah[ks], al[ks], bh[j], bl[j], acc[j]);
     }
   }
 }
 
 // acc[j] += A[row tile mt_j] . B[column tile nt_j], both operands in LDS, tiles t = t0 + 8 j of a grid of mtn row tiles;
-// SHARE: all NT tiles have the same row tile (mtn == 8): its A fragment is read once per k-step
+// SHARE: all NT tiles have the same row tile (mtn == 8): its A fragment is read once per k-step.  Straight-line code, as above
+// (double-buffering these fragments in the source as well costs 120 spilled registers: the compiler hoists what fits).
 template <int NT, bool SHARE>
 DFT_DEV void dft_product_lds(f32x16v* acc, int ksn, const u32x4v* A, int astride, const u32x4v* B, int bstride, int t0, int mtn, int l31,
                              int hw) {
+  constexpr int NA = SHARE ? 1 : NT;
   int tm[NT], tn[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -279,9 +286,9 @@ DFT_DEV void dft_product_lds(f32x16v* acc, int ksn, const u32x4v* A, int astride
     tm[j] = t - tn[j] * mtn;
   }
   for (int ks = 0; ks < ksn; ++ks) {
-    half8 ah[SHARE ? 1 : NT], al[SHARE ? 1 : NT], bh[NT], bl[NT];
+    half8 ah[NA], al[NA], bh[NT], bl[NT];
 #pragma unroll
-    for (int j = 0; j < (SHARE ? 1 : NT); ++j) {
+    for (int j = 0; j < NA; ++j) {
       ah[j] = dft_frag(A + (size_t)((2 * ks + hw) * 2 + 0) * astride + tm[j] * 32 + l31);
       al[j] = dft_frag(A + (size_t)((2 * ks + hw) * 2 + 1) * astride + tm[j] * 32 + l31);
     }
@@ -467,21 +474,19 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
       for (int s = 0; s < NSLOT; ++s) {
         DFT_FWD_POS(tl, s)
         if (i_ < npos) {
-          bool ok[4];
+          // inverse norm x 2^15, zero outside the window / the map: relu(a) * 0 = 0 for every finite a
+          float nsc[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            ok[e] = FAST ? (r_ < LH && 4 * c4_ < LW) : (r_ < LH && y_ >= 0 && y_ < H && 4 * c4_ + e < LW && x_ + e >= 0 && x_ + e < W);
+          for (int e = 0; e < 4; ++e) {
+            const bool ok = FAST ? (r_ < LH && 4 * c4_ < LW) : (r_ < LH && y_ >= 0 && y_ < H && 4 * c4_ + e < LW && x_ + e >= 0 && x_ + e < W);
+            nsc[e] = ok ? pn[s][e] * 32768.0f : 0.f;
+          }
 #pragma unroll
           for (int g = 0; g < DFT_G; ++g) {
-            const bool cok = c0_ + g < C;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float a = pc[s][g][e], n = pn[s][e];
-              v[e] = (ok[e] && cok) ? fmaxf(a, 0.f) * n * 32768.0f : 0.f;
-            }
-            u32x2v hi, lo;
-            dft_split4(v[0], v[1], v[2], v[3], &hi, &lo);
+            u32x2v hi = {0u, 0u}, lo = {0u, 0u};
+            if (c0_ + g < C)         // (uniform: only the last channel group of a pair has channels beyond C)
+              dft_split4(fmaxf(pc[s][g][0], 0.f) * nsc[0], fmaxf(pc[s][g][1], 0.f) * nsc[1], fmaxf(pc[s][g][2], 0.f) * nsc[2],
+                         fmaxf(pc[s][g][3], 0.f) * nsc[3], &hi, &lo);
             const int m = g * Pp + r_;
             unsigned char* dst = ldsUb + ((size_t)((c4_ >> 1) * 2) * MxS + m) * 16 + (c4_ & 1) * 8;
             *reinterpret_cast<u32x2v*>(dst) = hi;
@@ -524,8 +529,10 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
       const int n = tn[j] * 32 + l31, v = n >> 1, ri = n & 1;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int m0 = tm[j] * 32 + 8 * q + 4 * hw;
-        const int img = m0 / Pp, h0 = m0 - img * Pp;
+        // rows tm * 32 + 8 q (+ 4 for the upper half-wave): Pp is a multiple of 8, so both half-waves are in the same image -
+        // the division is wave-uniform (scalar unit, by multiplication)
+        const int mb = tm[j] * 32 + 8 * q;
+        const int img = dft_div(mb, pl.inv_pp), h0 = mb - img * Pp + 4 * hw;
         if (v < V && img < DFT_G) {
           u32x2v hi, lo;
           const float sc = 1.0f / 2097152.0f;      // 2^-21 = 2^8 / (2^15 * 2^14)
@@ -814,11 +821,12 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBINS / 4][NBT][Cout][4
           *reinterpret_cast<unsigned*>(d0 + DFT_G * 16 + (size_t)MBS * 16) = lo[1];
         }
       }
-      const int vpad = KB / 2 - V;       // v slots V .. KB / 2 - 1
-      for (int i = tl; i < vpad * MB * 2; i += DFT_THR) {
-        const int m = i % MB, rest = i / MB, hl = rest & 1, v = V + (rest >> 1);
-        *reinterpret_cast<unsigned*>(ldsUb + ((size_t)((v >> 2) * 2 + hl) * MBS + m) * 16 + (v & 3) * 4) = 0u;
-      }
+      for (int v = V; v < KB / 2; ++v)       // v slots V .. KB / 2 - 1
+        for (int m = tl; m < MB; m += DFT_THR) {
+          unsigned char* d0 = ldsUb + ((size_t)((v >> 2) * 2) * MBS + m) * 16 + (v & 3) * 4;
+          *reinterpret_cast<unsigned*>(d0) = 0u;
+          *reinterpret_cast<unsigned*>(d0 + (size_t)MBS * 16) = 0u;
+        }
     }
     DFT_BARRIER();
     DFT_STAMP(3)

@@ -18,6 +18,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char os2d_dft_smem[];
 #define DFT_SHFL_XOR(v, m) __shfl_xor(v, m, 64)
 #define DFT_BALLOT(p) __builtin_amdgcn_ballot_w64(p)
 #define DFT_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#define DFT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define DFT_RAISE(p) __hip_atomic_store(p, OS2D_STATUS_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 #ifdef OS2D_DIAG_DFT_STAMPS
 // diagnostic build: thread 0 of every work-group accumulates the wall-clock ticks (100 MHz) between the phase barriers; the sums

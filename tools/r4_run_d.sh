@@ -1,0 +1,21 @@
+#!/bin/bash
+# round 4, GPU call D: perf iteration of the matrix-product transforms (their tests, phase stamps, the bench line)
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out/r4d
+( timeout 600 python -m pytest tests/test_dft_gpu.py tests/test_decode_gpu.py -q -x -p no:cacheprovider ) > gpurun_out/r4d/dft.log 2>&1
+echo "dft+decode tests rc=$?"; tail -3 gpurun_out/r4d/dft.log
+for nb in 64 1024; do
+  OS2D_HIP_LIB=tools/diag_libs/stamps/libos2d_hip.so timeout 300 python tools/time_dft_phases.py $nb 2>&1 | grep "^dft" | tee -a gpurun_out/r4d/phases.txt
+done
+( timeout 600 python bench.py --no-live-counters --no-cpu-baseline --no-end-to-end ) > gpurun_out/r4d/bench.json 2> gpurun_out/r4d/bench.err
+python - <<'PY'
+import json
+try:
+    d=json.loads([l for l in open("gpurun_out/r4d/bench.json") if l.startswith("{")][-1])
+    print({k:d[k] for k in ("value","ms_per_step","stages_ms")})
+    print({k:(v["avg_launch_ms"], v["frac"]) for k,v in d["roofline_other"].items()})
+    print("config", json.dumps({k:v for k,v in d["config"].items() if k.startswith(("classes_","pyramid"))}))
+    print("dev", d.get("max_abs_diff_vs_f32",{}).get("fftx3"))
+except Exception as e:
+    print("no bench line", e)
+PY

@@ -43,6 +43,9 @@
 #ifndef DFT_HD
 #define DFT_HD static inline      /* host + device helpers (the device build says __host__ __device__) */
 #endif
+#ifndef DFT_PREFETCH_SEGMENTED
+#define DFT_PREFETCH_SEGMENTED 0  /* 1: the next iteration's global loads between segments of a product (diagnostic: more registers) */
+#endif
 #ifndef DFT_SCHED_FENCE
 #define DFT_SCHED_FENCE()         /* device build: __builtin_amdgcn_sched_barrier(0) - the scheduler moves nothing across it */
 #endif
@@ -84,6 +87,8 @@ struct DftPlan {
   int MB;                          // G * (MA / 2) : rows of step B = (h, img)
   int KB;                          // 2 V rounded up to 16: k of step B
   int NBo;                         // columns of step B that are needed (ox + TW | W) rounded up to 32
+  int G;                           // images per work-group iteration of the FORWARD kernel this plan is for (4, or 2: two work-groups
+                                   // of 256 work items per CU); the inverse kernel always takes 4
   int eT;                          // ceil(log2 P) + 1
   int fast;                        // 1: W % 4 == 0 and untiled (16-byte loads of the correlation rows)
   unsigned inv_cg, inv_t, inv_tx, inv_c4, inv_v, inv_pq, inv_og, inv_kg, inv_pp;   // ceil(2^32 / d) (0 where d == 1)
@@ -105,7 +110,8 @@ DFT_HD size_t dft_matrices_units(int P, int Q) {
 }
 
 // plan of ONE transform: window LH x LW -> P x Q, RH rows of the inverse needed, NBo output columns needed
-static inline bool dft_plan_transform(int LH, int LW, int RH, int ncols, int minP, int minQ, DftPlan* pl) {
+static inline bool dft_plan_transform(int LH, int LW, int RH, int ncols, int minP, int minQ, int G, DftPlan* pl) {
+  pl->G = G;
   pl->P = dft_round_up(minP, 4);
   pl->Q = dft_round_up(minQ, 2);
   pl->V = pl->Q / 2 + 1;
@@ -117,8 +123,8 @@ static inline bool dft_plan_transform(int LH, int LW, int RH, int ncols, int min
   pl->Wk = dft_round_up(LW, 16);
   pl->N1 = dft_round_up(2 * pl->V, 32);
   pl->M2 = dft_round_up(2 * pl->P, 32);
-  pl->Mx = dft_round_up(DFT_G * pl->Pp, 32);
-  pl->N2 = dft_round_up(DFT_G * pl->V, 32);
+  pl->Mx = dft_round_up(G * pl->Pp, 32);
+  pl->N2 = dft_round_up(G * pl->V, 32);
   pl->MA = dft_round_up(2 * RH, 32);
   pl->MB = DFT_G * (pl->MA / 2);
   pl->KB = dft_round_up(2 * pl->V, 16);
@@ -131,13 +137,21 @@ static inline bool dft_plan_transform(int LH, int LW, int RH, int ncols, int min
   // the union region holds, one after the other, x | R2 | X staging (forward) and Y2 | Tt (inverse)
   const int fqt = (pl->Wk / 8) * 2 * pl->N1 * 16, gq = (pl->KB / 8) * 2 * pl->NBo * 16;
   const int x = (pl->Wk / 8) * 2 * (pl->Mx + 1) * 16, r2 = (2 * pl->Pp / 8) * 2 * (pl->N2 + 1) * 16;
-  const int xs = pl->V * (pl->P * 8 * DFT_G + 16);
+  const int xs = pl->V * (pl->P * 8 * G + 16);
   const int y2 = r2, tt = (pl->KB / 8) * 2 * (pl->MB + 1) * 16;
   int u = x;
   if (r2 > u) u = r2;
   if (xs > u) u = xs;
   if (y2 > u) u = y2;
   if (tt > u) u = tt;
+  if (G != DFT_G) {      // a forward-only plan: FqT + x | R2 | X staging
+    u = x > r2 ? x : r2;
+    if (xs > u) u = xs;
+    pl->lds_const = fqt;
+    pl->lds_union = dft_round_up(u, 256);
+    pl->lds_total = pl->lds_const + pl->lds_union;
+    return 2 * dft_round_up(pl->lds_total, 512) <= 160 * 1024;    // two work-groups per CU
+  }
   pl->lds_const = fqt > gq ? fqt : gq;
   pl->lds_union = dft_round_up(u, 256);
   pl->lds_total = pl->lds_const + pl->lds_union + 1024;      // + per-image maxima / scales
@@ -159,7 +173,7 @@ static inline void dft_set_tiles(DftPlan* pl, int H, int W, int TY, int TX, int 
   pl->inv_tx = dft_magic((unsigned)TX);
   pl->inv_c4 = dft_magic((unsigned)(pl->Wk / 4));
   pl->inv_v = dft_magic((unsigned)pl->V);
-  pl->inv_pq = dft_magic((unsigned)(pl->P / 4 * DFT_G * 2));
+  pl->inv_pq = dft_magic((unsigned)(pl->P / 4 * pl->G * 2));
   pl->inv_kg = dft_magic((unsigned)(pl->Pp / 8));
   pl->inv_pp = dft_magic((unsigned)pl->Pp);
 }
@@ -180,7 +194,7 @@ static const DftSize DFT_CANONICAL[6] = {{36, 46}, {44, 54}, {48, 62}, {52, 68},
 // The whole map in one transform when it fits (P >= H + 3, Q >= W + 3: the zero padding is the halo), otherwise the tiling
 // with the fewest bins in total; an axis is either untiled or cut into >= 2 tiles of ceil(n / k) outputs whose window is 6
 // longer.
-static inline bool dft_make_plan_policy(int H, int W, int canonical, DftPlan* out) {
+static inline bool dft_make_plan_policy(int H, int W, int canonical, DftPlan* out, int G = DFT_G) {
   bool found = false;
   long best = 0;
   for (int TY = 1; TY <= 48; ++TY)
@@ -194,7 +208,7 @@ static inline bool dft_make_plan_policy(int H, int W, int canonical, DftPlan* ou
         if (canonical && (DFT_CANONICAL[k].P < minP || DFT_CANONICAL[k].Q < minQ)) continue;
         DftPlan c = {};
         if (!dft_plan_transform(LH, LW, TY > 1 ? TH + 3 : H, TX > 1 ? TW + 3 : W, canonical ? DFT_CANONICAL[k].P : minP,
-                                canonical ? DFT_CANONICAL[k].Q : minQ, &c))
+                                canonical ? DFT_CANONICAL[k].Q : minQ, G, &c))
           continue;
         dft_set_tiles(&c, H, W, TY, TX, TH, TW);
         const long cost = (long)c.T * c.NBINS;
@@ -220,6 +234,21 @@ static inline int dft_size_policy() {
 static inline int dft_size_policy() { return emu_dft_policy; }
 #endif
 static inline bool dft_make_plan(int H, int W, DftPlan* out) { return dft_make_plan_policy(H, W, dft_size_policy(), out); }
+// The forward kernel's plan with G images per iteration: the SAME tiling and transform size as dft_make_plan (the spectra layouts
+// must agree with the GEMM's and the inverse kernel's), its own operand sizes; false when two such work-groups do not fit a CU.
+static inline bool dft_make_forward_plan(int H, int W, int G, DftPlan* out) {
+  DftPlan base;
+  if (!dft_make_plan(H, W, &base)) return false;
+  if (G == DFT_G) {
+    *out = base;
+    return true;
+  }
+  DftPlan c = {};
+  if (!dft_plan_transform(base.LH, base.LW, base.RH, base.TX > 1 ? base.TW + 3 : W, base.P, base.Q, G, &c)) return false;
+  dft_set_tiles(&c, H, W, base.TY, base.TX, base.TH, base.TW);
+  *out = c;
+  return true;
+}
 
 // ---------------------------------------------------------------------------------------------------- device helpers
 DFT_DEV int dft_div(int x, unsigned magic) { return magic ? (int)(((unsigned long long)(unsigned)x * magic) >> 32) : x; }
@@ -254,38 +283,48 @@ DFT_DEV f32x16v dft_mma3(half8 ah, half8 al, half8 bh, half8 bl, f32x16v acc) {
 // requested before the matrix instructions of k-step ks (round 4, first version: a uniform branch per k-step and tile made
 // every scheduling region one read-wait-multiply sequence; measured 5.1 us for 2.2 us of matrix time).
 template <int NT>
-DFT_DEV void dft_product_rega(f32x16v* acc, const half8* ah, const half8* al, int ksn, const u32x4v* B, int bstride, int nt0, int ntstep,
-                              int l31, int hw) {
-  // one column tile after the other (A is in registers: no fragment is read twice); the k loop is unrolled over the register
-  // arrays with a wave-uniform guard per k-step
+DFT_DEV void dft_product_rega(f32x16v* acc, const half8* ah, const half8* al, int ks0, int ks1, const u32x4v* B, int bstride, int nt0,
+                              int ntstep, int l31, int hw) {
+  // k-steps [ks0, ks1) (callers cut a product into segments and issue the next iteration's global loads between them).  The
+  // tiles of a k-step are INDEPENDENT accumulators interleaved in the matrix pipe: one tile after the other - a chain of 3 K
+  // dependent instructions - measured 5.7 against 5.1 us
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const u32x4v* Bj = B + (size_t)(hw * 2) * bstride + (nt0 + ntstep * j) * 32 + l31;
+  for (int ks = 0; ks < DFT_KREG; ++ks) {
+    if (ks >= ks0 && ks < ks1) {
+      half8 bh[NT], bl[NT];
 #pragma unroll
-    for (int ks = 0; ks < DFT_KREG; ++ks) {
-      if (ks < ksn) {
-        const half8 bh = dft_frag(Bj + (size_t)(4 * ks) * bstride), bl = dft_frag(Bj + (size_t)(4 * ks + 1) * bstride);
-        acc[j] = dft_mma3(ah[ks], al[ks], bh, bl, acc[j]);
+      for (int j = 0; j < NT; ++j) {
+        bh[j] = dft_frag(B + (size_t)((2 * ks + hw) * 2 + 0) * bstride + (nt0 + ntstep * j) * 32 + l31);
+        bl[j] = dft_frag(B + (size_t)((2 * ks + hw) * 2 + 1) * bstride + (nt0 + ntstep * j) * 32 + l31);
       }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = dft_mma3(ah[ks], al[ks], bh[j], bl[j], acc[j]);
     }
   }
+}
+
+DFT_DEV void dft_product_rega_any(f32x16v* acc, int ntiles, const half8* ah, const half8* al, int ks0, int ks1, const u32x4v* B, int bstride,
+                                  int nt0, int ntstep, int l31, int hw) {
+  if (ntiles == 3) dft_product_rega<3>(acc, ah, al, ks0, ks1, B, bstride, nt0, ntstep, l31, hw);
+  else if (ntiles == 2) dft_product_rega<2>(acc, ah, al, ks0, ks1, B, bstride, nt0, ntstep, l31, hw);
+  else if (ntiles == 1) dft_product_rega<1>(acc, ah, al, ks0, ks1, B, bstride, nt0, ntstep, l31, hw);
 }
 
 // acc[j] += A[row tile mt_j] . B[column tile nt_j], both operands in LDS, tiles t = t0 + 8 j of a grid of mtn row tiles;
 // SHARE: all NT tiles have the same row tile (mtn == 8): its A fragment is read once per k-step.  Straight-line code, as above
 // (double-buffering these fragments in the source as well costs 120 spilled registers: the compiler hoists what fits).
-template <int NT, bool SHARE>
-DFT_DEV void dft_product_lds(f32x16v* acc, int ksn, const u32x4v* A, int astride, const u32x4v* B, int bstride, int t0, int mtn, int l31,
-                             int hw) {
+template <int NT, bool SHARE, int NW>
+DFT_DEV void dft_product_lds(f32x16v* acc, int ks0, int ks1, const u32x4v* A, int astride, const u32x4v* B, int bstride, int t0, int mtn,
+                             int l31, int hw) {
   constexpr int NA = SHARE ? 1 : NT;
   int tm[NT], tn[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int t = t0 + DFT_WAVES * j;
+    const int t = t0 + NW * j;
     tn[j] = t / mtn;
     tm[j] = t - tn[j] * mtn;
   }
-  for (int ks = 0; ks < ksn; ++ks) {
+  for (int ks = ks0; ks < ks1; ++ks) {
     half8 ah[NA], al[NA], bh[NT], bl[NT];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
@@ -302,17 +341,18 @@ DFT_DEV void dft_product_lds(f32x16v* acc, int ksn, const u32x4v* A, int astride
   }
 }
 
-DFT_DEV void dft_product_lds_any(f32x16v* acc, int ntiles, int ksn, const u32x4v* A, int astride, const u32x4v* B, int bstride, int t0,
-                                 int mtn, int l31, int hw) {
-  const bool share = mtn == DFT_WAVES;
+template <int NW>
+DFT_DEV void dft_product_lds_any(f32x16v* acc, int ntiles, int ks0, int ks1, const u32x4v* A, int astride, const u32x4v* B, int bstride,
+                                 int t0, int mtn, int l31, int hw) {
+  const bool share = mtn == NW;
   if (ntiles == 3) {
-    if (share) dft_product_lds<3, true>(acc, ksn, A, astride, B, bstride, t0, mtn, l31, hw);
-    else dft_product_lds<3, false>(acc, ksn, A, astride, B, bstride, t0, mtn, l31, hw);
+    if (share) dft_product_lds<3, true, NW>(acc, ks0, ks1, A, astride, B, bstride, t0, mtn, l31, hw);
+    else dft_product_lds<3, false, NW>(acc, ks0, ks1, A, astride, B, bstride, t0, mtn, l31, hw);
   } else if (ntiles == 2) {
-    if (share) dft_product_lds<2, true>(acc, ksn, A, astride, B, bstride, t0, mtn, l31, hw);
-    else dft_product_lds<2, false>(acc, ksn, A, astride, B, bstride, t0, mtn, l31, hw);
+    if (share) dft_product_lds<2, true, NW>(acc, ks0, ks1, A, astride, B, bstride, t0, mtn, l31, hw);
+    else dft_product_lds<2, false, NW>(acc, ks0, ks1, A, astride, B, bstride, t0, mtn, l31, hw);
   } else if (ntiles == 1) {
-    dft_product_lds<1, true>(acc, ksn, A, astride, B, bstride, t0, mtn, l31, hw);
+    dft_product_lds<1, true, NW>(acc, ks0, ks1, A, astride, B, bstride, t0, mtn, l31, hw);
   }
 }
 
@@ -382,22 +422,24 @@ DFT_DEV void dft_matrix_unit(int which, int unit, int P, int Q, const double* tw
 
 // ---------------------------------------------------------------------------------------------------- forward transform
 // iteration it -> (pair' = it / CG, channel group cg = it % CG), pair' = nb * T + tile; channels 4 cg .. 4 cg + 3
-template <bool TILED, bool FAST>
+template <bool TILED, bool FAST, int G, int NW>
 DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
                               const float* invn,      // [NB][H * W]
                               float* X,               // [NBINS / 4][NBT][Cpad][4][2]
                               const u32x4v* FqT, const u32x4v* Fp2, const DftPlan& pl, int C, int Cpad, int NBT, int iters) {
+  constexpr int THR = NW * 64;     // G = 4: 8 waves, one work-group per CU; G = 2: 4 waves, TWO independent work-groups per CU -
+                                   // their phases (VALU conversions, LDS-bound and matrix-bound products, stores) overlap
   unsigned char* smem = DFT_LDS;
   const int tid = DFT_TID, lane = tid & 63, l31 = lane & 31, hw = lane >> 5;
   const int wv = DFT_UNIFORM(tid >> 6);      // wave-uniform (a scalar register): the tile ownership below is real branching, not exec masks
   const int P = pl.P, V = pl.V, Pp = pl.Pp, Wk = pl.Wk, N1 = pl.N1, Mx = pl.Mx, N2 = pl.N2, LH = pl.LH, LW = pl.LW, W = pl.W, H = pl.H;
   const int MxS = Mx + 1, N2S = N2 + 1;
-  const int CG = (C + DFT_G - 1) / DFT_G, HW = H * W;
+  const int CG = (C + G - 1) / G, HW = H * W;
   u32x4v* ldsF = reinterpret_cast<u32x4v*>(smem);                                   // FqT [Wk / 8][2][N1]
   u32x4v* ldsU = reinterpret_cast<u32x4v*>(smem + pl.lds_const);                    // x | R2 | X staging
   unsigned char* ldsUb = smem + pl.lds_const;
   const int nF = (Wk / 8) * 2 * N1;
-  for (int i = tid; i < nF; i += DFT_THR) ldsF[i] = FqT[i];
+  for (int i = tid; i < nF; i += THR) ldsF[i] = FqT[i];
 
   // the wave's tiles.  step 1: (row tile of x, column tile of FqT), round robin - with 8 row tiles a wave keeps ONE row tile
   // and its A fragment serves all column tiles; step 2: row tile wv & 3 of Fp2 in REGISTERS, column tiles (wv >> 2) + 2 j
@@ -414,30 +456,31 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
 
   // ---- register prefetch of the next iteration's window: position slot s of a thread = (row r, 4 columns c4) of the window,
   // all G images; raw values only (any arithmetic here would make the compiler wait for each load where it is issued)
-  constexpr int NSLOT = 3;                                     // ceil(Pp * Wk / 4 / 512) <= 64 * 24 / 512
+  constexpr int NSLOT = 3 * 512 / THR;                         // ceil(Pp * Wk / 4 / THR) <= 64 * 24 / THR
   const int npos = Pp * (Wk / 4);
-  f32x4v pc[NSLOT][DFT_G], pn[NSLOT];
+  f32x4v pc[NSLOT][G], pn[NSLOT];
 #define DFT_FWD_ITER(IT)                                                                                     \
   const int pr_ = dft_div((IT), pl.inv_cg), cg_ = (IT)-pr_ * CG;                                             \
   const int nb_ = TILED ? dft_div(pr_, pl.inv_t) : pr_, tile_ = TILED ? pr_ - nb_ * pl.T : 0;               \
   const int ty_ = TILED ? dft_div(tile_, pl.inv_tx) : 0, tx_ = TILED ? tile_ - ty_ * pl.TX : 0;             \
   const int Y0 = TILED ? ty_ * pl.TH - pl.oy : 0, X0 = TILED ? tx_ * pl.TW - pl.ox : 0;                     \
-  const int c0_ = cg_ * DFT_G;
+  const int c0_ = cg_ * G;
 #define DFT_FWD_POS(TID, S)                                                                                  \
-  const int i_ = (TID) + (S)*DFT_THR;                                                                        \
+  const int i_ = (TID) + (S)*THR;                                                                        \
   const int r_ = dft_div(i_, pl.inv_c4), c4_ = i_ - r_ * (Wk / 4);                                          \
   const int y_ = Y0 + r_, x_ = X0 + 4 * c4_;
   // (a macro, not a lambda: register arrays captured by a closure end up in scratch memory with this compiler)
-#define DFT_FWD_PREFETCH(IT, TID)                                                                            \
+#define DFT_FWD_PREFETCH(IT, TID) DFT_FWD_PREFETCH_SLOTS(IT, TID, 0, NSLOT)
+#define DFT_FWD_PREFETCH_SLOTS(IT, TID, S0, S1)                                                              \
   {                                                                                                          \
     DFT_FWD_ITER(IT)                                                                                         \
-    _Pragma("unroll") for (int s = 0; s < NSLOT; ++s) {                                                      \
+    _Pragma("unroll") for (int s = (S0); s < (S1); ++s) {                                                    \
       DFT_FWD_POS(TID, s)                                                                                    \
       if (FAST) {                                                                                            \
         const bool ok = i_ < npos && r_ < LH && 4 * c4_ < LW;                                                \
         const int off = ok ? y_ * W + x_ : 0;                                                                \
         pn[s] = *reinterpret_cast<const f32x4v*>(invn + (size_t)nb_ * HW + off);                             \
-        _Pragma("unroll") for (int g = 0; g < DFT_G; ++g) {                                                  \
+        _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                  \
           const int c = c0_ + g < C ? c0_ + g : C - 1;                                                       \
           pc[s][g] = *reinterpret_cast<const f32x4v*>(corr + ((size_t)nb_ * C + c) * HW + off);              \
         }                                                                                                    \
@@ -447,7 +490,7 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
           const bool ok = rok && 4 * c4_ + e < LW && x_ + e >= 0 && x_ + e < W;                              \
           const int off = ok ? y_ * W + x_ + e : 0;                                                          \
           pn[s][e] = invn[(size_t)nb_ * HW + off];                                                           \
-          _Pragma("unroll") for (int g = 0; g < DFT_G; ++g) {                                                \
+          _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                \
             const int c = c0_ + g < C ? c0_ + g : C - 1;                                                     \
             pc[s][g][e] = corr[((size_t)nb_ * C + c) * HW + off];                                            \
           }                                                                                                  \
@@ -482,7 +525,7 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
             nsc[e] = ok ? pn[s][e] * 32768.0f : 0.f;
           }
 #pragma unroll
-          for (int g = 0; g < DFT_G; ++g) {
+          for (int g = 0; g < G; ++g) {
             u32x2v hi = {0u, 0u}, lo = {0u, 0u};
             if (c0_ + g < C)         // (uniform: only the last channel group of a pair has channels beyond C)
               dft_split4(fmaxf(pc[s][g][0], 0.f) * nsc[0], fmaxf(pc[s][g][1], 0.f) * nsc[1], fmaxf(pc[s][g][2], 0.f) * nsc[2],
@@ -495,8 +538,8 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
         }
       }
       // rows G * Pp .. Mx of the last row tile (only when G * Pp is not a multiple of 32): zeros
-      for (int i = tid; i < (Mx - DFT_G * Pp) * (Wk / 8) * 2; i += DFT_THR) {
-        const int m = DFT_G * Pp + i % (Mx - DFT_G * Pp), kh = i / (Mx - DFT_G * Pp);
+      for (int i = tid; i < (Mx - G * Pp) * (Wk / 8) * 2; i += THR) {
+        const int m = G * Pp + i % (Mx - G * Pp), kh = i / (Mx - G * Pp);
         ldsU[(size_t)kh * MxS + m] = u32x4v{0u, 0u, 0u, 0u};
       }
     }
@@ -509,7 +552,7 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
     int nt1w = 0;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const int t = wv + DFT_WAVES * j;
+      const int t = wv + NW * j;
       const bool mine = t < mt1n * nt1n;
       tn[j] = mine ? t / mt1n : 0;
       tm[j] = mine ? t - tn[j] * mt1n : -1;
@@ -517,7 +560,21 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     }
-    dft_product_lds_any(acc, nt1w, ks1n, ldsU, MxS, ldsF, N1, wv, mt1n, l31, hw);
+    // (diagnostic DFT_PREFETCH_SEGMENTED: in three segments with the loads of the next window's position slots between them -
+    // in one burst, 8 waves x 15 loads hold the matrix instructions behind them up - but the loaded values then live through
+    // both products: 120 spilled registers)
+    if (DFT_PREFETCH_SEGMENTED) {
+      const int ka = (ks1n + 2) / 3, kb = (2 * ks1n + 2) / 3;
+      const bool more = it + DFT_GRID < iters;
+      dft_product_lds_any<NW>(acc, nt1w, 0, ka, ldsU, MxS, ldsF, N1, wv, mt1n, l31, hw);
+      if (more) DFT_FWD_PREFETCH_SLOTS(it + DFT_GRID, tl, 0, 1)
+      dft_product_lds_any<NW>(acc, nt1w, ka, kb, ldsU, MxS, ldsF, N1, wv, mt1n, l31, hw);
+      if (more) DFT_FWD_PREFETCH_SLOTS(it + DFT_GRID, tl, 1, 2)
+      dft_product_lds_any<NW>(acc, nt1w, kb, ks1n, ldsU, MxS, ldsF, N1, wv, mt1n, l31, hw);
+      if (more) DFT_FWD_PREFETCH_SLOTS(it + DFT_GRID, tl, 2, 3)
+    } else {
+      dft_product_lds_any<NW>(acc, nt1w, 0, ks1n, ldsU, MxS, ldsF, N1, wv, mt1n, l31, hw);
+    }
     DFT_BARRIER();      // every wave is done reading x: the region becomes R2
     DFT_STAMP(1)
 
@@ -533,7 +590,7 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
         // the division is wave-uniform (scalar unit, by multiplication)
         const int mb = tm[j] * 32 + 8 * q;
         const int img = dft_div(mb, pl.inv_pp), h0 = mb - img * Pp + 4 * hw;
-        if (v < V && img < DFT_G) {
+        if (v < V && img < G) {
           u32x2v hi, lo;
           const float sc = 1.0f / 2097152.0f;      // 2^-21 = 2^8 / (2^15 * 2^14)
           dft_split4(acc[j][4 * q] * sc, acc[j][4 * q + 1] * sc, acc[j][4 * q + 2] * sc, acc[j][4 * q + 3] * sc, &hi, &lo);
@@ -546,9 +603,6 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
     }
     DFT_BARRIER();
     DFT_STAMP(2)
-    // the next window's loads are issued here - the accumulators of step 1 are dead, the values are needed a whole step 2 +
-    // store phase later - so that their registers do not overlap the first product's
-    if (it + DFT_GRID < iters) DFT_FWD_PREFETCH(it + DFT_GRID, tl)
 
     // ---- step 2: X = Fp2 . R2 (Fp2 fragments in registers); this wave's column tiles (wv >> 2) + 2 j of row tile wv & 3
     f32x16v xc[3];
@@ -556,22 +610,23 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
     int nt2w = 0;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const int nt = (wv >> 2) + 2 * j;
+      const int nt = (wv >> 2) + (NW / 4) * j;
       const bool mine = nt < nt2n && mt2 < mt2n;
       un[j] = mine ? nt : -1;
       nt2w += mine ? 1 : 0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) xc[j][r] = 0.f;
     }
-    if (nt2w == 3) dft_product_rega<3>(xc, fp2h, fp2l, ks2n, ldsU, N2S, wv >> 2, 2, l31, hw);
-    else if (nt2w == 2) dft_product_rega<2>(xc, fp2h, fp2l, ks2n, ldsU, N2S, wv >> 2, 2, l31, hw);
-    else if (nt2w == 1) dft_product_rega<1>(xc, fp2h, fp2l, ks2n, ldsU, N2S, wv >> 2, 2, l31, hw);
+    // the next window's loads are issued here - the accumulators of step 1 are dead, the values are needed a whole step 2 +
+    // store phase later - so that their registers do not overlap the first product's
+    if (!DFT_PREFETCH_SEGMENTED && it + DFT_GRID < iters) DFT_FWD_PREFETCH(it + DFT_GRID, tl)
+    dft_product_rega_any(xc, nt2w, fp2h, fp2l, 0, ks2n, ldsU, N2S, wv >> 2, NW / 4, l31, hw);
     DFT_BARRIER();      // every wave is done reading R2: the region becomes the staging buffer of X
     DFT_STAMP(3)
 
     // ---- XS: X = acc * 2^-22 staged as [v][u / 4][img][u % 4][re|im] (+16 bytes per v: consecutive lanes = consecutive v land
     // in different banks); a lane owns (img, v) and per accumulator run two consecutive u
-    const int XS = P * 8 * DFT_G + 16;
+    const int XS = P * 8 * G + 16;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       if (un[j] < 0) continue;
@@ -580,14 +635,14 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int u0 = (mt2 * 32 + 8 * q + 4 * hw) >> 1;
-        if (img < DFT_G && u0 < P) {
+        if (img < G && u0 < P) {
           const float sc = 1.0f / 4194304.0f;      // 2^-22 = 1 / (2^8 * 2^14)
           f32x4v o;
           o[0] = xc[j][4 * q] * sc;
           o[1] = xc[j][4 * q + 1] * sc;
           o[2] = xc[j][4 * q + 2] * sc;
           o[3] = xc[j][4 * q + 3] * sc;
-          *reinterpret_cast<f32x4v*>(ldsUb + (size_t)v * XS + (u0 >> 2) * (DFT_G * 32) + img * 32 + (u0 & 3) * 8) = o;
+          *reinterpret_cast<f32x4v*>(ldsUb + (size_t)v * XS + (u0 >> 2) * (G * 32) + img * 32 + (u0 & 3) * 8) = o;
         }
       }
     }
@@ -596,18 +651,18 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
 
     // ---- ST: 16-byte pieces, 8 per quad of bins = the 128 contiguous bytes of the 4 channels; then the padding bins
     {
-      const int per_v = (P / 4) * (DFT_G * 2), npieces = V * per_v;
+      const int per_v = (P / 4) * (G * 2), npieces = V * per_v;
       float* dstbase = X + ((size_t)pr_ * Cpad + c0_) * 8;
       const size_t qstride = (size_t)NBT * Cpad * 8;             // floats between consecutive quads of bins
-      for (int i = tl; i < npieces; i += DFT_THR) {
+      for (int i = tl; i < npieces; i += THR) {
         const int v = dft_div(i, pl.inv_pq), rem = i - v * per_v;
-        const int uq = rem >> 3, jj = rem & 7;
-        const f32x4v val = *reinterpret_cast<const f32x4v*>(ldsUb + (size_t)v * XS + uq * (DFT_G * 32) + jj * 16);
+        const int uq = rem / (2 * G), jj = rem - uq * (2 * G);
+        const f32x4v val = *reinterpret_cast<const f32x4v*>(ldsUb + (size_t)v * XS + uq * (G * 32) + jj * 16);
         *reinterpret_cast<f32x4v*>(dstbase + (size_t)(v * (P / 4) + uq) * qstride + jj * 4) = val;
       }
       const int qpad0 = (P * V) / 4, qpad1 = pl.NBINS / 4;
-      for (int i = tl; i < (qpad1 - qpad0) * 8; i += DFT_THR)
-        *reinterpret_cast<f32x4v*>(dstbase + (size_t)(qpad0 + (i >> 3)) * qstride + (i & 7) * 4) = f32x4v{0.f, 0.f, 0.f, 0.f};
+      for (int i = tl; i < (qpad1 - qpad0) * 2 * G; i += THR)
+        *reinterpret_cast<f32x4v*>(dstbase + (size_t)(qpad0 + i / (2 * G)) * qstride + (i % (2 * G)) * 4) = f32x4v{0.f, 0.f, 0.f, 0.f};
     }
     DFT_BARRIER();      // the staging buffer is free: the next window may be written
     DFT_STAMP(5)
@@ -616,6 +671,7 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
 #undef DFT_FWD_ITER
 #undef DFT_FWD_POS
 #undef DFT_FWD_PREFETCH
+#undef DFT_FWD_PREFETCH_SLOTS
 }
 
 // ---------------------------------------------------------------------------------------------------- inverse transform
@@ -659,11 +715,12 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBINS / 4][NBT][Cout][4
   const int uoct = Pp / 8, nitem = DFT_G * V * uoct;
   f32x4v py[NITEM][4];
   const size_t qstride = (size_t)NBT * Cout * 8;
-#define DFT_INV_PREFETCH(IT, TID)                                                           \
+#define DFT_INV_PREFETCH(IT, TID) DFT_INV_PREFETCH_ITEMS(IT, TID, 0, NITEM)
+#define DFT_INV_PREFETCH_ITEMS(IT, TID, S0, S1)                                             \
   {                                                                                         \
     const int pr_ = dft_div((IT), pl.inv_og), og_ = (IT)-pr_ * OG;                          \
     const float* src_ = Y + ((size_t)pr_ * Cout + og_ * DFT_G) * 8;                         \
-    _Pragma("unroll") for (int s = 0; s < NITEM; ++s) {                                     \
+    _Pragma("unroll") for (int s = (S0); s < (S1); ++s) {                                   \
       const int e_ = (TID) + s * DFT_THR;                                                   \
       const int ec_ = e_ < nitem ? e_ : 0;                                                  \
       const int pimg_ = ec_ & (DFT_G - 1), prest_ = ec_ >> 2;                               \
@@ -777,7 +834,6 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBINS / 4][NBT][Cout][4
     }
     DFT_BARRIER();
     DFT_STAMP(1)
-    if (it + DFT_GRID < iters) DFT_INV_PREFETCH(it + DFT_GRID, tl)
 
     // ---- step A: T = E2 . Y2 (E2 fragments in registers)
     f32x16v ta[3];
@@ -792,9 +848,19 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBINS / 4][NBT][Cout][4
 #pragma unroll
       for (int r = 0; r < 16; ++r) ta[j][r] = 0.f;
     }
-    if (ntaw == 3) dft_product_rega<3>(ta, e2h, e2l, ksAn, ldsU, N2S, wv >> 2, 2, l31, hw);
-    else if (ntaw == 2) dft_product_rega<2>(ta, e2h, e2l, ksAn, ldsU, N2S, wv >> 2, 2, l31, hw);
-    else if (ntaw == 1) dft_product_rega<1>(ta, e2h, e2l, ksAn, ldsU, N2S, wv >> 2, 2, l31, hw);
+    if (!DFT_PREFETCH_SEGMENTED) {
+      if (it + DFT_GRID < iters) DFT_INV_PREFETCH(it + DFT_GRID, tl)
+      dft_product_rega_any(ta, ntaw, e2h, e2l, 0, ksAn, ldsU, N2S, wv >> 2, 2, l31, hw);
+    } else {   // in three segments with the next spectra's loads (one item each) between them, see the forward kernel
+      const int ka = (ksAn + 2) / 3, kb = (2 * ksAn + 2) / 3;
+      const bool more = it + DFT_GRID < iters;
+      dft_product_rega_any(ta, ntaw, e2h, e2l, 0, ka, ldsU, N2S, wv >> 2, 2, l31, hw);
+      if (more) DFT_INV_PREFETCH_ITEMS(it + DFT_GRID, tl, 0, 1)
+      dft_product_rega_any(ta, ntaw, e2h, e2l, ka, kb, ldsU, N2S, wv >> 2, 2, l31, hw);
+      if (more) DFT_INV_PREFETCH_ITEMS(it + DFT_GRID, tl, 1, 2)
+      dft_product_rega_any(ta, ntaw, e2h, e2l, kb, ksAn, ldsU, N2S, wv >> 2, 2, l31, hw);
+      if (more) DFT_INV_PREFETCH_ITEMS(it + DFT_GRID, tl, 2, 3)
+    }
     DFT_BARRIER();      // every wave is done reading Y2: the region becomes Tt
     DFT_STAMP(2)
 
@@ -845,7 +911,7 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBINS / 4][NBT][Cout][4
 #pragma unroll
       for (int r = 0; r < 16; ++r) yc[j][r] = 0.f;
     }
-    dft_product_lds_any(yc, ntbw, ksBn, ldsU, MBS, ldsG, NBo, wv, mtBn, l31, hw);
+    dft_product_lds_any<DFT_WAVES>(yc, ntbw, 0, ksBn, ldsU, MBS, ldsG, NBo, wv, mtBn, l31, hw);
     DFT_STAMP(4)
 
     // ---- epilogue: a lane owns window column w and, per accumulator run, the 4 channels of one row: + bias, ReLU, channel
@@ -894,6 +960,7 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBINS / 4][NBT][Cout][4
   }
 #undef DFT_INV_ITEM
 #undef DFT_INV_PREFETCH
+#undef DFT_INV_PREFETCH_ITEMS
 }
 
 }  // namespace os2d_dft

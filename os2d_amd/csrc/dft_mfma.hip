@@ -45,12 +45,12 @@ namespace {
 
 using namespace os2d_dft;
 
-template <bool TILED, bool FAST>
-__global__ __launch_bounds__(DFT_THR, 1) void dft_forward_kernel(const float* __restrict__ corr, const float* __restrict__ invn,
-                                                                 float* __restrict__ X, const u32x4v* __restrict__ FqT,
-                                                                 const u32x4v* __restrict__ Fp2, DftPlan pl, int C, int Cpad, int NBT,
-                                                                 int iters) {
-  dft_forward_body<TILED, FAST>(corr, invn, X, FqT, Fp2, pl, C, Cpad, NBT, iters);
+template <bool TILED, bool FAST, int G, int NW>
+__global__ __launch_bounds__(NW * 64, 8 / NW) void dft_forward_kernel(const float* __restrict__ corr, const float* __restrict__ invn,
+                                                                      float* __restrict__ X, const u32x4v* __restrict__ FqT,
+                                                                      const u32x4v* __restrict__ Fp2, DftPlan pl, int C, int Cpad, int NBT,
+                                                                      int iters) {
+  dft_forward_body<TILED, FAST, G, NW>(corr, invn, X, FqT, Fp2, pl, C, Cpad, NBT, iters);
 }
 
 template <bool TILED>
@@ -81,9 +81,23 @@ int dft_check(const char* what) {
   return 0;
 }
 
-int dft_grid(int iters) {
-  int g = iters < 256 ? iters : 256;            // one work-group per CU (126 - 137 KB of LDS)
+int dft_grid(int iters, int per_cu = 1) {
+  int g = iters < 256 * per_cu ? iters : 256 * per_cu;      // work-groups resident on the chip at once (126 - 137 KB of LDS each, or 2 x 80)
   return (g + 7) / 8 * 8;                       // multiple of 8: XCD-aware iteration order
+}
+
+// images per iteration of the forward kernel: 4 (one 8-wave work-group per CU).  $OS2D_DFT_FORWARD_G = 2 selects the other
+// shape - 2 images, 4 waves, TWO independent work-groups per CU when they fit its LDS - which was built to let the phases of two
+// groups overlap and measured no faster (profiles/r04/dft_phases_g2.txt: an iteration of 2 images takes 14.4 us against 15.0 us
+// for 4: 0.261 vs 0.244 ms per 64 pairs standalone): every phase is bound by a CU-wide resource (VALU conversions, LDS reads,
+// the matrix pipe at the ~50 % of its peak rate this chip sustains), not by latency that a second group could hide.
+int dft_forward_g(int H, int W, DftPlan* pl) {
+  static const int pinned = [] {
+    const char* e = getenv("OS2D_DFT_FORWARD_G");
+    return e ? atoi(e) : 0;
+  }();
+  if (pinned == 2 && dft_make_forward_plan(H, W, 2, pl)) return 2;
+  return dft_make_forward_plan(H, W, DFT_G, pl) ? DFT_G : 0;
 }
 
 }  // namespace
@@ -123,7 +137,8 @@ int os2d_launch_dft_matrices(const double* twP64, const double* twQ64, int P, in
 int os2d_launch_dft_forward(const float* corr, const float* inv, float* X, const void* matrices, int NB, int C, int Cpad, int H, int W,
                             hipStream_t stream) {
   DftPlan pl;
-  if (!dft_make_plan(H, W, &pl)) {
+  const int G = dft_forward_g(H, W, &pl);
+  if (!G) {
     os2d_set_error("dft_forward: no transform plan for a %dx%d map", H, W);
     return -3;
   }
@@ -131,17 +146,19 @@ int os2d_launch_dft_forward(const float* corr, const float* inv, float* X, const
     os2d_set_error("dft_forward: channel stride %d < %d", Cpad, dft_round_up(C, DFT_G));
     return -1;
   }
-  const int CG = (C + DFT_G - 1) / DFT_G, NBT = NB * pl.T, iters = NBT * CG;
+  const int CG = (C + G - 1) / G, NBT = NB * pl.T, iters = NBT * CG;
   pl.inv_cg = dft_magic((unsigned)CG);
   const u32x4v* FqT = static_cast<const u32x4v*>(matrices);
   const u32x4v* Fp2 = FqT + dft_units_fqt(pl.P, pl.Q);
-  auto kern = pl.T > 1 ? dft_forward_kernel<true, false> : (pl.fast ? dft_forward_kernel<false, true> : dft_forward_kernel<false, false>);
+  auto kern = G == 2 ? (pl.T > 1 ? dft_forward_kernel<true, false, 2, 4> : (pl.fast ? dft_forward_kernel<false, true, 2, 4> : dft_forward_kernel<false, false, 2, 4>))
+                     : (pl.T > 1 ? dft_forward_kernel<true, false, 4, 8> : (pl.fast ? dft_forward_kernel<false, true, 4, 8> : dft_forward_kernel<false, false, 4, 8>));
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds_total);
   if (e != hipSuccess) {
     os2d_set_error("hipFuncSetAttribute(dft_forward): %s", hipGetErrorString(e));
     return -4;
   }
-  hipLaunchKernelGGL(kern, dim3(dft_grid(iters)), dim3(DFT_THR), pl.lds_total, stream, corr, inv, X, FqT, Fp2, pl, C, Cpad, NBT, iters);
+  hipLaunchKernelGGL(kern, dim3(dft_grid(iters, G == 2 ? 2 : 1)), dim3(G == 2 ? 256 : DFT_THR), pl.lds_total, stream, corr, inv, X, FqT, Fp2, pl,
+                     C, Cpad, NBT, iters);
   return dft_check("dft_forward");
 }
 

@@ -67,13 +67,27 @@ static int check_case(int H, int W, int C, int NB, int grid) {
   for (auto& v : corr) v = (float)(frand(seed) * 2.0 - 0.7);
   for (auto& v : invn) v = (float)(0.2 + 0.5 * frand(seed));          // relu(corr) * invn <= 1.3 * 0.7 < 1
   std::vector<float> X((size_t)(pl.NBINS / 4) * NBT * Cpad * 8, 777.0f);
-  const int CG = (C + DFT_G - 1) / DFT_G, iters = NBT * CG;
-  pl.inv_cg = dft_magic((unsigned)CG);
-  emu::launch(grid, DFT_THR, pl.lds_total, [&] {
-    if (pl.T > 1) dft_forward_body<true, false>(corr.data(), invn.data(), X.data(), FqT, Fp2, pl, C, Cpad, NBT, iters);
-    else if (pl.fast) dft_forward_body<false, true>(corr.data(), invn.data(), X.data(), FqT, Fp2, pl, C, Cpad, NBT, iters);
-    else dft_forward_body<false, false>(corr.data(), invn.data(), X.data(), FqT, Fp2, pl, C, Cpad, NBT, iters);
-  });
+  // both shapes of the forward kernel: 4 images per iteration / 8 waves, and (when two such work-groups fit a CU) 2 images / 4 waves
+  for (int G = 4; G >= 2; G -= 2) {
+    DftPlan fp;
+    if (!dft_make_forward_plan(H, W, G, &fp)) {
+      std::printf("  (no G = %d forward plan: %d bytes of LDS)\n", G, fp.lds_total);
+      continue;
+    }
+    const int CGf = (C + G - 1) / G, itf = NBT * CGf;
+    fp.inv_cg = dft_magic((unsigned)CGf);
+    std::fill(X.begin(), X.end(), 777.0f);
+    emu::launch(grid, G == 4 ? 512 : 256, fp.lds_total, [&] {
+      if (G == 4) {
+        if (fp.T > 1) dft_forward_body<true, false, 4, 8>(corr.data(), invn.data(), X.data(), FqT, Fp2, fp, C, Cpad, NBT, itf);
+        else if (fp.fast) dft_forward_body<false, true, 4, 8>(corr.data(), invn.data(), X.data(), FqT, Fp2, fp, C, Cpad, NBT, itf);
+        else dft_forward_body<false, false, 4, 8>(corr.data(), invn.data(), X.data(), FqT, Fp2, fp, C, Cpad, NBT, itf);
+      } else {
+        if (fp.T > 1) dft_forward_body<true, false, 2, 4>(corr.data(), invn.data(), X.data(), FqT, Fp2, fp, C, Cpad, NBT, itf);
+        else if (fp.fast) dft_forward_body<false, true, 2, 4>(corr.data(), invn.data(), X.data(), FqT, Fp2, fp, C, Cpad, NBT, itf);
+        else dft_forward_body<false, false, 2, 4>(corr.data(), invn.data(), X.data(), FqT, Fp2, fp, C, Cpad, NBT, itf);
+      }
+    });
   double worst = 0.0, scale = 0.0;
   for (int nb = 0; nb < NB; ++nb)
     for (int tile = 0; tile < T; ++tile) {
@@ -126,10 +140,11 @@ static int check_case(int H, int W, int C, int NB, int grid) {
         }
       }
     }
-  std::printf("  forward: max |X - float64| = %.3e (largest |X| %.1f)\n", worst, scale);
+  std::printf("  forward (G = %d): max |X - float64| = %.3e (largest |X| %.1f)\n", G, worst, scale);
   if (!(worst <= 2e-6 * scale + 1e-5)) {
     std::printf("FORWARD MISMATCH\n");
     return 1;
+  }
   }
 
   // ---------------- inverse (Cout = 8 output channels = 2 groups)

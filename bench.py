@@ -695,7 +695,8 @@ class Workload(object):
             out["spectral_gemm"] = self.roofline_fft(stage_ms, precision)
             out["spectral_gemm"]["pmc_kernel"] = "spectral_gemm_f16_kernel" if precision == "fftx3" else "spectral_gemm_kernel"
             out["fft_forward"] = hbm("forward transform of the 7x7 layer's input (relu + normalisation folded into the load): reads corr + inverse "
-                                     "norms, writes the input spectra", "fft_forward_kernel",
+                                     "norms, writes the input spectra" + (" (matrix products, v_mfma_f32_32x32x16_f16 x3)" if mm else " (in-LDS FFT)"),
+                                     "dft_forward_kernel" if mm else "fft_forward_kernel",
                                      B * (225 * HW * 4 + HW * 4 + 225 * bins * 8), stage_ms[5])
             out["fft_inverse"] = hbm("inverse transform + bias / ReLU / fp16 split epilogue: reads the output spectra, writes the 5x5 layer's "
                                      "activations" + (" (matrix products, v_mfma_f32_32x32x16_f16 x3)" if mm else " (in-LDS FFT)"),

@@ -23,7 +23,7 @@ SOURCES = ["abi.hip", "prep.hip", "corr_mfma.hip", "conv_mfma.hip", "conv_f16x3.
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 # No packed-FP32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) in the translation units listed in
-# NO_PACKED_FP32 - all of them.  Measured on MI355X (profiles/r03_packed_fp32/): such instructions
+# NO_PACKED_FP32 - all of them.  Measured on MI355X (docs/DESIGN_HISTORY_r1-r3.md section 8, profiles/r03_packed_fp32/): such instructions
 # occasionally return wrong values in lanes 48 - 63 of a wave while waves of ANOTHER kernel on the same CU issue fp16 MFMA
 # instructions at full rate (other HIP streams); a register-only victim without LDS, barriers or memory accesses reproduces
 # it (tools/repro_packed_fp32.hip), scalar v_fma_f32 code never does, fp32-MFMA / plain-VALU neighbours never trigger it, and

@@ -1,4 +1,4 @@
-// The 7x7 TransformNet layer in the frequency domain (gfx950) - building blocks, round 2 ("next").
+// The 7x7 TransformNet layer in the frequency domain (gfx950) - building blocks, round 2 (docs/DESIGN_HISTORY_r1-r3.md section 8, "next").
 //
 // A zero-padded 7x7 convolution of a 60x80 map is a pointwise product of 72x96 spectra: for every frequency bin the
 // layer (reference os2d/modeling/head.py:619-623: Conv 225 -> 128 k7 + BatchNorm) is one small COMPLEX matrix product

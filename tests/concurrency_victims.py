@@ -1,4 +1,4 @@
-"""Victim / aggressor harness of the multi-stream stability checks (the packed-FP32 finding).
+"""Victim / aggressor harness of the multi-stream stability checks (docs/DESIGN_HISTORY_r1-r3.md section 8, the packed-FP32 finding).
 
 A *victim* is one kernel (or kernel pair) of the head launched through the C ABI with fixed inputs; its output must be the
 same bytes whether it runs alone or on four streams while the direct 7x7 kernel (half-precision MFMA at full rate) runs on

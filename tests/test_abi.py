@@ -67,7 +67,7 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 
 
 def test_packed_fp32_setting_is_per_translation_unit():
-    """v_pk_*_f32 results were wrong in 16-lane groups next to MFMA-heavy kernels of other streams.
+    """docs/DESIGN_HISTORY_r1-r3.md section 8: v_pk_*_f32 results were wrong in 16-lane groups next to MFMA-heavy kernels of other streams.
     The switch is per translation unit (build.NO_PACKED_FP32); the transforms - the kernels it was found in - are always in."""
     from os2d_amd import build
     assert "fft.hip" in build.NO_PACKED_FP32
@@ -81,7 +81,7 @@ def test_packed_fp32_setting_is_per_translation_unit():
 
 def test_compiler_flags_are_part_of_the_build_stamp(monkeypatch):
     """Object files carry no record of their flags: a flag change must invalidate the stamp (and with it every object) -
-    the first -packed-fp32-ops build left the untouched sources compiled the old way."""
+    the first -packed-fp32-ops build left the untouched sources compiled the old way (docs/DESIGN_HISTORY_r1-r3.md section 8)."""
     from os2d_amd import build
     h0 = build.source_hash()
     monkeypatch.setattr(build, "FLAGS", build.FLAGS + ["-DOS2D_SOME_EXPERIMENT"])

@@ -419,7 +419,7 @@ def test_quad_layout_of_the_inverse_transform_equals_the_row_layout(H, W, NB, de
 
 @pytest.mark.parametrize("kind", ["fft", "dft", "gemm16", "corr", "sample"])
 def test_kernels_are_stable_next_to_mfma_kernels(kind, device):
-    """Regression test of the packed-FP32 finding: a victim kernel on four streams while the direct
+    """Regression test of the packed-FP32 finding (docs/DESIGN_HISTORY_r1-r3.md section 8): a victim kernel on four streams while the direct
     7x7 kernel (half-precision MFMA at full rate) runs on three others must return exactly the bytes it returns alone.
     Victims: the transforms (with v_pk_*_f32 instructions 8 of 16 such runs differed in 16-lane groups of single registers)
     and the two other kernels with hand-made LDS-only barriers and LDS-DMA pipelines - the split-half spectral GEMM and the

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic (the packed-FP32 finding): a victim kernel on four streams while the direct 7x7 kernel
+"""Diagnostic (docs/DESIGN_HISTORY_r1-r3.md section 8, the packed-FP32 finding): a victim kernel on four streams while the direct 7x7 kernel
 (half-precision MFMA at full rate) runs on three others - are the victim's outputs still the bytes it produces alone?
 
     OS2D_HIP_LIB=tools/diag_libs/<tag>/libos2d_hip.so python tools/diag_aggressor.py [--rounds 200] [--victims fft,gemm16,corr] [--quiet-control]

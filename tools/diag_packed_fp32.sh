@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 discrimination runs of the packed-FP32 finding.  Everything is BUILT in the development
+# Round-3 discrimination runs of the packed-FP32 finding (docs/DESIGN_HISTORY_r1-r3.md section 8).  Everything is BUILT in the development
 # container (python -m os2d_amd.build --variant ..., hipcc tools/repro_packed_fp32.hip -> tools/bin/) and only RUN here.
 #   1. the minimal victim (register-only complex multiply-add chain) next to MFMA aggressors: packed / scalar code,
 #      shared CUs / CU-exclusive victim;

@@ -1,4 +1,4 @@
-// Minimal victim / aggressor pair for the packed-FP32 finding of DESIGN.md section 8 (MI355X, gfx950).
+// Minimal victim / aggressor pair for the packed-FP32 finding of docs/DESIGN_HISTORY_r1-r3.md section 8 (MI355X, gfx950).
 //
 //   victim     a chain of complex multiply-adds held entirely in registers: no LDS, no barrier, no memory access inside the
 //              loop.  Built twice from this file: with v_pk_{mul,add,fma}_f32 (default codegen) and with scalar v_fma_f32

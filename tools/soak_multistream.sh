@@ -1,5 +1,5 @@
 #!/bin/bash
-# Soak of the multi-stream guarantees with the PRODUCT library: the victim / aggressor harness for many
+# Soak of the multi-stream guarantees with the PRODUCT library (docs/DESIGN_HISTORY_r1-r3.md section 8): the victim / aggressor harness for many
 # rounds, and the 7-level pyramid on 7 HIP streams against the serial run in every frequency-domain mode (incl. the tiled
 # 96 x 128 level), repeated.  Writes gpurun_out/soak.txt.
 R=${1:-1000}

@@ -164,6 +164,19 @@ int os2d_corr(const float* fm, const float* qp, const float* sumsq, float* corr,
 size_t os2d_corr_f16x3_workspace_bytes(int A, int C, int H, int W);
 int os2d_corr_f16x3(const float* fm, const void* qs, float* corr, void* rshb, int A, int B, int C, int H, int W,
                     void* workspace, size_t workspace_bytes, void* stream);
+/* That stage as the frequency-domain heads (fft / fftx3) run it: outputs corr [A*B,225,H*W] and inv_norm [A*B,H*W] =
+ * 1 / (L2 over the 225 relu'd channels + 1e-6) (head.py:650, 597) instead of the normalised tensor.  Two forms of the kernel:
+ *   form 0  one padded 256-row tile per class (as os2d_corr_f16x3);
+ *   form 1  the classes PACKED along the matrix rows: class b owns the stacked rows [228 b, 228 b + 225) and a work-group takes
+ *           256 consecutive stacked rows across class boundaries - 228 / 256 of the matrix instructions;
+ *   form -1 the head's own choice (packed when that saves a round of the 256 CUs: 128 classes and up on a 60 x 80 map).
+ * Both give the SAME BITS: the per-position sums of relu^2 are accumulated as 2^-44 fixed-point integers (an accumulator run
+ * of 4 rows in fp32, then integers: LDS / 64-bit atomics), which do not depend on the order of arrival nor on where in a batch
+ * a class sits - a class alone and the same class anywhere in a batch give identical correlation values and norms.
+ * workspace: os2d_corr_f16x3_packed_workspace_bytes (that of os2d_corr_f16x3 + A*B*H*W 64-bit sums), 256-byte aligned.     */
+size_t os2d_corr_f16x3_packed_workspace_bytes(int A, int B, int C, int H, int W);
+int os2d_corr_f16x3_packed(const float* fm, const void* qs, float* corr, float* inv_norm, int A, int B, int C, int H, int W,
+                           int form, void* workspace, size_t workspace_bytes, void* stream);
 /* standalone TransformNet input normalisation head.py:650 (relu, L2 over 225 channels, eps 1e-6) of an arbitrary
  * correlation tensor corr [NB,225,H*W] -> rnorm [NB,226,PLANE]; used by TransformationNet.forward.               */
 int os2d_corr_normalize(const float* corr, float* rnorm, int NB, int H, int W, void* stream);
@@ -322,8 +335,14 @@ int os2d_spectral_gemm_f16(const void* w16, const float* X, float* Y, int NB, in
  *   os2d_dft_forward         relu(corr [NB,C,H*W]) * inv_norm [NB,H*W] -> X [nbins/4, NB*T, Cpad, 4] complex64 (quads of bins x
  *                            channels: 128-byte runs per work-group iteration, 256-byte runs per k-step of the GEMM)
  *   os2d_spectral_weights_build_dft   the split weight spectra of os2d_spectral_gemm_f16 in that bin order
- *   os2d_spectral_gemm_f16_quads      the per-bin GEMM reading X in that layout (xscale: os2d_dft_xscale(H, W)); Y as before,
+ *   os2d_spectral_gemm_f16_quads      the per-bin GEMM reading X in that layout (xscale: os2d_dft_xscale(H, W)); Y
  *                            [nbins/4, NB*T, Cout, 4]
+ *   BLOCKS OF 64 PAIRS: with more than 64 pairs (pair' = class x tile) both X and Y are stored block after block,
+ *                            [pair' / 64][nbins/4][pair' % 64][channels][4], the last block holding the NB*T % 64 remaining
+ *                            pairs without padding (the buffer sizes do not change).  A block is the pair tile of a GEMM
+ *                            work-group: its operands are one contiguous slab, and the 688 runs a transform iteration touches
+ *                            are 475 / 262 KB apart at any batch size instead of 7.6 / 4 MB at 1024 pairs.  Up to 64 pairs the
+ *                            layout is exactly the one written above.
  *   os2d_dft_inverse         Y -> the layer's activations (bias, ReLU, channel scale, fp16 hi | lo) in the split-half blocked
  *                            buffer, as os2d_fft_inverse                                                                   */
 int os2d_dft_sizes(int H, int W, int* P, int* Q, int* nbins, int* tiles);

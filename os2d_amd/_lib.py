@@ -71,6 +71,8 @@ SIGNATURES = {
     "os2d_corr_normalize": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "os2d_corr_f16x3_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "os2d_corr_f16x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "os2d_corr_f16x3_packed_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "os2d_corr_f16x3_packed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "os2d_transform_conv": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "os2d_sample_decode": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "os2d_decode_boxes": (_i, [_vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp]),

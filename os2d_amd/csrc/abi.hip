@@ -30,7 +30,7 @@ int os2d_conv1_steps_padded() { return 25; }
 
 // workspace carve for a chunk of Bc classes
 struct Carve {
-  size_t sumsq, fs, corr, rpad, h1, h2, params, invn, xspec, yspec, total;
+  size_t sumsq, fs, corr, rpad, h1, h2, params, invn, sumfx, xspec, yspec, total;
 };
 Carve carve(int A, int Bc, int C, int H, int W, int P, int fft_bins = 0, int fft_tiles = 1, int xspec_channels = OS2D_K) {
   const size_t HW = (size_t)H * W, PL = os2d_plane(H, W), NB = (size_t)A * Bc;
@@ -49,9 +49,10 @@ Carve carve(int A, int Bc, int C, int H, int W, int P, int fft_bins = 0, int fft
   c.h1 = take(NB * 128 * PL);
   c.h2 = take(NB * 64 * PL);
   c.params = take(NB * P * HW);
-  c.invn = c.xspec = c.yspec = 0;
+  c.invn = c.sumfx = c.xspec = c.yspec = 0;
   if (fft_bins > 0) {  // frequency-domain 7x7 layer: inverse norms, input / output spectra (complex64)
     c.invn = take(NB * HW);
+    c.sumfx = take(NB * HW * 2);           // 64-bit fixed-point sums of the packed correlation kernel (corr_f16x3.hip, STACK)
     c.xspec = take(NB * fft_tiles * xspec_channels * (size_t)fft_bins * 2);     // a tile of a tiled map is one more "pair" (fft.hip)
     c.yspec = take(NB * fft_tiles * 128 * (size_t)fft_bins * 2);
   }
@@ -275,9 +276,36 @@ int os2d_corr_f16x3(const float* fm, const void* qs, float* corr, void* rshb, in
   float* sumsq = static_cast<float*>(workspace);
   void* fs = static_cast<char*>(workspace) + align_up((size_t)A * H * W * sizeof(float), 256);
   int rc = os2d_launch_fm_sumsq(fm, sumsq, A, C, H * W, S(stream));
-  if (!rc) rc = os2d_launch_split_fm(fm, sumsq, fs, A, C, H * W, S(stream));
+  if (!rc) rc = os2d_launch_split_fm(fm, sumsq, fs, A, C, H * W, nullptr, 0, S(stream));
   if (!rc) rc = os2d_launch_border_zero_shb(rshb, A * B, H, W, S(stream));
-  if (!rc) rc = os2d_launch_corr_f16x3(fs, qs, corr, rshb, nullptr, A, B, C, H, W, S(stream));
+  if (!rc) rc = os2d_launch_corr_f16x3(fs, qs, corr, rshb, nullptr, nullptr, 0, A, B, C, H, W, S(stream));
+  return rc;
+}
+
+size_t os2d_corr_f16x3_packed_workspace_bytes(int A, int B, int C, int H, int W) {
+  if (A < 1 || B < 1 || C < 1 || H < 1 || W < 1) return 0;
+  return align_up(os2d_corr_f16x3_workspace_bytes(A, C, H, W), 256) + (size_t)A * B * H * W * sizeof(unsigned long long);
+}
+
+int os2d_corr_f16x3_packed(const float* fm, const void* qs, float* corr, float* inv_norm, int A, int B, int C, int H, int W,
+                           int form, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!fm || !qs || !corr || !inv_norm || !workspace) {
+    os2d_set_error("os2d_corr_f16x3_packed: null pointer");
+    return -1;
+  }
+  if (!head_args_ok(A, B, C, H, W, 6)) return -1;
+  if (workspace_bytes < os2d_corr_f16x3_packed_workspace_bytes(A, B, C, H, W) || (reinterpret_cast<uintptr_t>(workspace) & 255)) {
+    os2d_set_error("os2d_corr_f16x3_packed: workspace too small or not 256-byte aligned");
+    return -2;
+  }
+  float* sumsq = static_cast<float*>(workspace);
+  void* fs = static_cast<char*>(workspace) + align_up((size_t)A * H * W * sizeof(float), 256);
+  void* sumfx = static_cast<char*>(workspace) + align_up(os2d_corr_f16x3_workspace_bytes(A, C, H, W), 256);
+  int rc = os2d_launch_fm_sumsq(fm, sumsq, A, C, H * W, S(stream));
+  if (!rc) rc = os2d_launch_split_fm(fm, sumsq, fs, A, C, H * W, nullptr, 0, S(stream));
+  const bool packed = form > 0 || (form < 0 && os2d_corr_f16x3_use_packed(A, B, H, W));
+  if (!rc && packed) rc = os2d_launch_corr_sums_clear(sumfx, A, B, H, W, S(stream));
+  if (!rc) rc = os2d_launch_corr_f16x3(fs, qs, corr, nullptr, inv_norm, packed ? sumfx : nullptr, 0, A, B, C, H, W, S(stream));
   return rc;
 }
 
@@ -439,6 +467,10 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
   char* ws = static_cast<char*>(workspace);
   const Carve c = carve(A, Bc, C, H, W, P, fft_bins, fft_T, xch);
   float* invn = fft_bins ? reinterpret_cast<float*>(ws + c.invn) : nullptr;
+  // half-precision correlation on the frequency-domain route: classes packed along M (no padded rows 225 .. 255 per class)
+  // - when that saves a round of the chip (os2d_corr_f16x3_use_packed: both forms give the same bits; decided on the chunk size
+  // so that every chunk but a shorter last one takes the same form)
+  void* sumfx = (fft_bins && !fp32_ops && os2d_corr_f16x3_use_packed(A, Bc, H, W)) ? ws + c.sumfx : nullptr;
   float* xspec = fft_bins ? reinterpret_cast<float*>(ws + c.xspec) : nullptr;
   float* yspec = fft_bins ? reinterpret_cast<float*>(ws + c.yspec) : nullptr;
   float* sumsq = reinterpret_cast<float*>(ws + c.sumsq);
@@ -456,7 +488,8 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
   };
   int rc = os2d_launch_fm_sumsq(fm, sumsq, A, C, H * W, st);
   if (rc) return rc;
-  if (!fp32_ops && (rc = os2d_launch_split_fm(fm, sumsq, fsplit, A, C, H * W, st))) return rc;
+  // (the packed correlation kernel's sums are cleared by the same launch; every chunk's norms pass leaves them cleared again)
+  if (!fp32_ops && (rc = os2d_launch_split_fm(fm, sumsq, fsplit, A, C, H * W, sumfx, sumfx ? (size_t)A * Bc * H * W : 0, st))) return rc;
   for (int b0 = 0; b0 < B; b0 += Bc) {
     const int bc = (B - b0 < Bc) ? (B - b0) : Bc;
     const int NB = A * bc;
@@ -471,7 +504,8 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     }
     if (f16) {
       const char* qsb = static_cast<const char*>(qs) + (size_t)b0 * os2d_corr_groups(C) * 2 * 256 * 16;
-      if ((rc = os2d_launch_corr_f16x3(fsplit, qsb, corr, fft_bins ? nullptr : rpad, invn, A, bc, C, H, W, st))) return rc;
+      // packed form: the sums become inverse norms in the border launch below (before the forward transform reads them)
+      if ((rc = os2d_launch_corr_f16x3(fsplit, qsb, corr, fft_bins ? nullptr : rpad, invn, sumfx, 1, A, bc, C, H, W, st))) return rc;
     } else {
       if ((rc = os2d_launch_corr(fm, qp + (size_t)b0 * C * OS2D_QROWS, sumsq, corr, fft_bins ? nullptr : rpad, invn, A, bc, C, H, W,
                                  0, st)))
@@ -483,7 +517,7 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
       // the 7x7 layer in the frequency domain (fft.hip, spectral.hip): fp32 FFT of relu(corr) / norm -> one complex GEMM
       // per bin on the fp32 matrix cores -> inverse FFT + bias + ReLU + split into the activation buffer of the 5x5 layer
       if (f16) {
-        if ((rc = os2d_launch_border_zero_shb_planes(h1, NB * 16 * 2, H, W, st))) return rc;
+        if ((rc = os2d_launch_border_zero_shb_planes_norms(h1, NB * 16 * 2, H, W, sumfx, invn, (size_t)NB * H * W, st))) return rc;
       } else if ((rc = os2d_launch_border_zero(h1, NB * 128, H, W, st))) {     // all-fp32 mode: fp32 planes for the fp32 5x5 kernel
         return rc;
       }

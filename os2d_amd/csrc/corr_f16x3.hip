@@ -13,6 +13,19 @@
 // kernels.  With 256-wide tiles a group moves 2 MB per 134 MFLOP (3 x that in executed half-precision FLOPs), i.e. the
 // kernel needs ~5 TB/s of L2->LDS traffic at full matrix rate: it is the most bandwidth-hungry kernel of the head.
 // Outputs: corr [A*B][225][H*W] fp32 (for the resampler) and the relu+L2-normalised tensor in SHB layout.
+//
+// STACK (round 4): with a class per 256-row tile, rows 225..255 - 12 % of the matrix instructions - are
+// padding.  The frequency-domain route (no normalised SHB tensor to write) packs the classes along M instead: class b owns the
+// stacked rows [228 b, 228 b + 225) (a stride of 228 = 4 x 57 keeps every class 4-row aligned: 1.3 % padding) and a work-group
+// takes 256 CONSECUTIVE stacked rows, whatever classes they belong to - B x 228 / 256 row tiles instead of B.  The class operand
+// keeps its per-class layout: the LDS-DMA already takes a per-lane global offset, so a lane simply fetches row p of class b.
+// The per-position sum of relu^2 over a class's 225 rows now crosses wave and work-group boundaries, and the result must not
+// depend on where in a batch a class sits (slices of a batch are bit-identical to the class on its own).  So the sum is made
+// ORDER-INDEPENDENT: a lane adds the 4 rows of an accumulator run in fp32 (a run = rows 4 k .. 4 k + 3 of ONE class, the same
+// four values in the same order for every placement), converts the group sum to 2^-44 fixed point (exact for sums >= 2^-20;
+// below that the dropped bits are < 2^-44 absolute) and accumulates integers: lanes, waves and work-groups combine with 64-bit
+// integer atomics, which commute and associate.  corr_norm_finalize_kernel turns the sums into 1 / (sqrt(s) + 1e-6) and
+// clears them for the next call.
 #include "os2d_common.h"
 
 namespace {
@@ -33,12 +46,15 @@ constexpr int CH_UNITS = GC * 2 * 256;   // 16-byte units of one class-operand c
 // lane, two waves per SIMD); 2 -> 4 waves of 128 x 128 (NI = 4: 256 accumulators, one wave per SIMD with the whole register
 // file: 24 fragment reads per 48 matrix instructions become 32 per 96 - a third less LDS traffic per MFMA, which is what the
 // live counters say bounds the 8-wave shape: matrix pipe 0.58 busy with 2/3 of the LDS bandwidth in use).
-template <int NI, int WNW>
+constexpr int STACK_STRIDE = 228;   // stacked rows per class (225 rounded up to a multiple of 4)
+
+template <int NI, int WNW, bool STACK>
 __global__ __launch_bounds__(128 * WNW, WNW == 2 ? 1 : 2) void corr_f16x3_kernel(const u32x4* fs,  // [A][CGP][2][HW]  (no __restrict__, see
                                                              const u32x4* qs,  // [B][CGP][2][256]   conv_f16x3.hip)
                                                              float* __restrict__ corr, char* __restrict__ rshb,
-                                                             float* __restrict__ invn /*[A*B][HW] 1/(norm+eps) or NULL*/, int A,
-                                                             int B, int CGP /*channel groups, padded to a multiple of GC*/,
+                                                             float* __restrict__ invn /*[A*B][HW] 1/(norm+eps) or NULL*/,
+                                                             unsigned long long* __restrict__ sumfx /*STACK: [A*B][HW] fixed-point sums*/,
+                                                             int A, int B, int CGP /*channel groups, padded to a multiple of GC*/,
                                                              int H, int W, int PLANE, float unscale) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
   constexpr int NTHR = 128 * WNW;
@@ -48,7 +64,7 @@ __global__ __launch_bounds__(128 * WNW, WNW == 2 ? 1 : 2) void corr_f16x3_kernel
   constexpr int NPFB = BUNITS / NTHR;    // image units per thread
   u32x4* ldsA = smem16;                 // [2][CH_UNITS]
   u32x4* ldsB = smem16 + 2 * CH_UNITS;  // [2][BUNITS]
-  __shared__ float red[2][NT];
+  __shared__ unsigned long long red[2][NT];
 
   const int HW = H * W;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -58,17 +74,20 @@ __global__ __launch_bounds__(128 * WNW, WNW == 2 ? 1 : 2) void corr_f16x3_kernel
   // logical order (image, group of 4 classes, position tile, class in group).  The 32 groups resident on an XCD (one per
   // CU) are then ~8 tiles x 4 classes marching through K together: 12 MB of distinct operand bytes per 32 groups in
   // that XCD's L2 instead of 20+ MB with classes or tiles spread round-robin over the XCDs.
+  // STACK: "b" below is a ROW TILE of the stacked class matrix (RT of them), not a class
+  const int RT = STACK ? (B * STACK_STRIDE + 255) / 256 : B;
   const int tiles = (HW + NT - 1) / NT;
   const int per = gridDim.x >> 3;
   const int logical = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if (logical >= tiles * B * A) return;
-  const int a = logical / (tiles * B);
-  const int r_ = logical - a * tiles * B;
-  const int gb0 = (r_ / (4 * tiles)) * 4, gsz = min(4, B - gb0);
+  if (logical >= tiles * RT * A) return;
+  const int a = logical / (tiles * RT);
+  const int r_ = logical - a * tiles * RT;
+  const int gb0 = (r_ / (4 * tiles)) * 4, gsz = min(4, RT - gb0);
   const int r2_ = r_ - gb0 * tiles;
   const int b = gb0 + r2_ % gsz;
   const int n0 = (r2_ / gsz) * NT;
   const int nb = a * B + b;
+  const int R0 = b * 256;                        // STACK: first stacked row of this work-group
 
   f32x16 acc[4][NI];
 #pragma unroll
@@ -78,7 +97,8 @@ __global__ __launch_bounds__(128 * WNW, WNW == 2 ? 1 : 2) void corr_f16x3_kernel
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  const u32x4* qb = qs + (size_t)b * CGP * 2 * 256;
+  const int bfirst = STACK ? R0 / STACK_STRIDE : b;                 // first class this work-group touches
+  const u32x4* qb = qs + (size_t)bfirst * CGP * 2 * 256;
   const u32x4* fa = fs + (size_t)a * CGP * 2 * HW;
   const int nchunks = CGP / GC;
   // ---- staging: global -> LDS directly (LDS-DMA, global_load_lds_dwordx4): no staging registers, no ds_write pass.
@@ -93,10 +113,14 @@ __global__ __launch_bounds__(128 * WNW, WNW == 2 ? 1 : 2) void corr_f16x3_kernel
   typedef const void __attribute__((address_space(1))) * gptr_t;
   typedef void __attribute__((address_space(3))) * lptr_t;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index as a scalar
-  const unsigned voffA = (unsigned)lane * 16u;
+  // STACK: this thread always stages the same stacked row (its units are 256 apart): row p of class bfirst + d, clamped to the
+  // last class (rows 225 .. 255 of every class are zero in the operand: the 3 padding rows of the stride need nothing else)
+  const int rowA = (wv * 64 + lane) & 255, RA = min(R0 + rowA, B * STACK_STRIDE - 1);
+  const int bA = RA / STACK_STRIDE, pA = RA - bA * STACK_STRIDE;
+  const unsigned voffA = STACK ? (unsigned)(bA - bfirst) * (unsigned)(CGP * 2 * 256 * 16) + (unsigned)pA * 16u : (unsigned)lane * 16u;
   const int colB = (wv * 64) % NT + lane;
   const unsigned voffB = (unsigned)min(colB, HW - 1 - n0) * 16u;
-  const char* baseA0 = reinterpret_cast<const char*>(qb) + (size_t)wv * 64 * 16;
+  const char* baseA0 = reinterpret_cast<const char*>(qb) + (STACK ? (size_t)((wv * 64) >> 8) * 256 * 16 : (size_t)wv * 64 * 16);
   const char* baseB0 = reinterpret_cast<const char*>(fa) + ((size_t)((wv * 64) / NT) * HW + n0) * 16;
 #define CF_DMA1(T, K)                                                                                             \
   {                                                                                                               \
@@ -187,21 +211,55 @@ __global__ __launch_bounds__(128 * WNW, WNW == 2 ? 1 : 2) void corr_f16x3_kernel
   const int Ws = os2d_ws(W), BASE = os2d_base(W);
   const bool vec4 = (HW & 3) == 0;
   const int qc = lane & 3;                    // column of this lane inside its quad = the row it owns after the transpose
-  float part[NI];
+  // Sums of relu^2 over a class's rows, per position, in 2^-44 FIXED POINT - in both forms of the kernel, so that they give the
+  // same inverse norms bit for bit and the launcher may pick either: a lane adds the 4 rows of an accumulator run in fp32 (rows
+  // 4 k .. 4 k + 3 of ONE class, the same values in the same order wherever the class sits), converts the run's sum and adds
+  // integers from there on.  Slot 1 (STACK only): the second class of the wave's 128 rows (they touch at most two: class cw0 up
+  // to row `bound`, cw0 + 1 after).
+  const int Rw = R0 + wm * 128, cw0 = Rw / STACK_STRIDE, bound = (cw0 + 1) * STACK_STRIDE;
+  constexpr int NSL = STACK ? 2 : 1;
+  unsigned fxh[NSL][NI], fxl[NSL][NI];
+  bool fxbad[NSL][NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int ncol0 = n0 + wn * (32 * NI) + ni * 32;
     const int n = ncol0 + l31;
     const bool nin = n < HW;
-    float s = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl) {
+      fxh[sl][ni] = fxl[sl][ni] = 0u;
+      fxbad[sl][ni] = false;
+    }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = acc[mi][ni][r] * unscale;
-        acc[mi][ni][r] = v;
-        const float rl = fmaxf(v, 0.f);
-        s += rl * rl;
+      for (int q = 0; q < 4; ++q) {
+        float g = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float v = acc[mi][ni][4 * q + k] * unscale;
+          acc[mi][ni][4 * q + k] = v;
+          const float rl = fmaxf(v, 0.f);
+          g = fmaf(rl, rl, g);
+        }
+        // g <= 4 (cosines); anything else is a non-finite input: flagged, the norm then becomes NaN like the reference's
+        const bool gbad = !(g < 1024.f);
+        const float ga = fminf(g, 1024.f) * 1048576.f;                   // 2^20
+        const unsigned gh = (unsigned)ga;
+        const unsigned gl = (unsigned)((ga - (float)gh) * 16777216.f);   // the next 24 bits
+        if (STACK) {
+          const bool second = Rw + mi * 32 + 8 * q + 4 * hw >= bound;    // rows .. + 3: one class (4-row alignment)
+          fxh[0][ni] += second ? 0u : gh;
+          fxl[0][ni] += second ? 0u : gl;
+          fxh[NSL - 1][ni] += second ? gh : 0u;
+          fxl[NSL - 1][ni] += second ? gl : 0u;
+          fxbad[0][ni] |= gbad && !second;
+          fxbad[NSL - 1][ni] |= gbad && second;
+        } else {
+          fxh[0][ni] += gh;              // rows 225 .. 255 of the tile are zero operand rows: they add nothing
+          fxl[0][ni] += gl;
+          fxbad[0][ni] |= gbad;
+        }
       }
       if (vec4) {
 #pragma unroll
@@ -233,25 +291,69 @@ __global__ __launch_bounds__(128 * WNW, WNW == 2 ? 1 : 2) void corr_f16x3_kernel
           // this lane now holds row (.. + qc) at the 4 columns of its quad
           const int m = wm * 128 + mi * 32 + 8 * q + 4 * hw + qc;
           const int nq = ncol0 + (l31 & ~3);
-          if (m < OS2D_K && nq < HW) {
+          bool mok = m < OS2D_K;
+          size_t orow = (size_t)nb * OS2D_K + m;
+          if (STACK) {     // stacked row -> (class, template cell): the run of 8 rows starts in class cg (uniform), a lane may be one on
+            const int Rg = Rw + mi * 32 + 8 * q, cg = Rg / STACK_STRIDE;
+            int pc = Rg - cg * STACK_STRIDE + 4 * hw + qc, cc = cg;
+            if (pc >= STACK_STRIDE) {
+              pc -= STACK_STRIDE;
+              ++cc;
+            }
+            mok = pc < OS2D_K && cc < B;
+            orow = ((size_t)a * B + cc) * OS2D_K + pc;
+          }
+          if (mok && nq < HW) {
             f32x4 o4 = {__int_as_float(t0), __int_as_float(t1), __int_as_float(t2), __int_as_float(t3)};
-            *reinterpret_cast<f32x4*>(corr + ((size_t)nb * OS2D_K + m) * HW + nq) = o4;
+            *reinterpret_cast<f32x4*>(corr + orow * HW + nq) = o4;
           }
         }
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hw;
-          if (nin && m < OS2D_K) corr[((size_t)nb * OS2D_K + m) * HW + n] = acc[mi][ni][r];
+          bool mok = m < OS2D_K;
+          size_t orow = (size_t)nb * OS2D_K + m;
+          if (STACK) {
+            const int Rr = R0 + m, cc = Rr / STACK_STRIDE, pc = Rr - cc * STACK_STRIDE;
+            mok = pc < OS2D_K && cc < B;
+            orow = ((size_t)a * B + cc) * OS2D_K + pc;
+          }
+          if (nin && mok) corr[orow * HW + n] = acc[mi][ni][r];
         }
       }
     }
-    s += __shfl_xor(s, 32);
-    part[ni] = s;
   }
-  if (hw == 0) {
+  if (STACK) {
+    // both half-waves hold rows of the same columns: add them (integers), then one 64-bit atomic per (class, position) from the
+    // lower half-wave.  A class spans at most two row tiles x two waves: <= 4 contributions per position, any order.
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) red[wm][wn * (32 * NI) + ni * 32 + l31] = part[ni];
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0 + wn * (32 * NI) + ni * 32 + l31;
+#pragma unroll
+      for (int sl = 0; sl < NSL; ++sl) {
+        const unsigned h2 = fxh[sl][ni] + (unsigned)__shfl_xor((int)fxh[sl][ni], 32);
+        const unsigned l2 = fxl[sl][ni] + (unsigned)__shfl_xor((int)fxl[sl][ni], 32);
+        const bool bad2 = (((int)fxbad[sl][ni]) | __shfl_xor((int)fxbad[sl][ni], 32)) != 0;
+        const int cc = cw0 + sl;
+        const bool live = cc < B && (sl == 0 || bound < Rw + 128);          // wave-uniform
+        if (live && hw == 0 && n < HW) {
+          unsigned long long* dst = sumfx + ((size_t)a * B + cc) * HW + n;
+          atomicAdd(dst, ((unsigned long long)h2 << 24) + (unsigned long long)l2);
+          if (bad2) atomicOr(dst, 1ull << 62);
+        }
+      }
+    }
+    return;
+  }
+  // one class per tile: the two half-waves, then the two waves of a column (LDS), all integers
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const unsigned h2 = fxh[0][ni] + (unsigned)__shfl_xor((int)fxh[0][ni], 32);
+    const unsigned l2 = fxl[0][ni] + (unsigned)__shfl_xor((int)fxl[0][ni], 32);
+    const bool bad2 = (((int)fxbad[0][ni]) | __shfl_xor((int)fxbad[0][ni], 32)) != 0;
+    if (hw == 0)
+      red[wm][wn * (32 * NI) + ni * 32 + l31] = (((unsigned long long)h2 << 24) + (unsigned long long)l2) | (bad2 ? 1ull << 62 : 0ull);
   }
   __syncthreads();
 #pragma unroll
@@ -261,7 +363,9 @@ __global__ __launch_bounds__(128 * WNW, WNW == 2 ? 1 : 2) void corr_f16x3_kernel
     const bool nin = n < HW;   // lanes l and l+32 share n: both take part in the exchange below or neither stores
     // head.py:650,597 (eps 1e-6); the normalised values (<= 1) are stored scaled by 2^OS2D_RNORM_EXP so that their lo halves
     // stay normal fp16 numbers (the conv 7x7 epilogue undoes the scale exactly)
-    const float inv_r = 1.0f / (sqrtf(red[0][col] + red[1][col]) + 1e-6f);
+    const unsigned long long vs = red[0][col] + red[1][col];      // < 2^53; bit 62 / 63: a non-finite term
+    const float ssum = (vs >> 62) ? __builtin_nanf("") : (float)((double)vs * 5.6843418860808015e-14);    // 2^-44, as os2d_corr_norm_finalize_one
+    const float inv_r = 1.0f / (sqrtf(ssum) + 1e-6f);
     if (invn != nullptr && wm == 0 && hw == 0 && nin) invn[(size_t)nb * HW + n] = inv_r;   // for the frequency-domain 7x7 layer
     const float rscale = ldexpf(1.0f, OS2D_RNORM_EXP);
     const int nc = nin ? n : 0;
@@ -302,9 +406,14 @@ __global__ __launch_bounds__(128 * WNW, WNW == 2 ? 1 : 2) void corr_f16x3_kernel
 
 // image features [A][C][HW] fp32 -> L2-normalised over channels (head.py:339, eps 1e-5), scaled, split, blocked
 __global__ __launch_bounds__(256) void split_fm_kernel(const float* __restrict__ fm, const float* __restrict__ sumsq,
-                                                       u32x4* __restrict__ fs, int C, int HW, float scale) {
+                                                       u32x4* __restrict__ fs, int C, int HW, float scale,
+                                                       unsigned long long* __restrict__ clear, size_t clear_words) {
   const int n = blockIdx.x * 256 + threadIdx.x;
   const int g = blockIdx.y, a = blockIdx.z;
+  if (clear_words) {       // the packed correlation kernel's sums, zeroed on the way (grid-stride over all work items)
+    const size_t nthr = (size_t)gridDim.x * gridDim.y * gridDim.z * 256;
+    for (size_t i = ((size_t)(a * gridDim.y + g) * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < clear_words; i += nthr) clear[i] = 0ull;
+  }
   if (n >= HW) return;
   const int CG = os2d_round_up((C + 7) / 8, GC);  // zero groups pad the channel dimension to whole K chunks
   const float inv = scale / (sqrtf(sumsq[(size_t)a * HW + n]) + 1e-5f);
@@ -342,6 +451,14 @@ __global__ __launch_bounds__(256) void split_qp_kernel(const float* __restrict__
   *reinterpret_cast<half8*>(o + 256) = lo;
 }
 
+// STACK: fixed-point sums of relu(corr)^2 -> 1 / (sqrt(s) + 1e-6) (head.py:650, 597: what the per-class kernel writes), and the
+// sums are cleared for the next launch.  acc = s * 2^44 < 2^53: the conversion to double is exact, the one to float rounds once.
+__global__ __launch_bounds__(256) void corr_norm_finalize_kernel(unsigned long long* __restrict__ sumfx, float* __restrict__ invn,
+                                                                 size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) os2d_corr_norm_finalize_one(sumfx, invn, i);
+}
+
 #ifndef OS2D_CORR_W4
 #define OS2D_CORR_W4 0
 #endif
@@ -360,9 +477,11 @@ int check(const char* what) {
 
 int os2d_corr_groups(int C) { return os2d_round_up((C + 7) / 8, GC); }
 
-int os2d_launch_split_fm(const float* fm, const float* sumsq, void* fs, int A, int C, int HW, hipStream_t stream) {
+int os2d_launch_split_fm(const float* fm, const float* sumsq, void* fs, int A, int C, int HW, void* clear, size_t clear_words,
+                         hipStream_t stream) {
   hipLaunchKernelGGL(split_fm_kernel, dim3((HW + 255) / 256, os2d_round_up((C + 7) / 8, GC), A), dim3(256), 0, stream, fm, sumsq,
-                     reinterpret_cast<u32x4*>(fs), C, HW, ldexpf(1.0f, SCALE_LOG2));
+                     reinterpret_cast<u32x4*>(fs), C, HW, ldexpf(1.0f, SCALE_LOG2), static_cast<unsigned long long*>(clear),
+                     clear ? clear_words : (size_t)0);
   return check("split_fm");
 }
 
@@ -374,37 +493,79 @@ int os2d_launch_split_qp(const float* qp, void* qs, int B, int C, hipStream_t st
 
 namespace {
 
-template <int NI, int WNW>
-int launch_corr(const void* fs, const void* qs, float* corr, void* rshb, float* invn, int A, int B, int C, int H, int W,
-                hipStream_t stream) {
+template <int NI, int WNW, bool STACK>
+int launch_corr(const void* fs, const void* qs, float* corr, void* rshb, float* invn, unsigned long long* sumfx, int defer_norms, int A,
+                int B, int C, int H, int W, hipStream_t stream) {
   constexpr int NT = WNW * 32 * NI, NTHR = 128 * WNW;
   const int HW = H * W;
   const size_t lds = (size_t)(2 * CH_UNITS + 2 * GC * 2 * NT) * 16;  // 128 KB (NI = 2) / 96 KB dynamic (+ static)
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_f16x3_kernel<NI, WNW>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_f16x3_kernel<NI, WNW, STACK>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) {
     os2d_set_error("hipFuncSetAttribute(corr f16x3): %s", hipGetErrorString(e));
     return -4;
   }
-  const long long groups = (long long)((HW + NT - 1) / NT) * B * A;
+  const int RT = STACK ? (B * STACK_STRIDE + 255) / 256 : B;       // row tiles: stacked classes | one per class
+  const long long groups = (long long)((HW + NT - 1) / NT) * RT * A;
   dim3 grid((unsigned)((groups + 7) / 8 * 8));  // multiple of 8: every XCD gets the same number of logical slots
-  hipLaunchKernelGGL((corr_f16x3_kernel<NI, WNW>), grid, dim3(NTHR), lds, stream, reinterpret_cast<const u32x4*>(fs),
-                     reinterpret_cast<const u32x4*>(qs), corr, reinterpret_cast<char*>(rshb), invn, A, B,
+  hipLaunchKernelGGL((corr_f16x3_kernel<NI, WNW, STACK>), grid, dim3(NTHR), lds, stream, reinterpret_cast<const u32x4*>(fs),
+                     reinterpret_cast<const u32x4*>(qs), corr, reinterpret_cast<char*>(rshb), invn, sumfx, A, B,
                      os2d_round_up((C + 7) / 8, GC), H, W,
                      os2d_plane(H, W), ldexpf(1.0f, -2 * SCALE_LOG2));
-  return check("corr_f16x3");
+  int rc = check("corr_f16x3");
+  if (rc || !STACK || defer_norms) return rc;
+  const size_t n = (size_t)A * B * HW;
+  hipLaunchKernelGGL(corr_norm_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, sumfx, invn, n);
+  return check("corr_norm_finalize");
 }
 
 }  // namespace
 
-int os2d_launch_corr_f16x3(const void* fs, const void* qs, float* corr, void* rshb, float* invn, int A, int B, int C, int H,
-                           int W,
-                           hipStream_t stream) {
+// Which form the head runs.  Both give the same bits (correlation AND inverse norms), so this is a pure scheduling decision:
+// the packed form executes 228 / 256 of the matrix instructions, but its sums cross work-groups as atomics and need the norms
+// pass, and - the package being power-limited - the all-zero padding rows of the padded form cost less time than their share
+// of the instructions (measured: packed is 1 % slower per step at 64 classes, where both forms need 5 rounds of 256
+// work-groups, 1 - 2 % faster at 256 and 1024 classes).  Packed when it saves at least one round of the 256 CUs.
+// $OS2D_CORR_PACKED = 0 | 1 forces one form (measurements).
+int os2d_corr_f16x3_use_packed(int A, int B, int H, int W) {
+  static const int forced = [] {
+    const char* e = getenv("OS2D_CORR_PACKED");
+    return !e ? -1 : (e[0] == '0' ? 0 : 1);
+  }();
+  if (forced >= 0) return forced;
+  const long long tiles = (H * W + 255) / 256;
+  const long long plain = (tiles * B * A + 255) / 256, packed = (tiles * ((B * STACK_STRIDE + 255) / 256) * A + 255) / 256;
+  return packed < plain ? 1 : 0;
+}
+
+// the packed sums of the stacked kernel: cleared once per buffer (the finalize kernel leaves them cleared)
+int os2d_launch_corr_sums_clear(void* sumfx, int A, int B, int H, int W, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(sumfx, 0, (size_t)A * B * H * W * sizeof(unsigned long long), stream);
+  if (e != hipSuccess) {
+    os2d_set_error("hipMemsetAsync(corr sums): %s", hipGetErrorString(e));
+    return -4;
+  }
+  return 0;
+}
+
+// sumfx != NULL: the classes packed along M (STACK; needs rshb == NULL and invn != NULL: the frequency-domain route), sumfx =
+// A * B * H * W cleared 64-bit words (os2d_launch_corr_sums_clear once; every launch leaves them cleared again)
+int os2d_launch_corr_f16x3(const void* fs, const void* qs, float* corr, void* rshb, float* invn, void* sumfx, int defer_norms, int A,
+                           int B, int C, int H, int W, hipStream_t stream) {
+  unsigned long long* sx = static_cast<unsigned long long*>(sumfx);
+  if (sx && (rshb || !invn)) {
+    os2d_set_error("corr_f16x3: the packed form writes inverse norms only (rshb must be NULL, invn not)");
+    return -1;
+  }
   // the 128-position shape as long as its work-groups still fit the chip in one round (see the kernel's comment)
-  if ((long long)((H * W + 127) / 128) * B * A <= 256) return launch_corr<1, 4>(fs, qs, corr, rshb, invn, A, B, C, H, W, stream);
+  const int RT = sx ? (B * STACK_STRIDE + 255) / 256 : B;
+  if ((long long)((H * W + 127) / 128) * RT * A <= 256)
+    return sx ? launch_corr<1, 4, true>(fs, qs, corr, rshb, invn, sx, defer_norms, A, B, C, H, W, stream)
+              : launch_corr<1, 4, false>(fs, qs, corr, rshb, invn, sx, defer_norms, A, B, C, H, W, stream);
 #if OS2D_CORR_W4
-  return launch_corr<4, 2>(fs, qs, corr, rshb, invn, A, B, C, H, W, stream);     // 4 waves of 128 x 128
+  return launch_corr<4, 2, false>(fs, qs, corr, rshb, invn, nullptr, defer_norms, A, B, C, H, W, stream);     // 4 waves of 128 x 128 (diagnostic)
 #else
-  return launch_corr<2, 4>(fs, qs, corr, rshb, invn, A, B, C, H, W, stream);     // 8 waves of 128 x 64
+  return sx ? launch_corr<2, 4, true>(fs, qs, corr, rshb, invn, sx, defer_norms, A, B, C, H, W, stream)        // 8 waves of 128 x 64
+            : launch_corr<2, 4, false>(fs, qs, corr, rshb, invn, sx, defer_norms, A, B, C, H, W, stream);
 #endif
 }

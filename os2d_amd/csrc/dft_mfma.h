@@ -21,7 +21,7 @@
 //   buffer of the 5x5 layer), as in fft.hip.
 // G = 4 images per work-group iteration: 4 consecutive channels of one pair (forward) / 4 consecutive output channels (inverse).
 // That makes the spectra layouts of BOTH sides of the per-bin GEMM "quads x channels": X [bins/4][pair'][Cpad][4] and
-// Y [bins/4][pair'][Cout][4] complex64 with bin = v * P + u (u fastest, P % 4 == 0: a quad never straddles v) - the forward
+// Y [bins/4][pair'][Cout][4] complex64 (in blocks of 64 pairs: dft_spectra_pair0) with bin = v * P + u (u fastest, P % 4 == 0: a quad never straddles v) - the forward
 // kernel writes 128-byte runs (4 channels x 4 bins), the GEMM reads 256-byte runs per (pair, k-step of 8 channels) instead of
 // 32-byte pieces 22 KB apart, its Y stores stay 1 KB runs, and the inverse kernel reads 128-byte runs.
 //
@@ -250,21 +250,34 @@ static inline bool dft_make_forward_plan(int H, int W, int G, DftPlan* out) {
   return true;
 }
 
+// Spectra in quads of bins, BLOCKED by 64 pairs (the pair tile of the per-bin GEMM):
+//   [pair' / 64][bins / 4][pair' % 64][channel stride][4] complex64, the last block holding NBT % 64 pairs (no padding: the
+//   buffers keep their size NBT x bins x channels).
+// With one block - up to 64 pairs - this is [bins / 4][pair'][channel][4].  With 1024 pairs the quads of one pair were 7.6 MB
+// (X) / 4 MB (Y) apart: every 128-byte run of a transform iteration in its own DRAM page and translation entry; blocked, the
+// distance is that of the 64-pair case (475 / 262 KB) whatever the batch, and a GEMM work-group's operands are one contiguous
+// slab.  Returns the float offset of (pair', quad 0, channel 0); *qstride = floats between consecutive quads of that pair.
+constexpr int DFT_PBLK = 64;
+DFT_HD size_t dft_spectra_pair0(int pr, int NBT, int NQ, int cstride, size_t* qstride) {
+  const int pb = pr / DFT_PBLK, pl = pr - pb * DFT_PBLK;
+  const int nbl = NBT - pb * DFT_PBLK < DFT_PBLK ? NBT - pb * DFT_PBLK : DFT_PBLK;
+  *qstride = (size_t)nbl * cstride * 8;
+  return ((size_t)pb * DFT_PBLK * NQ + pl) * cstride * 8;
+}
+
 // ---------------------------------------------------------------------------------------------------- device helpers
 DFT_DEV int dft_div(int x, unsigned magic) { return magic ? (int)(((unsigned long long)(unsigned)x * magic) >> 32) : x; }
 
-// fp16 hi + lo of four values: two 8-byte halves-of-a-unit
+// fp16 hi + lo of four values: two 8-byte halves-of-a-unit.  Vector conversions: gfx950 has v_cvt_pk_f16_f32 (two values per
+// instruction, round to nearest even like the scalar form) - 12 instructions per call instead of ~20 with scalar conversions
+// and integer packing; the split conversions are a third of the VALU work of the W / R / WY / WT phases.
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 DFT_DEV void dft_split4(float a, float b, float c, float d, u32x2v* hi, u32x2v* lo) {
-  const _Float16 ha = (_Float16)a, hb = (_Float16)b, hc = (_Float16)c, hd = (_Float16)d;
-  const _Float16 la = (_Float16)(a - (float)ha), lb = (_Float16)(b - (float)hb), lc = (_Float16)(c - (float)hc),
-                 ld = (_Float16)(d - (float)hd);
-  u32x2v h, l;
-  h[0] = (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
-  h[1] = (unsigned)__builtin_bit_cast(unsigned short, hc) | ((unsigned)__builtin_bit_cast(unsigned short, hd) << 16);
-  l[0] = (unsigned)__builtin_bit_cast(unsigned short, la) | ((unsigned)__builtin_bit_cast(unsigned short, lb) << 16);
-  l[1] = (unsigned)__builtin_bit_cast(unsigned short, lc) | ((unsigned)__builtin_bit_cast(unsigned short, ld) << 16);
-  *hi = h;
-  *lo = l;
+  const f32x4v x = {a, b, c, d};
+  const half4v h = __builtin_convertvector(x, half4v);
+  const half4v l = __builtin_convertvector(x - __builtin_convertvector(h, f32x4v), half4v);
+  *hi = __builtin_bit_cast(u32x2v, h);
+  *lo = __builtin_bit_cast(u32x2v, l);
 }
 
 DFT_DEV half8 dft_frag(const u32x4v* p) { return __builtin_bit_cast(half8, *p); }
@@ -425,7 +438,7 @@ DFT_DEV void dft_matrix_unit(int which, int unit, int P, int Q, const double* tw
 template <bool TILED, bool FAST, int G, int NW>
 DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
                               const float* invn,      // [NB][H * W]
-                              float* X,               // [NBINS / 4][NBT][Cpad][4][2]
+                              float* X,               // [NBT / 64][NBINS / 4][64][Cpad][4][2] (dft_spectra_pair0)
                               const u32x4v* FqT, const u32x4v* Fp2, const DftPlan& pl, int C, int Cpad, int NBT, int iters) {
   constexpr int THR = NW * 64;     // G = 4: 8 waves, one work-group per CU; G = 2: 4 waves, TWO independent work-groups per CU -
                                    // their phases (VALU conversions, LDS-bound and matrix-bound products, stores) overlap
@@ -652,8 +665,8 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
     // ---- ST: 16-byte pieces, 8 per quad of bins = the 128 contiguous bytes of the 4 channels; then the padding bins
     {
       const int per_v = (P / 4) * (G * 2), npieces = V * per_v;
-      float* dstbase = X + ((size_t)pr_ * Cpad + c0_) * 8;
-      const size_t qstride = (size_t)NBT * Cpad * 8;             // floats between consecutive quads of bins
+      size_t qstride;                                            // floats between consecutive quads of bins
+      float* dstbase = X + dft_spectra_pair0(pr_, NBT, pl.NBINS / 4, Cpad, &qstride) + (size_t)c0_ * 8;
       for (int i = tl; i < npieces; i += THR) {
         const int v = dft_div(i, pl.inv_pq), rem = i - v * per_v;
         const int uq = rem / (2 * G), jj = rem - uq * (2 * G);
@@ -677,7 +690,7 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
 // ---------------------------------------------------------------------------------------------------- inverse transform
 // iteration it -> (pair' = it / OG, output channel group og = it % OG): output channels 4 og .. 4 og + 3 of pair' = nb * T + tile
 template <bool TILED>
-DFT_DEV void dft_inverse_body(const float* Y,        // [NBINS / 4][NBT][Cout][4][2]
+DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64][Cout][4][2] (dft_spectra_pair0)
                               const float* bp,       // [3][MTP]: bias | - | 2^out_exp
                               int MTP, unsigned char* out,   // SHB [NB][Cout / 8][2][PLANE] x 16 B
                               const u32x4v* E2, const u32x4v* Gq, const DftPlan& pl, int Cout, int NBT, int PLANE, int Ws,
@@ -714,12 +727,12 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBINS / 4][NBT][Cout][4
   constexpr int NITEM = 3;                                      // ceil(G * V * Pp / 8 / 512) <= 4 * 48 * 8 / 512
   const int uoct = Pp / 8, nitem = DFT_G * V * uoct;
   f32x4v py[NITEM][4];
-  const size_t qstride = (size_t)NBT * Cout * 8;
 #define DFT_INV_PREFETCH(IT, TID) DFT_INV_PREFETCH_ITEMS(IT, TID, 0, NITEM)
 #define DFT_INV_PREFETCH_ITEMS(IT, TID, S0, S1)                                             \
   {                                                                                         \
     const int pr_ = dft_div((IT), pl.inv_og), og_ = (IT)-pr_ * OG;                          \
-    const float* src_ = Y + ((size_t)pr_ * Cout + og_ * DFT_G) * 8;                         \
+    size_t qstride;                                                                         \
+    const float* src_ = Y + dft_spectra_pair0(pr_, NBT, pl.NBINS / 4, Cout, &qstride) + (size_t)og_ * DFT_G * 8; \
     _Pragma("unroll") for (int s = (S0); s < (S1); ++s) {                                   \
       const int e_ = (TID) + s * DFT_THR;                                                   \
       const int ec_ = e_ < nitem ? e_ : 0;                                                  \

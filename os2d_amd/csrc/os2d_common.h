@@ -38,6 +38,15 @@ static inline __host__ __device__ int os2d_plane(int H, int W) {
   return os2d_round_up(os2d_base(W) + (H + OS2D_PAD) * os2d_ws(W) + OS2D_PAD, 64);
 }
 // is flat plane index n an interior (data) cell?
+// Packed correlation kernel (corr_f16x3.hip, STACK): a position's sum of relu(corr)^2 in 2^-44 fixed point (bit 62: a
+// non-finite term) -> 1 / (sqrt(s) + 1e-6) (head.py:650, 597); the word is cleared for the next launch.  acc < 2^53: the
+// conversion to double is exact, the one to float rounds once.
+__device__ __forceinline__ void os2d_corr_norm_finalize_one(unsigned long long* __restrict__ sumfx, float* __restrict__ invn, size_t i) {
+  const unsigned long long v = sumfx[i];
+  sumfx[i] = 0ull;
+  const float s = (v >> 62) ? __builtin_nanf("") : (float)((double)v * 5.6843418860808015e-14);    // 2^-44
+  invn[i] = 1.0f / (sqrtf(s) + 1e-6f);
+}
 static inline __host__ __device__ bool os2d_interior(int n, int H, int W) {
   const int r = n - os2d_base(W);
   return r >= 0 && r < H * os2d_ws(W) && (r % os2d_ws(W)) < W;
@@ -192,6 +201,8 @@ int os2d_launch_pack_conv(const float* w, const float* b, const float* bn_w, con
                           int MT, float* wp, float* bp, hipStream_t stream);
 int os2d_launch_border_zero_shb(void* rnorm, int NB, int H, int W, hipStream_t stream);
 int os2d_launch_border_zero_shb_planes(void* buf, int planes, int H, int W, hipStream_t stream);
+// the same launch + the inverse norms of the packed correlation kernel (corr_f16x3.hip): sumfx [n] -> invn [n], sums cleared
+int os2d_launch_border_zero_shb_planes_norms(void* buf, int planes, int H, int W, void* sumfx, float* invn, size_t n, hipStream_t stream);
 int os2d_launch_pack_conv_f16(const float* w, const float* b, const float* bn_w, const float* bn_b, const float* bn_mean,
                               const float* bn_var, float bn_eps, int Cout, int Cin, int KS, int MT, int steps_padded,
                               const int* wexp, const int* in_exp, const int* out_exp, void* wp, float* bp,
@@ -260,7 +271,13 @@ int os2d_launch_dft_inverse(const float* Y, const float* bp, int MTP, void* out,
                             int* status, hipStream_t stream);
 // corr_f16x3.hip
 int os2d_corr_groups(int C);  // 8-channel groups of the split correlation operands, padded to whole K chunks
-int os2d_launch_split_fm(const float* fm, const float* sumsq, void* fs, int A, int C, int HW, hipStream_t stream);
+// clear / clear_words: 64-bit words zeroed by the same launch (the packed correlation kernel's sums; NULL / 0: none)
+int os2d_launch_split_fm(const float* fm, const float* sumsq, void* fs, int A, int C, int HW, void* clear, size_t clear_words,
+                         hipStream_t stream);
 int os2d_launch_split_qp(const float* qp, void* qs, int B, int C, hipStream_t stream);
-int os2d_launch_corr_f16x3(const void* fs, const void* qs, float* corr, void* rshb, float* invn, int A, int B, int C, int H, int W,
-                           hipStream_t stream);
+// defer_norms != 0 (packed form only): the sums stay in sumfx; the caller's next launch turns them into invn
+// (os2d_launch_border_zero_shb_planes_norms) - one launch less on the per-step path
+int os2d_launch_corr_f16x3(const void* fs, const void* qs, float* corr, void* rshb, float* invn, void* sumfx, int defer_norms, int A,
+                           int B, int C, int H, int W, hipStream_t stream);
+int os2d_corr_f16x3_use_packed(int A, int B, int H, int W);     // the head's choice between the two forms (same bits either way)
+int os2d_launch_corr_sums_clear(void* sumfx, int A, int B, int H, int W, hipStream_t stream);

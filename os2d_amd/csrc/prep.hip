@@ -331,7 +331,14 @@ __global__ __launch_bounds__(256) void pack_conv_f16_kernel(const float* __restr
 
 // border cells of the split-half blocked normalised-correlation buffer [NB][29][2][PLANE] x 16 B
 // (the pad cells are enumerated directly: the BASE cells in front, the 3 cells after every row, the tail)
-__global__ __launch_bounds__(256) void border_zero_shb_kernel(uint4* __restrict__ p, int H, int W, int PLANE) {
+// (blocks beyond `planes`: the inverse norms of the packed correlation kernel, 256 positions each - one launch for both)
+__global__ __launch_bounds__(256) void border_zero_shb_kernel(uint4* __restrict__ p, int H, int W, int PLANE, int planes,
+                                                              unsigned long long* __restrict__ sumfx, float* __restrict__ invn, size_t n) {
+  if ((int)blockIdx.x >= planes) {
+    const size_t i = (size_t)(blockIdx.x - planes) * 256 + threadIdx.x;
+    if (i < n) os2d_corr_norm_finalize_one(sumfx, invn, i);
+    return;
+  }
   uint4* q = p + (size_t)blockIdx.x * PLANE;
   const int Ws = os2d_ws(W), BASE = os2d_base(W);
   const int rows = H * OS2D_PAD, tail0 = BASE + H * Ws;
@@ -369,16 +376,19 @@ int os2d_launch_border_zero(float* rpad, int planes_total, int H, int W, hipStre
   return check_launch("border_zero");
 }
 
-int os2d_launch_border_zero_shb(void* rnorm, int NB, int H, int W, hipStream_t stream) {
-  hipLaunchKernelGGL(border_zero_shb_kernel, dim3(NB * OS2D_G * 2), dim3(256), 0, stream,
-                     reinterpret_cast<uint4*>(rnorm), H, W, os2d_plane(H, W));
+int os2d_launch_border_zero_shb_planes_norms(void* buf, int planes, int H, int W, void* sumfx, float* invn, size_t n, hipStream_t stream) {
+  const size_t extra = sumfx ? (n + 255) / 256 : 0;
+  hipLaunchKernelGGL(border_zero_shb_kernel, dim3((unsigned)(planes + extra)), dim3(256), 0, stream, reinterpret_cast<uint4*>(buf), H, W,
+                     os2d_plane(H, W), planes, static_cast<unsigned long long*>(sumfx), invn, sumfx ? n : (size_t)0);
   return check_launch("border_zero_shb");
 }
 
+int os2d_launch_border_zero_shb(void* rnorm, int NB, int H, int W, hipStream_t stream) {
+  return os2d_launch_border_zero_shb_planes_norms(rnorm, NB * OS2D_G * 2, H, W, nullptr, nullptr, 0, stream);
+}
+
 int os2d_launch_border_zero_shb_planes(void* buf, int planes, int H, int W, hipStream_t stream) {
-  hipLaunchKernelGGL(border_zero_shb_kernel, dim3(planes), dim3(256), 0, stream, reinterpret_cast<uint4*>(buf), H, W,
-                     os2d_plane(H, W));
-  return check_launch("border_zero_shb");
+  return os2d_launch_border_zero_shb_planes_norms(buf, planes, H, W, nullptr, nullptr, 0, stream);
 }
 
 int os2d_launch_pack_conv_f16(const float* w, const float* b, const float* bn_w, const float* bn_b, const float* bn_mean,

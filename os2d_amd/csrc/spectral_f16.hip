@@ -73,7 +73,7 @@ template <bool XQ>
 __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x4* w16,            // [G][2][KS][8][2][2][64] units
                                                                       const float* __restrict__ wscale,  // [128] 2^-wexp[o]
                                                                       const f32x2* __restrict__ X,       // [C][NB][NBINS] | quads
-                                                                      f32x2* __restrict__ Y,             // [NBINS/4][NB][Cout][4]
+                                                                      f32x2* __restrict__ Y,             // [NBINS/4][NB][Cout][4] (XQ: blocked)
                                                                       int NB, int C, int Cpad, int Cout, int NBINS, int G, float xscale,
                                                                       int nunits) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -129,7 +129,11 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
   const int xj = XQ ? (lane & 1) : (lane >> 4) & 1, xg = XQ ? (lane >> 2) & 1 : lane >> 5;
   const int xwh = XQ ? (lane >> 1) & 1 : wh;
   const bool xn_ok = nb0 + xn < NB;
-  const f32x2* xrow = XQ ? X + (((size_t)(bin0 >> 2) * NB + min(nb0 + xn, NB - 1)) * Cpad) * 4 + 2 * xj
+  // XQ: both spectra in blocks of 64 pairs = this work-group's pair tile: [pair tile][bins / 4][pair in tile][channel][4]
+  // (dft_mfma.h, dft_spectra_pair0): the operands of a work-group are one contiguous slab whatever the batch size
+  const int nbl = min(SH_NB, NB - nb0);                                        // pairs in this tile (the last one may be short)
+  const size_t qblk = XQ ? (size_t)nb0 * (NBINS >> 2) + (size_t)(bin0 >> 2) * nbl : 0;   // in pairs: start of (tile, quad)
+  const f32x2* xrow = XQ ? X + ((qblk + min(xn, nbl - 1)) * Cpad) * 4 + 2 * xj
                          : X + (size_t)min(nb0 + xn, NB - 1) * NBINS + bin0 + 2 * xj;
   const size_t xcs = XQ ? 4 : (size_t)NB * NBINS;      // channel stride: 4 bins | X [C][NB][NBINS]
   u32x4 pfa[2], pfb[2];     // two k-steps of spectra in flight (even / odd k-steps)
@@ -158,9 +162,10 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
   h_[2 * i_ + p_] = hv_;                                                                                            \
   l_[2 * i_ + p_] = (_Float16)(v_ - (float)hv_);
 #endif
-#define SH_STORE_X(S, pfx)                                                                                          \
+#define SH_STORE_X(S, pfx) SH_STORE_X_PART(S, pfx, 0, 2)
+#define SH_STORE_X_PART(S, pfx, B0, B1)                                                                             \
   {                                                                                                                 \
-    _Pragma("unroll") for (int b2_ = 0; b2_ < 2; ++b2_) {                                                           \
+    _Pragma("unroll") for (int b2_ = (B0); b2_ < (B1); ++b2_) {                                                     \
       half4 h_, l_;                                                                                                 \
       _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                            \
         const bool ok_ = xn_ok && (S)*SH_KC + xg * 4 + xwh * 2 + i_ < C;                                            \
@@ -174,7 +179,9 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
       *reinterpret_cast<half4*>(dst_ + 64 * 16) = l_;                                                               \
     }                                                                                                               \
   }
-#define SH_COMPUTE(S)                                                                                               \
+#define SH_NOHOOK(J)
+#define SH_COMPUTE(S) SH_COMPUTE_H(S, SH_NOHOOK)
+#define SH_COMPUTE_H(S, HOOK)                                                                                       \
   {                                                                                                                 \
     /* [half][bin][group = hw][hi|lo][o 64] and [bin][group][hi|lo][pair 64] */                                     \
     const u32x4* aB = ldsW + ((S) % SH_WRING) * SH_WSTAGE + (ot >> 1) * SH_STAGE + (hw * 2) * 64 + (ot & 1) * 32 + l31; \
@@ -199,6 +206,7 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
       yi[j] = SH_MM(bhf, ail, yi[j]);                                                                               \
       yi[j] = SH_MM(blf, aih, yi[j]);                                                                               \
       yi[j] = SH_MM(bhf, aih, yi[j]);                                                                               \
+      HOOK(j)                                                                                                       \
     }                                                                                                               \
   }
   // one k-step: spectra of step S+2 -> registers PN (the registers PC hold step S+1, loaded one step ago), weights of step
@@ -206,6 +214,36 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
   // memory operations complete in issue order and the weights of a step are issued BEFORE its spectra: when the spectra of
   // step S+1 have arrived (the split below waits for them) its weights are in LDS as well; the barrier itself waits for LDS
   // traffic only.
+#ifndef OS2D_SH_INTERLEAVE
+#define OS2D_SH_INTERLEAVE 0
+#endif
+#if OS2D_SH_INTERLEAVE
+  // DIAGNOSTIC (-DOS2D_SH_INTERLEAVE=1; round 4, measured 7 % SLOWER: 3.18 against 2.96 ms at 1024 pairs, 0.305 against 0.289 at
+  // 64, profiles/r04/spectral_gemm_interleave.txt): the split + store of the next k-step's spectra in two halves BETWEEN the
+  // matrix instructions of the bins instead of after the last one.  The idea: with every global load removed a k-step still
+  // takes 2,250 cycles against 1,536 of matrix time (profiles/r04/spectral_gemm_components.txt) because all 8 waves convert while
+  // the matrix pipes idle and multiply while the vector units idle.  What happens: the conversion waits for spectra loaded one
+  // k-step ago; placed after the first bin that wait stalls the wave with 18 matrix instructions still to issue, placed at the
+  // end it is covered by the 24 already in the pipe.
+#define SH_STEP(S, PC, PN)                                                                                          \
+  {                                                                                                                 \
+    if ((S) + SH_WRING - 1 < KS) SH_DMA_W((S) + SH_WRING - 1)                                                       \
+    if ((S) + 2 < KS) SH_LOAD_X((S) + 2, PN)                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    const bool more_ = (S) + 1 < KS;                                                                                \
+    const int sh_next_ = (S) + 1;                                                                                   \
+    SH_COMPUTE_H(S, SH_STORE_HOOK_##PC)                                                                             \
+    sh_lds_barrier();                                                                                               \
+  }
+#define SH_STORE_HOOK_pfa(J) SH_STORE_HOOK(J, pfa)
+#define SH_STORE_HOOK_pfb(J) SH_STORE_HOOK(J, pfb)
+#define SH_STORE_HOOK(J, PC)                                                                                        \
+  if (more_ && ((J) == 1 || (J) == 2)) {                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    SH_STORE_X_PART(sh_next_, PC, (J)-1, (J))                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+  }
+#else
 #define SH_STEP(S, PC, PN)                                                                                          \
   {                                                                                                                 \
     if ((S) + SH_WRING - 1 < KS) SH_DMA_W((S) + SH_WRING - 1)                                                       \
@@ -216,6 +254,7 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
     if ((S) + 1 < KS) SH_STORE_X((S) + 1, PC)                                                                       \
     sh_lds_barrier();                                                                                               \
   }
+#endif
 
   static_assert(SH_WRING >= 3, "the spectra run two k-steps ahead: the weight ring must reach at least as far");
   SH_DMA_W(0)
@@ -235,6 +274,12 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
     if (s + 1 < KS) SH_STEP(s + 1, pfb, pfa)
   }
 #undef SH_STEP
+#undef SH_STORE_HOOK
+#undef SH_STORE_HOOK_pfa
+#undef SH_STORE_HOOK_pfb
+#undef SH_COMPUTE_H
+#undef SH_NOHOOK
+#undef SH_STORE_X_PART
 #undef SH_COMPUTE
 #undef SH_DMA_W
 #undef SH_LOAD_X
@@ -258,7 +303,8 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
 #ifdef OS2D_DIAG_SPECTRA_ROWS
         float4* dst = reinterpret_cast<float4*>(Y + ((size_t)nb * Cout + o) * NBINS + bin0);
 #else
-        float4* dst = reinterpret_cast<float4*>(Y + (((size_t)(bin0 >> 2) * NB + nb) * Cout + o) * 4);
+        float4* dst = XQ ? reinterpret_cast<float4*>(Y + ((qblk + (nb - nb0)) * Cout + o) * 4)
+                         : reinterpret_cast<float4*>(Y + (((size_t)(bin0 >> 2) * NB + nb) * Cout + o) * 4);
 #endif
         dst[0] = make_float4(yr[0][r] * sc, yi[0][r] * sc, yr[1][r] * sc, yi[1][r] * sc);
         dst[1] = make_float4(yr[2][r] * sc, yi[2][r] * sc, yr[3][r] * sc, yi[3][r] * sc);

@@ -1,6 +1,7 @@
 // Host check of os2d_amd/csrc/dft_mfma.h on the SPMD emulator (spmd_emu.h): the forward and the inverse transform kernels -
 // the same source the GPU runs - against float64 DFTs, for an untiled fast-path map, a map whose width is not a multiple of 4,
 // a small map and tiled maps (ragged tiles).  Built and run by tests/test_dft_mfma_host.py.   usage: dft_mfma_check [H W C NB]...
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +23,13 @@ static int emu_dft_policy = 0;      // 0: smallest transform per map, 1: the can
 #define DFT_RAISE(p) (*(p) = 1)
 #define DFT_UNIFORM(x) (x)
 #include "dft_mfma.h"
+
+// The spectra layouts, stated independently of the kernels' helper (include/os2d_hip.h): blocks of 64 pairs,
+// [pair / 64][quad of bins][pair % 64 (last block: what is left)][channel][4 bins][re | im]
+static size_t spec_index(int bin, int pair, int NBT, int nquads, int chans, int c) {
+  const int blk = pair / 64, in_blk = pair % 64, held = std::min(64, NBT - 64 * blk);
+  return ((((size_t)blk * 64 * nquads + (size_t)(bin / 4) * held + in_blk) * chans + c) * 4 + (bin & 3)) * 2;
+}
 
 using namespace os2d_dft;
 
@@ -127,12 +135,12 @@ static int check_case(int H, int W, int C, int NB, int grid) {
               si += rr[(size_t)r * V + v] * ci + ri[(size_t)r * V + v] * cr;
             }
             const int bin = v * P + u;
-            const float* got = &X[(((size_t)(bin / 4) * NBT + pair) * Cpad + c) * 8 + (bin & 3) * 2];
+            const float* got = &X[spec_index(bin, pair, NBT, pl.NBINS / 4, Cpad, c)];
             worst = std::fmax(worst, std::fmax(std::fabs(got[0] - sr), std::fabs(got[1] - si)));
             scale = std::fmax(scale, std::fmax(std::fabs(sr), std::fabs(si)));
           }
         for (int bin = P * V; bin < pl.NBINS; ++bin) {
-          const float* got = &X[(((size_t)(bin / 4) * NBT + pair) * Cpad + c) * 8 + (bin & 3) * 2];
+          const float* got = &X[spec_index(bin, pair, NBT, pl.NBINS / 4, Cpad, c)];
           if (got[0] != 0.f || got[1] != 0.f) {
             std::printf("padding bin %d not zero\n", bin);
             return 1;
@@ -173,7 +181,7 @@ static int check_case(int H, int W, int C, int NB, int grid) {
             double sr = 0, si = 0;
             for (int u = 0; u < P; ++u) {
               const int bin = v * P + u;
-              const float* y = &Y[(((size_t)(bin / 4) * NBT + pair) * Cout + o) * 8 + (bin & 3) * 2];
+              const float* y = &Y[spec_index(bin, pair, NBT, pl.NBINS / 4, Cout, o)];
               const int a = (int)(((long long)u * hwin) % P);
               const double cr = tp[2 * a], ci = -tp[2 * a + 1];      // e^{+i}
               sr += y[0] * cr - y[1] * ci;

@@ -21,7 +21,7 @@ def test_dft_mfma_kernels_on_the_host_emulator(tmp_path):
                    check=True, timeout=300)
     # small untiled (W % 4 != 0, partial channel group), fast path with several work-groups, a tiled map with ragged tiles, a
     # level of the pyramid with P % 8 == 4
-    out = subprocess.run([exe, "11", "13", "5", "1", "20", "24", "4", "2", "70", "100", "5", "1", "30", "43", "6", "2"],
+    out = subprocess.run([exe, "11", "13", "5", "1", "20", "24", "4", "2", "70", "100", "5", "1", "30", "43", "6", "2", "9", "11", "4", "66"],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-3000:] + out.stderr[-2000:]
     # the same kernels planned on the canonical transform sizes (the default policy): a map much smaller than its transform, and

@@ -662,6 +662,79 @@ def test_correlation_stage_matches_reference(name, device):
     assert float(border.abs().max()) == 0.0                                                    # zero borders baked in
 
 
+def _packed_corr(lib, fm, qs, B, device, form=1):
+    from os2d_amd import _lib
+    A, C, H, W = fm.shape
+    ws = torch.empty(lib.os2d_corr_f16x3_packed_workspace_bytes(A, B, C, H, W), dtype=torch.uint8, device=device)
+    corr = torch.full((A * B, 225, H * W), float("nan"), device=device)
+    invn = torch.full((A * B, H * W), float("nan"), device=device)
+    _lib.check(lib.os2d_corr_f16x3_packed(_lib.ptr(fm), _lib.ptr(qs), _lib.ptr(corr), _lib.ptr(invn), A, B, C, H, W, form, _lib.ptr(ws), ws.numel(),
+                                          _lib.current_stream(device)), "os2d_corr_f16x3_packed")
+    return corr, invn
+
+
+@pytest.mark.parametrize("name", ["v2_affine_inv", "affine_noinv", "v2_c256_wide"])
+def test_packed_correlation_stage_matches_reference(name, device):
+    """The correlation of the frequency-domain heads (classes packed along the matrix rows) against the
+    reference's correlation tensor, its inverse norms against relu + L2 of that tensor (head.py:650), and against the padded
+    one-class-per-tile kernel: the correlation values bit for bit (the same products in the same order), the norms to rounding."""
+    from os2d_amd import _lib
+    lib = _lib.load()
+    fx = util.load_head_fixture(name)
+    creator = util.make_head_creator(fx["P"], fx["inverse"], fx["state"], device)
+    fm = fx["fm"].to(device)
+    A, C, H, W = fm.shape
+    with torch.no_grad():
+        head = creator.create_os2d_head([c.to(device) for c in fx["class_fms"]])
+    B = head.class_batch_size
+    NB, HW = A * B, H * W
+    corr, invn = _packed_corr(lib, fm, head._split_class_operand(), B, device)
+    ref = fx["ref_corr"].reshape(NB, 225, HW)
+    assert util.maxdiff(corr, ref) < 2e-6
+    inv_ref = 1.0 / (torch.relu(fx["ref_corr"].double()).reshape(NB, 225, HW).norm(dim=1) + 1e-6)
+    assert float(((invn.double().cpu() - inv_ref).abs() / inv_ref).max()) < 3e-6
+    # the padded kernel: same correlation bits
+    ws = torch.empty(lib.os2d_corr_f16x3_workspace_bytes(A, C, H, W), dtype=torch.uint8, device=device)
+    corr16 = torch.empty(NB, 225, HW, device=device)
+    rshb = torch.empty(NB * lib.os2d_shb_bytes(225, H, W), dtype=torch.uint8, device=device)
+    _lib.check(lib.os2d_corr_f16x3(_lib.ptr(fm), _lib.ptr(head._split_class_operand()), _lib.ptr(corr16), _lib.ptr(rshb), A, B, C, H, W,
+                                   _lib.ptr(ws), ws.numel(), _lib.current_stream(device)), "os2d_corr_f16x3")
+    assert torch.equal(corr, corr16)
+
+
+@pytest.mark.parametrize("H,W,C,B", [(60, 80, 256, 23), (13, 17, 64, 70), (30, 40, 128, 9)])
+def test_packed_correlation_is_independent_of_the_batch_composition(H, W, C, B, device):
+    """A class's correlation AND its inverse norms are the same bits whether it is computed alone, at another position of the
+    batch or in a sub-batch: the packed kernel's per-position sums cross work-groups as fixed-point integers, so neither the
+    alignment of a class inside a row tile nor the order of the atomics can show.  Also: exact against float64 sums of the
+    kernel's own correlation values (the fixed point drops < 2^-44 per group of four rows), and a map whose H*W is not a
+    multiple of 4 (scalar store path)."""
+    from os2d_amd import _lib
+    from os2d_amd.utils import synthetic
+    lib = _lib.load()
+    P = 6
+    creator = util.make_head_creator(P, True, synthetic.make_transform_net_state(P, seed=2), device)
+    fm = synthetic.make_feature_map(C, H, W, seed=11).to(device)
+    cls = [c.to(device) for c in synthetic.make_class_feature_maps(B, C, seed=77)]
+    with torch.no_grad():
+        head = creator.create_os2d_head(cls)
+        corr, invn = _packed_corr(lib, fm, head._split_class_operand(), B, device)
+        assert torch.isfinite(corr).all() and torch.isfinite(invn).all()
+        s64 = torch.relu(corr.double()).pow(2).sum(dim=1)
+        want = (1.0 / (torch.sqrt(s64.float()) + 1e-6))
+        assert float(((invn - want).abs() / want).max()) < 5e-7              # fp32 group sums of 4, one rounding of s, sqrt, add, divide
+        for picks in ([B - 1], [3, 0], list(range(B - 1, -1, -2))):
+            sub = creator.create_os2d_head([cls[i] for i in picks])
+            c2, i2 = _packed_corr(lib, fm, sub._split_class_operand(), len(picks), device)
+            assert torch.equal(c2, corr[picks]) and torch.equal(i2, invn[picks])
+        again = _packed_corr(lib, fm, head._split_class_operand(), B, device)
+        assert torch.equal(again[0], corr) and torch.equal(again[1], invn)
+        # the padded form (one 256-row tile per class) and whatever the head would pick: the same bits
+        for form in (0, -1):
+            other = _packed_corr(lib, fm, head._split_class_operand(), B, device, form=form)
+            assert torch.equal(other[0], corr) and torch.equal(other[1], invn), form
+
+
 def test_dump_variant_builds_and_runs(device, tmp_path):
     """the -DOS2D_DIAG_DUMP build (tools/diag_pyramid_dump.py needs it) dead-locked in its first head forward -
     ``dumps_active()`` called itself under a non-recursive mutex.  Build the variant, register a dump slot, run one forward in

@@ -94,6 +94,23 @@ def y_quads_to_rows(Yq, NBT, Cout, nbins):
     return Yq.view(nbins // 4, NBT, Cout, 4, 2).permute(1, 2, 0, 3, 4).reshape(NBT, Cout, nbins, 2).contiguous()
 
 
+def quads_to_blocked(T):
+    """[nq, NBT, C, 4, 2] -> the flat buffer in blocks of 64 pairs the matrix-product transforms and the quads GEMM use
+    ([pair' / 64][nq][pair' % 64][C][4], include/os2d_hip.h): identical for up to 64 pairs."""
+    NBT = T.shape[1]
+    return torch.cat([T[:, b0:b0 + 64].contiguous().reshape(-1) for b0 in range(0, NBT, 64)])
+
+
+def blocked_to_quads(flat, nq, NBT, C):
+    out, off = [], 0
+    for b0 in range(0, NBT, 64):
+        n = min(64, NBT - b0)
+        out.append(flat[off:off + nq * n * C * 8].view(nq, n, C, 4, 2))
+        off += nq * n * C * 8
+    assert off == flat.numel()
+    return torch.cat(out, dim=1)
+
+
 def y_rows_to_quads(Y):
     NBT, Cout, nbins, _ = Y.shape
     return Y.view(NBT, Cout, nbins // 4, 4, 2).permute(2, 0, 1, 3, 4).contiguous()
@@ -378,9 +395,11 @@ def test_split_half_spectral_gemm_matches_float64(H, W, NB, device):
                 cpad = lib.os2d_dft_channel_stride(225)
                 Xq = torch.full((nbins // 4, NB, cpad, 4, 2), float("nan"))                # pad channels: never read as numbers
                 Xq[:, :, :225] = X.view(NB, 225, nbins // 4, 4, 2).permute(2, 0, 1, 3, 4)
-                Xq = Xq.to(device)
-                _lib.check(lib.os2d_spectral_gemm_f16_quads(_lib.ptr(w16), _lib.ptr(Xq), _lib.ptr(Yq), NB, 225, 128, nbins, xs, st), "gemm16 quads")
-            Y = y_quads_to_rows(Yq, NB, 128, nbins)
+                Xq = quads_to_blocked(Xq).to(device)                                       # both sides in blocks of 64 pairs
+                Yb = torch.full((Yq.numel(),), float("nan"), device=device)
+                _lib.check(lib.os2d_spectral_gemm_f16_quads(_lib.ptr(w16), _lib.ptr(Xq), _lib.ptr(Yb), NB, 225, 128, nbins, xs, st), "gemm16 quads")
+                Yq = blocked_to_quads(Yb, nbins // 4, NB, 128)
+            Y = y_quads_to_rows(Yq.contiguous(), NB, 128, nbins)
         got = torch.view_as_complex(Y.cpu()[:, :, :P * V].contiguous()).to(torch.complex128)
         err = float((got - ref).abs().max())
         print("spectral GEMM {} {}x{} NB={}: max err {:.3g} of {:.3g}".format(name, H, W, NB, err, scale))

@@ -49,7 +49,10 @@ constexpr int SH_WSTAGE = 2 * SH_STAGE;        // weights of both output-channel
 #ifndef OS2D_SH_WRING
 #define OS2D_SH_WRING 3
 #endif
-constexpr int SH_WRING = OS2D_SH_WRING;        // weight stages in LDS (ring): the DMA of k-step s + WRING - 1 is in flight
+#ifndef OS2D_SH_REGW
+#define OS2D_SH_REGW 1        /* 1: weights staged through registers (round 4); 0: by LDS-DMA into a ring of 3 (round 3) */
+#endif
+constexpr int SH_WRING = OS2D_SH_REGW ? 2 : OS2D_SH_WRING;        // weight stages in LDS (ring): the DMA of k-step s + WRING - 1 is in flight
                                                // while k-step s is multiplied; the spectra are two k-steps ahead in registers
 
 #ifdef OS2D_DIAG_SH_NOMFMA   /* diagnostic: fragments are read and derived, the matrix instructions are skipped */
@@ -107,7 +110,36 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
   // weights of k-step s for this work-group's 4 bins: 1024 contiguous units per output-channel half (waves 0-3 stage half 0,
   // waves 4-7 half 1)
   const u32x4* wbase = w16 + ((size_t)(g * 2 + wh) * KS) * (SH_BINS * 256) + bh * SH_STAGE;
-#ifdef OS2D_DIAG_SH_NOW      /* diagnostic: no weight DMA (tools/diag_spectral.sh) */
+#if OS2D_SH_REGW
+  // REGISTER staging (round 4).  The LDS-DMA of round 3 (global_load_lds) looked like a 2-step-deep pipeline and was none: the
+  // compiler treats a FLAT-encoded instruction that may touch LDS as returning out of order, and from the first DMA on every
+  // vmcnt wait it inserts is vmcnt(0).  The one wait this loop needs - for the spectra registers before their conversion - thus
+  // also waited for the weight DMA and the spectra loads issued at the top of the SAME k-step: each of the 29 k-steps paid the
+  // full load latency minus its 0.75 us of matrix work (2.3 us per k-step at 1024 pairs; 1.07 with every load removed,
+  // profiles/r04/spectral_gemm_components.txt).  With plain loads the counter is exact: a k-step requests the weights and the
+  // spectra of step S + 2 into one of two register sets, multiplies step S, then moves the set requested a step ago (S + 1)
+  // into the other LDS stage - vmcnt(6): this step's 4 + 2 requests stay in flight through the barrier and the next k-step's
+  // matrix work.  Costs 32 registers and 4 LDS stores per thread and k-step; the LDS ring shrinks to 2 stages (96 KB in all).
+  u32x4 wra[4], wrb[4];
+#ifdef OS2D_DIAG_SH_NOW
+#define SH_LOAD_W(S, wr)                                                                                            \
+  {                                                                                                                 \
+    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) wr[k_] = u32x4{(unsigned)(S), 0x3c003c00u, 0u, (unsigned)lane};  \
+  }
+#else
+#define SH_LOAD_W(S, wr)                                                                                            \
+  {                                                                                                                 \
+    const u32x4* src_ = wbase + (size_t)(S) * (SH_BINS * 256);                                                      \
+    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) wr[k_] = src_[(wq * 4 + k_) * 64 + lane];                      \
+  }
+#endif
+#define SH_STORE_W(S, wr)                                                                                           \
+  {                                                                                                                 \
+    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_)                                                                \
+        ldsW[((S) % SH_WRING) * SH_WSTAGE + wh * SH_STAGE + (wq * 4 + k_) * 64 + lane] = wr[k_];                    \
+  }
+#define SH_DMA_W(S) {}
+#elif defined(OS2D_DIAG_SH_NOW)      /* diagnostic: no weight DMA (tools/diag_spectral.sh) */
 #define SH_DMA_W(S) {}
 #else
 #define SH_DMA_W(S)                                                                                                 \
@@ -163,6 +195,9 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
   l_[2 * i_ + p_] = (_Float16)(v_ - (float)hv_);
 #endif
 #define SH_STORE_X(S, pfx) SH_STORE_X_PART(S, pfx, 0, 2)
+  // (the four values of a store as ONE vector conversion: v_cvt_pk_f16_f32 converts two values per instruction - a third fewer
+  // conversion instructions than value by value; same roundings)
+#if defined(OS2D_DIAG_SH_NOSPLIT)
 #define SH_STORE_X_PART(S, pfx, B0, B1)                                                                             \
   {                                                                                                                 \
     _Pragma("unroll") for (int b2_ = (B0); b2_ < (B1); ++b2_) {                                                     \
@@ -170,15 +205,35 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
       _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                            \
         const bool ok_ = xn_ok && (S)*SH_KC + xg * 4 + xwh * 2 + i_ < C;                                            \
         _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_) {                                                          \
-          const unsigned raw_ = pfx[i_][2 * b2_ + p_];   /* (scalar copy first: see the ext-vector note in corr_f16x3.hip) */ \
+          const unsigned raw_ = pfx[i_][2 * b2_ + p_];                                                              \
           SH_SPLIT_VALUE                                                                                            \
         }                                                                                                           \
       }                                                                                                             \
+      char* dst_ = reinterpret_cast<char*>(ldsX + ((S)&1) * SH_STAGE + (((2 * xj + b2_) * 2 + xg) * 2) * 64 + xn) + xwh * 8; \
+      *reinterpret_cast<half4*>(dst_) = h_;                                                                         \
+      *reinterpret_cast<half4*>(dst_ + 64 * 16) = l_;                                                               \
+    }                                                                                                               \
+  }
+#else
+#define SH_STORE_X_PART(S, pfx, B0, B1)                                                                             \
+  {                                                                                                                 \
+    _Pragma("unroll") for (int b2_ = (B0); b2_ < (B1); ++b2_) {                                                     \
+      f32x4 v4_;                                                                                                    \
+      _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                            \
+        const bool ok_ = xn_ok && (S)*SH_KC + xg * 4 + xwh * 2 + i_ < C;                                            \
+        _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_) {                                                          \
+          const unsigned raw_ = pfx[i_][2 * b2_ + p_];   /* (scalar copy first: see the ext-vector note in corr_f16x3.hip) */ \
+          v4_[2 * i_ + p_] = ok_ ? __uint_as_float(raw_) * xscale : 0.f;                                            \
+        }                                                                                                           \
+      }                                                                                                             \
+      const half4 h_ = __builtin_convertvector(v4_, half4);                                                         \
+      const half4 l_ = __builtin_convertvector(v4_ - __builtin_convertvector(h_, f32x4), half4);                    \
       char* dst_ = reinterpret_cast<char*>(ldsX + ((S)&1) * SH_STAGE + (((2 * xj + b2_) * 2 + xg) * 2) * 64 + xn) + xwh * 8; \
       *reinterpret_cast<half4*>(dst_) = h_;              /* channels 2 wh, 2 wh + 1 of the unit (re, im each) */      \
       *reinterpret_cast<half4*>(dst_ + 64 * 16) = l_;                                                               \
     }                                                                                                               \
   }
+#endif
 #define SH_NOHOOK(J)
 #define SH_COMPUTE(S) SH_COMPUTE_H(S, SH_NOHOOK)
 #define SH_COMPUTE_H(S, HOOK)                                                                                       \
@@ -256,6 +311,60 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
   }
 #endif
 
+#if OS2D_SH_REGW
+  // k-step S: requests of step S + 2 -> set N (weights WN, spectra PN); multiply step S; the set requested a step ago (WC, PC:
+  // step S + 1) -> the other LDS stage; barrier.  The sets alternate, so the loop runs two k-steps per pass.
+#define SH_STEPR(S, WC, PC, WN, PN)                                                                                 \
+  {                                                                                                                 \
+    if ((S) + 2 < KS) {                                                                                             \
+      SH_LOAD_W((S) + 2, WN)                                                                                        \
+      SH_LOAD_X((S) + 2, PN)                                                                                        \
+    }                                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    SH_COMPUTE(S)                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    if ((S) + 1 < KS) {                                                                                             \
+      SH_STORE_W((S) + 1, WC)                                                                                       \
+      SH_STORE_X((S) + 1, PC)                                                                                       \
+    }                                                                                                               \
+    sh_lds_barrier();                                                                                               \
+  }
+  SH_LOAD_W(0, wrb)
+  SH_LOAD_X(0, pfb)
+  if (1 < KS) {
+    SH_LOAD_W(1, wra)
+    SH_LOAD_X(1, pfa)
+  }
+  SH_STORE_W(0, wrb)
+  SH_STORE_X(0, pfb)
+  sh_lds_barrier();
+  // the passes whose requests are all known to exist run without guards: behind "if (S + 2 < KS)" the compiler cannot tell how
+  // many loads are in flight when it needs the older set, and waits for all of them (vmcnt(0) instead of vmcnt(6))
+#define SH_STEPF(S, WC, PC, WN, PN)                                                                                 \
+  {                                                                                                                 \
+    SH_LOAD_W((S) + 2, WN)                                                                                          \
+    SH_LOAD_X((S) + 2, PN)                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    SH_COMPUTE(S)                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    SH_STORE_W((S) + 1, WC)                                                                                         \
+    SH_STORE_X((S) + 1, PC)                                                                                         \
+    sh_lds_barrier();                                                                                               \
+  }
+  int s = 0;
+  for (; s + 3 < KS; s += 2) {
+    SH_STEPF(s, wra, pfa, wrb, pfb)
+    SH_STEPF(s + 1, wrb, pfb, wra, pfa)
+  }
+  for (; s < KS; s += 2) {
+    SH_STEPR(s, wra, pfa, wrb, pfb)
+    if (s + 1 < KS) SH_STEPR(s + 1, wrb, pfb, wra, pfa)
+  }
+#undef SH_STEPF
+#undef SH_STEPR
+#undef SH_LOAD_W
+#undef SH_STORE_W
+#else
   static_assert(SH_WRING >= 3, "the spectra run two k-steps ahead: the weight ring must reach at least as far");
   SH_DMA_W(0)
   SH_LOAD_X(0, pfb)
@@ -273,6 +382,7 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
     SH_STEP(s, pfa, pfb)
     if (s + 1 < KS) SH_STEP(s + 1, pfb, pfa)
   }
+#endif
 #undef SH_STEP
 #undef SH_STORE_HOOK
 #undef SH_STORE_HOOK_pfa

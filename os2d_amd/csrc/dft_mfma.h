@@ -511,6 +511,9 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
       }                                                                                                      \
     }                                                                                                        \
   }
+  // (round 4, tried: converting the prefetched window to fp16 pairs IN REGISTERS before the store loop, as the inverse kernel now
+  // does with its maxima - the W phase fell from 1.6 to 1.0 us but the conversion cost 0.9 us where it went and the stores 0.3 us
+  // more: 14.7 against 14.3 us per iteration, profiles/r04/dft_phases_v4_convert_before_stores.txt.  Not kept.)
   // XCD-aware order (work-group L runs on XCD L % 8): every XCD takes a contiguous range of iterations, so work-groups whose
   // outputs share cache lines / 16-byte units (neighbouring channel groups) run on ONE XCD at about the same time
   const int first = (DFT_GRID & 7) == 0 ? (DFT_BID & 7) * (DFT_GRID >> 3) + (DFT_BID >> 3) : DFT_BID;
@@ -752,9 +755,37 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
   const int img_ = (E) & (DFT_G - 1), rest_ = (E) >> 2;                                     \
   const int v_ = dft_div(rest_, pl.inv_kg), uo_ = rest_ - v_ * uoct;                        \
   const bool two_ = 8 * uo_ + 4 < P;
+  // ---- M: the largest |component| of every image among the spectra in the prefetch registers (a thread's items all belong to
+  // image tid % 4) -> smaxw.  Run for the NEXT iteration's spectra right after step B, BEFORE the epilogue's stores: the first
+  // use of the prefetched registers makes the compiler wait for them, and a wait placed after a loop of stores cannot count
+  // what is in flight - it becomes vmcnt(0) and the work-group sat out the write latency of its own epilogue at the top of
+  // every iteration (phase stamps: 1.1 us for this handful of instructions).  Up here the loads are the youngest requests.
+#define DFT_INV_MAXIMA(TID)                                                                 \
+  {                                                                                         \
+    float m = 0.f;                                                                          \
+    _Pragma("unroll") for (int s = 0; s < NITEM; ++s)                                       \
+      if ((TID) + s * DFT_THR < nitem) {                                                    \
+        DFT_INV_ITEM((TID) + s * DFT_THR)                                                   \
+        (void)img_;                                                                         \
+        (void)v_;                                                                           \
+        (void)uo_;                                                                          \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k)                                       \
+          if (k < 2 || two_) {                                                              \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(py[s][k][e])); \
+          }                                                                                 \
+      }                                                                                     \
+    m = fmaxf(m, DFT_SHFL_XOR(m, 4));                                                       \
+    m = fmaxf(m, DFT_SHFL_XOR(m, 8));                                                       \
+    m = fmaxf(m, DFT_SHFL_XOR(m, 16));                                                      \
+    m = fmaxf(m, DFT_SHFL_XOR(m, 32));                                                      \
+    if (lane < DFT_G) smaxw[wv * DFT_G + lane] = m;                                         \
+  }
   bool bad = false;
   const int first = (DFT_GRID & 7) == 0 ? (DFT_BID & 7) * (DFT_GRID >> 3) + (DFT_BID >> 3) : DFT_BID;     // XCD-aware (see the forward kernel)
-  if (first < iters) DFT_INV_PREFETCH(first, tid)
+  if (first < iters) {
+    DFT_INV_PREFETCH(first, tid)
+    DFT_INV_MAXIMA(tid)
+  }
   DFT_BARRIER();
 
   DFT_STAMP_BEGIN()
@@ -770,28 +801,7 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
     const int TH_ = TILED ? pl.TH : H, TW_ = TILED ? pl.TW : W;
     const int o0 = og * DFT_G;
 
-    // ---- M: the largest |component| of every image (this thread's items all belong to image tid % 4)
-    {
-      float m = 0.f;
-#pragma unroll
-      for (int s = 0; s < NITEM; ++s)
-        if (tl + s * DFT_THR < nitem) {
-          DFT_INV_ITEM(tl + s * DFT_THR)
-          (void)img_;
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (k < 2 || two_) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(py[s][k][e]));
-            }
-        }
-      m = fmaxf(m, DFT_SHFL_XOR(m, 4));
-      m = fmaxf(m, DFT_SHFL_XOR(m, 8));
-      m = fmaxf(m, DFT_SHFL_XOR(m, 16));
-      m = fmaxf(m, DFT_SHFL_XOR(m, 32));
-      if (lane < DFT_G) smaxw[wv * DFT_G + lane] = m;
-    }
-    DFT_BARRIER();
+    // (the maxima of this iteration's spectra are in smaxw: written before the previous iteration's epilogue / in the prologue)
     DFT_STAMP(0)
     float simg = 1.f, cinv[DFT_G];
     {
@@ -925,6 +935,7 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
       for (int r = 0; r < 16; ++r) yc[j][r] = 0.f;
     }
     dft_product_lds_any<DFT_WAVES>(yc, ntbw, 0, ksBn, ldsU, MBS, ldsG, NBo, wv, mtBn, l31, hw);
+    if (it + DFT_GRID < iters) DFT_INV_MAXIMA(tl)      // of the NEXT iteration's spectra (requested before step A)
     DFT_STAMP(4)
 
     // ---- epilogue: a lane owns window column w and, per accumulator run, the 4 channels of one row: + bias, ReLU, channel
@@ -971,6 +982,7 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
   if (bad_flag != nullptr && DFT_BALLOT(bad) != 0ull) {
     if ((tid & 63) == 0) DFT_RAISE(bad_flag);
   }
+#undef DFT_INV_MAXIMA
 #undef DFT_INV_ITEM
 #undef DFT_INV_PREFETCH
 #undef DFT_INV_PREFETCH_ITEMS

@@ -514,10 +514,22 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     mark(b0, 1);
     mark(b0, 2);
     if (fft_bins) {
+      bool inv_borders = false;
       // the 7x7 layer in the frequency domain (fft.hip, spectral.hip): fp32 FFT of relu(corr) / norm -> one complex GEMM
       // per bin on the fp32 matrix cores -> inverse FFT + bias + ReLU + split into the activation buffer of the 5x5 layer
       if (f16) {
-        if ((rc = os2d_launch_border_zero_shb_planes_norms(h1, NB * 16 * 2, H, W, sumfx, invn, (size_t)NB * H * W, st))) return rc;
+        // the matrix-product inverse transform writes the zero borders of the planes it fills; what is left for this launch on
+        // that route is the norms pass of the packed correlation (none for the padded form: no launch at all)
+        // ($OS2D_BORDERS_IN_INVERSE=0: the separate launch as before, for measurements)
+        static const bool borders_in_inverse = [] {
+          const char* e = getenv("OS2D_BORDERS_IN_INVERSE");
+          return !(e && e[0] == '0');
+        }();
+        inv_borders = dft && borders_in_inverse;
+        const int planes = inv_borders ? 0 : NB * 16 * 2;
+        if ((planes || sumfx) &&
+            (rc = os2d_launch_border_zero_shb_planes_norms(h1, planes, H, W, sumfx, invn, (size_t)NB * H * W, st)))
+          return rc;
       } else if ((rc = os2d_launch_border_zero(h1, NB * 128, H, W, st))) {     // all-fp32 mode: fp32 planes for the fp32 5x5 kernel
         return rc;
       }
@@ -538,7 +550,7 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
                                                 os2d_spectral_xscale_for(tiles[4], tiles[5]), 1, xch, st)))
           return rc;
         mark(b0, 12);
-        if ((rc = os2d_launch_dft_inverse(yspec, b1, 128, h1, mats, NB, 128, H, W, status, st))) return rc;
+        if ((rc = os2d_launch_dft_inverse(yspec, b1, 128, h1, mats, NB, 128, H, W, status, inv_borders ? 1 : 0, st))) return rc;
       } else {
         if ((rc = os2d_launch_fft_forward(corr, invn, xspec, twQ, twP, NB, OS2D_K, H, W, st))) return rc;
         mark(b0, 11);
@@ -818,9 +830,7 @@ int os2d_dft_inverse(const float* Y, const float* packed_b, void* out, const voi
     os2d_set_error("os2d_dft_inverse: bad arguments (Cout must be 128: the 7x7 layer)");
     return -1;
   }
-  int rc = os2d_launch_border_zero_shb_planes(out, NB * (Cout / 8) * 2, H, W, S(stream));
-  if (rc) return rc;
-  return os2d_launch_dft_inverse(Y, packed_b, 128, out, matrices, NB, Cout, H, W, status, S(stream));
+  return os2d_launch_dft_inverse(Y, packed_b, 128, out, matrices, NB, Cout, H, W, status, 1, S(stream));   // incl. the plane borders
 }
 
 int os2d_spectral_weights_build_dft(const double* wfold, const double* twP64, const double* twQ64, int C, int Cout, int P, int Q,

@@ -57,8 +57,8 @@ template <bool TILED>
 __global__ __launch_bounds__(DFT_THR, 1) void dft_inverse_kernel(const float* __restrict__ Y, const float* __restrict__ bp, int MTP,
                                                                  unsigned char* __restrict__ out, const u32x4v* __restrict__ E2,
                                                                  const u32x4v* __restrict__ Gq, DftPlan pl, int Cout, int NBT, int PLANE,
-                                                                 int Ws, int BASE, int iters, int* status) {
-  dft_inverse_body<TILED>(Y, bp, MTP, out, E2, Gq, pl, Cout, NBT, PLANE, Ws, BASE, iters, status);
+                                                                 int Ws, int BASE, int iters, int* status, int zero_borders) {
+  dft_inverse_body<TILED>(Y, bp, MTP, out, E2, Gq, pl, Cout, NBT, PLANE, Ws, BASE, iters, status, zero_borders);
 }
 
 // FqT | Fp2 | E2 | Gq of a (P, Q) transform, one thread per 16-byte unit
@@ -162,8 +162,9 @@ int os2d_launch_dft_forward(const float* corr, const float* inv, float* X, const
   return dft_check("dft_forward");
 }
 
+// zero_borders != 0: the kernel also writes the zero border cells of the planes it fills (no os2d_launch_border_zero_shb_planes)
 int os2d_launch_dft_inverse(const float* Y, const float* bp, int MTP, void* out, const void* matrices, int NB, int Cout, int H, int W,
-                            int* status, hipStream_t stream) {
+                            int* status, int zero_borders, hipStream_t stream) {
   DftPlan pl;
   if (!dft_make_plan(H, W, &pl)) {
     os2d_set_error("dft_inverse: no transform plan for a %dx%d map", H, W);
@@ -184,7 +185,7 @@ int os2d_launch_dft_inverse(const float* Y, const float* bp, int MTP, void* out,
     return -4;
   }
   hipLaunchKernelGGL(kern, dim3(dft_grid(iters)), dim3(DFT_THR), pl.lds_total, stream, Y, bp, MTP, static_cast<unsigned char*>(out), E2, Gq,
-                     pl, Cout, NBT, os2d_plane(H, W), os2d_ws(W), os2d_base(W), iters, status);
+                     pl, Cout, NBT, os2d_plane(H, W), os2d_ws(W), os2d_base(W), iters, status, zero_borders);
   return dft_check("dft_inverse");
 }
 

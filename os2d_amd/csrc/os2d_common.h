@@ -37,7 +37,6 @@ static inline __host__ __device__ int os2d_base(int W) { return os2d_round_up(OS
 static inline __host__ __device__ int os2d_plane(int H, int W) {
   return os2d_round_up(os2d_base(W) + (H + OS2D_PAD) * os2d_ws(W) + OS2D_PAD, 64);
 }
-// is flat plane index n an interior (data) cell?
 // Packed correlation kernel (corr_f16x3.hip, STACK): a position's sum of relu(corr)^2 in 2^-44 fixed point (bit 62: a
 // non-finite term) -> 1 / (sqrt(s) + 1e-6) (head.py:650, 597); the word is cleared for the next launch.  acc < 2^53: the
 // conversion to double is exact, the one to float rounds once.
@@ -47,6 +46,7 @@ __device__ __forceinline__ void os2d_corr_norm_finalize_one(unsigned long long* 
   const float s = (v >> 62) ? __builtin_nanf("") : (float)((double)v * 5.6843418860808015e-14);    // 2^-44
   invn[i] = 1.0f / (sqrtf(s) + 1e-6f);
 }
+// is flat plane index n an interior (data) cell?
 static inline __host__ __device__ bool os2d_interior(int n, int H, int W) {
   const int r = n - os2d_base(W);
   return r >= 0 && r < H * os2d_ws(W) && (r % os2d_ws(W)) < W;
@@ -268,7 +268,7 @@ int os2d_launch_dft_matrices(const double* twP64, const double* twQ64, int P, in
 int os2d_launch_dft_forward(const float* corr, const float* inv, float* X, const void* matrices, int NB, int C, int Cpad, int H, int W,
                             hipStream_t stream);
 int os2d_launch_dft_inverse(const float* Y, const float* bp, int MTP, void* out, const void* matrices, int NB, int Cout, int H, int W,
-                            int* status, hipStream_t stream);
+                            int* status, int zero_borders, hipStream_t stream);
 // corr_f16x3.hip
 int os2d_corr_groups(int C);  // 8-channel groups of the split correlation operands, padded to whole K chunks
 // clear / clear_words: 64-bit words zeroed by the same launch (the packed correlation kernel's sums; NULL / 0: none)

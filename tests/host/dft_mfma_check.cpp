@@ -209,13 +209,13 @@ static int check_case(int H, int W, int C, int NB, int grid) {
     bp[o] = (float)(0.1 * (o - 3) * ymaxo[o]);
     bp[2 * MTP + o] = (float)std::ldexp(1.0, (int)std::floor(std::log2(4096.0 / (1.4 * ymaxo[o]))));
   }
-  std::vector<unsigned char> out((size_t)NB * ((Cout + 7) / 8) * 2 * PLANE * 16, 0);
+  std::vector<unsigned char> out((size_t)NB * ((Cout + 7) / 8) * 2 * PLANE * 16, 0x5A);     // a pattern: the kernel writes the borders too
   int flag = 0;
   const int OG = Cout / DFT_G, iters_i = NBT * OG;
   pl.inv_og = dft_magic((unsigned)OG);
   emu::launch(grid, DFT_THR, pl.lds_total, [&] {
-    if (pl.T > 1) dft_inverse_body<true>(Y.data(), bp.data(), MTP, out.data(), E2, Gq, pl, Cout, NBT, PLANE, Ws, BASE, iters_i, &flag);
-    else dft_inverse_body<false>(Y.data(), bp.data(), MTP, out.data(), E2, Gq, pl, Cout, NBT, PLANE, Ws, BASE, iters_i, &flag);
+    if (pl.T > 1) dft_inverse_body<true>(Y.data(), bp.data(), MTP, out.data(), E2, Gq, pl, Cout, NBT, PLANE, Ws, BASE, iters_i, &flag, 1);
+    else dft_inverse_body<false>(Y.data(), bp.data(), MTP, out.data(), E2, Gq, pl, Cout, NBT, PLANE, Ws, BASE, iters_i, &flag, 1);
   });
   double worst_rel = 0.0;
   for (int nb = 0; nb < NB; ++nb)
@@ -231,6 +231,20 @@ static int check_case(int H, int W, int C, int NB, int grid) {
           const double want = std::fmax(yref[((size_t)nb * Cout + o) * HW + (size_t)h * W + w] + (double)bp[o], 0.0) * (double)bp[2 * MTP + o];
           worst_rel = std::fmax(worst_rel, std::fabs((double)hv + (double)lv - want) / unit);
         }
+    }
+  // the kernel also writes the zero borders of the planes (the buffer was filled with a pattern)
+  for (int nb = 0; nb < NB; ++nb)
+    for (int pln = 0; pln < ((Cout + 7) / 8) * 2; ++pln) {
+      const unsigned char* base = &out[((size_t)nb * ((Cout + 7) / 8) * 2 + pln) * (size_t)PLANE * 16];
+      for (int cell = 0; cell < PLANE; ++cell) {
+        const int rel = cell - BASE, hh = rel >= 0 ? rel / Ws : -1, ww = rel >= 0 ? rel % Ws : -1;
+        if (rel >= 0 && hh < H && ww < W) continue;
+        for (int b = 0; b < 16; ++b)
+          if (base[(size_t)cell * 16 + b] != 0) {
+            std::printf("border cell %d of plane %d (pair %d) not zero\n", cell, pln, nb);
+            return 1;
+          }
+      }
     }
   std::printf("  inverse: max |y - float64| / max |y| = %.3e, flag %d\n", worst_rel, flag);
   if (!(worst_rel <= 1.5e-6) || flag != 0) {

@@ -140,6 +140,23 @@ class Harness:
             def outputs(i):
                 return [torch.zeros(NB, 225, H * W, device=dev), torch.zeros(rshb_bytes, dtype=torch.uint8, device=dev)]
             keep = (fm, qp, qs, ws)
+        elif kind == "corrp":
+            # the correlation with the classes packed along M: fixed-point sums combined by 64-bit atomics + the norms pass
+            Cf = 1024
+            fm = [synthetic.make_feature_map(Cf, H, W, seed=10 + i).to(dev) for i in range(NF)]
+            qp = torch.rand(NB, Cf, 256, generator=g).to(dev) / 32.0
+            qp[:, :, 225:] = 0.0                                   # rows 225 .. 255 of the class operand are zero by contract
+            qs = torch.zeros(lib.os2d_class_split_bytes(NB, Cf), dtype=torch.uint8, device=dev)
+            _lib.check(lib.os2d_class_split(_lib.ptr(qp), _lib.ptr(qs), NB, Cf, _lib.current_stream(dev)), "class_split")
+            ws = [torch.zeros(lib.os2d_corr_f16x3_packed_workspace_bytes(1, NB, Cf, H, W), dtype=torch.uint8, device=dev) for _ in range(NF)]
+
+            def run(i, out, st):
+                _lib.check(lib.os2d_corr_f16x3_packed(_lib.ptr(fm[i]), _lib.ptr(qs), _lib.ptr(out[0]), _lib.ptr(out[1]), 1, NB, Cf, H, W, 1,
+                                                      _lib.ptr(ws[i]), ws[i].numel(), ctypes.c_void_p(st.cuda_stream)), "corr packed")
+
+            def outputs(i):
+                return [torch.zeros(NB, 225, H * W, device=dev), torch.zeros(NB, H * W, device=dev)]
+            keep = (fm, qp, qs, ws)
         elif kind == "sample":          # the resampler: the other kernel with hundreds of packed-FP32 instructions when they are on
             corr = [torch.randn(NB, 225, H * W, generator=g).to(dev) for _ in range(NF)]
             par = torch.zeros(NB, 6, H * W)

@@ -436,7 +436,7 @@ def test_quad_layout_of_the_inverse_transform_equals_the_row_layout(H, W, NB, de
     assert torch.equal(out_q, out_r)
 
 
-@pytest.mark.parametrize("kind", ["fft", "dft", "gemm16", "corr", "sample"])
+@pytest.mark.parametrize("kind", ["fft", "dft", "gemm16", "corr", "corrp", "sample"])
 def test_kernels_are_stable_next_to_mfma_kernels(kind, device):
     """Regression test of the packed-FP32 finding (docs/DESIGN_HISTORY_r1-r3.md section 8): a victim kernel on four streams while the direct
     7x7 kernel (half-precision MFMA at full rate) runs on three others must return exactly the bytes it returns alone.

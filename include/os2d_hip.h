@@ -344,7 +344,8 @@ int os2d_spectral_gemm_f16(const void* w16, const float* X, float* Y, int NB, in
  *                            are 475 / 262 KB apart at any batch size instead of 7.6 / 4 MB at 1024 pairs.  Up to 64 pairs the
  *                            layout is exactly the one written above.
  *   os2d_dft_inverse         Y -> the layer's activations (bias, ReLU, channel scale, fp16 hi | lo) in the split-half blocked
- *                            buffer, as os2d_fft_inverse                                                                   */
+ *                            buffer, as os2d_fft_inverse; the kernel also writes the ZERO BORDERS of the planes it fills (the
+ *                            buffer may hold anything before the call)                                                     */
 int os2d_dft_sizes(int H, int W, int* P, int* Q, int* nbins, int* tiles);
 int os2d_dft_channel_stride(int C);
 size_t os2d_dft_matrices_bytes(int P, int Q);

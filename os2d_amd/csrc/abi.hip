@@ -305,7 +305,7 @@ int os2d_corr_f16x3_packed(const float* fm, const void* qs, float* corr, float* 
   if (!rc) rc = os2d_launch_split_fm(fm, sumsq, fs, A, C, H * W, nullptr, 0, S(stream));
   const bool packed = form > 0 || (form < 0 && os2d_corr_f16x3_use_packed(A, B, H, W));
   if (!rc && packed) rc = os2d_launch_corr_sums_clear(sumfx, A, B, H, W, S(stream));
-  if (!rc) rc = os2d_launch_corr_f16x3(fs, qs, corr, nullptr, inv_norm, packed ? sumfx : nullptr, 0, A, B, C, H, W, S(stream));
+  if (!rc) rc = os2d_launch_corr_f16x3(fs, qs, corr, nullptr, inv_norm, packed ? sumfx : nullptr, form == 2 ? 2 : 0, A, B, C, H, W, S(stream));
   return rc;
 }
 

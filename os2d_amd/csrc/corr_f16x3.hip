@@ -48,8 +48,17 @@ constexpr int CH_UNITS = GC * 2 * 256;   // 16-byte units of one class-operand c
 // live counters say bounds the 8-wave shape: matrix pipe 0.58 busy with 2/3 of the LDS bandwidth in use).
 constexpr int STACK_STRIDE = 228;   // stacked rows per class (225 rounded up to a multiple of 4)
 
-template <int NI, int WNW, bool STACK>
-__global__ __launch_bounds__(128 * WNW, WNW == 2 ? 1 : 2) void corr_f16x3_kernel(const u32x4* fs,  // [A][CGP][2][HW]  (no __restrict__, see
+// WM = waves along the rows (2: a 256-row tile; 1: a 128-row tile - STACK only), KC = 8-channel groups per K chunk (4 | 2).
+// <2, 4, true, 1, 2> is the HALF-TILE shape (round 4): 4 waves, 128 stacked rows x 256 positions, chunks of 16 channels, 48 KB
+// of LDS - TWO independent work-groups per CU.  A quarter of the full-tile launch does not depend on K
+// (profiles/r04/corr_fixed_cost.txt): at the end of its K loop every work-group of a lockstep round writes its 262 KB of output
+// while the matrix pipes idle.  Two half-size groups per CU drift apart and each one's epilogue runs under the other's K loop;
+// the price is the image operand staged twice (once per row half) and a barrier every 24 instead of 48 matrix instructions.
+// MEASURED (profiles/r04/corr_fixed_cost.txt): the fixed part of a launch falls from 0.091 to 0.065 ms, the K-proportional part
+// grows from 0.313 to 0.375 ms per 1024 channels - 11 % slower.  Not used by the head (form 2 of os2d_corr_f16x3_packed /
+// $OS2D_CORR_HALF=1 for measurements; same bits as the other forms).
+template <int NI, int WNW, bool STACK, int WM = 2, int KC = GC>
+__global__ __launch_bounds__(64 * WM * WNW, (WM == 1 || WNW == 4) ? 2 : 1) void corr_f16x3_kernel(const u32x4* fs,  // [A][CGP][2][HW]  (no __restrict__, see
                                                              const u32x4* qs,  // [B][CGP][2][256]   conv_f16x3.hip)
                                                              float* __restrict__ corr, char* __restrict__ rshb,
                                                              float* __restrict__ invn /*[A*B][HW] 1/(norm+eps) or NULL*/,
@@ -57,13 +66,17 @@ __global__ __launch_bounds__(128 * WNW, WNW == 2 ? 1 : 2) void corr_f16x3_kernel
                                                              int A, int B, int CGP /*channel groups, padded to a multiple of GC*/,
                                                              int H, int W, int PLANE, float unscale) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
-  constexpr int NTHR = 128 * WNW;
+  static_assert(WM == 2 || STACK, "128-row tiles exist for the packed form only (the norms cross work-groups)");
+  constexpr int NTHR = 64 * WM * WNW;
+  constexpr int TM = 128 * WM;           // rows per work-group
   constexpr int NT = WNW * 32 * NI;      // positions per work-group
-  constexpr int BUNITS = GC * 2 * NT;    // 16-byte units of one image-operand chunk
-  constexpr int NPF = CH_UNITS / NTHR;   // class units per thread (4 or 8)
+  constexpr int AUNITS = KC * 2 * TM;    // 16-byte units of one class-operand chunk
+  constexpr int BUNITS = KC * 2 * NT;    // 16-byte units of one image-operand chunk
+  constexpr int NPF = AUNITS / NTHR;     // class units per thread
   constexpr int NPFB = BUNITS / NTHR;    // image units per thread
-  u32x4* ldsA = smem16;                 // [2][CH_UNITS]
-  u32x4* ldsB = smem16 + 2 * CH_UNITS;  // [2][BUNITS]
+  static_assert((NPF > NPFB ? NPF : NPFB) <= (KC / 2) * 4, "one DMA piece per matrix-instruction group of a chunk");
+  u32x4* ldsA = smem16;                 // [2][AUNITS]
+  u32x4* ldsB = smem16 + 2 * AUNITS;    // [2][BUNITS]
   __shared__ unsigned long long red[2][NT];
 
   const int HW = H * W;
@@ -75,7 +88,7 @@ __global__ __launch_bounds__(128 * WNW, WNW == 2 ? 1 : 2) void corr_f16x3_kernel
   // CU) are then ~8 tiles x 4 classes marching through K together: 12 MB of distinct operand bytes per 32 groups in
   // that XCD's L2 instead of 20+ MB with classes or tiles spread round-robin over the XCDs.
   // STACK: "b" below is a ROW TILE of the stacked class matrix (RT of them), not a class
-  const int RT = STACK ? (B * STACK_STRIDE + 255) / 256 : B;
+  const int RT = STACK ? (B * STACK_STRIDE + TM - 1) / TM : B;
   const int tiles = (HW + NT - 1) / NT;
   const int per = gridDim.x >> 3;
   const int logical = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
@@ -87,7 +100,7 @@ __global__ __launch_bounds__(128 * WNW, WNW == 2 ? 1 : 2) void corr_f16x3_kernel
   const int b = gb0 + r2_ % gsz;
   const int n0 = (r2_ / gsz) * NT;
   const int nb = a * B + b;
-  const int R0 = b * 256;                        // STACK: first stacked row of this work-group
+  const int R0 = b * TM;                         // STACK: first stacked row of this work-group
 
   f32x16 acc[4][NI];
 #pragma unroll
@@ -100,7 +113,7 @@ __global__ __launch_bounds__(128 * WNW, WNW == 2 ? 1 : 2) void corr_f16x3_kernel
   const int bfirst = STACK ? R0 / STACK_STRIDE : b;                 // first class this work-group touches
   const u32x4* qb = qs + (size_t)bfirst * CGP * 2 * 256;
   const u32x4* fa = fs + (size_t)a * CGP * 2 * HW;
-  const int nchunks = CGP / GC;
+  const int nchunks = CGP / KC;
   // ---- staging: global -> LDS directly (LDS-DMA, global_load_lds_dwordx4): no staging registers, no ds_write pass.
   // A wave instruction writes 64 consecutive 16-byte units starting at a wave-uniform LDS address, which is exactly how
   // a chunk is laid out (unit i = row i/256 = (group, part), column i%256; 64 consecutive threads = 64 consecutive
@@ -115,21 +128,22 @@ __global__ __launch_bounds__(128 * WNW, WNW == 2 ? 1 : 2) void corr_f16x3_kernel
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index as a scalar
   // STACK: this thread always stages the same stacked row (its units are 256 apart): row p of class bfirst + d, clamped to the
   // last class (rows 225 .. 255 of every class are zero in the operand: the 3 padding rows of the stride need nothing else)
-  const int rowA = (wv * 64 + lane) & 255, RA = min(R0 + rowA, B * STACK_STRIDE - 1);
+  // (unit u of a class chunk in LDS = [(group, part) = u / TM][row u % TM]; in memory a (group, part) row is 256 units long)
+  const int rowA = (wv * 64 + lane) & (TM - 1), RA = min(R0 + rowA, B * STACK_STRIDE - 1);
   const int bA = RA / STACK_STRIDE, pA = RA - bA * STACK_STRIDE;
-  const unsigned voffA = STACK ? (unsigned)(bA - bfirst) * (unsigned)(CGP * 2 * 256 * 16) + (unsigned)pA * 16u : (unsigned)lane * 16u;
+  const unsigned voffA = STACK ? (unsigned)(bA - bfirst) * (unsigned)(CGP * 2 * 256 * 16) + (unsigned)pA * 16u : (unsigned)rowA * 16u;
   const int colB = (wv * 64) % NT + lane;
   const unsigned voffB = (unsigned)min(colB, HW - 1 - n0) * 16u;
-  const char* baseA0 = reinterpret_cast<const char*>(qb) + (STACK ? (size_t)((wv * 64) >> 8) * 256 * 16 : (size_t)wv * 64 * 16);
+  const char* baseA0 = reinterpret_cast<const char*>(qb);
   const char* baseB0 = reinterpret_cast<const char*>(fa) + ((size_t)((wv * 64) / NT) * HW + n0) * 16;
 #define CF_DMA1(T, K)                                                                                             \
   {                                                                                                               \
     if ((K) < NPF) {                                                                                              \
-      const char* ga_ = baseA0 + ((size_t)(T)*CH_UNITS + (size_t)(K)*NTHR) * 16;                                  \
-      __builtin_amdgcn_global_load_lds((gptr_t)(ga_ + voffA), (lptr_t)(ldsA + ((T)&1) * CH_UNITS + (K)*NTHR + wv * 64), 16, 0, 0); \
+      const char* ga_ = baseA0 + ((size_t)((T)*KC * 2 + ((K)*NTHR + wv * 64) / TM) * 256) * 16;                    \
+      __builtin_amdgcn_global_load_lds((gptr_t)(ga_ + voffA), (lptr_t)(ldsA + ((T)&1) * AUNITS + (K)*NTHR + wv * 64), 16, 0, 0); \
     }                                                                                                             \
     if ((K) < NPFB) {                                                                                             \
-      const char* gb_ = baseB0 + ((size_t)((T)*GC * 2 + ((K)*NTHR) / NT) * HW) * 16;                              \
+      const char* gb_ = baseB0 + ((size_t)((T)*KC * 2 + ((K)*NTHR) / NT) * HW) * 16;                              \
       __builtin_amdgcn_global_load_lds((gptr_t)(gb_ + voffB), (lptr_t)(ldsB + ((T)&1) * BUNITS + (K)*NTHR + wv * 64), 16, 0, 0); \
     }                                                                                                             \
   }
@@ -142,15 +156,15 @@ __global__ __launch_bounds__(128 * WNW, WNW == 2 ? 1 : 2) void corr_f16x3_kernel
 #if defined(OS2D_DIAG_CORR_NO_MFMA)  /* diagnostic builds only: DMA + barriers, no fragment reads / MFMAs */
 #define CF_COMPUTE_H(T, HOOK)                                                                                     \
   {                                                                                                               \
-    _Pragma("unroll") for (int mi = 0; mi < 8; ++mi) { HOOK(mi) }                                                 \
+    _Pragma("unroll") for (int mi = 0; mi < (KC / 2) * 4; ++mi) { HOOK(mi) }                                      \
   }
 #else
 #define CF_COMPUTE_H(T, HOOK)                                                                                     \
   {                                                                                                               \
-    const u32x4* aB_ = ldsA + ((T)&1) * CH_UNITS + wm * 128 + l31;                                                \
+    const u32x4* aB_ = ldsA + ((T)&1) * AUNITS + wm * 128 + l31;                                                  \
     const u32x4* bB_ = ldsB + ((T)&1) * BUNITS + wn * (32 * NI) + l31;                                            \
-    _Pragma("unroll") for (int ks = 0; ks < GC / 2; ++ks) {                                                       \
-      const int rowh_ = ((2 * ks + hw) * 2 + 0) * 256, rowl_ = ((2 * ks + hw) * 2 + 1) * 256;                     \
+    _Pragma("unroll") for (int ks = 0; ks < KC / 2; ++ks) {                                                       \
+      const int rowh_ = ((2 * ks + hw) * 2 + 0) * TM, rowl_ = ((2 * ks + hw) * 2 + 1) * TM;                       \
       half8 bh_[NI], bl_[NI];                                                                                     \
       _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                                         \
         bh_[ni] = *reinterpret_cast<const half8*>(bB_ + ((2 * ks + hw) * 2 + 0) * NT + ni * 32);                  \
@@ -493,27 +507,27 @@ int os2d_launch_split_qp(const float* qp, void* qs, int B, int C, hipStream_t st
 
 namespace {
 
-template <int NI, int WNW, bool STACK>
+template <int NI, int WNW, bool STACK, int WM = 2, int KC = GC>
 int launch_corr(const void* fs, const void* qs, float* corr, void* rshb, float* invn, unsigned long long* sumfx, int defer_norms, int A,
                 int B, int C, int H, int W, hipStream_t stream) {
-  constexpr int NT = WNW * 32 * NI, NTHR = 128 * WNW;
+  constexpr int NT = WNW * 32 * NI, NTHR = 64 * WM * WNW, TM = 128 * WM;
   const int HW = H * W;
-  const size_t lds = (size_t)(2 * CH_UNITS + 2 * GC * 2 * NT) * 16;  // 128 KB (NI = 2) / 96 KB dynamic (+ static)
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_f16x3_kernel<NI, WNW, STACK>),
+  const size_t lds = (size_t)(2 * KC * 2 * TM + 2 * KC * 2 * NT) * 16;  // 128 KB (NI = 2) / 96 KB / 48 KB (half tile) dynamic (+ static)
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_f16x3_kernel<NI, WNW, STACK, WM, KC>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) {
     os2d_set_error("hipFuncSetAttribute(corr f16x3): %s", hipGetErrorString(e));
     return -4;
   }
-  const int RT = STACK ? (B * STACK_STRIDE + 255) / 256 : B;       // row tiles: stacked classes | one per class
+  const int RT = STACK ? (B * STACK_STRIDE + TM - 1) / TM : B;       // row tiles: stacked classes | one per class
   const long long groups = (long long)((HW + NT - 1) / NT) * RT * A;
   dim3 grid((unsigned)((groups + 7) / 8 * 8));  // multiple of 8: every XCD gets the same number of logical slots
-  hipLaunchKernelGGL((corr_f16x3_kernel<NI, WNW, STACK>), grid, dim3(NTHR), lds, stream, reinterpret_cast<const u32x4*>(fs),
+  hipLaunchKernelGGL((corr_f16x3_kernel<NI, WNW, STACK, WM, KC>), grid, dim3(NTHR), lds, stream, reinterpret_cast<const u32x4*>(fs),
                      reinterpret_cast<const u32x4*>(qs), corr, reinterpret_cast<char*>(rshb), invn, sumfx, A, B,
                      os2d_round_up((C + 7) / 8, GC), H, W,
                      os2d_plane(H, W), ldexpf(1.0f, -2 * SCALE_LOG2));
   int rc = check("corr_f16x3");
-  if (rc || !STACK || defer_norms) return rc;
+  if (rc || !STACK || (defer_norms & 1)) return rc;
   const size_t n = (size_t)A * B * HW;
   hipLaunchKernelGGL(corr_norm_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, sumfx, invn, n);
   return check("corr_norm_finalize");
@@ -565,6 +579,13 @@ int os2d_launch_corr_f16x3(const void* fs, const void* qs, float* corr, void* rs
 #if OS2D_CORR_W4
   return launch_corr<4, 2, false>(fs, qs, corr, rshb, invn, nullptr, defer_norms, A, B, C, H, W, stream);     // 4 waves of 128 x 128 (diagnostic)
 #else
+  // ($OS2D_CORR_HALF=1: the packed form in half tiles - two 4-wave groups per CU; measurements)
+  static const bool half_tiles = [] {
+    const char* e = getenv("OS2D_CORR_HALF");
+    return e && e[0] == '1';
+  }();
+  if (sx && (half_tiles || (defer_norms & 2)))
+    return launch_corr<2, 4, true, 1, 2>(fs, qs, corr, rshb, invn, sx, defer_norms & 1, A, B, C, H, W, stream);
   return sx ? launch_corr<2, 4, true>(fs, qs, corr, rshb, invn, sx, defer_norms, A, B, C, H, W, stream)        // 8 waves of 128 x 64
             : launch_corr<2, 4, false>(fs, qs, corr, rshb, invn, sx, defer_norms, A, B, C, H, W, stream);
 #endif

@@ -275,7 +275,7 @@ int os2d_corr_groups(int C);  // 8-channel groups of the split correlation opera
 int os2d_launch_split_fm(const float* fm, const float* sumsq, void* fs, int A, int C, int HW, void* clear, size_t clear_words,
                          hipStream_t stream);
 int os2d_launch_split_qp(const float* qp, void* qs, int B, int C, hipStream_t stream);
-// defer_norms != 0 (packed form only): the sums stay in sumfx; the caller's next launch turns them into invn
+// defer_norms & 1 (packed form only): the sums stay in sumfx; the caller's next launch turns them into invn; & 2: half tiles
 // (os2d_launch_border_zero_shb_planes_norms) - one launch less on the per-step path
 int os2d_launch_corr_f16x3(const void* fs, const void* qs, float* corr, void* rshb, float* invn, void* sumfx, int defer_norms, int A,
                            int B, int C, int H, int W, hipStream_t stream);

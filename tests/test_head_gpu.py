@@ -730,7 +730,7 @@ def test_packed_correlation_is_independent_of_the_batch_composition(H, W, C, B, 
         again = _packed_corr(lib, fm, head._split_class_operand(), B, device)
         assert torch.equal(again[0], corr) and torch.equal(again[1], invn)
         # the padded form (one 256-row tile per class) and whatever the head would pick: the same bits
-        for form in (0, -1):
+        for form in (0, 2, -1):
             other = _packed_corr(lib, fm, head._split_class_operand(), B, device, form=form)
             assert torch.equal(other[0], corr) and torch.equal(other[1], invn), form
 

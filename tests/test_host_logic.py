@@ -185,3 +185,54 @@ def test_dataloader_style_inverse_transforms_are_traced_exactly():
     for _ in range(7):
         long_chain.append(lambda b: b.resize(orig))
     assert trace_box_transform(long_chain, size) is None                                               # more than 6 operations
+
+
+def test_fixed_point_norm_sums_of_the_correlation_kernels():
+    """The arithmetic of corr_f16x3.hip's per-position sums of relu(corr)^2, restated in numpy (float32 operations as the kernel
+    does them): a run of 4 rows is added in fp32, the run's sum g goes to 2^-44 fixed point as two integers
+    (hi = trunc(g * 2^20), lo = trunc((g * 2^20 - hi) * 2^24)), integers are added from there on and the total becomes
+    float32(total * 2^-44).  Checked here: the conversion is exact for g >= 2^-20 and drops less than 2^-44 below; a class's 57 runs
+    cannot overflow the two 32-bit accumulators; any order and any split of the runs over lanes / waves / work-groups gives
+    the same integer; the result is the correctly rounded float32 of the exact sum of the run sums."""
+    import numpy as np
+    rng = np.random.RandomState(7)
+    f32 = np.float32
+
+    def convert(g):
+        ga = np.minimum(g, f32(1024.0)) * f32(1048576.0)
+        hi = np.floor(ga).astype(np.uint32)                        # v_cvt_u32_f32 truncates (ga >= 0)
+        lo = np.floor((ga - hi.astype(np.float32)) * f32(16777216.0)).astype(np.uint32)
+        return hi, lo
+
+    for scale in (1.0, 1e-2, 1e-5, 1e-9):
+        rows = (rng.rand(228, 64).astype(np.float32) * f32(scale))                     # 57 runs of 4 rows, 64 positions
+        rows[225:] = 0                                                                  # the padding rows of the stride
+        sq = rows * rows                                                                # relu(v)^2, v >= 0 here
+        g = np.zeros((57, 64), np.float32)
+        for k in range(4):                                                              # g = fma chain over the run, from 0
+            g = (sq.reshape(57, 4, 64)[:, k].astype(np.float64) + g.astype(np.float64)).astype(np.float32)
+        hi, lo = convert(g)
+        exact = g.astype(np.float64) * 2.0 ** 44
+        fixed = hi.astype(np.float64) * 2.0 ** 24 + lo.astype(np.float64)
+        assert np.all(fixed <= exact) and np.all(exact - fixed < 1.0)                   # < 2^-44 dropped per run
+        big = g >= f32(2.0 ** -20)
+        assert np.all(fixed[big] == exact[big])                                         # exact from 2^-20 up
+        # no overflow of the 32-bit accumulators over a class's 57 runs, even at the largest values (g <= 4)
+        assert int(hi.astype(np.uint64).sum(axis=0).max()) < 2 ** 32 and int(lo.astype(np.uint64).sum(axis=0).max()) < 2 ** 32
+        assert 57 * (4 << 20) < 2 ** 32 and 57 * (2 ** 24 - 1) < 2 ** 32
+        total = (hi.astype(np.uint64) << np.uint64(24)).sum(axis=0) + lo.astype(np.uint64).sum(axis=0)
+        # any grouping / order of the runs: integer addition
+        perm = rng.permutation(57)
+        cut = 23
+        part_a = (hi[perm[:cut]].astype(np.uint64) << np.uint64(24)).sum(axis=0) + lo[perm[:cut]].astype(np.uint64).sum(axis=0)
+        part_b = (hi[perm[cut:]].astype(np.uint64) << np.uint64(24)).sum(axis=0) + lo[perm[cut:]].astype(np.uint64).sum(axis=0)
+        assert np.array_equal(part_a + part_b, total)
+        assert int(total.max()) < 2 ** 53                                               # exact as a double
+        s = (total.astype(np.float64) * 2.0 ** -44).astype(np.float32)                  # one rounding
+        want = fixed.sum(axis=0) * 2.0 ** -44
+        assert np.array_equal(s, want.astype(np.float32))
+        if scale >= 1e-2:                                                               # and that is the sum of the run sums
+            ref = g.astype(np.float64).sum(axis=0)
+            assert np.all(np.abs(s.astype(np.float64) - ref) <= np.abs(ref) * 2.0 ** -23)
+    # a non-finite or absurd run sum is flagged, not converted
+    assert not (f32(np.nan) < f32(1024.0)) and not (f32(np.inf) < f32(1024.0)) and (f32(4.0) < f32(1024.0))

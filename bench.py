@@ -178,7 +178,7 @@ PMC_KERNELS = {"spectral_gemm_f16_kernel": "%spectral_gemm_f16_kernel%", "spectr
                "conv3_f16x3_kernel": "%conv3_f16x3_kernel%"}
 
 
-def live_counters(precision, classes, keep_dir=None, timeout_s=150):
+def live_counters(precision, classes, keep_dir=None, timeout_s=150, passes=None, tag=""):
     """HBM traffic and matrix-pipe counters of the step's kernels, measured NOW: rocprofv3 PMC passes over a short child run
     of this very script (same workload, 3 steps), one pass per counter group as the HBM / rocprofv3 section of
     MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE never share a pass; --kernel-trace only, no other trace
@@ -199,7 +199,7 @@ def live_counters(precision, classes, keep_dir=None, timeout_s=150):
     out = {"kernels": {}, "passes": [], "child": " ".join(child[1:])}
     t0 = time.perf_counter()
     try:
-        for group in PMC_PASSES:
+        for group in (passes or PMC_PASSES):
             d = os.path.join(root, "pmc_" + "_".join(group))
             cmd = [rocprof, "--pmc"] + list(group) + ["--kernel-trace", "-d", d, "-o", "pmc", "--"] + child
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
@@ -238,7 +238,7 @@ def live_counters(precision, classes, keep_dir=None, timeout_s=150):
     if keep_dir:
         try:
             os.makedirs(keep_dir, exist_ok=True)
-            with open(os.path.join(keep_dir, "live_counters_{}.json".format(precision)), "w") as f:
+            with open(os.path.join(keep_dir, "live_counters_{}{}.json".format(precision, tag)), "w") as f:
                 json.dump(out, f, indent=1)
         except OSError:
             pass
@@ -754,7 +754,7 @@ def sweep_entry(dev, name, classes, variant, pyramid, precision, steps, warmup):
         per_kernel = w.rooflines(stage_ms, w.head.last_precision or precision)
         longest = max(per_kernel, key=lambda k: per_kernel[k]["avg_launch_ms"])
         e["roofline"] = dict(per_kernel[longest], stage=longest)
-        e["roofline_other"] = {k: {f: v[f] for f in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms") if f in v}
+        e["roofline_other"] = {k: {f: v[f] for f in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "pmc_kernel", "traffic", "algorithmic_bytes") if f in v}
                                for k, v in per_kernel.items() if k != longest}
     else:
         e["roofline"] = w.roofline(precision, stage_ms, dt / steps)
@@ -1000,6 +1000,17 @@ def run_bench(args, rank, local_rank, world, dev, use_dist):
                     r[c] = k[c]
             r["counters_source"] = ("LIVE: rocprofv3 PMC passes of this run over a 3-step child run of the same workload ({} launches of {}; "
                                     "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes)".format(k.get("launches"), kname))
+    if single and not args.no_live_counters and not args.no_sweep and not args.pyramid:
+        # the same two traffic passes over the 1024-class workload (the correlation's operand re-fetch at scale)
+        lc = live_counters(args.precision, 1024, keep_dir=os.path.join(REPO, "gpurun_out", "live_counters")
+                           if os.path.isdir(os.path.join(REPO, "gpurun_out")) else None, passes=PMC_PASSES[:2], tag="_1024", timeout_s=240)
+        result["live_counters_1024"] = lc
+        for e in result.get("sweep", []):
+            if e["name"].startswith("configs[2]"):
+                for r in [e.get("roofline")] + list(e.get("roofline_other", {}).values()):
+                    k = lc.get("kernels", {}).get((r or {}).get("pmc_kernel"))
+                    if k and "hbm_bytes_per_launch" in k:
+                        r["traffic"] = k["hbm_bytes_per_launch"]
     if "other_precisions" in result:
         by_mode = {o["precision"]: o["value"] for o in result["other_precisions"]}
         if "f32" in by_mode:
@@ -1014,7 +1025,7 @@ def run_bench(args, rank, local_rank, world, dev, use_dist):
             allk = dict(e.get("roofline_other", {}))
             allk[e["roofline"].get("stage", "?")] = e["roofline"]
             result["config"]["classes_1024_one_gpu"] = {"pairs_per_s": e["value"], "ms_per_step": e["ms_per_step"],
-                                                        "longest_kernel": {k: e["roofline"].get(k) for k in ("stage", "bound", "frac", "avg_launch_ms")},
+                                                        "longest_kernel": {k: e["roofline"].get(k) for k in ("stage", "bound", "frac", "avg_launch_ms", "traffic", "algorithmic_bytes")},
                                                         "layer7x7_ms": {k: v["avg_launch_ms"] for k, v in allk.items()
                                                                         if k in ("fft_forward", "spectral_gemm", "fft_inverse")},
                                                         "layer7x7_hbm_frac": {k: v["frac"] for k, v in allk.items()
@@ -1024,13 +1035,85 @@ def run_bench(args, rank, local_rank, world, dev, use_dist):
         elif e["name"].startswith("configs[4]"):
             result["config"]["pyramid_7_levels_128_classes"] = {"pairs_per_s": e["value"], "streams_ms": e.get("pyramid_streams_ms"),
                                                                 "serial_ms": e.get("pyramid_serial_ms")}
-    # the figures a reader looks for first go first: a truncated copy of the line still shows them
-    front = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-             "dtype", "data", "config", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "stages_ms", "roofline_other",
-             "f32_pairs_per_s", "fft32_pairs_per_s", "scaling_reference"]
-    result = {**{k: result[k] for k in front if k in result}, **{k: v for k, v in result.items() if k not in front}}
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result)
+
+
+LINE_BUDGET = 6000      # bytes of the ONE stdout line (the 22 KB line of round 4 was not parsed by the driver)
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config", "roofline", "cpu_baseline")
+ROOFLINE_KEYS = ("kernel", "stage", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "flops_per_launch",
+                 "algorithmic_bytes", "executed_frac_of_peak", "hbm_gbps", "mfma_pipe_busy", "effective_clock_ghz", "counters")
+
+
+def _finite(o):
+    """Strict JSON: non-finite floats become null (json.loads of the driver must never meet NaN / Infinity)."""
+    if isinstance(o, float):
+        return o if o == o and o not in (float("inf"), float("-inf")) else None
+    if isinstance(o, dict):
+        return {str(k): _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    return o
+
+
+def compact_line(result, budget=LINE_BUDGET):
+    """The ONE line of stdout: the driver's contract keys, `roofline` (longest kernel, with its live `traffic`), `cpu_baseline`,
+    `roofline_other` as {kernel: [frac, avg_launch_ms]} and a few scalars - a few KB.  Everything else of `result` (the other
+    arithmetic modes, the sweep entries with their own roofline objects, the raw live counters, the end-to-end legs) goes to
+    bench_details.json and to stderr (emit()).  Optional keys are dropped, last first, should the line ever exceed `budget`."""
+    result = _finite(result)
+    line = {k: result[k] for k in CONTRACT_KEYS if k in result}
+    if isinstance(line.get("roofline"), dict):
+        r = dict(result["roofline"])
+        src = r.get("counters_source")
+        if src:
+            r["counters"] = "live rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate passes)" if src.startswith("LIVE") else "replayed (profiles/)"
+        line["roofline"] = {k: r[k] for k in ROOFLINE_KEYS if k in r}
+        line["roofline"].setdefault("traffic", None)
+    if isinstance(line.get("cpu_baseline"), dict) and len(line["cpu_baseline"].get("sample", "")) > 240:
+        line["cpu_baseline"] = dict(line["cpu_baseline"], sample=line["cpu_baseline"]["sample"][:237] + "...")
+    optional = []
+    if "stages_ms" in result:
+        optional.append(("stages_ms", result["stages_ms"]))
+    if isinstance(result.get("roofline_other"), dict):
+        optional.append(("roofline_other", {k: [v.get("frac"), v.get("avg_launch_ms")] for k, v in result["roofline_other"].items()}))
+        optional.append(("roofline_other_is", "{kernel: [frac of its bound (see bench_details.json), avg launch ms]}"))
+    for k in ("speedup_vs_cpu_baseline", "head_tflops_algorithmic", "f32_pairs_per_s", "fft32_pairs_per_s", "gather_wait_ms"):
+        if k in result:
+            optional.append((k, result[k]))
+    if isinstance(result.get("end_to_end"), dict):
+        optional.append(("end_to_end", {k: result["end_to_end"].get(k) for k in ("value", "ms_per_image", "backbone_ms", "head_ms", "decode_nms_ms")}))
+    if isinstance(result.get("allgather_probe"), dict):
+        optional.append(("allgather_probe", {k: result["allgather_probe"].get(k) for k in ("bytes_per_rank", "ms", "busbw_gbps")}))
+    if isinstance(result.get("other_gathers"), list):
+        optional.append(("other_gathers", {g.get("gather"): g.get("value") for g in result["other_gathers"]}))
+    optional.append(("details", "bench_details.json (same directory; also on stderr)"))
+    for k, v in optional:
+        line[k] = v
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    while len(text) > budget and optional:
+        line.pop(optional.pop()[0], None)
+        text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(text) > budget and isinstance(line.get("config"), dict):      # last resort: config down to its workload string
+        line["config"] = {"workload": line["config"].get("workload")}
+        text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    return text
+
+
+def emit(result):
+    """Rank 0: the full record to bench_details.json (repo root; and gpurun_out/ when present, which is what comes back from
+    the GPU box) and to stderr, the compact line - alone - to stdout."""
+    full = json.dumps(_finite(result), allow_nan=False, indent=1)
+    for d in (REPO, os.path.join(REPO, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_details.json"), "w") as f:
+                    f.write(full + "\n")
+            except OSError:
+                pass
+    print("[bench_details] " + json.dumps(_finite(result), allow_nan=False), file=sys.stderr, flush=True)
+    print(compact_line(result), flush=True)
 
 
 if __name__ == "__main__":

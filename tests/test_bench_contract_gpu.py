@@ -11,13 +11,52 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
+def _strict_loads(text):
+    def refuse(name):
+        raise ValueError("non-finite constant in the bench line: " + name)
+    return json.loads(text, parse_constant=refuse)
+
+
+def _one_line(out):
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.count("\n") == 1 and out.stdout.startswith("{"), out.stdout[-2000:]     # stdout is the line and nothing else
+    line = out.stdout.strip()
+    assert len(line) <= 6000, len(line)
+    return _strict_loads(line)
+
+
+def test_default_command_prints_one_compact_line(device):
+    """The driver's own command, nothing disabled: one line of at most 6000 bytes of strict JSON with
+    every contract key, the live roofline traffic and the cpu_baseline; the full record lands in bench_details.json."""
+    details = os.path.join(REPO, "bench_details.json")
+    if os.path.exists(details):
+        os.remove(details)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"],
+                         cwd=REPO, capture_output=True, text=True, timeout=900)
+    d = _one_line(out)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "roofline_other", "stages_ms"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak"
+    assert d["config"]["workload"].startswith("BASELINE.json configs[1]") and d["config"]["classes_total"] == 64
+    assert abs(d["value"] - 64 * 20 / (d["ms_per_step"] * 20e-3)) / d["value"] < 1e-2
+    r = d["roofline"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["avg_launch_ms"] <= d["ms_per_step"]
+    assert r["traffic"] is None or r["traffic"] > 0
+    assert all(len(v) == 2 for v in d["roofline_other"].values())
+    for k in ("classes_256_v1", "classes_1024_one_gpu", "pyramid_7_levels_128_classes"):
+        assert d["config"][k]["pairs_per_s"] > 0, k
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    full = _strict_loads(open(details).read())
+    for k in ("other_precisions", "sweep", "live_counters", "roofline_other", "end_to_end"):
+        assert k in full, k
+    assert "[bench_details] {" in out.stderr
+
+
 def test_bench_line_contract(device):
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "1", "--classes", "8",
                           "--cpu-seconds", "1.5", "--no-end-to-end", "--no-sweep"], cwd=REPO, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
+    d = _one_line(out)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key

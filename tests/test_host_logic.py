@@ -236,3 +236,30 @@ def test_fixed_point_norm_sums_of_the_correlation_kernels():
             assert np.all(np.abs(s.astype(np.float64) - ref) <= np.abs(ref) * 2.0 ** -23)
     # a non-finite or absurd run sum is flagged, not converted
     assert not (f32(np.nan) < f32(1024.0)) and not (f32(np.inf) < f32(1024.0)) and (f32(4.0) < f32(1024.0))
+
+
+def test_bench_compact_line_fits_the_driver():
+    """bench.py's stdout line from a full record (round 4's 22 KB line, which the driver could not parse): at most 6000
+    bytes, strict JSON, contract keys intact, optional keys dropped before contract ones under a smaller budget."""
+    import json
+    import os
+    import bench
+    REPO = os.path.dirname(os.path.abspath(bench.__file__))
+    with open(os.path.join(REPO, "profiles", "r04_w_bench.json")) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 20000
+    line = bench.compact_line(full)
+    assert len(line) <= bench.LINE_BUDGET and "\n" not in line
+    d = json.loads(line)
+    for k in bench.CONTRACT_KEYS:
+        assert k in d, k
+    assert d["value"] == full["value"] and d["roofline"]["frac"] == full["roofline"]["frac"]
+    assert d["roofline"]["traffic"] == full["roofline"]["traffic"] and d["cpu_baseline"]["value"] == full["cpu_baseline"]["value"]
+    assert d["roofline_other"]["conv2"] == [full["roofline_other"]["conv2"]["frac"], full["roofline_other"]["conv2"]["avg_launch_ms"]]
+    for k in ("other_precisions", "sweep", "live_counters"):
+        assert k not in d
+    small = json.loads(bench.compact_line(full, budget=2600))
+    assert all(k in small for k in bench.CONTRACT_KEYS) and "end_to_end" not in small
+    bad = dict(full, value=float("nan"), roofline=dict(full["roofline"], hbm_gbps=float("inf")))
+    d = json.loads(bench.compact_line(bad), parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
+    assert d["value"] is None and d["roofline"]["hbm_gbps"] is None

@@ -95,7 +95,7 @@ bool head_args_ok(int A, int B, int C, int H, int W, int P) {
     return false;
   }
   if (W > OS2D_MAX_W) {
-    os2d_set_error("feature map width %d > %d: the 5x5 kernels keep 2 halo rows of their input in LDS (images wider than %d px "
+    os2d_set_error("feature map width %d > %d: beyond what the transform planner of the 7x7 layer tiles (images wider than %d px "
                    "at stride 16 are not supported)", W, OS2D_MAX_W, OS2D_MAX_W * 16);
     return false;
   }

@@ -10,6 +10,7 @@
 // cells of one map: per channel group the input slab (256 + 2 x (2 rows + 2) halo cells, hi and lo) and the group's weights
 // (28 x 2 x 16 units) arrive by LDS-DMA into the other half of a double buffer while the current group is multiplied.
 // Every output element accumulates its products in ONE order whatever the batch size (one kernel shape for all).
+// Maps wider than OS2D_MAX_W_LINEAR5 run in column strips (SP > 0: the strip-plane geometry of conv_f16x3.hip).
 #include "os2d_common.h"
 
 namespace {
@@ -37,10 +38,12 @@ constexpr int C3_WG = C3_TAPS * 2 * 32;       // ... in the packed global layout
 constexpr int C3_BUFS = OS2D_C3_BUFS;
 __global__ __launch_bounds__(C3_THR, C3_BUFS == 1 ? 5 : 2) void conv3_f16x3_kernel(const u32x4* in, const u32x4* wp, const float* __restrict__ bp,
                                                                 float* __restrict__ out, int P, int H, int W, int PLANE,
-                                                                int TILES, int NB) {
+                                                                int TILES, int NB, int SP /*0: linear; else row pitch of a strip-plane*/,
+                                                                int TPS /*tiles per strip*/) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
   const int Ws = W + OS2D_PAD, BASE = os2d_base(W), DATA = H * Ws;
-  const int HALO = 2 * Ws + 2, SLAB = C3_NT + 2 * HALO;
+  const int PW = SP ? SP : Ws;                     // row pitch of the cells in the LDS slab
+  const int HALO = 2 * PW + 2, SLAB = C3_NT + 2 * HALO;
   const int SLABP = (2 * SLAB + 63) & ~63;         // slab area rounded up to whole DMA instructions (64 units)
   const int STAGE = SLABP + C3_WUNITS;             // units of one double-buffer half: slab hi | slab lo | pad | weights
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
@@ -49,7 +52,9 @@ __global__ __launch_bounds__(C3_THR, C3_BUFS == 1 ? 5 : 2) void conv3_f16x3_kern
   const int logical = (blockIdx.x & 7) * per + (blockIdx.x >> 3);   // XCD-aware order, see conv_f16x3.hip
   if (logical >= TILES * NB) return;
   const int tile = logical % TILES, nb = logical / TILES;
-  const int n0 = BASE + tile * C3_NT;
+  const int strip = SP ? tile / TPS : 0;
+  const int c0mR = SP ? strip * (SP - 4) - 2 : 0;  // map column of strip-plane column 0
+  const int n0 = SP ? (tile - strip * TPS) * C3_NT : BASE + tile * C3_NT;
   const u32x4* inb = in + (size_t)nb * C3_G * 2 * PLANE;
 
   typedef const void __attribute__((address_space(1))) * gptr_t;
@@ -64,7 +69,12 @@ __global__ __launch_bounds__(C3_THR, C3_BUFS == 1 ? 5 : 2) void conv3_f16x3_kern
       const int u_ = i_ * 64 + lane;                     /* unit in [0, 2 SLAB): part = u / SLAB */               \
       const int part_ = u_ >= SLAB ? 1 : 0;                                                                       \
       int c_ = n0 - HALO + (u_ - part_ * SLAB);                                                                   \
-      c_ = min(max(c_, 0), PLANE - 1);                                                                            \
+      if (SP) {                                          /* strip-plane index -> map cell, 0 (a zero cell) outside */ \
+        const int h_ = c_ / SP, cc_ = c0mR + (c_ - h_ * SP);                                                      \
+        c_ = (c_ >= 0 && u_ < 2 * SLAB && h_ < H && cc_ >= 0 && cc_ < W) ? BASE + h_ * Ws + cc_ : 0;              \
+      } else {                                                                                                    \
+        c_ = min(max(c_, 0), PLANE - 1);                                                                          \
+      }                                                                                                           \
       const u32x4* src_ = inb + ((size_t)(GRP)*2 + part_) * PLANE + c_;                                           \
       __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(dst_ + i_ * 64), 16, 0, 0);                         \
     }                                                                                                             \
@@ -81,7 +91,7 @@ __global__ __launch_bounds__(C3_THR, C3_BUFS == 1 ? 5 : 2) void conv3_f16x3_kern
 #pragma unroll
   for (int p = 0; p < 7; ++p) {
     const int t = 4 * p + kq;
-    toff[p] = t < 25 ? (t / 5 - 2) * Ws + (t % 5 - 2) : 0;
+    toff[p] = t < 25 ? (t / 5 - 2) * PW + (t % 5 - 2) : 0;
   }
   f32x4 acc[4];
 #pragma unroll
@@ -128,9 +138,18 @@ __global__ __launch_bounds__(C3_THR, C3_BUFS == 1 ? 5 : 2) void conv3_f16x3_kern
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) {
     const int n = n0 + wv * 64 + cb * 16 + l15;
-    const int r = n - BASE;
-    const int hr = r / Ws, wc = r - hr * Ws;
-    if (n >= PLANE || r >= DATA || wc >= W) continue;
+    int hr, wc;
+    if (SP) {
+      hr = n / SP;
+      const int j = n - hr * SP;
+      wc = c0mR + j;
+      if (j < 2 || j >= SP - 2 || hr >= H || wc >= W) continue;
+    } else {
+      const int r = n - BASE;
+      hr = r / Ws;
+      wc = r - hr * Ws;
+      if (n >= PLANE || r >= DATA || wc >= W) continue;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int m = 4 * kq + k;
@@ -147,7 +166,9 @@ __global__ __launch_bounds__(C3_THR, C3_BUFS == 1 ? 5 : 2) void conv3_f16x3_kern
 int os2d_launch_conv3_f16x3(const void* in, const void* wp, const float* bp, void* out, int NB, int P, int H, int W,
                             hipStream_t stream) {
   const int Ws = os2d_ws(W), PLANE = os2d_plane(H, W);
-  const int SLAB = C3_NT + 2 * (2 * Ws + 2);
+  int NS = 1, SP = 0;
+  if (W > OS2D_MAX_W_LINEAR5) os2d_conv_strips(W, 2, &NS, &SP);
+  const int SLAB = C3_NT + 2 * (2 * (SP ? SP : Ws) + 2);
   const size_t lds = (size_t)C3_BUFS * (((2 * SLAB + 63) & ~63) + C3_WUNITS) * 16;
   if (lds > 160 * 1024) {
     os2d_set_error("conv3 (f16x3): feature map too wide for the input slab (W=%d)", W);
@@ -159,7 +180,8 @@ int os2d_launch_conv3_f16x3(const void* in, const void* wp, const float* bp, voi
     os2d_set_error("hipFuncSetAttribute(conv3 f16x3): %s", hipGetErrorString(e));
     return -4;
   }
-  const int tiles = (H * Ws + C3_NT - 1) / C3_NT;
+  const int TPS = SP ? (H * SP + C3_NT - 1) / C3_NT : 0;
+  const int tiles = SP ? NS * TPS : (H * Ws + C3_NT - 1) / C3_NT;
   const long long groups = (long long)tiles * NB;
   if (groups + 7 > 0x7fffffffLL) {
     os2d_set_error("conv3 f16x3: too many work-groups (%lld)", groups);
@@ -167,7 +189,7 @@ int os2d_launch_conv3_f16x3(const void* in, const void* wp, const float* bp, voi
   }
   dim3 grid((unsigned)((groups + 7) / 8 * 8));
   hipLaunchKernelGGL(conv3_f16x3_kernel, grid, dim3(C3_THR), lds, stream, static_cast<const u32x4*>(in),
-                     static_cast<const u32x4*>(wp), bp, static_cast<float*>(out), P, H, W, PLANE, tiles, NB);
+                     static_cast<const u32x4*>(wp), bp, static_cast<float*>(out), P, H, W, PLANE, tiles, NB, SP, TPS);
   e = hipGetLastError();
   if (e != hipSuccess) {
     os2d_set_error("conv3 f16x3 launch: %s", hipGetErrorString(e));

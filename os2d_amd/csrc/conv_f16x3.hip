@@ -31,6 +31,19 @@ __device__ __forceinline__ void split_half(float x, _Float16& hi, _Float16& lo) 
   lo = (_Float16)(x - (float)hi);
 }
 
+// STRIP mode (maps wider than the linear slab allows: 256 + 2 * HALO <= 1536 units, W <= 316 for a 5x5 layer; the reference has
+// no width limit, head.py:622-629).  The map is cut into NS column strips of SW output columns.  A strip is treated as a
+// zero-bordered plane of its own with row pitch SP = SW + 2 R: strip-plane cell (h, j) is map cell (h, c0 - R + j), zero
+// outside the map - so the R columns either side of the strip's outputs hold the NEIGHBOURING strips' data instead of
+// zeros - and the convolution is again a shift-and-accumulate over the flat strip-plane index n' = h * SP + j, exact for
+// the output columns R <= j < SP - R.  The matrix loop is the linear one with SP for the row pitch; only the slab loads and
+// the epilogue translate n' into map cells.  Returns the map-plane cell of strip-plane index np, or 0 - a border cell of
+// every plane, zero by contract - when np lies outside the map.
+__device__ __forceinline__ int os2d_strip_cell(int np, int SP, int c0mR, int H, int W, int Ws, int BASE) {
+  const int h = np / SP, c = c0mR + (np - h * SP);
+  return (np >= 0 && h < H && c >= 0 && c < W) ? BASE + h * Ws + c : 0;
+}
+
 // MTP = output rows of the packed weights (all output channels, padded), MT = rows handled by ONE work-group
 // (blockIdx.z selects the slice): splitting the output channels over two independent 4-wave groups per CU lets one
 // group's barrier / staging bubble be filled by the other's MFMAs.
@@ -38,14 +51,16 @@ __device__ __forceinline__ void split_half(float x, _Float16& hi, _Float16& lo) 
 // only (activations keep both halves): two thirds of the matrix-core work.  Used for the 7x7 layer under precision
 // "f16x2", where the averaging over K = 11025 keeps the box regression within 5e-5 of the fp32 result.
 template <int KS, int MTP, int MT, int WM, int WN, int NI, int SS, bool RELU, int OUT_MODE /*0 SHB, 1 fp32 plane, 2 fp32 compact [NB][Cout][H*W]*/,
-          int NBPF /*16-byte units per thread for the input-slab prefetch*/, int TERMS, int MINW /*waves per SIMD the register budget allows*/>
+          int NBPF /*16-byte units per thread for the input-slab prefetch*/, int TERMS, int MINW /*waves per SIMD the register budget allows*/,
+          bool STRIP = false>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_f16x3_kernel(const u32x4* in,  // SHB [NB][G][2][PLANE] (no __restrict__: invariant loads get
                                                              const u32x4* wp,  // rematerialised BEHIND the MFMAs by the register allocator)
                                                              const float* __restrict__ bp,  // [3][MTP] fp32 per output row: folded bias | 2^-weight_exp | 2^out_exp
                                                              int* __restrict__ status,
                                                              void* __restrict__ outv, int G,
                                                              int CoutStore, int H, int W, int PLANE, int HALO,
-                                                             int TILES, int NB) {
+                                                             int TILES, int NB, int SP /*STRIP: row pitch of a strip-plane*/,
+                                                             int TPS /*STRIP: tiles per strip*/) {
   constexpr int R = KS / 2;
   constexpr int TAPS = KS * KS;
   constexpr int STEPS = (TAPS + 1) / 2;
@@ -80,7 +95,10 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_f16x3_kernel(const u3
   if (logical >= TILES * NB * ZG) return;
   const int zg = logical % ZG, tile = (logical / ZG) % TILES;
   const int nb = logical / (ZG * TILES);
-  const int n0 = BASE + tile * NT;
+  const int PW = STRIP ? SP : Ws;                        // row pitch of the cells in the LDS slab
+  const int strip = STRIP ? tile / TPS : 0;
+  const int c0mR = STRIP ? strip * (SP - 2 * R) - R : 0; // map column of strip-plane column 0
+  const int n0 = STRIP ? (tile - strip * TPS) * NT : BASE + tile * NT;     // first output cell (strip-plane | plane index)
   const int mOff = zg * MT;  // first output row of this group
 
   f32x16 acc[MI][NI];
@@ -94,9 +112,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_f16x3_kernel(const u3
   const u32x4* inb = in + (size_t)nb * G * 2 * PLANE;
   const int aLane = wm * MW + l31;
   // B lane bases (units): same-row tap pair -> upper half-wave reads the next cell; row-crossing pair -> next row start
-  const int bLane = wn * NW + l31 + HALO - R * Ws - R;
+  const int bLane = wn * NW + l31 + HALO - R * PW - R;
   const int bSame = bLane + hw;
-  const int bCross = bLane + hw * (Ws - (KS - 1));
+  const int bCross = bLane + hw * (PW - (KS - 1));
 
   u32x4 pfA[NAPF], pfB[NBPF];
   half8 fah[2][MI], fal[2][MI], fbh[2][NI], fbl[2][NI];  // double-buffered MFMA fragments
@@ -119,7 +137,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_f16x3_kernel(const u3
     const int i_ = min(tid + (K)*NTHR, 2 * SLAB - 1);                                                             \
     const int part_ = i_ >= SLAB ? 1 : 0;                                                                         \
     int g_ = n0 - HALO + (i_ - part_ * SLAB);                                                                     \
-    g_ = (g_ >= 0 && g_ < PLANE) ? g_ : 0;                                                                        \
+    g_ = STRIP ? os2d_strip_cell(g_, SP, c0mR, H, W, Ws, BASE) : ((g_ >= 0 && g_ < PLANE) ? g_ : 0);              \
     pfB[K] = inb[((size_t)(GRP)*2 + part_) * PLANE + g_];                                                         \
   }
 #define F16_STORE_A(S)                                                                                            \
@@ -136,7 +154,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_f16x3_kernel(const u3
       const int i_ = min(tid + k * NTHR, 2 * SLAB - 1);                                                           \
       const int part_ = i_ >= SLAB ? 1 : 0;                                                                       \
       int g_ = n0 - HALO + (i_ - part_ * SLAB);                                                                   \
-      g_ = (g_ >= 0 && g_ < PLANE) ? g_ : 0;                                                                      \
+      g_ = STRIP ? os2d_strip_cell(g_, SP, c0mR, H, W, Ws, BASE) : ((g_ >= 0 && g_ < PLANE) ? g_ : 0);            \
       pfB[k] = inb[((size_t)(GRP)*2 + part_) * PLANE + g_];                                                       \
     }                                                                                                             \
   }
@@ -147,7 +165,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_f16x3_kernel(const u3
       if (i_ < 2 * SLAB) {                                                                                        \
         const int part_ = i_ >= SLAB ? 1 : 0;                                                                     \
         const int g_ = n0 - HALO + (i_ - part_ * SLAB);                                                           \
-        ldsB[i_] = (g_ >= 0 && g_ < PLANE) ? pfB[k] : U32X4_ZERO;                                 \
+        const bool in_ = STRIP ? os2d_strip_cell(g_, SP, c0mR, H, W, Ws, BASE) != 0 : (g_ >= 0 && g_ < PLANE);    \
+        ldsB[i_] = in_ ? pfB[k] : U32X4_ZERO;                                                                     \
       }                                                                                                           \
     }                                                                                                             \
   }
@@ -159,7 +178,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_f16x3_kernel(const u3
     const int t0_ = 2 * ps_, t1_ = (2 * ps_ + 1 < TAPS) ? 2 * ps_ + 1 : 2 * ps_;                                  \
     const int dy0_ = t0_ / KS, dx0_ = t0_ % KS, dy1_ = t1_ / KS;                                                  \
     const int bsel_ = (t1_ == t0_) ? bLane : (dy1_ == dy0_ ? bSame : bCross);                                     \
-    const u32x4* bS_ = ldsB + bsel_ + dy0_ * Ws + dx0_;                                                           \
+    const u32x4* bS_ = ldsB + bsel_ + dy0_ * PW + dx0_;                                                           \
     const u32x4* aS_ = ldsA + (BUF)*ASTAGE + aLane + (((P)*2 + hw) * AP) * MT;                                    \
     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                           \
       fah[SET][mi] = *reinterpret_cast<const half8*>(aS_ + mi * 32);                                              \
@@ -267,11 +286,21 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_f16x3_kernel(const u3
   bool out_of_range = false;
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
-    const int n = n0 + wn * NW + ni * 32 + l31;
-    const int r = n - BASE;
-    const int hr = r / Ws, wc = r - hr * Ws;
-    const bool valid = r < DATA && wc < W;
-    if (n >= PLANE) continue;
+    int n = n0 + wn * NW + ni * 32 + l31;
+    int hr, wc;
+    if (STRIP) {       // strip-plane index -> map cell; only the strip's own output columns (incl. the map's pad columns) are stored
+      hr = n / SP;
+      const int j = n - hr * SP;
+      wc = c0mR + j;
+      if (j < R || j >= SP - R || hr >= H || wc >= Ws) continue;
+      n = BASE + hr * Ws + wc;
+    } else {
+      const int r = n - BASE;
+      hr = r / Ws;
+      wc = r - hr * Ws;
+      if (n >= PLANE) continue;
+    }
+    const bool valid = hr < H && wc < W;      // (linear: r < DATA <=> hr < H)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -326,7 +355,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_f16x3_kernel(const u3
   }
   // pad rows above the data (first tile) and whatever lies beyond the last tile
   {
-    const int tail0 = BASE + TILES * NT, tail = PLANE - tail0;
+    const int tail0 = STRIP ? BASE + DATA : BASE + TILES * NT, tail = PLANE - tail0;
     const bool first = tile == 0 && zg == 0, last = tile == TILES - 1 && zg == 0;
     if (OUT_MODE == 0) {
       const int planes = ((CoutStore + 7) >> 3) * 2;
@@ -346,18 +375,21 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_f16x3_kernel(const u3
   }
 }
 
-template <int KS, int MTP, int MT, int WM, int WN, int NI, int SS, bool RELU, int OUT_MODE, int TERMS = 3, int NBPF = 0, int MINW = 2>
+template <int KS, int MTP, int MT, int WM, int WN, int NI, int SS, bool RELU, int OUT_MODE, int TERMS = 3, int NBPF = 0, int MINW = 2,
+          bool STRIP = false>
 int launch(const void* in, const void* wp, const float* bp, int* status, void* out, int NB, int G, int CoutStore, int H,
            int W, hipStream_t stream) {
   constexpr int R = KS / 2;
   constexpr int NT = WN * NI * 32;
   const int Ws = os2d_ws(W), PLANE = os2d_plane(H, W);
-  const int HALO = R * Ws + R;
+  int SP = 0, TPS = 0, NS = 1;
+  os2d_conv_strips(W, R, &NS, &SP);     // strips of equal width, at most 256 output columns each
+  const int HALO = STRIP ? R * SP + R : R * Ws + R;
   const int SLAB = NT + 2 * HALO;
   constexpr int NTHR = 64 * WM * WN;
   if (NBPF == 0) {  // pick the slab-prefetch depth: 8 units/thread up to W = 124 (fewer registers), 12 up to W = 209
-    if (2 * SLAB <= 8 * NTHR) return launch<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE, TERMS, 8, MINW>(in, wp, bp, status, out, NB, G, CoutStore, H, W, stream);
-    if (2 * SLAB <= 12 * NTHR) return launch<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE, TERMS, 12, MINW>(in, wp, bp, status, out, NB, G, CoutStore, H, W, stream);
+    if (2 * SLAB <= 8 * NTHR) return launch<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE, TERMS, 8, MINW, STRIP>(in, wp, bp, status, out, NB, G, CoutStore, H, W, stream);
+    if (2 * SLAB <= 12 * NTHR) return launch<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE, TERMS, 12, MINW, STRIP>(in, wp, bp, status, out, NB, G, CoutStore, H, W, stream);
     os2d_set_error("conv%dx%d (f16x3): feature map too wide for the input-slab prefetch (W=%d)", KS, KS, W);
     return -3;
   }
@@ -366,14 +398,15 @@ int launch(const void* in, const void* wp, const float* bp, int* status, void* o
     os2d_set_error("conv%dx%d (f16x3): LDS budget exceeded (%zu B, W=%d)", KS, KS, lds, W);
     return -3;
   }
-  auto kern = conv_f16x3_kernel<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE, (NBPF ? NBPF : 8), TERMS, MINW>;
+  auto kern = conv_f16x3_kernel<KS, MTP, MT, WM, WN, NI, SS, RELU, OUT_MODE, (NBPF ? NBPF : 8), TERMS, MINW, STRIP>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) {
     os2d_set_error("hipFuncSetAttribute(conv f16x3): %s", hipGetErrorString(e));
     return -4;
   }
-  const int tiles = (H * Ws + NT - 1) / NT;
+  TPS = STRIP ? (H * SP + NT - 1) / NT : 0;
+  const int tiles = STRIP ? NS * TPS : (H * Ws + NT - 1) / NT;
   const long long groups = (long long)tiles * NB * (MTP / MT);
   if (groups + 7 > 0x7fffffffLL) {
     os2d_set_error("conv f16x3: too many work-groups (%lld)", groups);
@@ -381,7 +414,7 @@ int launch(const void* in, const void* wp, const float* bp, int* status, void* o
   }
   dim3 grid((unsigned)((groups + 7) / 8 * 8));  // multiple of 8: every XCD gets the same number of logical slots
   hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds, stream, reinterpret_cast<const u32x4*>(in),
-                     reinterpret_cast<const u32x4*>(wp), bp, status, out, G, CoutStore, H, W, PLANE, HALO, tiles, NB);
+                     reinterpret_cast<const u32x4*>(wp), bp, status, out, G, CoutStore, H, W, PLANE, HALO, tiles, NB, SP, TPS);
   e = hipGetLastError();
   if (e != hipSuccess) {
     os2d_set_error("conv f16x3 launch: %s", hipGetErrorString(e));
@@ -406,6 +439,10 @@ int os2d_launch_conv_f16x3(int layer, const void* in, const void* wp, const floa
   // the last layer has its own kernel (16-row MFMA, conv3_f16x3.hip), one shape for every batch size
   if (layer == 3) return os2d_launch_conv3_f16x3(in, wp, bp, out, NB, P, H, W, stream);
 #endif
+  if (layer != 1 && W > OS2D_MAX_W_LINEAR5) {    // wider than the linear slab takes: column strips, one shape for every batch size
+    if (layer == 2) return launch<5, 64, 64, 1, 4, 2, 7, true, 0, 3, 0, 2, true>(in, wp, bp, status, out, NB, 16, 64, H, W, stream);
+    return launch<5, 32, 32, 1, 4, 2, 7, false, 2, 3, 0, 2, true>(in, wp, bp, status, out, NB, 8, P, H, W, stream);
+  }
   const long long std_groups = (long long)((H * os2d_ws(W) + 255) / 256) * NB;
   if (std_groups * (layer == 1 ? 2 : 1) < 384) {  // measured crossover at 60x80: finer shapes win up to 9 classes
     if (layer == 1 && terms == 2)

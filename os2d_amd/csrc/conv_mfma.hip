@@ -25,12 +25,21 @@ namespace {
 
 constexpr int NBPF = 3;  // max float4 per thread for the B-slab prefetch (SLAB <= 1536 floats)
 
-template <int KS, int RS, int MT, int WM, int WN, int NT, bool RELU, bool COMPACT>
+// STRIP: maps wider than the linear slab takes (SLAB <= 1536 floats) are cut into column strips - the strip-plane geometry of
+// conv_f16x3.hip (os2d_strip_cell): scalar slab loads through the index translation, the matrix loop unchanged with the strip
+// pitch SP for the row pitch.
+__device__ __forceinline__ int conv_strip_cell(int np, int SP, int c0mR, int H, int W, int Ws, int BASE) {
+  const int h = np / SP, c = c0mR + (np - h * SP);
+  return (np >= 0 && h < H && c >= 0 && c < W) ? BASE + h * Ws + c : 0;
+}
+
+template <int KS, int RS, int MT, int WM, int WN, int NT, bool RELU, bool COMPACT, bool STRIP = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const float* __restrict__ in,   // [NB][CinP][PLANE]
                                                            const float* __restrict__ wp,   // [CinP/2][KS*KS][2][MT]
                                                            const float* __restrict__ bp,   // [MT]
                                                            float* __restrict__ out, int CinP, int CoutStore,
-                                                           int H, int W, int PLANE, int HALO, int TILES, int NB) {
+                                                           int H, int W, int PLANE, int HALO, int TILES, int NB,
+                                                           int SPITCH /*STRIP: row pitch of a strip-plane*/, int TPS /*STRIP: tiles per strip*/) {
   constexpr int R = KS / 2;
   constexpr int SP = KS / RS;  // stages per channel pair
   static_assert(SP * RS == KS, "RS must divide KS");
@@ -59,7 +68,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const float* __restri
   if (logical >= TILES * NB) return;
   const int tile = logical % TILES;
   const int nb = logical / TILES;
-  const int n0 = BASE + tile * NT;
+  const int PW = STRIP ? SPITCH : Ws;                            // row pitch of the cells in the LDS slab
+  const int strip = STRIP ? tile / TPS : 0;
+  const int c0mR = STRIP ? strip * (SPITCH - 2 * R) - R : 0;     // map column of strip-plane column 0
+  const int n0 = STRIP ? (tile - strip * TPS) * NT : BASE + tile * NT;
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -70,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const float* __restri
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
   const int aOff = hi * MT + wm * MW + l31;
-  const int bOff = hi * SLAB + wn * NW + l31 + HALO - R * Ws - R;
+  const int bOff = hi * SLAB + wn * NW + l31 + HALO - R * PW - R;
   const int npairs = CinP >> 1;
   const int nstages = npairs * SP;
   const int q4 = SLAB >> 2;  // float4 per channel of the B slab
@@ -92,8 +104,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const float* __restri
         const int i_ = min(tid + k * 256, 2 * q4 - 1);                                                             \
         const int h2_ = i_ >= q4 ? 1 : 0;                                                                          \
         int g_ = n0 - HALO + ((i_ - h2_ * q4) << 2);                                                               \
-        g_ = (g_ >= 0 && g_ < PLANE) ? g_ : 0;                                                                     \
-        pfB[k] = *reinterpret_cast<const f32x4*>(inb + (size_t)(2 * cp_ + h2_) * PLANE + g_);                      \
+        if (STRIP) {                                                                                               \
+          const float* src_b_ = inb + (size_t)(2 * cp_ + h2_) * PLANE;                                             \
+          _Pragma("unroll") for (int e = 0; e < 4; ++e) pfB[k][e] = src_b_[conv_strip_cell(g_ + e, SPITCH, c0mR, H, W, Ws, BASE)]; \
+        } else {                                                                                                   \
+          g_ = (g_ >= 0 && g_ < PLANE) ? g_ : 0;                                                                   \
+          pfB[k] = *reinterpret_cast<const f32x4*>(inb + (size_t)(2 * cp_ + h2_) * PLANE + g_);                    \
+        }                                                                                                          \
       }                                                                                                            \
     }                                                                                                              \
   }
@@ -112,7 +129,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const float* __restri
           const int h2_ = i_ >= q4 ? 1 : 0;                                                                        \
           const int g_ = n0 - HALO + ((i_ - h2_ * q4) << 2);                                                       \
           const f32x4 z_ = {0.f, 0.f, 0.f, 0.f};                                                                   \
-          dstB_[i_] = (g_ >= 0 && g_ < PLANE) ? pfB[k] : z_;                                                       \
+          if (STRIP) {                                                                                             \
+            f32x4 v_ = pfB[k];                                                                                     \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                          \
+              if (conv_strip_cell(g_ + e, SPITCH, c0mR, H, W, Ws, BASE) == 0) v_[e] = 0.f;                         \
+            dstB_[i_] = v_;                                                                                        \
+          } else {                                                                                                 \
+            dstB_[i_] = (g_ >= 0 && g_ < PLANE) ? pfB[k] : z_;                                                     \
+          }                                                                                                        \
         }                                                                                                          \
       }                                                                                                            \
     }                                                                                                              \
@@ -125,9 +149,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const float* __restri
   {                                                                                                                \
     const int cp_ = (S) / SP, rg_ = (S)-cp_ * SP; /* row group of this stage */                                    \
     const float* aBase_ = ldsA + ((S)&1) * ASTAGE + aOff;                                                          \
-    const float* bBase_ = ldsB + (cp_ & 1) * 2 * SLAB + bOff + rg_ * RS * Ws;                                      \
+    const float* bBase_ = ldsB + (cp_ & 1) * 2 * SLAB + bOff + rg_ * RS * PW;                                      \
     _Pragma("unroll") for (int ry = 0; ry < RS; ++ry) {                                                           \
-      const float* bRow_ = bBase_ + ry * Ws;                                                                       \
+      const float* bRow_ = bBase_ + ry * PW;                                                                       \
       _Pragma("unroll") for (int dx = 0; dx < KS; ++dx) {                                                         \
         float a_[MI], b_[NI];                                                                                      \
         _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) a_[mi] = aBase_[(ry * KS + dx) * 2 * MT + mi * 32];     \
@@ -156,10 +180,20 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const float* __restri
   // ---- epilogue: bias (+ReLU); pad cells of a plane-layout output are written as exact zeros
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
-    const int n = n0 + wn * NW + ni * 32 + l31;
-    const int r = n - BASE;
-    const int hr = r / Ws, wc = r - hr * Ws;
-    const bool valid = r < DATA && wc < W;
+    int n = n0 + wn * NW + ni * 32 + l31;
+    int hr, wc;
+    if (STRIP) {       // strip-plane index -> map cell; only the strip's own output columns (incl. the map's pad columns) are stored
+      hr = n / SPITCH;
+      const int j = n - hr * SPITCH;
+      wc = c0mR + j;
+      if (j < R || j >= SPITCH - R || hr >= H || wc >= Ws) continue;
+      n = BASE + hr * Ws + wc;
+    } else {
+      const int r = n - BASE;
+      hr = r / Ws;
+      wc = r - hr * Ws;
+    }
+    const bool valid = hr < H && wc < W;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -181,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const float* __restri
     if (tile == 0)
       for (int i = tid; i < CoutStore * BASE; i += 256) out[((size_t)nb * CoutStore + i / BASE) * PLANE + i % BASE] = 0.f;
     if (tile == TILES - 1) {
-      const int tail0 = BASE + TILES * NT, tail = PLANE - tail0;
+      const int tail0 = STRIP ? BASE + DATA : BASE + TILES * NT, tail = PLANE - tail0;
       if (tail > 0)
         for (int i = tid; i < CoutStore * tail; i += 256)
           out[((size_t)nb * CoutStore + i / tail) * PLANE + tail0 + i % tail] = 0.f;
@@ -189,30 +223,33 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const float* __restri
   }
 }
 
-template <int KS, int RS, int MT, int WM, int WN, bool RELU, bool COMPACT>
+template <int KS, int RS, int MT, int WM, int WN, bool RELU, bool COMPACT, bool STRIP = false>
 int launch(const float* in, const float* wp, const float* bp, float* out, int NB, int CinP, int CoutStore, int H,
            int W, hipStream_t stream) {
   constexpr int NT = 256;
   constexpr int R = KS / 2;
   const int Ws = os2d_ws(W), PLANE = os2d_plane(H, W);
-  const int HALO = os2d_round_up(R * Ws + R, 4);
+  int NS = 1, SPITCH = 0;
+  os2d_conv_strips(W, R, &NS, &SPITCH);
+  const int HALO = os2d_round_up(R * (STRIP ? SPITCH : Ws) + R, 4);
   const int SLAB = NT + 2 * HALO;
   if (2 * (SLAB / 4) > NBPF * 256) {
     os2d_set_error("conv%dx%d: feature map too wide for the B-slab prefetch (W=%d)", KS, KS, W);
     return -3;
   }
   const size_t lds = (size_t)(2 * RS * KS * 2 * MT + 4 * SLAB) * sizeof(float);
-  auto kern = conv_mfma_kernel<KS, RS, MT, WM, WN, NT, RELU, COMPACT>;
+  auto kern = conv_mfma_kernel<KS, RS, MT, WM, WN, NT, RELU, COMPACT, STRIP>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) {
     os2d_set_error("hipFuncSetAttribute(conv): %s", hipGetErrorString(e));
     return -4;
   }
-  const int tiles = (H * Ws + NT - 1) / NT;
+  const int TPS = STRIP ? (H * SPITCH + NT - 1) / NT : 0;
+  const int tiles = STRIP ? NS * TPS : (H * Ws + NT - 1) / NT;
   const long long groups = (long long)tiles * NB;
   dim3 grid((unsigned)((groups + 7) / 8 * 8));  // multiple of 8: every XCD gets the same number of logical slots
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, in, wp, bp, out, CinP, CoutStore, H, W, PLANE, HALO, tiles, NB);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, in, wp, bp, out, CinP, CoutStore, H, W, PLANE, HALO, tiles, NB, SPITCH, TPS);
   e = hipGetLastError();
   if (e != hipSuccess) {
     os2d_set_error("conv launch: %s", hipGetErrorString(e));
@@ -227,6 +264,10 @@ int launch(const float* in, const float* wp, const float* bp, float* out, int NB
 // layer 3: 5x5 64->P (rows padded to 32 in the packed weights), compact [NB][P][H*W] out.
 int os2d_launch_conv(int layer, const float* in, const float* wp, const float* bp, float* out, int NB, int P, int H,
                      int W, hipStream_t stream) {
+  if (layer != 1 && W > OS2D_MAX_W_LINEAR5) {     // wider than the linear slab takes: column strips
+    if (layer == 2) return launch<5, 5, 64, 1, 4, true, false, true>(in, wp, bp, out, NB, 128, 64, H, W, stream);
+    if (layer == 3) return launch<5, 5, 32, 1, 4, false, true, true>(in, wp, bp, out, NB, 64, P, H, W, stream);
+  }
   switch (layer) {
     case 1: return launch<7, 1, 128, 2, 2, true, false>(in, wp, bp, out, NB, OS2D_KP, 128, H, W, stream);
     case 2: return launch<5, 5, 64, 1, 4, true, false>(in, wp, bp, out, NB, 128, 64, H, W, stream);

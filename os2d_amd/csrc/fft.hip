@@ -615,8 +615,8 @@ bool make_plan(int H, int W, FftPlan* pl, size_t* lds) {
   double best_cost = 0.0;
   size_t best_lds = 0;
   FftPlan best;
-  for (int TY = 1; TY <= 8; ++TY)
-    for (int TX = 1; TX <= 8; ++TX) {
+  for (int TY = 1; TY <= 48; ++TY)          // (up to 48 tiles per axis: any width the head accepts, OS2D_MAX_W)
+    for (int TX = 1; TX <= 48; ++TX) {
       if (TY * TX == 1) continue;
       const int TH = (H + TY - 1) / TY, TW = (W + TX - 1) / TX;
       if ((TY > 1 && (TY - 1) * TH >= H) || (TX > 1 && (TX - 1) * TW >= W)) continue;     // an empty last tile

@@ -21,8 +21,11 @@
 #define OS2D_KP 226          // padded to an even channel count (MFMA 32x32x2 consumes channel pairs)
 #define OS2D_QROWS 256       // correlation GEMM M tile: 225 rows padded with zeros
 #define OS2D_MAX_W_DIRECT7 209   // widest map of the DIRECT 7x7 kernels: 256 + 2*(3*(W+3)+3) slab units must fit their prefetch (<= 1536)
-#define OS2D_MAX_W 316       // widest feature map of the head: the 5x5 kernels' slabs, 256 + 2*(2*(W+3)+2) <= 1536 (5056-px images at
-                             // stride 16); beyond OS2D_MAX_W_DIRECT7 the 7x7 layer runs in the frequency domain (tiled) whatever the batch
+#define OS2D_MAX_W_LINEAR5 316   // widest map of the 5x5 kernels' LINEAR slabs, 256 + 2*(2*(W+3)+2) <= 1536 units; wider maps are cut into column
+                                 // strips (conv_f16x3.hip: STRIP mode); beyond OS2D_MAX_W_DIRECT7 the 7x7 layer runs in the frequency domain
+                                 // (tiled) whatever the batch
+#define OS2D_MAX_W 3600      // widest feature map of the head (57,600-px images at stride 16): the transform planner cuts an axis into at most
+                             // 48 overlap-save tiles of its largest canonical size (dft_mfma.h); the reference has no limit (head.py:619-629)
 #define OS2D_XSPEC_CPAD 232  // channel stride of the input spectra of the matrix-product transforms: 225 rounded up to the GEMM's k-steps of 8
 #define OS2D_G 29            // 8-channel groups of the 225 correlation channels (f16x3 path)
 #define OS2D_RNORM_EXP 12    // the relu+L2-normalised correlation (|x| <= 1) is stored as fp16 hi|lo of x * 2^12
@@ -36,6 +39,14 @@ static inline __host__ __device__ int os2d_ws(int W) { return W + OS2D_PAD; }
 static inline __host__ __device__ int os2d_base(int W) { return os2d_round_up(OS2D_PAD * os2d_ws(W) + OS2D_PAD, 4); }
 static inline __host__ __device__ int os2d_plane(int H, int W) {
   return os2d_round_up(os2d_base(W) + (H + OS2D_PAD) * os2d_ws(W) + OS2D_PAD, 64);
+}
+// Column strips of the 5x5 kernels for maps wider than OS2D_MAX_W_LINEAR5 (conv_f16x3.hip): NS strips of SW = ceil(Ws / NS)
+// output columns (the strips cover the W data columns and the 3 pad columns of a row), at most 256 each; *SP = SW + 2 R is the
+// row pitch of a strip-plane.
+static inline void os2d_conv_strips(int W, int R, int* NS, int* SP) {
+  const int Ws = os2d_ws(W);
+  *NS = (Ws + 255) / 256;
+  *SP = (Ws + *NS - 1) / *NS + 2 * R;
 }
 // Packed correlation kernel (corr_f16x3.hip, STACK): a position's sum of relu(corr)^2 in 2^-44 fixed point (bit 62: a
 // non-finite term) -> 1 / (sqrt(s) + 1e-6) (head.py:650, 597); the word is cleared for the next launch.  acc < 2^53: the

@@ -52,10 +52,12 @@ def test_library_loads_and_reports_abi(lib_path):
     assert lib.os2d_head_workspace_bytes(1, 1, 1023, 60, 80, 6, ctypes.byref(n)) == -1
     assert b"C%4" in lib.os2d_last_error() or b"C" in lib.os2d_last_error()
     assert lib.os2d_head_workspace_bytes(1, 1, 1024, 60, 80, 5, ctypes.byref(n)) == -1
-    # widest map: 316 columns (the 5x5 kernels' slabs); the direct 7x7 kernels stop at 209, beyond that the head runs the layer in
-    # the frequency domain (tiled) whatever the batch
+    # widest map: 3600 columns (the transform planner's 48 tiles per axis); the direct 7x7 kernels stop at 209 - beyond that the head
+    # runs the layer in the frequency domain (tiled) whatever the batch - and the 5x5 kernels' linear slabs at 316: column strips
     assert lib.os2d_head_workspace_bytes(1, 1, 1024, 60, 316, 6, ctypes.byref(n)) == 0
-    assert lib.os2d_head_workspace_bytes(1, 1, 1024, 60, 317, 6, ctypes.byref(n)) == -1 and b"width" in lib.os2d_last_error()
+    assert lib.os2d_head_workspace_bytes(1, 1, 1024, 60, 640, 6, ctypes.byref(n)) == 0
+    assert lib.os2d_head_workspace_bytes(1, 1, 1024, 4, 3600, 6, ctypes.byref(n)) == 0
+    assert lib.os2d_head_workspace_bytes(1, 1, 1024, 4, 3601, 6, ctypes.byref(n)) == -1 and b"width" in lib.os2d_last_error()
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
@@ -174,7 +176,7 @@ def test_dft_plan_host_logic():
     assert plan(96, 128)[1:8] == (56, 70, 2016, 2, 2, 48, 64)
     assert sum(p * (q // 2 + 1) for p, q in canonical) * 128 * 232 * 8 < 2.5e9          # all six sets of weight spectra
     for h in list(range(1, 100, 7)) + [120, 157, 300]:
-        for w in list(range(1, 130, 9)) + [150, 209, 260, 316]:
+        for w in list(range(1, 130, 9)) + [150, 209, 260, 316, 317, 400, 640, 1000, 3600]:
             rc, P, Q, nb, ty, tx, th, tw, lh, lw = plan(h, w)
             assert rc == 0, (h, w)
             assert ty >= 1 and tx >= 1 and ty * th >= h and tx * tw >= w and (ty - 1) * th < h and (tx - 1) * tw < w

@@ -278,8 +278,8 @@ def test_baseline_config_256_classes_v1_properties(precision, device):
 def test_widest_supported_level_and_clean_failure_beyond(precision, device):
     """W = 209 columns (a 3344-px wide image) is the widest level the DIRECT 7x7 kernels take; the reference has no width limit
     (head.py:619) and evaluates one class at a time (evaluate.py:226), so beyond it - here W = 260, B = 1 -
-    the layer runs in the frequency domain, tiled, whatever the class batch, in the arithmetic family that was asked for; only
-    beyond 316 columns (the 5x5 kernels' slabs) the head fails, loudly and BEFORE anything is launched."""
+    the layer runs in the frequency domain, tiled, whatever the class batch, in the arithmetic family that was asked for; W = 316
+    is the widest map of the 5x5 kernels' linear slabs."""
     from os2d_amd.utils import synthetic
     P, inverse, C = 6, True, 16
     state = synthetic.make_transform_net_state(P, seed=4)
@@ -296,9 +296,44 @@ def test_widest_supported_level_and_clean_failure_beyond(precision, device):
         assert util.maxdiff(cls, ref[1]) < TOL_CLS, W
         assert util.maxdiff(loc, ref[0]) < TOL_LOC, W
         assert util.maxdiff(corners, ref[3]) < 1.2e-2, W      # coordinates up to ~5000 px
-    wide = synthetic.make_feature_map(C, 4, 317, seed=6).to(device)
-    with pytest.raises(RuntimeError, match="width"):
-        head(wide, precision=precision)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("W,H", [(317, 6), (400, 9), (640, 7)])
+def test_maps_wider_than_the_linear_slabs_run_in_column_strips(W, H, precision, device):
+    """the reference has no width limit (head.py:619-629).  Beyond W = 316 the 5x5 kernels run in column
+    strips (conv_f16x3.hip STRIP mode, conv3_f16x3.hip, conv_mfma.hip; geometry restated in tests/test_conv_strips_model.py) and
+    the 7x7 layer in the tiled frequency domain - parity at B = 1 and B = 8 in every arithmetic mode, V2 and V1 heads, and the
+    1-class call equals the slice of the 8-class call bit for bit."""
+    from os2d_amd.utils import synthetic
+    C = 16
+    for P, inverse in ((6, True), (4, False)):
+        state = synthetic.make_transform_net_state(P, seed=4 + P)
+        class_fms = [c + 0.05 for c in synthetic.make_class_feature_maps(8, C, sizes=[(15, 15), (14, 16), (17, 13)], seed=78)]
+        creator = util.make_head_creator(P, inverse, state, device)
+        fm = synthetic.make_feature_map(C, H, W, seed=W) + 0.05
+        ref = _oracle(fm, class_fms, state, inverse)
+        with torch.no_grad():
+            head8 = creator.create_os2d_head([c.to(device) for c in class_fms])
+            loc8, cls8, _, cor8 = head8(fm.to(device), precision=precision)
+            head1 = creator.create_os2d_head([class_fms[3].to(device)])
+            loc1, cls1, _, cor1 = head1(fm.to(device), precision=precision)
+        assert head8.last_precision == {"f32": "fft32", "f16x3": "fftx3", "f16x2": "fftx3"}.get(precision, precision)
+        assert util.maxdiff(cls8, ref[1]) < TOL_CLS and util.maxdiff(loc8, ref[0]) < TOL_LOC, (W, P)
+        assert util.maxdiff(cor8, ref[3]) < 2.5e-2, (W, P)      # coordinates up to ~10,000 px
+        assert util.maxdiff(cls1, ref[1][:, 3:4]) < TOL_CLS and util.maxdiff(loc1, ref[0][:, 3:4]) < TOL_LOC, (W, P)
+        assert torch.equal(loc1, loc8[:, 3:4]) and torch.equal(cls1, cls8[:, 3:4]) and torch.equal(cor1, cor8[:, 3:4]), (W, P)
+
+
+def test_clean_failure_beyond_the_planner_width(device):
+    """Beyond OS2D_MAX_W = 3600 columns (57,600-px images) the head fails, loudly and BEFORE anything is launched."""
+    from os2d_amd.utils import synthetic
+    state = synthetic.make_transform_net_state(6, seed=4)
+    creator = util.make_head_creator(6, True, state, device)
+    with torch.no_grad():
+        head = creator.create_os2d_head([c.to(device) for c in synthetic.make_class_feature_maps(1, 16, sizes=[(15, 15)], seed=7)])
+        with pytest.raises(RuntimeError, match="width"):
+            head(torch.zeros(1, 16, 2, 3601, device=device))
 
 
 def _random_shapes(n, seed):

@@ -43,8 +43,14 @@
 #ifndef DFT_HD
 #define DFT_HD static inline      /* host + device helpers (the device build says __host__ __device__) */
 #endif
-#ifndef DFT_PREFETCH_SEGMENTED
-#define DFT_PREFETCH_SEGMENTED 0  /* 1: the next iteration's global loads between segments of a product (diagnostic: more registers) */
+#ifndef DFT_FWD_NPRE
+#define DFT_FWD_NPRE 3            /* position slots (of 3) of the next window requested BEFORE step 2, the others right after it */
+#endif
+#ifndef DFT_INV_NPRE
+#define DFT_INV_NPRE 3            /* items of the next spectra requested BEFORE step A (the others right after it) */
+#endif
+#ifndef DFT_LANDED
+#define DFT_LANDED(X)             /* device build: an empty asm that reads and writes X - see the Fp2 fragments in the forward kernel */
 #endif
 #ifndef DFT_SCHED_FENCE
 #define DFT_SCHED_FENCE()         /* device build: __builtin_amdgcn_sched_barrier(0) - the scheduler moves nothing across it */
@@ -295,15 +301,16 @@ DFT_DEV f32x16v dft_mma3(half8 ah, half8 al, half8 bh, half8 bl, f32x16v acc) {
 // "is this k-step live" branch between a fragment read and its matrix instructions - and the B fragments of k-step ks + 1 are
 // requested before the matrix instructions of k-step ks (round 4, first version: a uniform branch per k-step and tile made
 // every scheduling region one read-wait-multiply sequence; measured 5.1 us for 2.2 us of matrix time).
-template <int NT>
-DFT_DEV void dft_product_rega(f32x16v* acc, const half8* ah, const half8* al, int ks0, int ks1, const u32x4v* B, int bstride, int nt0,
+// KS > 0: the number of k-steps is a template parameter too (the canonical transform sizes: 2 Pp / 16 = 5 .. 8) - no branch at
+// all between the first fragment read and the last matrix instruction; KS == 0: any count up to DFT_KREG behind uniform guards.
+template <int NT, int KS>
+DFT_DEV void dft_product_rega(f32x16v* acc, const half8* ah, const half8* al, int ksn, const u32x4v* B, int bstride, int nt0,
                               int ntstep, int l31, int hw) {
-  // k-steps [ks0, ks1) (callers cut a product into segments and issue the next iteration's global loads between them).  The
-  // tiles of a k-step are INDEPENDENT accumulators interleaved in the matrix pipe: one tile after the other - a chain of 3 K
-  // dependent instructions - measured 5.7 against 5.1 us
+  // The tiles of a k-step are INDEPENDENT accumulators interleaved in the matrix pipe: one tile after the other - a chain of
+  // 3 K dependent instructions - measured 5.7 against 5.1 us
 #pragma unroll
-  for (int ks = 0; ks < DFT_KREG; ++ks) {
-    if (ks >= ks0 && ks < ks1) {
+  for (int ks = 0; ks < (KS ? KS : DFT_KREG); ++ks) {
+    if (KS || ks < ksn) {
       half8 bh[NT], bl[NT];
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -316,11 +323,12 @@ DFT_DEV void dft_product_rega(f32x16v* acc, const half8* ah, const half8* al, in
   }
 }
 
-DFT_DEV void dft_product_rega_any(f32x16v* acc, int ntiles, const half8* ah, const half8* al, int ks0, int ks1, const u32x4v* B, int bstride,
+template <int KS>
+DFT_DEV void dft_product_rega_any(f32x16v* acc, int ntiles, const half8* ah, const half8* al, int ksn, const u32x4v* B, int bstride,
                                   int nt0, int ntstep, int l31, int hw) {
-  if (ntiles == 3) dft_product_rega<3>(acc, ah, al, ks0, ks1, B, bstride, nt0, ntstep, l31, hw);
-  else if (ntiles == 2) dft_product_rega<2>(acc, ah, al, ks0, ks1, B, bstride, nt0, ntstep, l31, hw);
-  else if (ntiles == 1) dft_product_rega<1>(acc, ah, al, ks0, ks1, B, bstride, nt0, ntstep, l31, hw);
+  if (ntiles == 3) dft_product_rega<3, KS>(acc, ah, al, ksn, B, bstride, nt0, ntstep, l31, hw);
+  else if (ntiles == 2) dft_product_rega<2, KS>(acc, ah, al, ksn, B, bstride, nt0, ntstep, l31, hw);
+  else if (ntiles == 1) dft_product_rega<1, KS>(acc, ah, al, ksn, B, bstride, nt0, ntstep, l31, hw);
 }
 
 // acc[j] += A[row tile mt_j] . B[column tile nt_j], both operands in LDS, tiles t = t0 + 8 j of a grid of mtn row tiles;
@@ -435,7 +443,7 @@ DFT_DEV void dft_matrix_unit(int which, int unit, int P, int Q, const double* tw
 
 // ---------------------------------------------------------------------------------------------------- forward transform
 // iteration it -> (pair' = it / CG, channel group cg = it % CG), pair' = nb * T + tile; channels 4 cg .. 4 cg + 3
-template <bool TILED, bool FAST, int G, int NW>
+template <bool TILED, bool FAST, int G, int NW, int KS2 = 0>
 DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
                               const float* invn,      // [NB][H * W]
                               float* X,               // [NBT / 64][NBINS / 4][64][Cpad][4][2] (dft_spectra_pair0)
@@ -459,12 +467,24 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
   const int mt1n = Mx / 32, nt1n = N1 / 32, nt2n = N2 / 32, mt2n = pl.M2 / 32;
   const int ks1n = Wk / 16, ks2n = 2 * Pp / 16;
   const int mt2 = wv & 3;
-  half8 fp2h[DFT_KREG], fp2l[DFT_KREG];
+  constexpr int KR2 = KS2 ? KS2 : DFT_KREG;      // KS2 > 0: exactly the k-steps of step 2 (ks2n == KS2)
+  half8 fp2h[KR2], fp2l[KR2];
 #pragma unroll
-  for (int ks = 0; ks < DFT_KREG; ++ks) {
+  for (int ks = 0; ks < KR2; ++ks) {
     const int kc = ks < ks2n ? ks : 0, mc = mt2 < mt2n ? mt2 : 0;
     fp2h[ks] = dft_frag(Fp2 + ((size_t)((2 * kc + hw) * 2 + 0)) * pl.M2 + mc * 32 + l31);
     fp2l[ks] = dft_frag(Fp2 + ((size_t)((2 * kc + hw) * 2 + 1)) * pl.M2 + mc * 32 + l31);
+  }
+  // The fragments must have LANDED, as far as the compiler's wait-count pass is concerned, on EVERY path into the loop (round 5).
+  // Every wait on a global load below is conditional (a position slot beyond the window, the prefetch of an iteration that does
+  // not exist), so there is a path from these loads to step 2 on which nothing was waited for and nothing was issued after them -
+  // and since the pass merges paths pessimistically, it guarded the matrix instructions of k-step ks with vmcnt(15 - 2 ks) ..
+  // vmcnt(0) for good: in the steady state that made step 2 wait for the NEXT window's loads, issued right in front of it, one
+  // by one (step 2 measured 5.3 us for 1.9 us of matrix time).  An unconditional use right here settles it.
+#pragma unroll
+  for (int ks = 0; ks < KR2; ++ks) {
+    DFT_LANDED(fp2h[ks]);
+    DFT_LANDED(fp2l[ks]);
   }
 
   // ---- register prefetch of the next iteration's window: position slot s of a thread = (row r, 4 columns c4) of the window,
@@ -526,6 +546,10 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
 #ifndef OS2D_HOST_EMU
     asm volatile("" : "+v"(tl));       // per-iteration addresses are recomputed, not hoisted (register pressure)
 #endif
+    // ... including everything derived from the lane number: the fragment, staging and store addresses of the six phases are
+    // loop invariants, and hoisted out of the iteration loop they occupied ~30 registers through all of it (round 5: the
+    // spills of round 4's kernels were these, parked around step 1)
+    const int lane = tl & 63, l31 = lane & 31, hw = lane >> 5;
     DFT_FWD_ITER(it)
     // ---- W: x = relu(corr) * inv_norm * 2^15 as fp16 hi | lo units [w / 8][hi|lo][m = img * Pp + r]; zero outside the window
     {
@@ -576,21 +600,7 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     }
-    // (diagnostic DFT_PREFETCH_SEGMENTED: in three segments with the loads of the next window's position slots between them -
-    // in one burst, 8 waves x 15 loads hold the matrix instructions behind them up - but the loaded values then live through
-    // both products: 120 spilled registers)
-    if (DFT_PREFETCH_SEGMENTED) {
-      const int ka = (ks1n + 2) / 3, kb = (2 * ks1n + 2) / 3;
-      const bool more = it + DFT_GRID < iters;
-      dft_product_lds_any<NW>(acc, nt1w, 0, ka, ldsU, MxS, ldsF, N1, wv, mt1n, l31, hw);
-      if (more) DFT_FWD_PREFETCH_SLOTS(it + DFT_GRID, tl, 0, 1)
-      dft_product_lds_any<NW>(acc, nt1w, ka, kb, ldsU, MxS, ldsF, N1, wv, mt1n, l31, hw);
-      if (more) DFT_FWD_PREFETCH_SLOTS(it + DFT_GRID, tl, 1, 2)
-      dft_product_lds_any<NW>(acc, nt1w, kb, ks1n, ldsU, MxS, ldsF, N1, wv, mt1n, l31, hw);
-      if (more) DFT_FWD_PREFETCH_SLOTS(it + DFT_GRID, tl, 2, 3)
-    } else {
-      dft_product_lds_any<NW>(acc, nt1w, 0, ks1n, ldsU, MxS, ldsF, N1, wv, mt1n, l31, hw);
-    }
+    dft_product_lds_any<NW>(acc, nt1w, 0, ks1n, ldsU, MxS, ldsF, N1, wv, mt1n, l31, hw);
     DFT_BARRIER();      // every wave is done reading x: the region becomes R2
     DFT_STAMP(1)
 
@@ -635,8 +645,12 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
     }
     // the next window's loads are issued here - the accumulators of step 1 are dead, the values are needed a whole step 2 +
     // store phase later - so that their registers do not overlap the first product's
-    if (!DFT_PREFETCH_SEGMENTED && it + DFT_GRID < iters) DFT_FWD_PREFETCH(it + DFT_GRID, tl)
-    dft_product_rega_any(xc, nt2w, fp2h, fp2l, 0, ks2n, ldsU, N2S, wv >> 2, NW / 4, l31, hw);
+    // (DFT_FWD_NPRE < 3: only the first position slots here, the others right after the product - a knob from the hunt for the
+    // spilled registers of round 4, which turned out to be hoisted lane arithmetic; all slots here is the default)
+    constexpr int NPRE = DFT_FWD_NPRE < NSLOT ? DFT_FWD_NPRE : NSLOT;
+    if (it + DFT_GRID < iters) DFT_FWD_PREFETCH_SLOTS(it + DFT_GRID, tl, 0, NPRE)
+    dft_product_rega_any<KS2>(xc, nt2w, fp2h, fp2l, ks2n, ldsU, N2S, wv >> 2, NW / 4, l31, hw);
+    if (NPRE < NSLOT && it + DFT_GRID < iters) DFT_FWD_PREFETCH_SLOTS(it + DFT_GRID, tl, NPRE, NSLOT)
     DFT_BARRIER();      // every wave is done reading R2: the region becomes the staging buffer of X
     DFT_STAMP(3)
 
@@ -692,7 +706,7 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
 
 // ---------------------------------------------------------------------------------------------------- inverse transform
 // iteration it -> (pair' = it / OG, output channel group og = it % OG): output channels 4 og .. 4 og + 3 of pair' = nb * T + tile
-template <bool TILED>
+template <bool TILED, int KSA = 0>
 DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64][Cout][4][2] (dft_spectra_pair0)
                               const float* bp,       // [3][MTP]: bias | - | 2^out_exp
                               int MTP, unsigned char* out,   // SHB [NB][Cout / 8][2][PLANE] x 16 B
@@ -717,13 +731,19 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
   const int mtAn = pl.MA / 32, ntAn = N2 / 32, ksAn = 2 * Pp / 16;
   const int mtBn = MB / 32, ntBn = NBo / 32, ksBn = KB / 16;
   const int mtA = wv & 3;
-  half8 e2h[DFT_KREG], e2l[DFT_KREG];
+  constexpr int KRA = KSA ? KSA : DFT_KREG;      // KSA > 0: exactly the k-steps of step A (ksAn == KSA)
+  half8 e2h[KRA], e2l[KRA];
   const int MAfull = dft_round_up(2 * P, 32);                    // row count of the E2 array
 #pragma unroll
-  for (int ks = 0; ks < DFT_KREG; ++ks) {
+  for (int ks = 0; ks < KRA; ++ks) {
     const int kc = ks < ksAn ? ks : 0, mc = mtA < mtAn ? mtA : 0;
     e2h[ks] = dft_frag(E2 + ((size_t)((2 * kc + hw) * 2 + 0)) * MAfull + mc * 32 + l31);
     e2l[ks] = dft_frag(E2 + ((size_t)((2 * kc + hw) * 2 + 1)) * MAfull + mc * 32 + l31);
+  }
+#pragma unroll
+  for (int ks = 0; ks < KRA; ++ks) {      // landed on every path into the loop: see the Fp2 fragments of the forward kernel
+    DFT_LANDED(e2h[ks]);
+    DFT_LANDED(e2l[ks]);
   }
 
   // ---- register prefetch: item = (img, v, octet of u) -> the two quads of bins u0 .. u0 + 7 of column v: 2 x 32 bytes
@@ -794,6 +814,7 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
 #ifndef OS2D_HOST_EMU
     asm volatile("" : "+v"(tl));
 #endif
+    const int lane = tl & 63, l31 = lane & 31, hw = lane >> 5;      // (not hoisted: see the forward kernel)
     const int pr = dft_div(it, pl.inv_og), og = it - pr * OG;
     const int nb = TILED ? dft_div(pr, pl.inv_t) : pr, tile = TILED ? pr - nb * pl.T : 0;
     const int ty = TILED ? dft_div(tile, pl.inv_tx) : 0, tx = TILED ? tile - ty * pl.TX : 0;
@@ -871,19 +892,10 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
 #pragma unroll
       for (int r = 0; r < 16; ++r) ta[j][r] = 0.f;
     }
-    if (!DFT_PREFETCH_SEGMENTED) {
-      if (it + DFT_GRID < iters) DFT_INV_PREFETCH(it + DFT_GRID, tl)
-      dft_product_rega_any(ta, ntaw, e2h, e2l, 0, ksAn, ldsU, N2S, wv >> 2, 2, l31, hw);
-    } else {   // in three segments with the next spectra's loads (one item each) between them, see the forward kernel
-      const int ka = (ksAn + 2) / 3, kb = (2 * ksAn + 2) / 3;
-      const bool more = it + DFT_GRID < iters;
-      dft_product_rega_any(ta, ntaw, e2h, e2l, 0, ka, ldsU, N2S, wv >> 2, 2, l31, hw);
-      if (more) DFT_INV_PREFETCH_ITEMS(it + DFT_GRID, tl, 0, 1)
-      dft_product_rega_any(ta, ntaw, e2h, e2l, ka, kb, ldsU, N2S, wv >> 2, 2, l31, hw);
-      if (more) DFT_INV_PREFETCH_ITEMS(it + DFT_GRID, tl, 1, 2)
-      dft_product_rega_any(ta, ntaw, e2h, e2l, kb, ksAn, ldsU, N2S, wv >> 2, 2, l31, hw);
-      if (more) DFT_INV_PREFETCH_ITEMS(it + DFT_GRID, tl, 2, 3)
-    }
+    constexpr int NPRE = DFT_INV_NPRE < NITEM ? DFT_INV_NPRE : NITEM;      // (see the forward kernel)
+    if (it + DFT_GRID < iters) DFT_INV_PREFETCH_ITEMS(it + DFT_GRID, tl, 0, NPRE)
+    dft_product_rega_any<KSA>(ta, ntaw, e2h, e2l, ksAn, ldsU, N2S, wv >> 2, 2, l31, hw);
+    if (NPRE < NITEM && it + DFT_GRID < iters) DFT_INV_PREFETCH_ITEMS(it + DFT_GRID, tl, NPRE, NITEM)
     DFT_BARRIER();      // every wave is done reading Y2: the region becomes Tt
     DFT_STAMP(2)
 

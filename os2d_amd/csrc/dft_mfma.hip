@@ -19,6 +19,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char os2d_dft_smem[];
 #define DFT_BALLOT(p) __builtin_amdgcn_ballot_w64(p)
 #define DFT_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #define DFT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define DFT_LANDED(X) asm volatile("" : "+v"(X))
 #define DFT_RAISE(p) __hip_atomic_store(p, OS2D_STATUS_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 #ifdef OS2D_DIAG_DFT_STAMPS
 // diagnostic build: thread 0 of every work-group accumulates the wall-clock ticks (100 MHz) between the phase barriers; the sums
@@ -45,20 +46,54 @@ namespace {
 
 using namespace os2d_dft;
 
-template <bool TILED, bool FAST, int G, int NW>
+// KS = k-steps of the product whose row operand lives in registers (step 2 / step A: 2 Pp / 16): a template parameter for the
+// canonical transform sizes (5 .. 8: straight-line products, exactly as many fragment registers as the size needs), 0 = any
+// size behind uniform guards ($OS2D_DFT_SIZES=exact)
+template <bool TILED, bool FAST, int G, int NW, int KS>
 __global__ __launch_bounds__(NW * 64, 8 / NW) void dft_forward_kernel(const float* __restrict__ corr, const float* __restrict__ invn,
                                                                       float* __restrict__ X, const u32x4v* __restrict__ FqT,
                                                                       const u32x4v* __restrict__ Fp2, DftPlan pl, int C, int Cpad, int NBT,
                                                                       int iters) {
-  dft_forward_body<TILED, FAST, G, NW>(corr, invn, X, FqT, Fp2, pl, C, Cpad, NBT, iters);
+  dft_forward_body<TILED, FAST, G, NW, KS>(corr, invn, X, FqT, Fp2, pl, C, Cpad, NBT, iters);
 }
 
-template <bool TILED>
+template <bool TILED, int KS>
 __global__ __launch_bounds__(DFT_THR, 1) void dft_inverse_kernel(const float* __restrict__ Y, const float* __restrict__ bp, int MTP,
                                                                  unsigned char* __restrict__ out, const u32x4v* __restrict__ E2,
                                                                  const u32x4v* __restrict__ Gq, DftPlan pl, int Cout, int NBT, int PLANE,
                                                                  int Ws, int BASE, int iters, int* status, int zero_borders) {
-  dft_inverse_body<TILED>(Y, bp, MTP, out, E2, Gq, pl, Cout, NBT, PLANE, Ws, BASE, iters, status, zero_borders);
+  dft_inverse_body<TILED, KS>(Y, bp, MTP, out, E2, Gq, pl, Cout, NBT, PLANE, Ws, BASE, iters, status, zero_borders);
+}
+
+typedef void (*dft_forward_fn)(const float*, const float*, float*, const u32x4v*, const u32x4v*, DftPlan, int, int, int, int);
+typedef void (*dft_inverse_fn)(const float*, const float*, int, unsigned char*, const u32x4v*, const u32x4v*, DftPlan, int, int, int, int, int,
+                               int, int*, int);
+template <int G, int NW, int KS>
+dft_forward_fn dft_forward_variant(const DftPlan& pl) {
+  return pl.T > 1 ? dft_forward_kernel<true, false, G, NW, KS> : (pl.fast ? dft_forward_kernel<false, true, G, NW, KS> : dft_forward_kernel<false, false, G, NW, KS>);
+}
+template <int G, int NW>
+dft_forward_fn dft_forward_pick(const DftPlan& pl) {
+  switch (2 * pl.Pp / 16) {      // k-steps of step 2
+    case 5: return dft_forward_variant<G, NW, 5>(pl);
+    case 6: return dft_forward_variant<G, NW, 6>(pl);
+    case 7: return dft_forward_variant<G, NW, 7>(pl);
+    case 8: return dft_forward_variant<G, NW, 8>(pl);
+    default: return dft_forward_variant<G, NW, 0>(pl);
+  }
+}
+template <int KS>
+dft_inverse_fn dft_inverse_variant(const DftPlan& pl) {
+  return pl.T > 1 ? dft_inverse_kernel<true, KS> : dft_inverse_kernel<false, KS>;
+}
+dft_inverse_fn dft_inverse_pick(const DftPlan& pl) {
+  switch (2 * pl.Pp / 16) {      // k-steps of step A
+    case 5: return dft_inverse_variant<5>(pl);
+    case 6: return dft_inverse_variant<6>(pl);
+    case 7: return dft_inverse_variant<7>(pl);
+    case 8: return dft_inverse_variant<8>(pl);
+    default: return dft_inverse_variant<0>(pl);
+  }
 }
 
 // FqT | Fp2 | E2 | Gq of a (P, Q) transform, one thread per 16-byte unit
@@ -86,17 +121,18 @@ int dft_grid(int iters, int per_cu = 1) {
   return (g + 7) / 8 * 8;                       // multiple of 8: XCD-aware iteration order
 }
 
-// images per iteration of the forward kernel: 4 (one 8-wave work-group per CU).  $OS2D_DFT_FORWARD_G = 2 selects the other
-// shape - 2 images, 4 waves, TWO independent work-groups per CU when they fit its LDS - which was built to let the phases of two
-// groups overlap and measured no faster (profiles/r04/dft_phases_g2.txt: an iteration of 2 images takes 14.4 us against 15.0 us
-// for 4: 0.261 vs 0.244 ms per 64 pairs standalone): every phase is bound by a CU-wide resource (VALU conversions, LDS reads,
-// the matrix pipe at the ~50 % of its peak rate this chip sustains), not by latency that a second group could hide.
+// images per iteration of the forward kernel: 4 (one 8-wave work-group per CU).  The other shape - 2 images, 4 waves, TWO
+// independent work-groups per CU when they fit its LDS - was built to let the phases of two groups overlap and measured no faster
+// (profiles/r04/dft_phases_g2.txt: an iteration of 2 images takes 14.4 us against 15.0 us for 4: 0.261 vs 0.244 ms per 64 pairs
+// standalone); it is compiled into DIAGNOSTIC builds only (-DOS2D_DIAG_DFT_G2, then $OS2D_DFT_FORWARD_G = 2 selects it).
 int dft_forward_g(int H, int W, DftPlan* pl) {
+#ifdef OS2D_DIAG_DFT_G2
   static const int pinned = [] {
     const char* e = getenv("OS2D_DFT_FORWARD_G");
     return e ? atoi(e) : 0;
   }();
   if (pinned == 2 && dft_make_forward_plan(H, W, 2, pl)) return 2;
+#endif
   return dft_make_forward_plan(H, W, DFT_G, pl) ? DFT_G : 0;
 }
 
@@ -150,8 +186,11 @@ int os2d_launch_dft_forward(const float* corr, const float* inv, float* X, const
   pl.inv_cg = dft_magic((unsigned)CG);
   const u32x4v* FqT = static_cast<const u32x4v*>(matrices);
   const u32x4v* Fp2 = FqT + dft_units_fqt(pl.P, pl.Q);
-  auto kern = G == 2 ? (pl.T > 1 ? dft_forward_kernel<true, false, 2, 4> : (pl.fast ? dft_forward_kernel<false, true, 2, 4> : dft_forward_kernel<false, false, 2, 4>))
-                     : (pl.T > 1 ? dft_forward_kernel<true, false, 4, 8> : (pl.fast ? dft_forward_kernel<false, true, 4, 8> : dft_forward_kernel<false, false, 4, 8>));
+#ifdef OS2D_DIAG_DFT_G2
+  auto kern = G == 2 ? dft_forward_pick<2, 4>(pl) : dft_forward_pick<4, 8>(pl);
+#else
+  auto kern = dft_forward_pick<4, 8>(pl);
+#endif
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds_total);
   if (e != hipSuccess) {
     os2d_set_error("hipFuncSetAttribute(dft_forward): %s", hipGetErrorString(e));
@@ -178,7 +217,7 @@ int os2d_launch_dft_inverse(const float* Y, const float* bp, int MTP, void* out,
   pl.inv_og = dft_magic((unsigned)OG);
   const u32x4v* E2 = static_cast<const u32x4v*>(matrices) + dft_units_fqt(pl.P, pl.Q) + dft_units_fp2(pl.P, pl.Q);
   const u32x4v* Gq = E2 + dft_units_e2(pl.P, pl.Q);
-  auto kern = pl.T > 1 ? dft_inverse_kernel<true> : dft_inverse_kernel<false>;
+  auto kern = dft_inverse_pick(pl);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds_total);
   if (e != hipSuccess) {
     os2d_set_error("hipFuncSetAttribute(dft_inverse): %s", hipGetErrorString(e));

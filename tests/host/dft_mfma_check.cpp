@@ -87,9 +87,19 @@ static int check_case(int H, int W, int C, int NB, int grid) {
     std::fill(X.begin(), X.end(), 777.0f);
     emu::launch(grid, G == 4 ? 512 : 256, fp.lds_total, [&] {
       if (G == 4) {
-        if (fp.T > 1) dft_forward_body<true, false, 4, 8>(corr.data(), invn.data(), X.data(), FqT, Fp2, fp, C, Cpad, NBT, itf);
-        else if (fp.fast) dft_forward_body<false, true, 4, 8>(corr.data(), invn.data(), X.data(), FqT, Fp2, fp, C, Cpad, NBT, itf);
-        else dft_forward_body<false, false, 4, 8>(corr.data(), invn.data(), X.data(), FqT, Fp2, fp, C, Cpad, NBT, itf);
+        // the k-step count of step 2 as a template parameter where the device build has one (dft_mfma.hip: dft_forward_pick)
+#define FWD4(KS)                                                                                                             \
+  if (fp.T > 1) dft_forward_body<true, false, 4, 8, KS>(corr.data(), invn.data(), X.data(), FqT, Fp2, fp, C, Cpad, NBT, itf);  \
+  else if (fp.fast) dft_forward_body<false, true, 4, 8, KS>(corr.data(), invn.data(), X.data(), FqT, Fp2, fp, C, Cpad, NBT, itf); \
+  else dft_forward_body<false, false, 4, 8, KS>(corr.data(), invn.data(), X.data(), FqT, Fp2, fp, C, Cpad, NBT, itf);
+        switch (2 * fp.Pp / 16) {
+          case 5: FWD4(5) break;
+          case 6: FWD4(6) break;
+          case 7: FWD4(7) break;
+          case 8: FWD4(8) break;
+          default: FWD4(0) break;
+        }
+#undef FWD4
       } else {
         if (fp.T > 1) dft_forward_body<true, false, 2, 4>(corr.data(), invn.data(), X.data(), FqT, Fp2, fp, C, Cpad, NBT, itf);
         else if (fp.fast) dft_forward_body<false, true, 2, 4>(corr.data(), invn.data(), X.data(), FqT, Fp2, fp, C, Cpad, NBT, itf);
@@ -214,8 +224,17 @@ static int check_case(int H, int W, int C, int NB, int grid) {
   const int OG = Cout / DFT_G, iters_i = NBT * OG;
   pl.inv_og = dft_magic((unsigned)OG);
   emu::launch(grid, DFT_THR, pl.lds_total, [&] {
-    if (pl.T > 1) dft_inverse_body<true>(Y.data(), bp.data(), MTP, out.data(), E2, Gq, pl, Cout, NBT, PLANE, Ws, BASE, iters_i, &flag, 1);
-    else dft_inverse_body<false>(Y.data(), bp.data(), MTP, out.data(), E2, Gq, pl, Cout, NBT, PLANE, Ws, BASE, iters_i, &flag, 1);
+#define INV(KS)                                                                                                                     \
+  if (pl.T > 1) dft_inverse_body<true, KS>(Y.data(), bp.data(), MTP, out.data(), E2, Gq, pl, Cout, NBT, PLANE, Ws, BASE, iters_i, &flag, 1); \
+  else dft_inverse_body<false, KS>(Y.data(), bp.data(), MTP, out.data(), E2, Gq, pl, Cout, NBT, PLANE, Ws, BASE, iters_i, &flag, 1);
+    switch (2 * pl.Pp / 16) {      // as dft_inverse_pick of the device build
+      case 5: INV(5) break;
+      case 6: INV(6) break;
+      case 7: INV(7) break;
+      case 8: INV(8) break;
+      default: INV(0) break;
+    }
+#undef INV
   });
   double worst_rel = 0.0;
   for (int nb = 0; nb < NB; ++nb)

@@ -28,3 +28,8 @@ def test_dft_mfma_kernels_on_the_host_emulator(tmp_path):
     # a map that needs tiles although its smallest transform would fit
     out = subprocess.run([exe, "canonical", "11", "13", "5", "1", "50", "70", "4", "1"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-3000:] + out.stderr[-2000:]
+    # the levels of the benchmark pyramid whose transforms take 8 / 7 / 6 k-steps in step 2 / step A: the instantiations with the
+    # k-step count as a template parameter (round 5), which is what the default head launches
+    out = subprocess.run([exe, "canonical", "60", "80", "4", "1", "48", "64", "8", "1", "38", "50", "4", "2"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-3000:] + out.stderr[-2000:]
+    assert "P=64 Q=84" in out.stdout and "P=52 Q=68" in out.stdout and "P=44 Q=54" in out.stdout

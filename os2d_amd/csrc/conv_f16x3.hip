@@ -310,11 +310,12 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_f16x3_kernel(const u3
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float t = acc[mi][ni][4 * q + k] * bp[MTP + m0 + k] + bp[m0 + k];
-          if (RELU) t = fmaxf(t, 0.f);
           const bool live = valid && m0 + k < CoutStore;
+          if (OUT_MODE == 0 && live && t != t) out_of_range = true;   // before the ReLU: fmaxf(NaN, 0) = 0
+          if (RELU) t = fmaxf(t, 0.f);
           if (OUT_MODE == 0) {
             t *= bp[2 * MTP + m0 + k];
-            if (live && !(fabsf(t) <= 65504.f)) out_of_range = true;  // also true for NaN
+            if (live && !(fabsf(t) <= 65504.f)) out_of_range = true;
           }
           v[k] = live ? t : 0.f;
         }

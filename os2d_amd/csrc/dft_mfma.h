@@ -991,8 +991,10 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
             float t[DFT_G];
 #pragma unroll
             for (int g = 0; g < DFT_G; ++g) {
-              t[g] = fmaxf(yc[j][4 * q + g] * cinv[g] + bias[g], 0.f) * osc[g];
-              if (!(fabsf(t[g]) <= 65504.f)) bad = true;
+              const float pre = yc[j][4 * q + g] * cinv[g] + bias[g];
+              t[g] = fmaxf(pre, 0.f) * osc[g];
+              // out of the fp16 range, or NaN: the pre-activation is tested too, fmaxf(NaN, 0) = 0 hid a NaN spectrum
+              if (!(fabsf(t[g]) <= 65504.f) || pre != pre) bad = true;
             }
             u32x2v hi, lo;
             dft_split4(t[0], t[1], t[2], t[3], &hi, &lo);

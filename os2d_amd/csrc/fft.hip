@@ -440,6 +440,7 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
         if (i < cells && (!TILED || (h < H && w < W))) {
           const f32x2 z = R[((th + oy) >> 1) * QS + tw + ox];
           float t = (((th + oy) & 1) ? z[1] : z[0]) * norm + bias;
+          if (t != t) bad = true;          // fmaxf(NaN, 0) = 0 would hide a NaN spectrum from the range test below
           t = fmaxf(t, 0.f) * osc;
           if (!(fabsf(t) <= 65504.f)) bad = true;
           const _Float16 hv = (_Float16)t;
@@ -487,6 +488,7 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
           const int h = y0 + th, w = x0 + tw;
           const f32x2 z = R[((th + oy) >> 1) * QS + tw + ox];
           float t = (((th + oy) & 1) ? z[1] : z[0]) * norm + bias;
+          if (t != t) bad = true;          // fmaxf(NaN, 0) = 0 would hide a NaN spectrum from the range test below
           t = fmaxf(t, 0.f) * osc;
           if (!(fabsf(t) <= 65504.f)) bad = true;
           const _Float16 hv = (_Float16)t;

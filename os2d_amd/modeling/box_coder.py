@@ -8,6 +8,7 @@
 Only the inference half of the reference class is mirrored: target encoding / anchor matching / hard-negative
 remapping are training-only and out of scope.
 """
+import collections
 import ctypes
 from functools import lru_cache
 
@@ -137,6 +138,26 @@ def trace_box_transform(transform, img_size):
     bit-equal coordinates and the same output size, or they are not used."""
     if transform is None:
         return (), (), img_size
+    # the same callable on the same image size traces to the same chains: a small cache keyed by object identity - the entry
+    # holds the callable, so its id cannot be reused while it is cached (ADVICE r4: three closure runs + CPU probe tensors per
+    # level and image on the decode path; a dataloader that hands out one TransformList per image size hits this every time)
+    parts = getattr(transform, "transforms", None)       # a TransformList may be appended to after it was traced
+    ckey = (id(transform), int(img_size.w), int(img_size.h), tuple(id(t) for t in parts) if isinstance(parts, (list, tuple)) else None)
+    hit = _TRACE_CACHE.get(ckey)
+    if hit is not None and hit[0] is transform:
+        _TRACE_CACHE.move_to_end(ckey)
+        return hit[1]
+    result = _trace_box_transform(transform, img_size)
+    _TRACE_CACHE[ckey] = (transform, result)
+    while len(_TRACE_CACHE) > 64:
+        _TRACE_CACHE.popitem(last=False)
+    return result
+
+
+_TRACE_CACHE = collections.OrderedDict()
+
+
+def _trace_box_transform(transform, img_size):
     try:
         root = _BoxTrace(img_size)
         root.add_field("default_boxes", _BoxTrace(img_size))
@@ -499,18 +520,27 @@ class Os2dBoxCoder(object):
         from pageable memory on the per-image path."""
         cache = self.__dict__.setdefault("_slot_rows_cache", {})
         key = (ids, V, str(dev))
-        table = cache.get(key)
-        if table is None:
+        stream = torch.cuda.current_stream(dev)
+        entry = cache.get(key)
+        if entry is None:
             rows_of = {}
             for i, c in enumerate(ids):
                 rows_of.setdefault(c, []).append(i)
             host = torch.tensor([(rows_of[l] + [-1] * V)[:V] for l in labels], dtype=torch.int32).pin_memory()
             table = host.to(dev, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record(stream)
             if len(cache) >= 16:
                 cache.pop(next(iter(cache)))
-            cache[key] = (table, host)         # the pinned source lives as long as the copy may be in flight
-            return table
-        return table[0]
+            # the pinned source lives as long as the copy may be in flight; the event marks the end of the copy
+            entry = cache[key] = (table, host, event, stream.cuda_stream)
+        table, _, event, producer = entry
+        if stream.cuda_stream != producer:
+            # a decode on ANOTHER stream than the one that filled the table (ADVICE r4): wait for the copy, and tell the caching
+            # allocator that this stream reads the tensor too - an evicted entry must not be reused under a running kernel
+            stream.wait_event(event)
+            table.record_stream(stream)
+        return table
 
     def _decode_pyramid_fused(self, loc_pyr, cls_pyr, size_pyr, class_ids, score_thr, iou_thr, inverse, corners_pyr):
         """Several levels and / or merged labels (class-image views: several head rows with one class id, reference

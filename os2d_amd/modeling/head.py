@@ -14,6 +14,7 @@ memory, the stream and the parameter containers.  There is no CPU / eager fallba
 Training through the head (autograd) is out of scope and raises as well.
 """
 import collections
+import itertools
 import ctypes
 import logging
 import os
@@ -114,25 +115,46 @@ _STATUS_WORDS = {}
 STATUS_SLOTS = 1024
 
 
-def device_status_word(device):
+class _StatusSlots(object):
+    """The range-status words of one device: pinned arrays of ``STATUS_SLOTS`` int32 that are never freed, a free list, and
+    one slot per LIVE head."""
+
+    def __init__(self):
+        self.arrays = []
+        self.free = []
+
+    def take(self):
+        if not self.free:
+            words = torch.zeros(STATUS_SLOTS, dtype=torch.int32).pin_memory()
+            self.arrays.append(words)
+            self.free.extend(words[i:i + 1] for i in range(STATUS_SLOTS - 1, -1, -1))
+        word = self.free.pop()
+        word[0] = 0
+        return word
+
+    def give_back(self, word):
+        self.free.insert(0, word)          # reused last: kernels of the head that owned it have long drained by then
+
+
+def device_status_word(device, owner=None):
     """A sticky range-status word of the split-fp16 kernels for ONE head: an int32 in mapped pinned host memory.  The words
-    of a device live in one array that is allocated once and kept for the life of the process: kernels in flight store to a
+    of a device live in arrays that are allocated once and kept for the life of the process: kernels in flight store to a
     word through a raw pointer (only when an activation leaves the fp16 range), so the memory must never go back to the host
     allocator while any kernel of any head may still run - a per-head tensor (round 2) could be garbage-collected with its
-    head while that head's kernels were still queued.  Every head takes the next slot of the array (round 3 shared
-    ONE word between all heads of a device: a flag raised by head A's kernels could be consumed and cleared by head B, which
-    then ran a needless fp32 pass while A never recomputed - ADVICE r3); beyond ``STATUS_SLOTS`` heads per device and process
-    the slots are shared round-robin, with exactly that (harmless, conservative) cross-talk between the heads of one slot."""
+    head while that head's kernels were still queued.  Every LIVE head owns one word (round 3 shared ONE word
+    between all heads of a device: a flag raised by head A's kernels could be consumed and cleared by head B - ADVICE r3; round 4
+    handed slots out round-robin and zeroed a recycled slot under its live owner after 1024 heads - ADVICE r4): a word returns
+    to the free list when ``owner`` is garbage-collected, goes to the back of that list, and the arrays grow by another
+    ``STATUS_SLOTS`` words when every word is owned."""
     index = device.index if device.index is not None else torch.cuda.current_device()
-    entry = _STATUS_WORDS.get(index)
-    if entry is None:
-        entry = _STATUS_WORDS[index] = [torch.zeros(STATUS_SLOTS, dtype=torch.int32).pin_memory(), 0]
-    words, taken = entry
-    entry[1] = taken + 1
-    slot = taken % STATUS_SLOTS
-    if taken >= STATUS_SLOTS:
-        words[slot] = 0      # a recycled slot starts clean (its previous owner's late flag, if any, is dropped)
-    return words[slot:slot + 1]
+    slots = _STATUS_WORDS.get(index)
+    if slots is None:
+        slots = _STATUS_WORDS[index] = _StatusSlots()
+    word = slots.take()
+    if owner is not None:
+        import weakref
+        weakref.finalize(owner, slots.give_back, word)
+    return word
 
 
 class _StreamOrdered(object):
@@ -163,21 +185,24 @@ class _StreamOrdered(object):
         return sum(t.numel() * t.element_size() for t in self._tensors())
 
 
-def spectra_cache_cap_bytes():
-    """Upper bound for the cached weight spectra of the frequency-domain modes on ONE DEVICE - over all transform sizes and all
-    TransformationNets of the process (least recently used entries are dropped first; 654 MB for the 64 x 84 transform of a
-    60 x 80 map).  $OS2D_FFT_CACHE_BYTES; default: an eighth of the device's memory, at most 8 GiB.  Round 3 needed 64 GiB per
-    net: one set of spectra per FFT-friendly transform size, 52 sizes = 35.6 GB for a dataset fed at its own aspect ratios
-    and 7 pyramid scales (reference os2d/data/dataloader.py:326; tools/bench_size_churn.py).  The default precision now plans
-    every map on six canonical transform sizes (overlap-save tiles; os2d_amd/csrc/dft_mfma.h): 2.4 GB in total, whatever the
-    dataset - a cap below the working set would make an LRU cache miss on EVERY call of a cyclic access pattern."""
+def spectra_cache_cap_bytes(split=True):
+    """Upper bound for the cached weight spectra of one arithmetic FAMILY of the frequency-domain modes on ONE DEVICE - over all
+    transform sizes and all TransformationNets of the process (least recently used entries are dropped first; 654 MB for the
+    64 x 84 transform of a 60 x 80 map).  $OS2D_FFT_CACHE_BYTES overrides both families.
+      split = True  ("fftx3", the default precision): every map is planned on six canonical transform sizes (overlap-save tiles;
+                    os2d_amd/csrc/dft_mfma.h): 2.4 GB in total, whatever the dataset - an eighth of the device's memory, at
+                    most 8 GiB;
+      split = False ("fft" / "fft32"): one set of spectra per FFT-friendly transform size - 52 sizes = 35.6 GB for a dataset fed
+                    at its own aspect ratios and 7 pyramid scales (reference os2d/data/dataloader.py:326;
+                    tools/bench_size_churn.py) - a quarter of the device's memory, at most 64 GiB (under the 8 GiB
+                    cap of round 4 an LRU cache missed on EVERY call of such a cyclic access pattern)."""
     env = os.environ.get("OS2D_FFT_CACHE_BYTES")
     if env:
         return int(env)
     total = 64 << 30
     if torch.cuda.is_available():
         total = torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory
-    return int(min(8 << 30, total // 8))
+    return int(min(8 << 30, total // 8)) if split else int(min(64 << 30, total // 4))
 
 
 class _SpectraStore(object):
@@ -213,11 +238,13 @@ class _SpectraStore(object):
             del self.entries[k]
 
     def put(self, net_id, slot, entry):
-        cap, used = spectra_cache_cap_bytes(), entry.nbytes()
+        family = bool(slot[2])                                 # slot = (P, Q, split): the two families have caps of their own
+        cap, used = spectra_cache_cap_bytes(family), entry.nbytes()
         for k in list(self.entries):                          # oldest first, whichever net it belongs to
-            if used + sum(e.nbytes() for e in self.entries.values()) <= cap:
+            if used + sum(e.nbytes() for kk, e in self.entries.items() if bool(kk[1][2]) == family) <= cap:
                 break
-            del self.entries[k]
+            if bool(k[1][2]) == family:
+                del self.entries[k]
         self.entries[(net_id, slot)] = entry
 
     def slots_of(self, net_id):
@@ -253,6 +280,9 @@ def _require_device_f32(t, name):
     if t.dtype != torch.float32:
         raise RuntimeError("{} must be float32, got {}".format(name, t.dtype))
     return t.contiguous()
+
+
+_NET_IDS = itertools.count(1)
 
 
 # --------------------------------------------------------------------------------------------- TransformNet
@@ -319,12 +349,36 @@ class TransformationNet(nn.Module):
                 self.linear.bias[2] = 1
         self.output_dim = output_dim
         self._packed_cache = {}
-        import weakref
-        self._net_id = id(self)
-        weakref.finalize(self, _drop_spectra_of, self._net_id)
+        self._new_net_id()
         if use_cuda:
             self.conv.cuda()
             self.linear.cuda()
+
+    def _new_net_id(self):
+        """Key of this net's entries in the per-device spectra store: a process-wide counter, never reused (``id()`` values
+        are, after garbage collection), with a finalizer that drops the entries when the net goes away."""
+        import weakref
+        self._net_id = next(_NET_IDS)
+        weakref.finalize(self, _drop_spectra_of, self._net_id)
+
+    def __deepcopy__(self, memo):
+        """A copy is a net of its own: fresh id (sharing the original's made the two evict each other's spectra on every
+        alternating call, and the original's finalizer dropped the clone's entries - ADVICE r4), no cached packings."""
+        import copy
+        cls = self.__class__
+        clone = cls.__new__(cls)
+        memo[id(self)] = clone
+        for k, v in self.__dict__.items():
+            if k not in ("_net_id", "_packed_cache"):
+                setattr(clone, k, copy.deepcopy(v, memo))
+        clone._packed_cache = {}
+        clone._new_net_id()
+        return clone
+
+    def __setstate__(self, state):
+        super(TransformationNet, self).__setstate__(state)
+        self._packed_cache = {}
+        self._new_net_id()
 
     def freeze_bn(self):
         for layer in self.modules():
@@ -788,7 +842,7 @@ class Os2dHead(nn.Module):
 
     def _status_word(self):
         if self._status is None:
-            self._status = device_status_word(self._qp.device)
+            self._status = device_status_word(self._qp.device, owner=self)
         return self._status
 
     def range_status(self, synchronize=False):

@@ -452,6 +452,35 @@ def test_full_size_hostile_network_matches_f32_mode(precision, device):
     assert head.range_status(synchronize=True) == 0
 
 
+@pytest.mark.parametrize("precision", ["fftx3", "fft", "f16x3"])
+def test_nan_feature_map_raises_the_range_flag(precision, device):
+    """a NaN in the image feature map makes every spectrum of the frequency-domain 7x7 layer NaN - and
+    fmaxf(NaN, 0) = 0 in the inverse transform's ReLU epilogue used to turn that into finite zeros for the 5x5 layers, with no
+    flag and no fp32 re-run.  The epilogues now test the pre-activation: the flag is raised, ``strict_range`` re-runs in fp32
+    and the outputs carry the NaN."""
+    from os2d_amd.utils import synthetic
+    P, inverse = 6, True
+    state = synthetic.make_transform_net_state(P, seed=3)
+    fm = synthetic.make_feature_map(32, 12, 14, seed=2)
+    fm[0, 5, 3, 4] = float("nan")
+    class_fms = synthetic.make_class_feature_maps(8, 32, seed=20)
+    creator = util.make_head_creator(P, inverse, state, device)
+    ref = _oracle(fm, class_fms, state, inverse)
+    assert torch.isnan(ref[1]).any()
+    with torch.no_grad():
+        head = creator.create_os2d_head([c.to(device) for c in class_fms])
+        head(fm.to(device), precision=precision)
+        assert head.range_status(synchronize=True) == 1
+        out = head(fm.to(device), precision=precision, strict_range=True)
+        assert head.last_precision == "f32"
+        plain = creator.create_os2d_head([c.to(device) for c in class_fms])(fm.to(device), precision="f32")
+    # (the NaN PATTERN of the reference depends on torch's min / max / grid_sample treatment of NaN coordinates, which fminf /
+    # fmaxf do not share; what is pinned is that the NaN reaches the outputs and the re-run is the exact fp32 path)
+    assert torch.isnan(out[1]).any()
+    for a, b in zip(out, plain):
+        assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0))
+
+
 def test_range_flag_is_raised_not_clamped(device):
     """Non-finite input is the only way past the range plan: the split-fp16 kernels then raise the sticky status word
     (mapped host memory, no synchronisation needed to poll it) instead of clamping silently; ``strict_range`` re-runs

@@ -1,0 +1,41 @@
+#!/bin/bash
+# One GPU-box call (through gpurun), made of named steps; everything lands under gpurun_out/<tag>/.
+#   gpurun --timeout 1500 -- 'bash tools/gpu_call.sh <tag> <step> [<step> ...]'
+# steps:  tests            the whole GPU suite (pytest -m gpu)
+#         tests:<expr>     pytest -m gpu -k <expr>
+#         bench            the driver's command (python bench.py --gpus 1 --steps 20 --warmup 5): line + details + stderr
+#         bench1024        python bench.py --classes 1024 (stage times of the 1024-class step only)
+#         prof             rocprofv3 --kernel-trace --stats + PMC passes of the 64-class step (tools/profile_bench.sh)
+#         prof1024         the same at 1024 classes
+#         phases           phase stamps of the transforms (needs tools/diag_libs/stamps: build --variant stamps -DOS2D_DIAG_DFT_STAMPS)
+#         smoke            __graft_entry__.smoke()
+#         py:<script> ...  python <script> (rest of the arguments up to the next known step are NOT consumed: one script, no args)
+TAG=$1; shift
+cd "$GRAFT_REPO_ROOT" || exit 1
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+for STEP in "$@"; do
+  echo "=== $STEP"
+  case "$STEP" in
+    tests)
+      ( time timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider ) > $OUT/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest.log; tail -8 $OUT/pytest.log;;
+    tests:*)
+      ( time timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider -k "${STEP#tests:}" ) > $OUT/pytest_k.log 2>&1; echo "pytest -k rc=$?" | tee -a $OUT/pytest_k.log; tail -15 $OUT/pytest_k.log;;
+    bench)
+      ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$? line bytes=$(wc -c < $OUT/bench.json)"
+      cp -f gpurun_out/bench_details.json $OUT/bench_details.json 2>/dev/null; cat $OUT/bench.json;;
+    bench1024)
+      ( timeout 600 python bench.py --classes 1024 --steps 5 --warmup 2 --no-cpu-baseline --no-other-precision --no-end-to-end --no-sweep --no-live-counters ) > $OUT/bench1024.json 2> $OUT/bench1024.err; echo "rc=$?"; cat $OUT/bench1024.json;;
+    prof)
+      bash tools/profile_bench.sh ${TAG}_fftx3 --precision fftx3 > $OUT/prof.log 2>&1; python tools/summarize_prof.py gpurun_out/prof_${TAG}_fftx3 > $OUT/rocprof_summary.txt 2>&1; tail -40 $OUT/rocprof_summary.txt;;
+    prof1024)
+      bash tools/profile_bench.sh ${TAG}_fftx3_1024 --precision fftx3 --classes 1024 > $OUT/prof1024.log 2>&1; python tools/summarize_prof.py gpurun_out/prof_${TAG}_fftx3_1024 > $OUT/rocprof_summary_1024.txt 2>&1; tail -40 $OUT/rocprof_summary_1024.txt;;
+    phases)
+      for NB in 64 1024; do OS2D_HIP_LIB=tools/diag_libs/stamps/libos2d_hip.so timeout 300 python tools/time_dft_phases.py $NB 2>&1 | tee $OUT/dft_phases_$NB.txt | tail -12; done;;
+    smoke)
+      python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3;;
+    py:*)
+      timeout 900 python ${STEP#py:} 2>&1 | tee $OUT/$(basename ${STEP#py:} .py).txt | tail -40;;
+    *) echo "unknown step $STEP";;
+  esac
+done

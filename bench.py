@@ -1085,7 +1085,7 @@ def compact_line(result, budget=LINE_BUDGET):
     if isinstance(result.get("end_to_end"), dict):
         optional.append(("end_to_end", {k: result["end_to_end"].get(k) for k in ("value", "ms_per_image", "backbone_ms", "head_ms", "decode_nms_ms")}))
     if isinstance(result.get("allgather_probe"), dict):
-        optional.append(("allgather_probe", {k: result["allgather_probe"].get(k) for k in ("bytes_per_rank", "ms", "busbw_gbps")}))
+        optional.append(("allgather_probe", {k: result["allgather_probe"].get(k) for k in ("bytes_per_rank", "ms", "busbw_gbps", "algbw_gbps")}))
     if isinstance(result.get("other_gathers"), list):
         optional.append(("other_gathers", {g.get("gather"): g.get("value") for g in result["other_gathers"]}))
     optional.append(("details", "bench_details.json (same directory; also on stderr)"))

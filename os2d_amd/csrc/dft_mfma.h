@@ -52,6 +52,12 @@
 #ifndef DFT_LANDED
 #define DFT_LANDED(X)             /* device build: an empty asm that reads and writes X - see the Fp2 fragments in the forward kernel */
 #endif
+#ifndef DFT_PIPE_REGA
+#define DFT_PIPE_REGA 1           /* 1: step 2 / step A read the fragments of k-step ks + 1 before the matrix instructions of ks */
+#endif
+#ifndef DFT_PIPE_LDS
+#define DFT_PIPE_LDS 1            /* 1: the same in step 1 (every product) / step B (the row-sharing products: registers) */
+#endif
 #ifndef DFT_SCHED_FENCE
 #define DFT_SCHED_FENCE()         /* device build: __builtin_amdgcn_sched_barrier(0) - the scheduler moves nothing across it */
 #endif
@@ -297,30 +303,41 @@ DFT_DEV f32x16v dft_mma3(half8 ah, half8 al, half8 bh, half8 bl, f32x16v acc) {
 }
 
 // acc[j] += A . B[tile j] for this wave's NT column tiles, the row operand A resident in REGISTERS (its k-steps as fragment
-// arrays).  NT and the number of k-steps KS are template parameters: the body is straight-line code - no "is this tile mine" /
-// "is this k-step live" branch between a fragment read and its matrix instructions - and the B fragments of k-step ks + 1 are
-// requested before the matrix instructions of k-step ks (round 4, first version: a uniform branch per k-step and tile made
-// every scheduling region one read-wait-multiply sequence; measured 5.1 us for 2.2 us of matrix time).
-// KS > 0: the number of k-steps is a template parameter too (the canonical transform sizes: 2 Pp / 16 = 5 .. 8) - no branch at
-// all between the first fragment read and the last matrix instruction; KS == 0: any count up to DFT_KREG behind uniform guards.
+// arrays).  Software-pipelined in the source (round 5): the B fragments of k-step ks + 1 are read into the OTHER of two register
+// sets before the matrix instructions of k-step ks are issued, and the scheduler is fenced to that order.  Left to itself the
+// compiler placed every fragment read one or two instructions in front of its first use - each of the 3 NT matrix instructions of
+// a k-step then waited out the LDS latency (~100+ cycles) with one other wave per SIMD to cover it: the matrix phases ran at
+// ~45 % of the instruction rate (step 2: 5.3 us for 1.9 us of matrix time), spills or no spills.
+// KS > 0: the number of k-steps is a template parameter (the canonical transform sizes: 2 Pp / 16 = 5 .. 8) - no branch at all
+// between the first fragment read and the last matrix instruction; KS == 0: any count up to DFT_KREG behind uniform guards.
+// The tiles of a k-step are INDEPENDENT accumulators interleaved in the matrix pipe: one tile after the other - a chain of 3 K
+// dependent instructions - measured 5.7 against 5.1 us.
 template <int NT, int KS>
 DFT_DEV void dft_product_rega(f32x16v* acc, const half8* ah, const half8* al, int ksn, const u32x4v* B, int bstride, int nt0,
                               int ntstep, int l31, int hw) {
-  // The tiles of a k-step are INDEPENDENT accumulators interleaved in the matrix pipe: one tile after the other - a chain of
-  // 3 K dependent instructions - measured 5.7 against 5.1 us
+  constexpr int KR = KS ? KS : DFT_KREG;
+  half8 bh[2][NT], bl[2][NT];
+#define DFT_REGA_READ(KSTEP, SET)                                                                                          \
+  _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                                         \
+    bh[SET][j] = dft_frag(B + (size_t)((2 * (KSTEP) + hw) * 2 + 0) * bstride + (nt0 + ntstep * j) * 32 + l31);             \
+    bl[SET][j] = dft_frag(B + (size_t)((2 * (KSTEP) + hw) * 2 + 1) * bstride + (nt0 + ntstep * j) * 32 + l31);             \
+  }
+  if (DFT_PIPE_REGA) DFT_REGA_READ(0, 0)
 #pragma unroll
-  for (int ks = 0; ks < (KS ? KS : DFT_KREG); ++ks) {
+  for (int ks = 0; ks < KR; ++ks) {
     if (KS || ks < ksn) {
-      half8 bh[NT], bl[NT];
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        bh[j] = dft_frag(B + (size_t)((2 * ks + hw) * 2 + 0) * bstride + (nt0 + ntstep * j) * 32 + l31);
-        bl[j] = dft_frag(B + (size_t)((2 * ks + hw) * 2 + 1) * bstride + (nt0 + ntstep * j) * 32 + l31);
+      if (DFT_PIPE_REGA) {
+        if (ks + 1 < KR && (KS || ks + 1 < ksn)) DFT_REGA_READ(ks + 1, (ks + 1) & 1)
+        DFT_SCHED_FENCE();
+      } else {
+        DFT_REGA_READ(ks, ks & 1)
       }
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[j] = dft_mma3(ah[ks], al[ks], bh[j], bl[j], acc[j]);
+      for (int j = 0; j < NT; ++j) acc[j] = dft_mma3(ah[ks], al[ks], bh[ks & 1][j], bl[ks & 1][j], acc[j]);
+      if (DFT_PIPE_REGA) DFT_SCHED_FENCE();
     }
   }
+#undef DFT_REGA_READ
 }
 
 template <int KS>
@@ -331,10 +348,11 @@ DFT_DEV void dft_product_rega_any(f32x16v* acc, int ntiles, const half8* ah, con
   else if (ntiles == 1) dft_product_rega<1, KS>(acc, ah, al, ksn, B, bstride, nt0, ntstep, l31, hw);
 }
 
-// acc[j] += A[row tile mt_j] . B[column tile nt_j], both operands in LDS, tiles t = t0 + 8 j of a grid of mtn row tiles;
-// SHARE: all NT tiles have the same row tile (mtn == 8): its A fragment is read once per k-step.  Straight-line code, as above
-// (double-buffering these fragments in the source as well costs 120 spilled registers: the compiler hoists what fits).
-template <int NT, bool SHARE, int NW>
+// acc[j] += A[row tile mt_j] . B[column tile nt_j], both operands in LDS, tiles t = t0 + NW j of a grid of mtn row tiles;
+// SHARE: all NT tiles have the same row tile (mtn == NW): its A fragment is read once per k-step.  Pipelined like the product
+// above: two fragment sets, the k loop unrolled by two so that the sets keep their registers, the reads of k-step ks + 1 in front
+// of the matrix instructions of k-step ks (an index beyond the last k-step is clamped: one harmless re-read).
+template <int NT, bool SHARE, int NW, int PIPE_MODE>
 DFT_DEV void dft_product_lds(f32x16v* acc, int ks0, int ks1, const u32x4v* A, int astride, const u32x4v* B, int bstride, int t0, int mtn,
                              int l31, int hw) {
   constexpr int NA = SHARE ? 1 : NT;
@@ -345,35 +363,63 @@ DFT_DEV void dft_product_lds(f32x16v* acc, int ks0, int ks1, const u32x4v* A, in
     tn[j] = t / mtn;
     tm[j] = t - tn[j] * mtn;
   }
-  for (int ks = ks0; ks < ks1; ++ks) {
-    half8 ah[NA], al[NA], bh[NT], bl[NT];
-#pragma unroll
-    for (int j = 0; j < NA; ++j) {
-      ah[j] = dft_frag(A + (size_t)((2 * ks + hw) * 2 + 0) * astride + tm[j] * 32 + l31);
-      al[j] = dft_frag(A + (size_t)((2 * ks + hw) * 2 + 1) * astride + tm[j] * 32 + l31);
-    }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      bh[j] = dft_frag(B + (size_t)((2 * ks + hw) * 2 + 0) * bstride + tn[j] * 32 + l31);
-      bl[j] = dft_frag(B + (size_t)((2 * ks + hw) * 2 + 1) * bstride + tn[j] * 32 + l31);
-    }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] = dft_mma3(ah[SHARE ? 0 : j], al[SHARE ? 0 : j], bh[j], bl[j], acc[j]);
+  half8 ah[2][NA], al[2][NA], bh[2][NT], bl[2][NT];
+#define DFT_LDS_READ(KSTEP, SET)                                                                                           \
+  {                                                                                                                        \
+    const int kc_ = (KSTEP) < ks1 ? (KSTEP) : ks1 - 1;                                                                     \
+    _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                                                       \
+      ah[SET][j] = dft_frag(A + (size_t)((2 * kc_ + hw) * 2 + 0) * astride + tm[j] * 32 + l31);                            \
+      al[SET][j] = dft_frag(A + (size_t)((2 * kc_ + hw) * 2 + 1) * astride + tm[j] * 32 + l31);                            \
+    }                                                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                                       \
+      bh[SET][j] = dft_frag(B + (size_t)((2 * kc_ + hw) * 2 + 0) * bstride + tn[j] * 32 + l31);                            \
+      bl[SET][j] = dft_frag(B + (size_t)((2 * kc_ + hw) * 2 + 1) * bstride + tn[j] * 32 + l31);                            \
+    }                                                                                                                      \
   }
+#define DFT_LDS_MMA(SET)                                                                                                   \
+  DFT_SCHED_FENCE();                                                                                                       \
+  _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                           \
+    acc[j] = dft_mma3(ah[SET][SHARE ? 0 : j], al[SET][SHARE ? 0 : j], bh[SET][j], bl[SET][j], acc[j]);                    \
+  DFT_SCHED_FENCE();
+  if (ks0 >= ks1) return;
+  // (two sets of NA + NT fragment pairs: 64 registers when the tiles share their row tile, up to 96 when they do not - more than
+  // the inverse kernel has left next to its prefetched spectra: PIPE_MODE 2 = every product, 1 = the row-sharing ones, 0 = none)
+  constexpr bool PIPE = PIPE_MODE == 2 || (PIPE_MODE == 1 && SHARE);
+  if (!PIPE) {
+    for (int ks = ks0; ks < ks1; ++ks) {
+      DFT_LDS_READ(ks, 0)
+      _Pragma("unroll") for (int j = 0; j < NT; ++j)
+        acc[j] = dft_mma3(ah[0][SHARE ? 0 : j], al[0][SHARE ? 0 : j], bh[0][j], bl[0][j], acc[j]);
+    }
+    return;
+  }
+  DFT_LDS_READ(ks0, 0)
+  int ks = ks0;
+  for (; ks + 1 < ks1; ks += 2) {
+    DFT_LDS_READ(ks + 1, 1)
+    DFT_LDS_MMA(0)
+    DFT_LDS_READ(ks + 2, 0)
+    DFT_LDS_MMA(1)
+  }
+  if (ks < ks1) {
+    DFT_LDS_MMA(0)
+  }
+#undef DFT_LDS_READ
+#undef DFT_LDS_MMA
 }
 
-template <int NW>
+template <int NW, int PIPE_MODE>
 DFT_DEV void dft_product_lds_any(f32x16v* acc, int ntiles, int ks0, int ks1, const u32x4v* A, int astride, const u32x4v* B, int bstride,
                                  int t0, int mtn, int l31, int hw) {
   const bool share = mtn == NW;
   if (ntiles == 3) {
-    if (share) dft_product_lds<3, true, NW>(acc, ks0, ks1, A, astride, B, bstride, t0, mtn, l31, hw);
-    else dft_product_lds<3, false, NW>(acc, ks0, ks1, A, astride, B, bstride, t0, mtn, l31, hw);
+    if (share) dft_product_lds<3, true, NW, PIPE_MODE>(acc, ks0, ks1, A, astride, B, bstride, t0, mtn, l31, hw);
+    else dft_product_lds<3, false, NW, PIPE_MODE>(acc, ks0, ks1, A, astride, B, bstride, t0, mtn, l31, hw);
   } else if (ntiles == 2) {
-    if (share) dft_product_lds<2, true, NW>(acc, ks0, ks1, A, astride, B, bstride, t0, mtn, l31, hw);
-    else dft_product_lds<2, false, NW>(acc, ks0, ks1, A, astride, B, bstride, t0, mtn, l31, hw);
+    if (share) dft_product_lds<2, true, NW, PIPE_MODE>(acc, ks0, ks1, A, astride, B, bstride, t0, mtn, l31, hw);
+    else dft_product_lds<2, false, NW, PIPE_MODE>(acc, ks0, ks1, A, astride, B, bstride, t0, mtn, l31, hw);
   } else if (ntiles == 1) {
-    dft_product_lds<1, true, NW>(acc, ks0, ks1, A, astride, B, bstride, t0, mtn, l31, hw);
+    dft_product_lds<1, true, NW, PIPE_MODE>(acc, ks0, ks1, A, astride, B, bstride, t0, mtn, l31, hw);
   }
 }
 
@@ -600,7 +646,7 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     }
-    dft_product_lds_any<NW>(acc, nt1w, 0, ks1n, ldsU, MxS, ldsF, N1, wv, mt1n, l31, hw);
+    dft_product_lds_any<NW, DFT_PIPE_LDS ? 2 : 0>(acc, nt1w, 0, ks1n, ldsU, MxS, ldsF, N1, wv, mt1n, l31, hw);
     DFT_BARRIER();      // every wave is done reading x: the region becomes R2
     DFT_STAMP(1)
 
@@ -647,10 +693,15 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
     // store phase later - so that their registers do not overlap the first product's
     // (DFT_FWD_NPRE < 3: only the first position slots here, the others right after the product - a knob from the hunt for the
     // spilled registers of round 4, which turned out to be hoisted lane arithmetic; all slots here is the default)
+    // UNCONDITIONAL (round 5): the last iteration of a work-group requests its own window once more (cache hits, discarded).
+    // Behind "if (it + DFT_GRID < iters)" the prefetch registers stayed live through the whole iteration on the path that skips
+    // the loads - 60 registers the compiler had to keep next to the 64 of Fp2 in every phase - and the wait-count pass, merging
+    // the two paths, could not count what is in flight.
     constexpr int NPRE = DFT_FWD_NPRE < NSLOT ? DFT_FWD_NPRE : NSLOT;
-    if (it + DFT_GRID < iters) DFT_FWD_PREFETCH_SLOTS(it + DFT_GRID, tl, 0, NPRE)
+    const int itn = it + DFT_GRID < iters ? it + DFT_GRID : it;
+    DFT_FWD_PREFETCH_SLOTS(itn, tl, 0, NPRE)
     dft_product_rega_any<KS2>(xc, nt2w, fp2h, fp2l, ks2n, ldsU, N2S, wv >> 2, NW / 4, l31, hw);
-    if (NPRE < NSLOT && it + DFT_GRID < iters) DFT_FWD_PREFETCH_SLOTS(it + DFT_GRID, tl, NPRE, NSLOT)
+    if (NPRE < NSLOT) DFT_FWD_PREFETCH_SLOTS(itn, tl, NPRE, NSLOT)
     DFT_BARRIER();      // every wave is done reading R2: the region becomes the staging buffer of X
     DFT_STAMP(3)
 
@@ -893,9 +944,10 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
       for (int r = 0; r < 16; ++r) ta[j][r] = 0.f;
     }
     constexpr int NPRE = DFT_INV_NPRE < NITEM ? DFT_INV_NPRE : NITEM;      // (see the forward kernel)
-    if (it + DFT_GRID < iters) DFT_INV_PREFETCH_ITEMS(it + DFT_GRID, tl, 0, NPRE)
+    const int itn = it + DFT_GRID < iters ? it + DFT_GRID : it;      // unconditional: see the forward kernel
+    DFT_INV_PREFETCH_ITEMS(itn, tl, 0, NPRE)
     dft_product_rega_any<KSA>(ta, ntaw, e2h, e2l, ksAn, ldsU, N2S, wv >> 2, 2, l31, hw);
-    if (NPRE < NITEM && it + DFT_GRID < iters) DFT_INV_PREFETCH_ITEMS(it + DFT_GRID, tl, NPRE, NITEM)
+    if (NPRE < NITEM) DFT_INV_PREFETCH_ITEMS(itn, tl, NPRE, NITEM)
     DFT_BARRIER();      // every wave is done reading Y2: the region becomes Tt
     DFT_STAMP(2)
 
@@ -946,8 +998,8 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
 #pragma unroll
       for (int r = 0; r < 16; ++r) yc[j][r] = 0.f;
     }
-    dft_product_lds_any<DFT_WAVES>(yc, ntbw, 0, ksBn, ldsU, MBS, ldsG, NBo, wv, mtBn, l31, hw);
-    if (it + DFT_GRID < iters) DFT_INV_MAXIMA(tl)      // of the NEXT iteration's spectra (requested before step A)
+    dft_product_lds_any<DFT_WAVES, DFT_PIPE_LDS ? 1 : 0>(yc, ntbw, 0, ksBn, ldsU, MBS, ldsG, NBo, wv, mtBn, l31, hw);
+    DFT_INV_MAXIMA(tl)      // of the NEXT iteration's spectra (requested before step A; the last iteration's result is not used)
     DFT_STAMP(4)
 
     // ---- epilogue: a lane owns window column w and, per accumulator run, the 4 channels of one row: + bias, ReLU, channel

@@ -8,6 +8,7 @@
 #         prof             rocprofv3 --kernel-trace --stats + PMC passes of the 64-class step (tools/profile_bench.sh)
 #         prof1024         the same at 1024 classes
 #         phases           phase stamps of the transforms (needs tools/diag_libs/stamps: build --variant stamps -DOS2D_DIAG_DFT_STAMPS)
+#                          (the raw rocprofv3 databases are deleted after summarising: gpurun merges at most 64 MiB back)
 #         smoke            __graft_entry__.smoke()
 #         py:<script> ...  python <script> (rest of the arguments up to the next known step are NOT consumed: one script, no args)
 TAG=$1; shift
@@ -27,9 +28,9 @@ for STEP in "$@"; do
     bench1024)
       ( timeout 600 python bench.py --classes 1024 --steps 5 --warmup 2 --no-cpu-baseline --no-other-precision --no-end-to-end --no-sweep --no-live-counters ) > $OUT/bench1024.json 2> $OUT/bench1024.err; echo "rc=$?"; cat $OUT/bench1024.json;;
     prof)
-      bash tools/profile_bench.sh ${TAG}_fftx3 --precision fftx3 > $OUT/prof.log 2>&1; python tools/summarize_prof.py gpurun_out/prof_${TAG}_fftx3 > $OUT/rocprof_summary.txt 2>&1; tail -40 $OUT/rocprof_summary.txt;;
+      bash tools/profile_bench.sh ${TAG}_fftx3 --precision fftx3 > $OUT/prof.log 2>&1; python tools/summarize_prof.py gpurun_out/prof_${TAG}_fftx3 > $OUT/rocprof_summary.txt 2>&1; rm -rf gpurun_out/prof_${TAG}_fftx3; grep -v "at6native\|rocclr" $OUT/rocprof_summary.txt | cut -c1-260 | head -60;;
     prof1024)
-      bash tools/profile_bench.sh ${TAG}_fftx3_1024 --precision fftx3 --classes 1024 > $OUT/prof1024.log 2>&1; python tools/summarize_prof.py gpurun_out/prof_${TAG}_fftx3_1024 > $OUT/rocprof_summary_1024.txt 2>&1; tail -40 $OUT/rocprof_summary_1024.txt;;
+      bash tools/profile_bench.sh ${TAG}_fftx3_1024 --precision fftx3 --classes 1024 > $OUT/prof1024.log 2>&1; python tools/summarize_prof.py gpurun_out/prof_${TAG}_fftx3_1024 > $OUT/rocprof_summary_1024.txt 2>&1; rm -rf gpurun_out/prof_${TAG}_fftx3_1024; grep -v "at6native\|rocclr" $OUT/rocprof_summary_1024.txt | cut -c1-260 | head -60;;
     phases)
       for NB in 64 1024; do OS2D_HIP_LIB=tools/diag_libs/stamps/libos2d_hip.so timeout 300 python tools/time_dft_phases.py $NB 2>&1 | tee $OUT/dft_phases_$NB.txt | tail -12; done;;
     smoke)

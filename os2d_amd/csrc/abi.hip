@@ -276,7 +276,7 @@ int os2d_corr_f16x3(const float* fm, const void* qs, float* corr, void* rshb, in
   float* sumsq = static_cast<float*>(workspace);
   void* fs = static_cast<char*>(workspace) + align_up((size_t)A * H * W * sizeof(float), 256);
   int rc = os2d_launch_fm_sumsq(fm, sumsq, A, C, H * W, S(stream));
-  if (!rc) rc = os2d_launch_split_fm(fm, sumsq, fs, A, C, H * W, nullptr, 0, S(stream));
+  if (!rc) rc = os2d_launch_split_fm(fm, sumsq, fs, A, C, H * W, nullptr, 0, nullptr, S(stream));
   if (!rc) rc = os2d_launch_border_zero_shb(rshb, A * B, H, W, S(stream));
   if (!rc) rc = os2d_launch_corr_f16x3(fs, qs, corr, rshb, nullptr, nullptr, 0, A, B, C, H, W, S(stream));
   return rc;
@@ -302,7 +302,7 @@ int os2d_corr_f16x3_packed(const float* fm, const void* qs, float* corr, float* 
   void* fs = static_cast<char*>(workspace) + align_up((size_t)A * H * W * sizeof(float), 256);
   void* sumfx = static_cast<char*>(workspace) + align_up(os2d_corr_f16x3_workspace_bytes(A, C, H, W), 256);
   int rc = os2d_launch_fm_sumsq(fm, sumsq, A, C, H * W, S(stream));
-  if (!rc) rc = os2d_launch_split_fm(fm, sumsq, fs, A, C, H * W, nullptr, 0, S(stream));
+  if (!rc) rc = os2d_launch_split_fm(fm, sumsq, fs, A, C, H * W, nullptr, 0, nullptr, S(stream));
   const bool packed = form > 0 || (form < 0 && os2d_corr_f16x3_use_packed(A, B, H, W));
   if (!rc && packed) rc = os2d_launch_corr_sums_clear(sumfx, A, B, H, W, S(stream));
   if (!rc) rc = os2d_launch_corr_f16x3(fs, qs, corr, nullptr, inv_norm, packed ? sumfx : nullptr, form == 2 ? 2 : 0, A, B, C, H, W, S(stream));
@@ -489,7 +489,7 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
   int rc = os2d_launch_fm_sumsq(fm, sumsq, A, C, H * W, st);
   if (rc) return rc;
   // (the packed correlation kernel's sums are cleared by the same launch; every chunk's norms pass leaves them cleared again)
-  if (!fp32_ops && (rc = os2d_launch_split_fm(fm, sumsq, fsplit, A, C, H * W, sumfx, sumfx ? (size_t)A * Bc * H * W : 0, st))) return rc;
+  if (!fp32_ops && (rc = os2d_launch_split_fm(fm, sumsq, fsplit, A, C, H * W, sumfx, sumfx ? (size_t)A * Bc * H * W : 0, status, st))) return rc;
   for (int b0 = 0; b0 < B; b0 += Bc) {
     const int bc = (B - b0 < Bc) ? (B - b0) : Bc;
     const int NB = A * bc;

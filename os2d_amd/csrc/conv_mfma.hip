@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const float* __restri
         const int m = wm * MW + mi * 32 + (k & 3) + 8 * (k >> 2) + 4 * hi;
         if (m >= CoutStore) continue;
         float v = acc[mi][ni][k] + bp[m];
-        if (RELU) v = fmaxf(v, 0.f);
+        if (RELU) v = os2d_relu(v);
         if (COMPACT) {
           if (valid) out[((size_t)nb * CoutStore + m) * (H * W) + hr * W + wc] = v;
         } else if (n < PLANE) {

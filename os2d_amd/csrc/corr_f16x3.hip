@@ -421,7 +421,8 @@ __global__ __launch_bounds__(64 * WM * WNW, (WM == 1 || WNW == 4) ? 2 : 1) void 
 // image features [A][C][HW] fp32 -> L2-normalised over channels (head.py:339, eps 1e-5), scaled, split, blocked
 __global__ __launch_bounds__(256) void split_fm_kernel(const float* __restrict__ fm, const float* __restrict__ sumsq,
                                                        u32x4* __restrict__ fs, int C, int HW, float scale,
-                                                       unsigned long long* __restrict__ clear, size_t clear_words) {
+                                                       unsigned long long* __restrict__ clear, size_t clear_words,
+                                                       int* __restrict__ status) {
   const int n = blockIdx.x * 256 + threadIdx.x;
   const int g = blockIdx.y, a = blockIdx.z;
   if (clear_words) {       // the packed correlation kernel's sums, zeroed on the way (grid-stride over all work items)
@@ -430,7 +431,14 @@ __global__ __launch_bounds__(256) void split_fm_kernel(const float* __restrict__
   }
   if (n >= HW) return;
   const int CG = os2d_round_up((C + 7) / 8, GC);  // zero groups pad the channel dimension to whole K chunks
-  const float inv = scale / (sqrtf(sumsq[(size_t)a * HW + n]) + 1e-5f);
+  const float ss = sumsq[(size_t)a * HW + n];
+  // A non-finite feature (NaN / Inf anywhere in the 1024 channels of this location) makes the reference's outputs NaN through
+  // relu(NaN) = NaN (torch).  The ReLUs of this path are fmaxf(x, 0), which DROPS a NaN (the forward transform would hand finite
+  // zeros to the 7x7 layer - ADVICE r4), so the one place that sees every input value raises the sticky status word: the caller
+  // re-runs the call in the fp32 kernels, whose ReLU keeps a NaN (os2d_relu).
+  if (status != nullptr && g == 0 && __builtin_amdgcn_ballot_w64(!(ss <= 3.4028234e38f)) != 0ull && (threadIdx.x & 63) == 0)
+    __hip_atomic_store(status, OS2D_STATUS_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const float inv = scale / (sqrtf(ss) + 1e-5f);
   half8 hi, lo;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -492,10 +500,10 @@ int check(const char* what) {
 int os2d_corr_groups(int C) { return os2d_round_up((C + 7) / 8, GC); }
 
 int os2d_launch_split_fm(const float* fm, const float* sumsq, void* fs, int A, int C, int HW, void* clear, size_t clear_words,
-                         hipStream_t stream) {
+                         int* status, hipStream_t stream) {
   hipLaunchKernelGGL(split_fm_kernel, dim3((HW + 255) / 256, os2d_round_up((C + 7) / 8, GC), A), dim3(256), 0, stream, fm, sumsq,
                      reinterpret_cast<u32x4*>(fs), C, HW, ldexpf(1.0f, SCALE_LOG2), static_cast<unsigned long long*>(clear),
-                     clear ? clear_words : (size_t)0);
+                     clear ? clear_words : (size_t)0, status);
   return check("split_fm");
 }
 

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_kernel(const float* __restri
         acc[mi][ni][r] = v;
         const int m = wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         if (nin && m < OS2D_K) corr[((size_t)nb * OS2D_K + m) * HW + n] = v;
-        const float rl = fmaxf(v, 0.f);
+        const float rl = os2d_relu(v);
         s += rl * rl;
       }
     s += __shfl_xor(s, 32);  // the other 16 rows of each 32x32 block live in lane^32
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (m < OS2D_K) rpad[((size_t)nb * OS2D_KP + m) * PLANE + cell] = fmaxf(acc[mi][ni][r], 0.f) * inv_r;
+          if (m < OS2D_K) rpad[((size_t)nb * OS2D_KP + m) * PLANE + cell] = os2d_relu(acc[mi][ni][r]) * inv_r;
         }
     } else {
       // split-half blocked output for conv_f16x3.hip: [nb][29 groups][hi|lo][PLANE] units of 8 halves.  Registers
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_kernel(const float* __restri
           half4 h4, l4;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const float v = (m0 + k < OS2D_K) ? fmaxf(acc[mi][ni][4 * q + k], 0.f) * inv_r : 0.f;
+            const float v = (m0 + k < OS2D_K) ? os2d_relu(acc[mi][ni][4 * q + k]) * inv_r : 0.f;
             const _Float16 hv = (_Float16)v;
             h4[k] = hv;
             l4[k] = (_Float16)(v - (float)hv);

@@ -74,6 +74,7 @@ typedef float f32x16v __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // 4 floats at any float address (one dwordx4 load)
 
 constexpr int DFT_THR = 512, DFT_WAVES = 8;
 constexpr int DFT_G = 4;            // images per work-group iteration
@@ -564,14 +565,31 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
           pc[s][g] = *reinterpret_cast<const f32x4v*>(corr + ((size_t)nb_ * C + c) * HW + off);              \
         }                                                                                                    \
       } else {                                                                                               \
+        /* rows of any width / tiles: the slot's 4 columns as ONE 16-byte load with 4-byte alignment (global loads need no   \
+           more) wherever the 16 bytes lie inside the image's own plane - columns left of x = 0 / right of x = W - 1 then    \
+           come from the neighbouring rows and are zeroed in the W phase like everything outside the window; only the slots  \
+           that would leave the plane (first / last row) take the per-element loads, behind a branch that most waves skip.   \
+           Round 4 loaded every element on its own: 60 load instructions per thread and iteration instead of 15, and the     \
+           levels that take this path (W % 4 != 0, every tiled level) paid 1.8 - 2.1x per location for their forward         \
+           transform (profiles/r05/pyramid_levels.txt). */                                                                   \
         const bool rok = i_ < npos && r_ < LH && y_ >= 0 && y_ < H;                                          \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                      \
-          const bool ok = rok && 4 * c4_ + e < LW && x_ + e >= 0 && x_ + e < W;                              \
-          const int off = ok ? y_ * W + x_ + e : 0;                                                          \
-          pn[s][e] = invn[(size_t)nb_ * HW + off];                                                           \
-          _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                \
-            const int c = c0_ + g < C ? c0_ + g : C - 1;                                                     \
-            pc[s][g][e] = corr[((size_t)nb_ * C + c) * HW + off];                                            \
+        const int off0 = y_ * W + x_;                                                                        \
+        const bool vec = rok && off0 >= 0 && off0 + 3 < HW;                                                  \
+        const int offv = vec ? off0 : 0;                                                                     \
+        pn[s] = *reinterpret_cast<const f32x4u*>(invn + (size_t)nb_ * HW + offv);                            \
+        _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                      \
+          const int c = c0_ + g < C ? c0_ + g : C - 1;                                                       \
+          pc[s][g] = *reinterpret_cast<const f32x4u*>(corr + ((size_t)nb_ * C + c) * HW + offv);             \
+        }                                                                                                    \
+        if (rok && !vec) {                                                                                   \
+          _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                    \
+            const bool ok = 4 * c4_ + e < LW && x_ + e >= 0 && x_ + e < W;                                   \
+            const int off = ok ? y_ * W + x_ + e : 0;                                                        \
+            pn[s][e] = invn[(size_t)nb_ * HW + off];                                                         \
+            _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                  \
+              const int c = c0_ + g < C ? c0_ + g : C - 1;                                                   \
+              pc[s][g][e] = corr[((size_t)nb_ * C + c) * HW + off];                                          \
+            }                                                                                                \
           }                                                                                                  \
         }                                                                                                    \
       }                                                                                                      \

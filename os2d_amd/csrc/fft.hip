@@ -478,7 +478,7 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
         for (int tw = lane; tw < TW_ && x0 + tw < W; tw += 64) {
           const f32x2 z = R[((th + oy) >> 1) * QS + tw + ox];
           const float t = (((th + oy) & 1) ? z[1] : z[0]) * norm + bias;
-          plane[(size_t)(y0 + th) * Ws + x0 + tw] = fmaxf(t, 0.f);
+          plane[(size_t)(y0 + th) * Ws + x0 + tw] = os2d_relu(t);
         }
     } else {
       _Float16* hi = reinterpret_cast<_Float16*>(hi_unit) + slot;

@@ -57,6 +57,8 @@ __device__ __forceinline__ void os2d_corr_norm_finalize_one(unsigned long long* 
   const float s = (v >> 62) ? __builtin_nanf("") : (float)((double)v * 5.6843418860808015e-14);    // 2^-44
   invn[i] = 1.0f / (sqrtf(s) + 1e-6f);
 }
+// torch.relu of the fp32 kernels (the reference's own arithmetic, head.py:613-650): a NaN stays a NaN - fmaxf(NaN, 0) would return 0
+__device__ __forceinline__ float os2d_relu(float v) { return v < 0.f ? 0.f : v; }
 // is flat plane index n an interior (data) cell?
 static inline __host__ __device__ bool os2d_interior(int n, int H, int W) {
   const int r = n - os2d_base(W);
@@ -284,7 +286,7 @@ int os2d_launch_dft_inverse(const float* Y, const float* bp, int MTP, void* out,
 int os2d_corr_groups(int C);  // 8-channel groups of the split correlation operands, padded to whole K chunks
 // clear / clear_words: 64-bit words zeroed by the same launch (the packed correlation kernel's sums; NULL / 0: none)
 int os2d_launch_split_fm(const float* fm, const float* sumsq, void* fs, int A, int C, int HW, void* clear, size_t clear_words,
-                         hipStream_t stream);
+                         int* status, hipStream_t stream);
 int os2d_launch_split_qp(const float* qp, void* qs, int B, int C, hipStream_t stream);
 // defer_norms & 1 (packed form only): the sums stay in sumfx; the caller's next launch turns them into invn; & 2: half tiles
 // (os2d_launch_border_zero_shb_planes_norms) - one launch less on the per-step path

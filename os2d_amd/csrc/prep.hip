@@ -64,13 +64,13 @@ __global__ __launch_bounds__(256) void corr_normalize_kernel(const float* __rest
   const float* c = corr + (size_t)nb * OS2D_K * HW + n;
   float s = 0.f;
   for (int k = 0; k < OS2D_K; ++k) {
-    const float v = fmaxf(c[(size_t)k * HW], 0.f);
+    const float v = os2d_relu(c[(size_t)k * HW]);
     s += v * v;
   }
   const float inv = 1.0f / (sqrtf(s) + 1e-6f);
   const int h = n / W, w = n - h * W;
   float* o = rpad + (size_t)nb * OS2D_KP * PLANE + (size_t)os2d_base(W) + (size_t)h * Ws + w;
-  for (int k = 0; k < OS2D_K; ++k) o[(size_t)k * PLANE] = fmaxf(c[(size_t)k * HW], 0.f) * inv;
+  for (int k = 0; k < OS2D_K; ++k) o[(size_t)k * PLANE] = os2d_relu(c[(size_t)k * HW]) * inv;
 }
 
 // ---- class_prepare: grid 225 (one block per template cell) x classes, block 256 loops over channels

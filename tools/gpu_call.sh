@@ -7,7 +7,8 @@
 #         bench1024        python bench.py --classes 1024 (stage times of the 1024-class step only)
 #         prof             rocprofv3 --kernel-trace --stats + PMC passes of the 64-class step (tools/profile_bench.sh)
 #         prof1024         the same at 1024 classes
-#         phases           phase stamps of the transforms (needs tools/diag_libs/stamps: build --variant stamps -DOS2D_DIAG_DFT_STAMPS)
+#         phases[:<variant>]  phase stamps of the transforms (needs tools/diag_libs/<variant>, default "stamps": build --variant stamps
+#                          -DOS2D_DIAG_DFT_STAMPS [other -D flags])
 #                          (the raw rocprofv3 databases are deleted after summarising: gpurun merges at most 64 MiB back)
 #         smoke            __graft_entry__.smoke()
 #         py:<script> ...  python <script> (rest of the arguments up to the next known step are NOT consumed: one script, no args)
@@ -31,8 +32,9 @@ for STEP in "$@"; do
       bash tools/profile_bench.sh ${TAG}_fftx3 --precision fftx3 > $OUT/prof.log 2>&1; python tools/summarize_prof.py gpurun_out/prof_${TAG}_fftx3 > $OUT/rocprof_summary.txt 2>&1; rm -rf gpurun_out/prof_${TAG}_fftx3; grep -v "at6native\|rocclr" $OUT/rocprof_summary.txt | cut -c1-260 | head -60;;
     prof1024)
       bash tools/profile_bench.sh ${TAG}_fftx3_1024 --precision fftx3 --classes 1024 > $OUT/prof1024.log 2>&1; python tools/summarize_prof.py gpurun_out/prof_${TAG}_fftx3_1024 > $OUT/rocprof_summary_1024.txt 2>&1; rm -rf gpurun_out/prof_${TAG}_fftx3_1024; grep -v "at6native\|rocclr" $OUT/rocprof_summary_1024.txt | cut -c1-260 | head -60;;
-    phases)
-      for NB in 64 1024; do OS2D_HIP_LIB=tools/diag_libs/stamps/libos2d_hip.so timeout 300 python tools/time_dft_phases.py $NB 2>&1 | tee $OUT/dft_phases_$NB.txt | tail -12; done;;
+    phases|phases:*)
+      V=stamps; [ "$STEP" != phases ] && V=${STEP#phases:}
+      for ARGS in "64 60 80" "1024 60 80" "128 38 50" "128 72 96" "128 96 128"; do OS2D_HIP_LIB=tools/diag_libs/$V/libos2d_hip.so timeout 300 python tools/time_dft_phases.py $ARGS 2>&1 | grep -v amdgpu.ids | tee -a $OUT/dft_phases_${V}.txt | tail -12; done;;
     smoke)
       python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3;;
     py:*)

@@ -7,6 +7,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char os2d_dft_smem[];
 
 #define DFT_DEV __device__ __forceinline__
 #define DFT_HD __host__ __device__ static inline
+#define DFT_MEMBER __device__ __forceinline__
 #define DFT_TID ((int)threadIdx.x)
 #define DFT_BID ((int)blockIdx.x)
 #define DFT_GRID ((int)gridDim.x)

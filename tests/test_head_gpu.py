@@ -68,9 +68,12 @@ def test_full_size_matches_oracle(P, inverse, precision, device):
     ref = _oracle(fm, class_fms, state, inverse)
     assert util.maxdiff(cls, ref[1]) < TOL_CLS
     assert util.maxdiff(loc, ref[0]) < TOL_LOC
-    assert util.maxdiff(corners, ref[3]) < 5e-3   # coordinates up to ~1400 px at this size
     if precision in util.FP32_EQUIVALENT:         # every mode but the opt-in f16x2: pinned at 3x the measured error
         assert util.maxdiff(cls, ref[1]) < util.PIN_CLS and util.maxdiff(loc, ref[0]) < util.PIN_LOC
+        # corners: 1.2e-4 px measured (one fp32 ulp of a coordinate near 1400 px) - pinned at 5x that
+        assert util.maxdiff(corners, ref[3]) < 6e-4
+    else:
+        assert util.maxdiff(corners, ref[3]) < 5e-3   # f16x2 (opt-in): loc within 5e-5 -> a few 1e-3 px at 240-px boxes
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)

@@ -29,6 +29,24 @@ def kernel_stats(db):
     return out
 
 
+def timeline(db, last=14):
+    """The last dispatches of the trace in start order: start relative to the first of them, duration, and the gap between the end
+    of the previous dispatch and this one's start (launch gaps between the dependent kernels of one head call)."""
+    cur = db.cursor()
+    rows = cur.execute("select s.kernel_name, d.start, d.end from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s "
+                       "on d.kernel_id = s.id order by d.start desc limit ?", (last,)).fetchall()[::-1]
+    if not rows:
+        return []
+    t0, prev_end, out, gaps = rows[0][1], None, [], 0.0
+    for name, a, b in rows:
+        gap = (a - prev_end) / 1e3 if prev_end is not None else 0.0
+        gaps += max(gap, 0.0)
+        out.append("  t={:>9.2f} us  dur {:>9.2f} us  gap {:>7.2f} us  {}".format((a - t0) / 1e3, (b - a) / 1e3, gap, short(name)[:70]))
+        prev_end = b
+    out.append("  span {:.2f} us, of which gaps {:.2f} us".format((rows[-1][2] - t0) / 1e3, gaps))
+    return out
+
+
 def counters(db):
     cur = db.cursor()
     try:
@@ -102,6 +120,8 @@ def main(root):
         print("==", os.path.relpath(path, root))
         if "stats" in os.path.basename(os.path.dirname(path)):
             print("\n".join(kernel_stats(db)))
+            print("== timeline of the last dispatches")
+            print("\n".join(timeline(db)))
         else:
             print("\n".join(counters(db)))
 

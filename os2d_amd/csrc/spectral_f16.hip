@@ -49,6 +49,9 @@ constexpr int SH_WSTAGE = 2 * SH_STAGE;        // weights of both output-channel
 #ifndef OS2D_SH_WRING
 #define OS2D_SH_WRING 3
 #endif
+#ifndef OS2D_SH_XAHEAD
+#define OS2D_SH_XAHEAD 2      /* k-steps the spectra loads run ahead of the matrix instructions; 4 (two more register sets) measured no faster */
+#endif
 #ifndef OS2D_SH_REGW
 #define OS2D_SH_REGW 1        /* 1: weights staged through registers (round 4); 0: by LDS-DMA into a ring of 3 (round 3) */
 #endif
@@ -352,6 +355,61 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
     sh_lds_barrier();                                                                                               \
   }
   int s = 0;
+#if OS2D_SH_XAHEAD == 4
+  // DIAGNOSTIC (-DOS2D_SH_XAHEAD=4; round 5, measured NO faster: 2.97 / 3.00 against 2.94 / 2.95 ms at 1024 pairs, 0.283 / 0.292
+  // against 0.287 / 0.290 at 64, profiles/r05/spectral_gemm_xahead.txt - the k-step is not waiting for late spectra).  The idea:
+  // the SPECTRA four k-steps ahead, the weights two: the spectra come from HBM in 256-byte runs and every k-step ends
+  // in a barrier, so a k-step lasts as long as the slowest of the 512 x 2 spectra loads it waits for - with a lookahead of two
+  // k-steps (~4 us) the tail of the latency distribution showed (no spectra loads: 3.04 -> 2.23 ms at 1024 pairs, no matrix
+  // instructions: 2.65 ms, profiles/r04/spectral_gemm_components.txt); the weights hit in L2.  Two more register sets (16
+  // registers); the sets of the spectra rotate with period 4, those of the weights with period 2: four k-steps per pass.  A
+  // wave's loads complete in issue order, so the wait for the weights of step S + 1 (requested one step ago) also covers the
+  // spectra of steps S + 1 and S + 2; those of S + 3 and S + 4 stay in flight: vmcnt(8).
+#define SH_STEPF4(S, WC, WN, PC, PN)                                                                                \
+  {                                                                                                                 \
+    SH_LOAD_W((S) + 2, WN)                                                                                          \
+    SH_LOAD_X((S) + 4, PN)                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    SH_COMPUTE(S)                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    SH_STORE_W((S) + 1, WC)                                                                                         \
+    SH_STORE_X((S) + 1, PC)                                                                                         \
+    sh_lds_barrier();                                                                                               \
+  }
+#define SH_STEPR4(S, WC, WN, PC, PN)                                                                                \
+  {                                                                                                                 \
+    if ((S) + 2 < KS) SH_LOAD_W((S) + 2, WN)                                                                        \
+    if ((S) + 4 < KS) SH_LOAD_X((S) + 4, PN)                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    SH_COMPUTE(S)                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    if ((S) + 1 < KS) {                                                                                             \
+      SH_STORE_W((S) + 1, WC)                                                                                       \
+      SH_STORE_X((S) + 1, PC)                                                                                       \
+    }                                                                                                               \
+    sh_lds_barrier();                                                                                               \
+  }
+  // (the prologue above requested the spectra of k-steps 0 and 1 into pfb and pfa: pfb = set 0, pfa = set 1; now sets 2 and 3)
+  // (unconditional: SH_LOAD_X clamps its channel index, and a conditional request would make the wait counts of the loop
+  // pessimistic - DESIGN 4.4)
+  u32x4 pfc[2], pfd[2];
+  SH_LOAD_X(2, pfc)
+  SH_LOAD_X(3, pfd)
+  for (; s + 7 < KS; s += 4) {
+    SH_STEPF4(s, wra, wrb, pfa, pfb)
+    SH_STEPF4(s + 1, wrb, wra, pfc, pfa)
+    SH_STEPF4(s + 2, wra, wrb, pfd, pfc)
+    SH_STEPF4(s + 3, wrb, wra, pfb, pfd)
+  }
+  for (; s < KS; s += 4) {
+    SH_STEPR4(s, wra, wrb, pfa, pfb)
+    if (s + 1 < KS) SH_STEPR4(s + 1, wrb, wra, pfc, pfa)
+    if (s + 2 < KS) SH_STEPR4(s + 2, wra, wrb, pfd, pfc)
+    if (s + 3 < KS) SH_STEPR4(s + 3, wrb, wra, pfb, pfd)
+  }
+#undef SH_STEPF4
+#undef SH_STEPR4
+#else
   for (; s + 3 < KS; s += 2) {
     SH_STEPF(s, wra, pfa, wrb, pfb)
     SH_STEPF(s + 1, wrb, pfb, wra, pfa)
@@ -360,6 +418,7 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
     SH_STEPR(s, wra, pfa, wrb, pfb)
     if (s + 1 < KS) SH_STEPR(s + 1, wrb, pfb, wra, pfa)
   }
+#endif
 #undef SH_STEPF
 #undef SH_STEPR
 #undef SH_LOAD_W

@@ -10,6 +10,7 @@
 #         phases[:<variant>]  phase stamps of the transforms (needs tools/diag_libs/<variant>, default "stamps": build --variant stamps
 #                          -DOS2D_DIAG_DFT_STAMPS [other -D flags])
 #                          (the raw rocprofv3 databases are deleted after summarising: gpurun merges at most 64 MiB back)
+#         gemm[:<variant>] tools/time_spectral16_quads.py 64 256 1024 (the per-bin GEMM alone) with the product library or a variant
 #         mfma             tools/bin/mfma_peak: what v_mfma_f32_32x32x16_f16 sustains (register-only loop, zero / random operands)
 #         smoke            __graft_entry__.smoke()
 #         py:<script> ...  python <script> (rest of the arguments up to the next known step are NOT consumed: one script, no args)
@@ -36,6 +37,10 @@ for STEP in "$@"; do
     phases|phases:*)
       V=stamps; [ "$STEP" != phases ] && V=${STEP#phases:}
       for ARGS in "64 60 80" "1024 60 80" "128 38 50" "128 72 96" "128 96 128"; do OS2D_HIP_LIB=tools/diag_libs/$V/libos2d_hip.so timeout 300 python tools/time_dft_phases.py $ARGS 2>&1 | grep -v amdgpu.ids | tee -a $OUT/dft_phases_${V}.txt | tail -12; done;;
+    gemm|gemm:*)
+      V=""; [ "$STEP" != gemm ] && V=${STEP#gemm:}
+      if [ -n "$V" ]; then export OS2D_HIP_LIB=tools/diag_libs/$V/libos2d_hip.so; fi
+      timeout 300 python tools/time_spectral16_quads.py 64 256 1024 2>&1 | grep -v amdgpu.ids | sed "s/^/[${V:-product}] /" | tee -a $OUT/gemm_times.txt | tail -6; unset OS2D_HIP_LIB;;
     mfma)
       tools/bin/mfma_peak 2>&1 | tee $OUT/mfma_peak.txt;;
     smoke)

@@ -49,6 +49,9 @@ constexpr int SH_WSTAGE = 2 * SH_STAGE;        // weights of both output-channel
 #ifndef OS2D_SH_WRING
 #define OS2D_SH_WRING 3
 #endif
+#ifndef OS2D_SH_PINGPONG
+#define OS2D_SH_PINGPONG 0    /* 1: the two halves of the work-group run half a k-step apart (one multiplies while the other converts): measured no faster */
+#endif
 #ifndef OS2D_SH_XAHEAD
 #define OS2D_SH_XAHEAD 2      /* k-steps the spectra loads run ahead of the matrix instructions; 4 (two more register sets) measured no faster */
 #endif
@@ -334,10 +337,8 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
   }
   SH_LOAD_W(0, wrb)
   SH_LOAD_X(0, pfb)
-  if (1 < KS) {
-    SH_LOAD_W(1, wra)
-    SH_LOAD_X(1, pfa)
-  }
+  SH_LOAD_W(min(1, KS - 1), wra)       // (unconditional, clamped: a conditional request makes the loop's wait counts pessimistic)
+  SH_LOAD_X(min(1, KS - 1), pfa)
   SH_STORE_W(0, wrb)
   SH_STORE_X(0, pfb)
   sh_lds_barrier();
@@ -355,7 +356,61 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
     sh_lds_barrier();                                                                                               \
   }
   int s = 0;
-#if OS2D_SH_XAHEAD == 4
+#if OS2D_SH_PINGPONG
+  // DIAGNOSTIC (-DOS2D_SH_PINGPONG=1; round 5, correct - tests/test_spectral_gpu.py passes - and measured NO faster: 2.95 / 2.94
+  // against 2.90 / 2.91 ms at 1024 pairs, 0.288 / 0.294 against 0.284 / 0.281 at 64, profiles/r05/spectral_gemm_pingpong.txt).
+  // PING-PONG.  In the loop below all 8 waves multiply together and then convert / store together: the matrix pipes idle
+  // while the vector units and the LDS stores work, and the other way round - with every global load removed a k-step took 2,250
+  // cycles for 1,536 of matrix time, with them 4,570 (profiles/r04/spectral_gemm_components.txt).  Here the two halves of the
+  // work-group - waves 0 .. 3 own pairs 0 .. 31, waves 4 .. 7 pairs 32 .. 63; both use all the weights - run half a k-step apart:
+  //   phase 1:  group 0 multiplies k-step S                     group 1 converts / stores ITS spectra and weight share of S + 1
+  //   barrier
+  //   phase 2:  group 0 converts / stores its share of S + 1     group 1 multiplies k-step S
+  //   barrier
+  // Stage (S + 1) % 2 of both operands is written while stage S % 2 is read; everybody's reads of stage (S + 1) % 2 (k-step
+  // S - 1) ended at the second barrier of k-step S - 1.  Two barriers per k-step instead of one, same requests, same wait counts.
+  // The requests are UNCONDITIONAL - a k-step beyond the last one is clamped to it (cache hits, never stored) - and the loop runs
+  // an even number of k-steps (the last one of an odd count multiplies and stores nothing): one loop per group, no guarded tail,
+  // every wait count exact.
+#define SH_PP0(S, WC, PC, WN, PN)                                                                                   \
+  {                                                                                                                 \
+    SH_LOAD_W(min((S) + 2, KS - 1), WN)                                                                             \
+    SH_LOAD_X(min((S) + 2, KS - 1), PN)                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    if ((S) < KS) SH_COMPUTE(S)                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    sh_lds_barrier();                                                                                               \
+    SH_STORE_W((S) + 1, WC) /* (beyond the last k-step: the clamped request's data, into a stage nobody reads again) */ \
+    SH_STORE_X((S) + 1, PC)                                                                                         \
+    sh_lds_barrier();                                                                                               \
+  }
+#define SH_PP1(S, WC, PC, WN, PN)                                                                                   \
+  {                                                                                                                 \
+    SH_LOAD_W(min((S) + 2, KS - 1), WN)                                                                             \
+    SH_LOAD_X(min((S) + 2, KS - 1), PN)                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    SH_STORE_W((S) + 1, WC) /* (beyond the last k-step: the clamped request's data, into a stage nobody reads again) */ \
+    SH_STORE_X((S) + 1, PC)                                                                                         \
+    sh_lds_barrier();                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    if ((S) < KS) SH_COMPUTE(S)                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    sh_lds_barrier();                                                                                               \
+  }
+  if (pt == 0) {
+    for (; s < KS; s += 2) {
+      SH_PP0(s, wra, pfa, wrb, pfb)
+      SH_PP0(s + 1, wrb, pfb, wra, pfa)
+    }
+  } else {
+    for (; s < KS; s += 2) {
+      SH_PP1(s, wra, pfa, wrb, pfb)
+      SH_PP1(s + 1, wrb, pfb, wra, pfa)
+    }
+  }
+#undef SH_PP0
+#undef SH_PP1
+#elif OS2D_SH_XAHEAD == 4
   // DIAGNOSTIC (-DOS2D_SH_XAHEAD=4; round 5, measured NO faster: 2.97 / 3.00 against 2.94 / 2.95 ms at 1024 pairs, 0.283 / 0.292
   // against 0.287 / 0.290 at 64, profiles/r05/spectral_gemm_xahead.txt - the k-step is not waiting for late spectra).  The idea:
   // the SPECTRA four k-steps ahead, the weights two: the spectra come from HBM in 256-byte runs and every k-step ends

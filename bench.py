@@ -508,7 +508,7 @@ class Workload(object):
             flops = self.whole_head_flops_per_class() * B
             seconds = seconds_per_step
             kernel = "whole head of one rank (correlation + 3 TransformNet convolutions, all MFMA kernels of a step{})".format(
-                ", 7 levels on 7 HIP streams" if self.pyramid else "")
+                ", 7 levels" if self.pyramid else "")
         achieved = flops / seconds
         r = {"kernel": kernel, "bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": peak / 1e12, "unit": "TFLOP/s",
              "frac": round(achieved / peak, 4), "traffic": None, "flops_per_launch": flops,
@@ -594,7 +594,7 @@ class Workload(object):
         achieved = (f16 + f32) / seconds
         return {"kernel": "whole head of one rank: correlation + 5x5 layers on v_mfma_f32_32x32x16_f16 (algorithmic FLOPs, three "
                           "MFMA products each) + per-bin complex GEMMs of the 7x7 layer on v_mfma_f32_32x32x2_f32 (executed FLOPs)"
-                          + (", 7 levels on 7 HIP streams" if self.pyramid else ""),
+                          + (", 7 levels" if self.pyramid else ""),
                 "bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": None, "flops_per_launch": f16 + f32,
                 "flops_fp16_mfma_algorithmic": f16, "flops_fp32_mfma_executed": f32,
@@ -720,7 +720,7 @@ class Workload(object):
         return ("OS2D head, ResNet50-C4 features of one 1280x960 image ({}), {} classes in total ({} on this GPU), {}, {} "
                 "(P={}, inverse={}), head only, features resident in HBM".format(
                     "7-level pyramid 30x40..96x128, 39580 locations" if self.pyramid else "1x1024x60x80",
-                    self.classes_total, self.B_local, "7 scales 0.5-1.6, one HIP stream per level" if self.pyramid else "single scale",
+                    self.classes_total, self.B_local, "7 scales 0.5-1.6" if self.pyramid else "single scale",
                     self.variant.upper(), self.P, int(self.inverse)))
 
 
@@ -759,14 +759,15 @@ def sweep_entry(dev, name, classes, variant, pyramid, precision, steps, warmup):
     else:
         e["roofline"] = w.roofline(precision, stage_ms, dt / steps)
     if pyramid:
-        # the same levels one after the other on ONE stream (what do the per-level streams buy?)
+        # the runner's default is the levels back to back on one stream (measured faster in rounds 4 and 5); the same levels on
+        # one HIP stream per level (BASELINE.json configs[4]'s wording) right after, for the record
         from os2d_amd.engine.pyramid import PyramidHeadRunner
-        streams_runner = w.runner
-        w.runner = PyramidHeadRunner(w.head, num_streams=1, device=dev)
-        dt1, _ = w.run(precision, steps, warmup)
-        w.runner = streams_runner
-        e["pyramid_streams_ms"] = e["ms_per_step"]
-        e["pyramid_serial_ms"] = round(dt1 / steps * 1e3, 4)
+        serial_runner = w.runner
+        w.runner = PyramidHeadRunner(w.head, num_streams=len(LEVEL_HW), device=dev)
+        dt7, _ = w.run(precision, steps, warmup)
+        w.runner = serial_runner
+        e["pyramid_serial_ms"] = e["ms_per_step"]
+        e["pyramid_streams_ms"] = round(dt7 / steps * 1e3, 4)
     e["head_tflops_algorithmic"] = round(w.whole_head_flops_per_class() * classes * steps / dt / 1e12, 3)
     return e, w
 
@@ -960,7 +961,7 @@ def run_bench(args, rank, local_rank, world, dev, use_dist):
         result["sweep"] = []
         for name, classes, variant, pyr in (("configs[3]: 256 classes, V1 simplified-affine head", 256, "v1", False),
                                             ("configs[2] on one GPU: 1024 classes", 1024, "v2", False),
-                                            ("configs[4] per-GPU share: 7-level pyramid, 128 classes, one HIP stream per level", 128, "v2", True)):
+                                            ("configs[4] per-GPU share: 7-level pyramid, 128 classes, levels back to back (per-level streams timed alongside)", 128, "v2", True)):
             e, ws = sweep_entry(dev, name, classes, variant, pyr, args.precision, n, 1)
             result["sweep"].append(e)
             if name.startswith("configs[2]"):

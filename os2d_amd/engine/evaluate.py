@@ -69,19 +69,19 @@ def build_class_head(net, class_images, batch_same_size=True):
         return net.os2d_head_creator.create_os2d_head(feats)
 
 
-def extract_scores(net, image_levels, class_head, per_level_streams=True):
+def extract_scores(net, image_levels, class_head, per_level_streams=False):
     """image_levels: list of [A,3,h_l,w_l] tensors (the image pyramid, reference dataloader.py:326-347).
     Returns dict(loc, cls, corners, fm_sizes, img_sizes) with one entry per level, shaped like ``Os2dModel.forward``:
     loc [A,B,4,HW], cls [A,B,HW], corners [A,B,8,HW]."""
     runner = PyramidHeadRunner(class_head, features=net.net_feature_maps,
-                               num_streams=None if per_level_streams else 1, device=image_levels[0].device)
+                               num_streams=len(image_levels) if per_level_streams else 1, device=image_levels[0].device)
     loc, cls, corners, fm_sizes = runner.run(image_levels)
     return dict(loc=loc, cls=cls, corners=corners, fm_sizes=fm_sizes,
                 img_sizes=[FeatureMapSize(img=x) for x in image_levels])
 
 
 def detect(net, box_coder, image_levels, class_head, class_ids, orig_size=None, nms_score_threshold=float("-inf"),
-           nms_iou_threshold=0.3, image_index=0, per_level_streams=True):
+           nms_iou_threshold=0.3, image_index=0, per_level_streams=False):
     """Detections of ONE image (``image_index`` of the batch) over the whole pyramid as a ``BoxList`` in the
     coordinates of ``orig_size`` (default: the first level's size), fields scores / labels / default_boxes /
     transform_corners.  Thresholds default to the reference's eval config (config.py:198-200)."""

@@ -4,9 +4,12 @@ classes; os2d/data/dataloader.py:326 for the level sizes; os2d/config.py:194 for
 
 MI355X-first differences from the reference loop:
   * all classes go through ONE class-batched head call per level (the reference loops B=1 heads);
-  * every level runs on its own HIP stream with its own workspace, so the small levels (30x40 at scale 0.5) fill
-    the CUs left idle by the tail of the large ones, and the per-level all-gather of the class-sharded variant
-    overlaps the next level's compute;
+  * the levels run back to back on the caller's stream by default; ``num_streams=7`` (or $OS2D_PYRAMID_STREAMS=7) gives every
+    level its own HIP stream and workspace.  The streams were built so that the small levels fill the CUs left idle by the tail
+    of the large ones - and measured SLOWER on every box of rounds 3 - 5 (128 classes x 7 levels: 25.03 ms on 7 streams against
+    24.85 ms serial in round 4, 24.04 against 23.12 ms in round 5): every large kernel of the head owns its CU (>= 130 KB of LDS),
+    nothing co-resides, and the interleaved streams cost the L2 locality of a level's kernel chain.  The per-level all-gather of
+    the class-sharded variant runs on its own stream either way and overlaps the next level's compute;
   * nothing synchronises with the host until the caller asks for the results (the reference calls
     ``torch.cuda.synchronize()`` twice per level, evaluate.py:312,332).
 """
@@ -40,8 +43,8 @@ def pyramid_sizes(img_size, scales=DEFAULT_SCALES):
 
 
 class PyramidHeadRunner(object):
-    """Runs ``head`` (an ``Os2dHead`` / ``ClassShardedHead``) on the feature maps of every pyramid level, one HIP
-    stream per level.  ``features`` may be the backbone (a module mapping [1,3,h,w] -> [1,C,H,W]) or None when the
+    """Runs ``head`` (an ``Os2dHead`` / ``ClassShardedHead``) on the feature maps of every pyramid level - back to back on the
+    caller's stream (default) or on ``num_streams`` HIP streams, level i on stream i % num_streams.  ``features`` may be the backbone (a module mapping [1,3,h,w] -> [1,C,H,W]) or None when the
     caller passes feature maps directly."""
 
     def __init__(self, head, features=None, num_streams=None, device=None):
@@ -50,6 +53,8 @@ class PyramidHeadRunner(object):
         self.device = device or (head.class_feature_maps.device if hasattr(head, "class_feature_maps") else torch.device("cuda"))
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
+        if num_streams is None:
+            num_streams = int(os.environ.get("OS2D_PYRAMID_STREAMS", "1"))
         self._num_streams = num_streams
         self.largest_first = os.environ.get("OS2D_PYRAMID_ORDER", "given") == "largest"     # queue order of the levels
 
@@ -57,7 +62,7 @@ class PyramidHeadRunner(object):
         n = self._num_streams
         if n is not None and n <= 1:
             return torch.cuda.current_stream(self.device)
-        return level_stream(self.device, i if n is None else i % n)
+        return level_stream(self.device, i % n)
 
     def run(self, level_inputs, inputs_are_features=False):
         """level_inputs: list of image tensors [A,3,h_l,w_l] (or feature maps [A,C,H_l,W_l] if

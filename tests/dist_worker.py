@@ -55,7 +55,7 @@ def main():
                         assert torch.equal(r[0], full[0]) and torch.equal(r[3], full[3])
                 # inside the pyramid runner (one HIP stream per level; with gather="scores" loc / corners are None)
                 serial = PyramidHeadRunner(full_head, num_streams=1, device=dev).run(levels, inputs_are_features=True)
-                par = PyramidHeadRunner(sharded, device=dev).run(levels, inputs_are_features=True)
+                par = PyramidHeadRunner(sharded, num_streams=len(levels), device=dev).run(levels, inputs_are_features=True)
                 torch.cuda.synchronize(dev)
                 for lvl in range(len(levels)):
                     assert torch.equal(par[1][lvl], serial[1][lvl]), "pyramid scores, level {}".format(lvl)

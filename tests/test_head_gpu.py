@@ -663,7 +663,7 @@ def test_baseline_config_pyramid_streams_128_classes(device):
         serial = PyramidHeadRunner(head, num_streams=1, device=device).run(levels, inputs_are_features=True)
         torch.cuda.synchronize()
         for _ in range(2):
-            par = PyramidHeadRunner(head, device=device).run(levels, inputs_are_features=True)
+            par = PyramidHeadRunner(head, num_streams=len(levels), device=device).run(levels, inputs_are_features=True)
             torch.cuda.synchronize()
             for lvl in range(len(levels)):
                 for k in range(3):

@@ -65,7 +65,7 @@ def test_pyramid_runner_streams_match_single_stream(device):
         head = creator.create_os2d_head([c.to(device) for c in class_fms])
         seq = [head(fm) for fm in levels]
         torch.cuda.synchronize()
-        runner = PyramidHeadRunner(head)
+        runner = PyramidHeadRunner(head, num_streams=len(levels))
         for _ in range(3):          # repeat: workspaces are re-used per stream
             locs, clss, corners, fms = runner.run(levels, inputs_are_features=True)
         torch.cuda.synchronize()

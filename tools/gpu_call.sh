@@ -11,6 +11,7 @@
 #                          -DOS2D_DIAG_DFT_STAMPS [other -D flags])
 #                          (the raw rocprofv3 databases are deleted after summarising: gpurun merges at most 64 MiB back)
 #         gemm[:<variant>] tools/time_spectral16_quads.py 64 256 1024 (the per-bin GEMM alone) with the product library or a variant
+#         power            tools/power_probe.sh: package power / clocks while the correlation, the step and the register-only MFMA loop run
 #         mfma             tools/bin/mfma_peak: what v_mfma_f32_32x32x16_f16 sustains (register-only loop, zero / random operands)
 #         smoke            __graft_entry__.smoke()
 #         py:<script> ...  python <script> (rest of the arguments up to the next known step are NOT consumed: one script, no args)
@@ -41,6 +42,8 @@ for STEP in "$@"; do
       V=""; [ "$STEP" != gemm ] && V=${STEP#gemm:}
       if [ -n "$V" ]; then export OS2D_HIP_LIB=tools/diag_libs/$V/libos2d_hip.so; fi
       timeout 300 python tools/time_spectral16_quads.py 64 256 1024 2>&1 | grep -v amdgpu.ids | sed "s/^/[${V:-product}] /" | tee -a $OUT/gemm_times.txt | tail -6; unset OS2D_HIP_LIB;;
+    power)
+      bash tools/power_probe.sh > $OUT/power_probe.log 2>&1; cp -f gpurun_out/power/power_probe.txt $OUT/power_probe_raw.txt 2>/dev/null; grep -v "^LOOP\|{" $OUT/power_probe.log | tail -12; grep "^LOOP" $OUT/power_probe.log;;
     mfma)
       tools/bin/mfma_peak 2>&1 | tee $OUT/mfma_peak.txt;;
     smoke)

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -58,13 +59,18 @@ double run(const half8* dab, float* dout, int waves_per_simd, int iters, int rep
   return flops / (ms * 1e-3);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  // mfma_peak loop <zero|random> <seconds>: keep the loop running (for tools/power_probe.sh: package power while it does)
+  const bool forever = argc >= 4 && std::string(argv[1]) == "loop";
+  const int only_mode = forever ? (std::string(argv[2]) == "random" ? 1 : 0) : -1;
+  const double seconds = forever ? atof(argv[3]) : 0.0;
   std::vector<_Float16> h(4096 * 8);
   half8* dab;
   float* dout;
   hipMalloc(&dab, h.size() * 2);
   hipMalloc(&dout, 1 << 22);
   for (int mode = 0; mode < 2; ++mode) {
+    if (only_mode >= 0 && mode != only_mode) continue;
     srand(1);
     for (auto& x : h) {
       float u = 0.f;
@@ -72,6 +78,17 @@ int main() {
       x = mode ? (_Float16)((u - 6.f) * 64.f) : (_Float16)0.f;        // ~N(0, 64^2): all mantissa / exponent bits busy
     }
     hipMemcpy(dab, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+    if (forever) {
+      double done = 0.0, rate = 0.0;
+      int n = 0;
+      while (done < seconds) {
+        rate = run<4>(dab, dout, 2, 20000, 20);
+        done += 20.0 * 256 * 2 * 4 * 20000 * 4.0 * 4 * 32 * 32 * 16 * 2 / rate;
+        ++n;
+      }
+      printf("LOOP mfma_%s iterations %d last rate %.1f TFLOP/s\n", mode ? "random" : "zero", n, rate / 1e12);
+      continue;
+    }
     for (int wps : {1, 2, 4}) {
       const double f4 = run<4>(dab, dout, wps, 20000, 5);
       const double f2 = run<2>(dab, dout, wps, 20000, 5);

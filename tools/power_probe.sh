@@ -55,6 +55,12 @@ PY
   wait
 }
 for label in idle corr_padded corr_packed step_fftx3 step_f32; do loop $label >> $OUT 2>&1; done
+# the register-only matrix loop of tools/mfma_peak.hip (no LDS, no memory): all-zero and random operands
+for mode in zero random; do
+  tools/bin/mfma_peak loop $mode 6 >> $OUT 2>&1 &
+  sample mfma_$mode $!
+  wait
+done
 python - <<'PY'
 import json, collections
 acc=collections.defaultdict(lambda: collections.defaultdict(list))

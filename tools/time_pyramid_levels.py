@@ -52,7 +52,22 @@ for r in rows:
         r["level"][0], r["level"][1], r["locations"], r["transform"][0], r["transform"][1], r["tiles"][0], r["tiles"][1], r["total_ms"],
         r["ms"]["corr"], r["ms"]["fwd"], r["ms"]["gemm"], r["ms"]["inv"], r["ms"]["conv2"], r["ms"]["conv3"], r["ms"]["sample"],
         (r["total_ms"] / r["locations"]) / (ref["total_ms"] / ref["locations"]), rel("corr"), rel("fwd"), rel("gemm"), rel("inv"), rel("conv2")))
+# wall clock of the same 7 levels back to back on one stream (what bench.py's pyramid line times): launch gaps = wall - sum
+import time  # noqa: E402
+from os2d_amd.engine.pyramid import PyramidHeadRunner  # noqa: E402
+fms = [synthetic.make_feature_map(bench.C_FEAT, h, wd, seed=100 + i).to(dev) for i, (h, wd) in enumerate(bench.LEVEL_HW)]
+runner = PyramidHeadRunner(w.head, num_streams=1, device=dev)
+with torch.no_grad():
+    for _ in range(2):
+        runner.run(fms, inputs_are_features=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        runner.run(fms, inputs_are_features=True)
+    torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / steps * 1e3
 tot = sum(r["total_ms"] for r in rows)
+print("wall clock of the 7 levels back to back: {:.3f} ms per image (sum of the levels' stage times below: {:.3f} ms -> {:.3f} ms between the stages' kernels)".format(wall, tot, wall - tot))
 ideal = ref["total_ms"] / ref["locations"] * sum(r["locations"] for r in rows)
 print("sum of the levels {:.3f} ms; at the 60x80 level's per-location rate {:.3f} ms".format(tot, ideal))
 print(json.dumps({"classes": classes, "levels": rows}))

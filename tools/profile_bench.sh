@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-other-precision --no-end-to-end --no-sweep $@"
+BENCH="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-precision --no-end-to-end --no-sweep $@"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- $BENCH > $OUT/stats.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o pmc -- $BENCH > $OUT/pmc_$C.log 2>&1

@@ -291,9 +291,16 @@ typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 DFT_DEV void dft_split4(float a, float b, float c, float d, u32x2v* hi, u32x2v* lo) {
   const f32x4v x = {a, b, c, d};
   const half4v h = __builtin_convertvector(x, half4v);
-  const half4v l = __builtin_convertvector(x - __builtin_convertvector(h, f32x4v), half4v);
   *hi = __builtin_bit_cast(u32x2v, h);
+#ifdef DFT_SPLIT_LO_PAIR      /* device build: one mixed-precision instruction per lo half (os2d_split_lo_pair), same bits */
+  u32x2v l;
+  l[0] = DFT_SPLIT_LO_PAIR(a, b, (*hi)[0]);
+  l[1] = DFT_SPLIT_LO_PAIR(c, d, (*hi)[1]);
+  *lo = l;
+#else
+  const half4v l = __builtin_convertvector(x - __builtin_convertvector(h, f32x4v), half4v);
   *lo = __builtin_bit_cast(u32x2v, l);
+#endif
 }
 
 DFT_DEV half8 dft_frag(const u32x4v* p) { return __builtin_bit_cast(half8, *p); }

@@ -21,6 +21,9 @@ extern __shared__ __attribute__((aligned(16))) unsigned char os2d_dft_smem[];
 #define DFT_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #define DFT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define DFT_LANDED(X) asm volatile("" : "+v"(X))
+#ifndef OS2D_NO_MIX_SPLIT      /* (diagnostic: -DOS2D_NO_MIX_SPLIT restores the convert - subtract - convert form) */
+#define DFT_SPLIT_LO_PAIR(a, b, hi) os2d_split_lo_pair(a, b, hi)
+#endif
 #define DFT_RAISE(p) __hip_atomic_store(p, OS2D_STATUS_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 #ifdef OS2D_DIAG_DFT_STAMPS
 // diagnostic build: thread 0 of every work-group accumulates the wall-clock ticks (100 MHz) between the phase barriers; the sums

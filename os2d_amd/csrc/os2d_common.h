@@ -57,6 +57,19 @@ __device__ __forceinline__ void os2d_corr_norm_finalize_one(unsigned long long* 
   const float s = (v >> 62) ? __builtin_nanf("") : (float)((double)v * 5.6843418860808015e-14);    // 2^-44
   invn[i] = 1.0f / (sqrtf(s) + 1e-6f);
 }
+// lo halves of the fp16 hi + lo split of two fp32 values whose hi halves are packed in ``hi`` (x0 -> low 16 bits): rn16(x - hi) as
+// ONE mixed-precision instruction per value (v_fma_mixlo_f16 / v_fma_mixhi_f16: fma(x, 1.0, -hi) in fp32, rounded to fp16 into
+// the low / high half) instead of v_cvt_f32_f16 + v_sub_f32 per value and a v_cvt_pk_f16_f32 per pair - the split conversions
+// are a third of the vector work of the transform kernels' staging phases.  Bit-identical to the long form on 4M values incl.
+// subnormal lo parts, out-of-range and non-finite inputs (tools/split_mix_check.hip, profiles/r05/split_mix_check.txt).
+__device__ __forceinline__ unsigned os2d_split_lo_pair(float x0, float x1, unsigned hi) {
+  unsigned lo;
+  asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(lo)
+      : "v"(x0), "v"(x1), "v"(hi));
+  return lo;
+}
 // torch.relu of the fp32 kernels (the reference's own arithmetic, head.py:613-650): a NaN stays a NaN - fmaxf(NaN, 0) would return 0
 __device__ __forceinline__ float os2d_relu(float v) { return v < 0.f ? 0.f : v; }
 // is flat plane index n an interior (data) cell?

@@ -36,6 +36,7 @@ namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
@@ -48,6 +49,11 @@ constexpr int SH_STAGE = SH_WB * 2 * 2 * 64;   // 16-byte units of one operand s
 constexpr int SH_WSTAGE = 2 * SH_STAGE;        // weights of both output-channel halves: 32 KB
 #ifndef OS2D_SH_WRING
 #define OS2D_SH_WRING 3
+#endif
+#ifdef OS2D_NO_MIX_SPLIT
+#define SH_MIX_SPLIT 0
+#else
+#define SH_MIX_SPLIT 1
 #endif
 #ifndef OS2D_SH_PINGPONG
 #define OS2D_SH_PINGPONG 0    /* 1: the two halves of the work-group run half a k-step apart (one multiplies while the other converts): measured no faster */
@@ -233,7 +239,10 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
         }                                                                                                           \
       }                                                                                                             \
       const half4 h_ = __builtin_convertvector(v4_, half4);                                                         \
-      const half4 l_ = __builtin_convertvector(v4_ - __builtin_convertvector(h_, f32x4), half4);                    \
+      const u32x2 hp_ = __builtin_bit_cast(u32x2, h_);     /* lo halves: one mixed-precision instruction each (os2d_common.h) */ \
+      const u32x2 lp_ = {os2d_split_lo_pair(v4_[0], v4_[1], hp_[0]), os2d_split_lo_pair(v4_[2], v4_[3], hp_[1])};    \
+      const half4 l_ = SH_MIX_SPLIT ? __builtin_bit_cast(half4, lp_)                                                \
+                                    : __builtin_convertvector(v4_ - __builtin_convertvector(h_, f32x4), half4);     \
       char* dst_ = reinterpret_cast<char*>(ldsX + ((S)&1) * SH_STAGE + (((2 * xj + b2_) * 2 + xg) * 2) * 64 + xn) + xwh * 8; \
       *reinterpret_cast<half4*>(dst_) = h_;              /* channels 2 wh, 2 wh + 1 of the unit (re, im each) */      \
       *reinterpret_cast<half4*>(dst_ + 64 * 16) = l_;                                                               \

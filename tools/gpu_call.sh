@@ -12,6 +12,7 @@
 #                          (the raw rocprofv3 databases are deleted after summarising: gpurun merges at most 64 MiB back)
 #         gemm[:<variant>] tools/time_spectral16_quads.py 64 256 1024 (the per-bin GEMM alone) with the product library or a variant
 #         power            tools/power_probe.sh: package power / clocks while the correlation, the step and the register-only MFMA loop run
+#         bin:<name>       tools/bin/<name> (a standalone HIP program built on the dev box, e.g. split_mix_check)
 #         mfma             tools/bin/mfma_peak: what v_mfma_f32_32x32x16_f16 sustains (register-only loop, zero / random operands)
 #         smoke            __graft_entry__.smoke()
 #         py:<script> ...  python <script> (rest of the arguments up to the next known step are NOT consumed: one script, no args)
@@ -44,6 +45,8 @@ for STEP in "$@"; do
       timeout 300 python tools/time_spectral16_quads.py 64 256 1024 2>&1 | grep -v amdgpu.ids | sed "s/^/[${V:-product}] /" | tee -a $OUT/gemm_times.txt | tail -6; unset OS2D_HIP_LIB;;
     power)
       bash tools/power_probe.sh > $OUT/power_probe.log 2>&1; cp -f gpurun_out/power/power_probe.txt $OUT/power_probe_raw.txt 2>/dev/null; grep -v "^LOOP\|{" $OUT/power_probe.log | tail -12; grep "^LOOP" $OUT/power_probe.log;;
+    bin:*)
+      tools/bin/${STEP#bin:} 2>&1 | tee $OUT/${STEP#bin:}.txt | tail -12;;
     mfma)
       tools/bin/mfma_peak 2>&1 | tee $OUT/mfma_peak.txt;;
     smoke)

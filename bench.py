@@ -12,10 +12,11 @@ TransformNet) and resident in HBM before the timed region.
 
 Workloads
   N = 1 (default)  BASELINE.json configs[1]: 64 classes, V2 head.  The same run also times, with the driver's clock
-                   running, the other single-GPU readings of BASELINE.json's configs and reports them under "sweep":
-                   256 classes V1 head (configs[3]), all 1024 classes on one GPU (configs[2], N = 1) and the 7-level
-                   pyramid with one HIP stream per level at 128 classes (the per-GPU share of configs[4]); each entry
-                   carries its own roofline object.
+                   running, the other single-GPU readings of BASELINE.json's configs ("sweep" in bench_details.json, the
+                   headline figures inside `config` of the line): 256 classes V1 head (configs[3]), all 1024 classes on one
+                   GPU (configs[2], N = 1) and the 7-level pyramid at 128 classes (the per-GPU share of configs[4]: levels
+                   back to back - the runner's default - and on one HIP stream per level); each entry carries its own
+                   roofline object.
   N > 1 (default)  BASELINE.json configs[2]: STRONG scaling of 1024 classes, block-sharded over the N ranks (128 per GPU
                    at N = 8); every step ends with the RCCL all-gather of the per-class output maps so that every rank
                    holds a result it can decode (--gather all: loc | cls | corners, 250 KB per class; issued
@@ -51,22 +52,22 @@ Arithmetic (``--precision``):
 The primary line is measured in the selected mode; the other modes are timed right after and reported under
 "other_precisions" so all are always on record.
 
-Prints ONE JSON line on rank 0 with the driver's contract fields plus
-  roofline     - the dominant kernel: ALGORITHMIC FLOPs per launch divided by its mean launch duration, measured LIVE
-                 with HIP events recorded on the launch stream inside the timed steps, against the dense MFMA peak of
-                 the instruction it runs on.  fft mode: spectral_gemm_kernel (the per-bin complex GEMM [128 x 225] x
-                 [225 x pairs] over the P*(Q/2+1) bins of the transform, 8 real FLOPs per complex multiply-add; its
-                 operands are streamed once from HBM, so the HBM view of the same launch is given as well);
-                 direct modes: the conv 7x7 225->128 MFMA implicit GEMM.  `traffic` / `hbm_gbps` /
-                 `mfma_pipe_busy` / `effective_clock_ghz` are LIVE at N = 1: the run spawns rocprofv3 PMC passes (FETCH_SIZE,
-                 WRITE_SIZE, SQ / GRBM: one pass each) over a 3-step child run of the same workload and merges them
-                 (`live_counters`, `counters_source`); if the profiler is unavailable they fall back to the committed passes
-                 (profiles/*_traffic_<precision>.json) and say so
-  stages_ms    - mean duration of every stage of the step (same events)
-  sweep        - see above (N = 1)
-  end_to_end   - secondary: backbone + head + decode/NMS per image, and the one-off class-head construction (N=1 only)
-  cpu_baseline - the oracle (torch-CPU restatement of the reference head, driven one class at a time like the
-                 reference's evaluation) timed on the host cores, rank 0 / N=1 only, on a bounded class sample.
+Output (rank 0).  stdout carries ONE compact JSON line (<= 6000 bytes, strict JSON; round 4's 22 KB line could not be parsed by
+the driver): the driver's contract fields, `config` (incl. the same-run figures of the strict-fp32 modes, 256 classes V1, 1024 classes
+on one GPU with the longest kernel's live traffic, and the 7-level pyramid), and
+  roofline       - the LONGEST kernel of the step by live HIP-event time: ALGORITHMIC FLOPs (or bytes) per launch / its mean launch
+                   duration, measured with HIP events recorded on the launch stream inside the timed steps, against the dense MFMA
+                   peak of the instruction (or the 8 TB/s HBM peak); `traffic` / `hbm_gbps` / `mfma_pipe_busy` /
+                   `effective_clock_ghz` are LIVE at N = 1: the run spawns rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE, SQ / GRBM:
+                   one pass each) over a 3-step child run of the same workload and merges them
+  roofline_other - {kernel: [frac of its bound, avg launch ms]} of the other kernels of the step
+  stages_ms      - mean duration of every stage of the step (same events)
+  cpu_baseline   - the oracle (torch-CPU restatement of the reference head, driven one class at a time like the reference's
+                   evaluation) timed on the host cores, rank 0 / N=1 only, on a bounded class sample
+  end_to_end     - secondary: backbone + head + decode/NMS per image (N=1 only)
+The FULL record - every kernel's roofline object, the other arithmetic modes, the sweep entries with their own roofline objects, the
+raw live counters at 64 and 1024 classes, both end-to-end legs - goes to bench_details.json (repo root, and gpurun_out/ when present)
+and to stderr (one line prefixed "[bench_details] ").
 """
 import argparse
 import ctypes

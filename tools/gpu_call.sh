@@ -13,6 +13,7 @@
 #         gemm[:<variant>] tools/time_spectral16_quads.py 64 256 1024 (the per-bin GEMM alone) with the product library or a variant
 #         power            tools/power_probe.sh: package power / clocks while the correlation, the step and the register-only MFMA loop run
 #         bin:<name>       tools/bin/<name> (a standalone HIP program built on the dev box, e.g. split_mix_check)
+#         soak[:<rounds>]  tools/soak_multistream.sh: victim / aggressor rounds + the pyramid on 7 streams against the serial run (default 300)
 #         mfma             tools/bin/mfma_peak: what v_mfma_f32_32x32x16_f16 sustains (register-only loop, zero / random operands)
 #         smoke            __graft_entry__.smoke()
 #         py:<script> ...  python <script> (rest of the arguments up to the next known step are NOT consumed: one script, no args)
@@ -47,6 +48,9 @@ for STEP in "$@"; do
       bash tools/power_probe.sh > $OUT/power_probe.log 2>&1; cp -f gpurun_out/power/power_probe.txt $OUT/power_probe_raw.txt 2>/dev/null; grep -v "^LOOP\|{" $OUT/power_probe.log | tail -12; grep "^LOOP" $OUT/power_probe.log;;
     bin:*)
       tools/bin/${STEP#bin:} 2>&1 | tee $OUT/${STEP#bin:}.txt | tail -12;;
+    soak|soak:*)
+      R=300; [ "$STEP" != soak ] && R=${STEP#soak:}
+      ( time bash tools/soak_multistream.sh $R ) > $OUT/soak.log 2>&1; cp -f gpurun_out/soak.txt $OUT/soak.txt 2>/dev/null; grep -c "^ *[0-9]* same" $OUT/soak.txt; grep -i "DIFF\|RESULT\|real" $OUT/soak.log $OUT/soak.txt | cut -c1-200 | head -12;;
     mfma)
       tools/bin/mfma_peak 2>&1 | tee $OUT/mfma_peak.txt;;
     smoke)

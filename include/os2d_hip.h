@@ -81,8 +81,9 @@ int os2d_class_prepare_batch(const float* const* srcs, const int* sizes, int B, 
  *   stride / rec_field: backbone stride and receptive field (16 / 16 for ResNet-C4, feature_extractor.py:115-117)
  *   outputs loc [A,B,4,H,W], cls [A,B,1,H,W], corners [A,B,8,H,W]  (cls_detached aliases cls in eval, head.py:400-402)
  * The workspace may be smaller than os2d_head_workspace_bytes(A,B,...) reports: classes are then processed in
- * chunks; it must hold at least os2d_head_workspace_bytes(A,1,...) bytes.  C must be a multiple of 4 and W <= 209
- * (3344-px wide images at stride 16: the 7x7 kernels keep three halo rows in LDS); both are checked before any launch. */
+ * chunks; it must hold at least os2d_head_workspace_bytes(A,1,...) bytes.  C must be a multiple of 4; W <= 3600 (the transform
+ * planner's 48 tiles per axis), and W <= 209 for the DIRECT 7x7 kernels of os2d_head_forward / the non-frequency precisions
+ * (3344-px wide images at stride 16: they keep three halo rows in LDS); all checked before any launch. */
 int os2d_head_workspace_bytes(int A, int B, int C, int H, int W, int P, size_t* bytes);
 int os2d_head_workspace_bytes_ex(int A, int B, int C, int H, int W, int P, int precision, size_t* bytes);  /* + spectra (FFT mode) */
 int os2d_head_forward(const float* fm, const float* qp, const float* w1, const float* b1, const float* w2,
@@ -131,7 +132,8 @@ int os2d_class_split(const float* qp, void* qs, int B, int C, void* stream);
  *                 os2d_spectral_gemm and the two twiddle tables of os2d_fft_forward;
  *                 OS2D_PRECISION_FFTX3: wspec = the split weight spectra of os2d_spectral_weights_build_dft for the transform size
  *                 of os2d_dft_sizes(H, W), twQ = the operand matrices of os2d_dft_matrices_build for it, twP = NULL.
- * Width: maps up to 316 columns; beyond 209 (the direct 7x7 kernels' limit) only the frequency-domain precisions run.        */
+ * Width: maps up to 3600 columns (reference head.py:619-629 has no limit); beyond 209 (the direct 7x7 kernels' limit) only the
+ * frequency-domain precisions run (tiled), beyond 316 the 5x5 kernels run in column strips (conv_f16x3.hip).                   */
 #define OS2D_STATUS_F16_RANGE 1
 int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const float* b1, const void* w2,
                          const float* b2, const void* w3, const float* b3, int A, int B, int C, int H, int W, int P,

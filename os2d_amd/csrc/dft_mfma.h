@@ -55,6 +55,12 @@
 #ifndef DFT_INV_SPREAD
 #define DFT_INV_SPREAD 0          /* the same for the next spectra and step A */
 #endif
+#ifndef DFT_FWD_PREFETCH_AFTER
+#define DFT_FWD_PREFETCH_AFTER 0  /* 1: the next window's loads are issued right AFTER step 2 instead of in front of it */
+#endif
+#ifndef DFT_INV_PREFETCH_AFTER
+#define DFT_INV_PREFETCH_AFTER 0  /* the same for the next spectra and step A */
+#endif
 #ifndef DFT_PIPE_REGA
 #define DFT_PIPE_REGA 1           /* 1: step 2 / step A read the fragments of k-step ks + 1 before the matrix instructions of ks */
 #endif
@@ -773,6 +779,9 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
       };
       if (DFT_FWD_SPREAD && KS2 > 0) {      // (compile-time k-step count: every request lands at a compile-time position)
         dft_product_rega_any<KS2>(xc, nt2w, fp2h, fp2l, ks2n, ldsU, N2S, wv >> 2, NW / 4, l31, hw, request);
+      } else if (DFT_FWD_PREFETCH_AFTER) {      // the burst behind the product: its issue overlaps the tail of the matrix work
+        dft_product_rega_any<KS2>(xc, nt2w, fp2h, fp2l, ks2n, ldsU, N2S, wv >> 2, NW / 4, l31, hw, DftNoHook());
+        DFT_FWD_PREFETCH_SLOTS(itn, tl, 0, NSLOT)
       } else {
         DFT_FWD_PREFETCH_SLOTS(itn, tl, 0, NSLOT)
         dft_product_rega_any<KS2>(xc, nt2w, fp2h, fp2l, ks2n, ldsU, N2S, wv >> 2, NW / 4, l31, hw, DftNoHook());
@@ -1046,6 +1055,9 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
       };
       if (DFT_INV_SPREAD && KSA > 0) {
         dft_product_rega_any<KSA>(ta, ntaw, e2h, e2l, ksAn, ldsU, N2S, wv >> 2, 2, l31, hw, request);
+      } else if (DFT_INV_PREFETCH_AFTER) {
+        dft_product_rega_any<KSA>(ta, ntaw, e2h, e2l, ksAn, ldsU, N2S, wv >> 2, 2, l31, hw, DftNoHook());
+        DFT_INV_PREFETCH_ITEMS(itn, tl, 0, NITEM)
       } else {
         DFT_INV_PREFETCH_ITEMS(itn, tl, 0, NITEM)
         dft_product_rega_any<KSA>(ta, ntaw, e2h, e2l, ksAn, ldsU, N2S, wv >> 2, 2, l31, hw, DftNoHook());

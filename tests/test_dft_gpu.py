@@ -158,10 +158,12 @@ def test_dft_transforms_full_size_timing(device):
     for name, fn, nbytes in (("forward", fwd, NB * 225 * (H * W * 4 + nbins * 8)), ("inverse", invt, NB * 128 * (nbins * 8 + H * W * 4))):
         fn()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(10):
-            fn()
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / 10 * 1e3
+        ms = float("inf")
+        for _ in range(5):       # best of 5 x 10 launches: a wall-clock guard must survive one host / clock hiccup (round 5: a run of
+            t0 = time.perf_counter()      # the suite measured 8.7 ms once where every other run measures 0.2)
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
+            ms = min(ms, (time.perf_counter() - t0) / 10 * 1e3)
         print("dft {} 64 pairs 60x80: {:.3f} ms = {:.2f} TB/s algorithmic".format(name, ms, nbytes / ms / 1e9))
         assert ms < 2.0

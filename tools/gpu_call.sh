@@ -12,6 +12,7 @@
 #                          (the raw rocprofv3 databases are deleted after summarising: gpurun merges at most 64 MiB back)
 #         gemm[:<variant>] tools/time_spectral16_quads.py 64 256 1024 (the per-bin GEMM alone) with the product library or a variant
 #         power            tools/power_probe.sh: package power / clocks while the correlation, the step and the register-only MFMA loop run
+#         env:VAR=VALUE / unset:VAR   export / unset an environment variable for the steps that follow
 #         bin:<name>       tools/bin/<name> (a standalone HIP program built on the dev box, e.g. split_mix_check)
 #         soak[:<rounds>]  tools/soak_multistream.sh: victim / aggressor rounds + the pyramid on 7 streams against the serial run (default 300)
 #         mfma             tools/bin/mfma_peak: what v_mfma_f32_32x32x16_f16 sustains (register-only loop, zero / random operands)
@@ -46,6 +47,10 @@ for STEP in "$@"; do
       timeout 300 python tools/time_spectral16_quads.py 64 256 1024 2>&1 | grep -v amdgpu.ids | sed "s/^/[${V:-product}] /" | tee -a $OUT/gemm_times.txt | tail -6; unset OS2D_HIP_LIB;;
     power)
       bash tools/power_probe.sh > $OUT/power_probe.log 2>&1; cp -f gpurun_out/power/power_probe.txt $OUT/power_probe_raw.txt 2>/dev/null; grep -v "^LOOP\|{" $OUT/power_probe.log | tail -12; grep "^LOOP" $OUT/power_probe.log;;
+    env:*)
+      export "${STEP#env:}"; echo "exported ${STEP#env:}";;
+    unset:*)
+      unset "${STEP#unset:}";;
     bin:*)
       tools/bin/${STEP#bin:} 2>&1 | tee $OUT/${STEP#bin:}.txt | tail -12;;
     soak|soak:*)

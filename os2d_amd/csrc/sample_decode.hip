@@ -16,6 +16,10 @@
 // each of the 121x4 gathers is a near-coalesced L2 read of the 4.3 MB per-class correlation block.
 #include "os2d_common.h"
 
+#ifndef OS2D_SAMPLE_BATCH
+#define OS2D_SAMPLE_BATCH 1
+#endif
+
 namespace {
 
 constexpr int POOL_LO = 2, POOL_HI = OS2D_T - 2;  // head.py:280,296-302: pool_border_width = 2
@@ -99,6 +103,12 @@ __global__ __launch_bounds__(256) void sample_decode_kernel(const float* __restr
   const float wmax = (float)(W - 1), hmax = (float)(H - 1);
   const float* cbase = corr + (size_t)nb * OS2D_K * HW;
   float sum = 0.f;
+  // One template column (11 taps = 44 gathers) at a time, in two passes: ALL 44 loads are requested before the first one is
+  // used (round 5).  Written tap by tap the compiler kept 4 loads in flight per thread (24 registers): at 64 classes - 19 waves
+  // per CU - the kernel was a chain of 121 cache round trips per thread (0.087 ms against 0.052 ms per 64 classes inside the
+  // 1024-class launch, where occupancy hides them).  Same operations in the same order: the sums are bit-identical.
+  constexpr int NTAP = POOL_HI - POOL_LO;
+#if !OS2D_SAMPLE_BATCH       /* diagnostic (-DOS2D_SAMPLE_BATCH=0): tap by tap, as rounds 1 - 4 */
   for (int j = POOL_LO; j < POOL_HI; ++j) {
     const float xj = os2d_template_coord(j);
 #pragma unroll
@@ -118,6 +128,37 @@ __global__ __launch_bounds__(256) void sample_decode_kernel(const float* __restr
       sum += (v00 * (1.f - ax) + v01 * ax) * (1.f - ay) + (v10 * (1.f - ax) + v11 * ax) * ay;
     }
   }
+  (void)NTAP;
+#else
+  for (int j = POOL_LO; j < POOL_HI; ++j) {
+    const float xj = os2d_template_coord(j);
+    float axs[NTAP], ays[NTAP], v00[NTAP], v01[NTAP], v10[NTAP], v11[NTAP];
+#pragma unroll
+    for (int i = POOL_LO; i < POOL_HI; ++i) {
+      const float yi = os2d_template_coord(i);
+      const float gx = t00 * xj + t01 * yi + t02;
+      const float gy = t10 * xj + t11 * yi + t12;
+      const float X = fminf(fmaxf(gx * half_t + cx, 0.f), wmax);
+      const float Y = fminf(fmaxf(gy * half_t + cy, 0.f), hmax);
+      const float fx0 = floorf(X), fy0 = floorf(Y);
+      axs[i - POOL_LO] = X - fx0;
+      ays[i - POOL_LO] = Y - fy0;
+      const int x0 = (int)fx0, y0 = (int)fy0;
+      const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+      const float* c = cbase + (size_t)(j * OS2D_T + i) * HW;
+      v00[i - POOL_LO] = c[y0 * W + x0];
+      v01[i - POOL_LO] = c[y0 * W + x1];
+      v10[i - POOL_LO] = c[y1 * W + x0];
+      v11[i - POOL_LO] = c[y1 * W + x1];
+    }
+    __builtin_amdgcn_sched_barrier(0);      // the scheduler keeps the 44 requests in front of the arithmetic
+#pragma unroll
+    for (int k = 0; k < NTAP; ++k) {
+      const float ax = axs[k], ay = ays[k];
+      sum += (v00[k] * (1.f - ax) + v01[k] * ax) * (1.f - ay) + (v10[k] * (1.f - ax) + v11[k] * ax) * ay;
+    }
+  }
+#endif
   cls[ob * HW + n] = sum * (1.0f / ((POOL_HI - POOL_LO) * (POOL_HI - POOL_LO)));
 
   // ---- box of the transformed template in image coordinates (the 4 corners bound the affine image)

@@ -4,6 +4,7 @@
 # steps:  tests            the whole GPU suite (pytest -m gpu)
 #         tests:<expr>     pytest -m gpu -k <expr>
 #         bench            the driver's command (python bench.py --gpus 1 --steps 20 --warmup 5): line + details + stderr
+#         stages[:<variant>]  stage times of the 64- and the 1024-class step (product library or a variant)
 #         bench1024        python bench.py --classes 1024 (stage times of the 1024-class step only)
 #         prof             rocprofv3 --kernel-trace --stats + PMC passes of the 64-class step (tools/profile_bench.sh)
 #         prof1024         the same at 1024 classes
@@ -32,6 +33,10 @@ for STEP in "$@"; do
     bench)
       ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$? line bytes=$(wc -c < $OUT/bench.json)"
       cp -f gpurun_out/bench_details.json $OUT/bench_details.json 2>/dev/null; cat $OUT/bench.json;;
+    stages|stages:*)
+      V=""; [ "$STEP" != stages ] && V=${STEP#stages:}
+      if [ -n "$V" ]; then export OS2D_HIP_LIB=tools/diag_libs/$V/libos2d_hip.so; fi
+      for N in 64 1024; do timeout 300 python bench.py --classes $N --steps 10 --warmup 3 --no-cpu-baseline --no-other-precision --no-end-to-end --no-sweep --no-live-counters 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('[${V:-product}] classes $N', d['ms_per_step'], d['stages_ms'])" | tee -a $OUT/stages.txt; done; unset OS2D_HIP_LIB;;
     bench1024)
       ( timeout 600 python bench.py --classes 1024 --steps 5 --warmup 2 --no-cpu-baseline --no-other-precision --no-end-to-end --no-sweep --no-live-counters ) > $OUT/bench1024.json 2> $OUT/bench1024.err; echo "rc=$?"; cat $OUT/bench1024.json;;
     prof)

@@ -58,6 +58,9 @@ constexpr int SH_WSTAGE = 2 * SH_STAGE;        // weights of both output-channel
 #ifndef OS2D_SH_PINGPONG
 #define OS2D_SH_PINGPONG 0    /* 1: the two halves of the work-group run half a k-step apart (one multiplies while the other converts): measured no faster */
 #endif
+#ifndef OS2D_SH_AHEAD
+#define OS2D_SH_AHEAD 2       /* k-steps both operands run ahead (3: one more register set of each, experiment) */
+#endif
 #ifndef OS2D_SH_XAHEAD
 #define OS2D_SH_XAHEAD 2      /* k-steps the spectra loads run ahead of the matrix instructions; 4 (two more register sets) measured no faster */
 #endif
@@ -419,6 +422,33 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
   }
 #undef SH_PP0
 #undef SH_PP1
+#elif OS2D_SH_AHEAD == 3
+  // DIAGNOSTIC (-DOS2D_SH_AHEAD=3; measured no faster at 64 / 256 / 1024 pairs, profiles/r05/spectral_gemm_xahead.txt).  BOTH operands
+  // three k-steps ahead: at 64 pairs the weights - 634 of the launch's 1,131 MB - come from HBM,
+  // not from L2 as in the 16 pair blocks of a 1024-pair launch, and a k-step takes 3.3 us against 2.2 us there.  Three register sets
+  // of each operand (+ 24 registers), period 3: three k-steps per pass; requests unconditional and clamped, the pass count rounded
+  // up (a k-step beyond the last multiplies nothing and stores into a stage nobody reads): exact wait counts, no guarded tail.
+  u32x4 wrc[4], pfc[2];
+#define SH_STEP3(S, WC, PC, WN, PN)                                                                                 \
+  {                                                                                                                 \
+    SH_LOAD_W(min((S) + 3, KS - 1), WN)                                                                             \
+    SH_LOAD_X(min((S) + 3, KS - 1), PN)                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    if ((S) < KS) SH_COMPUTE(S)                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    SH_STORE_W((S) + 1, WC)                                                                                         \
+    SH_STORE_X((S) + 1, PC)                                                                                         \
+    sh_lds_barrier();                                                                                               \
+  }
+  // sets by k-step % 3: 0 -> (wrb, pfb) [k-step 0 was loaded there by the prologue], 1 -> (wra, pfa), 2 -> (wrc, pfc)
+  SH_LOAD_W(min(2, KS - 1), wrc)
+  SH_LOAD_X(min(2, KS - 1), pfc)
+  for (; s < KS; s += 3) {
+    SH_STEP3(s, wra, pfa, wrb, pfb)
+    SH_STEP3(s + 1, wrc, pfc, wra, pfa)
+    SH_STEP3(s + 2, wrb, pfb, wrc, pfc)
+  }
+#undef SH_STEP3
 #elif OS2D_SH_XAHEAD == 4
   // DIAGNOSTIC (-DOS2D_SH_XAHEAD=4; round 5, measured NO faster: 2.97 / 3.00 against 2.94 / 2.95 ms at 1024 pairs, 0.283 / 0.292
   // against 0.287 / 0.290 at 64, profiles/r05/spectral_gemm_xahead.txt - the k-step is not waiting for late spectra).  The idea:

@@ -302,7 +302,7 @@ def test_widest_supported_level_and_clean_failure_beyond(precision, device):
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
-@pytest.mark.parametrize("W,H", [(317, 6), (400, 9), (640, 7)])
+@pytest.mark.parametrize("W,H", [(317, 6), (400, 9), (640, 7), (1030, 3)])
 def test_maps_wider_than_the_linear_slabs_run_in_column_strips(W, H, precision, device):
     """the reference has no width limit (head.py:619-629).  Beyond W = 316 the 5x5 kernels run in column
     strips (conv_f16x3.hip STRIP mode, conv3_f16x3.hip, conv_mfma.hip; geometry restated in tests/test_conv_strips_model.py) and

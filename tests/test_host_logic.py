@@ -263,3 +263,27 @@ def test_bench_compact_line_fits_the_driver():
     bad = dict(full, value=float("nan"), roofline=dict(full["roofline"], hbm_gbps=float("inf")))
     d = json.loads(bench.compact_line(bad), parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
     assert d["value"] is None and d["roofline"]["hbm_gbps"] is None
+
+
+def test_bench_compact_line_of_a_multi_rank_record():
+    """The N > 1 record (no sweep / cpu_baseline / stage events; all-gather probe, gather wait, the other exchanges) through the
+    same compaction: contract keys first, the diagnosis fields of a first real multi-GPU run kept, still one short line."""
+    import json
+    import bench
+    rec = {"metric": "query-image-pairs/s (1280-px input, ResNet50, N-class)", "value": 400000.0, "unit": "query-image-pairs/s", "n_gpus": 8,
+           "steps": 20, "warmup": 5, "ms_per_step": 2.56, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "fftx3 (...)",
+           "data": "synthetic", "config": {"workload": "BASELINE.json configs[2]: ...", "classes_per_gpu": [128] * 8, "classes_total": 1024,
+                                           "feature_map": [1024, 60, 80], "precision": "fftx3", "parallelism": "class-sharded x8 ...", "dist_timeout_s": 180.0},
+           "roofline": {"kernel": "whole head of one rank: ...", "bound": "mfma", "achieved": 900.0, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.36,
+                        "traffic": None, "flops_per_launch": 1, "avg_launch_ms": 2.56, "timing": "wall clock", "peak_is": "x" * 300},
+           "head_tflops_algorithmic": 7000.0, "gather_wait_ms": 0.01,
+           "allgather_probe": {"bytes_per_rank": 32 << 20, "ms": 0.9, "busbw_gbps": 260.0, "algbw_gbps": 298.0, "what": "y" * 400},
+           "other_gathers": [{"gather": "scores", "what": "score maps only", "value": 410000.0, "ms_per_step": 2.5, "steps": 10},
+                             {"gather": "detections", "what": "...", "value": 380000.0, "ms_per_step": 2.7, "steps": 10}]}
+    line = bench.compact_line(rec)
+    d = json.loads(line)
+    assert len(line) < 2000 and list(d)[:len(bench.CONTRACT_KEYS) - 1] == [k for k in bench.CONTRACT_KEYS if k in rec]
+    assert "cpu_baseline" not in d and d["roofline"]["traffic"] is None and "peak_is" not in d["roofline"]
+    assert d["allgather_probe"] == {"bytes_per_rank": 32 << 20, "ms": 0.9, "busbw_gbps": 260.0, "algbw_gbps": 298.0}
+    assert d["other_gathers"] == {"scores": 410000.0, "detections": 380000.0} and d["gather_wait_ms"] == 0.01
+    assert d["config"]["classes_per_gpu"] == [128] * 8

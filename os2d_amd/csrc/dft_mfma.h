@@ -56,10 +56,12 @@
 #define DFT_INV_SPREAD 0          /* the same for the next spectra and step A */
 #endif
 #ifndef DFT_FWD_PREFETCH_AFTER
-#define DFT_FWD_PREFETCH_AFTER 0  /* 1: the next window's loads are issued right AFTER step 2 instead of in front of it */
+#define DFT_FWD_PREFETCH_AFTER 2  /* the next window's loads right AFTER step 2 instead of in front of it: 0 never, 1 always, 2 for the
+                                     transforms of up to 6 k-steps (measured: 4 - 5 % faster for (44,54), neutral for (56,70), slower for
+                                     (64,84): profiles/r05/dft_phases_prefetch_after.txt) */
 #endif
 #ifndef DFT_INV_PREFETCH_AFTER
-#define DFT_INV_PREFETCH_AFTER 0  /* the same for the next spectra and step A */
+#define DFT_INV_PREFETCH_AFTER 2  /* the same for the next spectra and step A */
 #endif
 #ifndef DFT_PIPE_REGA
 #define DFT_PIPE_REGA 1           /* 1: step 2 / step A read the fragments of k-step ks + 1 before the matrix instructions of ks */
@@ -779,7 +781,7 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
       };
       if (DFT_FWD_SPREAD && KS2 > 0) {      // (compile-time k-step count: every request lands at a compile-time position)
         dft_product_rega_any<KS2>(xc, nt2w, fp2h, fp2l, ks2n, ldsU, N2S, wv >> 2, NW / 4, l31, hw, request);
-      } else if (DFT_FWD_PREFETCH_AFTER) {      // the burst behind the product: its issue overlaps the tail of the matrix work
+      } else if (DFT_FWD_PREFETCH_AFTER == 1 || (DFT_FWD_PREFETCH_AFTER == 2 && KS2 > 0 && KS2 <= 6)) {      // the burst behind the product
         dft_product_rega_any<KS2>(xc, nt2w, fp2h, fp2l, ks2n, ldsU, N2S, wv >> 2, NW / 4, l31, hw, DftNoHook());
         DFT_FWD_PREFETCH_SLOTS(itn, tl, 0, NSLOT)
       } else {
@@ -1055,7 +1057,7 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
       };
       if (DFT_INV_SPREAD && KSA > 0) {
         dft_product_rega_any<KSA>(ta, ntaw, e2h, e2l, ksAn, ldsU, N2S, wv >> 2, 2, l31, hw, request);
-      } else if (DFT_INV_PREFETCH_AFTER) {
+      } else if (DFT_INV_PREFETCH_AFTER == 1 || (DFT_INV_PREFETCH_AFTER == 2 && KSA > 0 && KSA <= 6)) {
         dft_product_rega_any<KSA>(ta, ntaw, e2h, e2l, ksAn, ldsU, N2S, wv >> 2, 2, l31, hw, DftNoHook());
         DFT_INV_PREFETCH_ITEMS(itn, tl, 0, NITEM)
       } else {

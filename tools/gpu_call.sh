@@ -33,6 +33,10 @@ for STEP in "$@"; do
     bench)
       ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$? line bytes=$(wc -c < $OUT/bench.json)"
       cp -f gpurun_out/bench_details.json $OUT/bench_details.json 2>/dev/null; cat $OUT/bench.json;;
+    levels|levels:*)
+      V=""; [ "$STEP" != levels ] && V=${STEP#levels:}
+      if [ -n "$V" ]; then export OS2D_HIP_LIB=tools/diag_libs/$V/libos2d_hip.so; fi
+      timeout 300 python tools/time_pyramid_levels.py 2>&1 | grep -v "amdgpu.ids\|^{" | sed "s/^/[${V:-product}] /" | tee -a $OUT/levels.txt | tail -11; unset OS2D_HIP_LIB;;
     stages|stages:*)
       V=""; [ "$STEP" != stages ] && V=${STEP#stages:}
       if [ -n "$V" ]; then export OS2D_HIP_LIB=tools/diag_libs/$V/libos2d_hip.so; fi

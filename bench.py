@@ -118,6 +118,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-precision", action="store_true")
     ap.add_argument("--no-other-gather", action="store_true")
+    ap.add_argument("--no-one-gpu-reference", action="store_true",
+                    help="N > 1: skip rank 0's single-GPU timing of the same workload (one_gpu_same_workload / speedup_vs_one_gpu)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the 256-class V1 / 1024-class / pyramid lines (N=1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-live-counters", action="store_true",
@@ -125,6 +127,33 @@ def parse():
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="skip the secondary end-to-end leg (backbone + class-head build + head + decode/NMS)")
     return ap.parse_args()
+
+
+def host_cpu_topology():
+    """{"logical_cpus", "physical_cores", "sockets"} of the host from /proc/cpuinfo (state the physical core count, not only
+    the hardware threads); None for what cannot be read."""
+    logical = os.cpu_count()
+    cores, sockets = set(), set()
+    try:
+        with open("/proc/cpuinfo") as f:
+            phys = core = None
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                        sockets.add(phys)
+                    phys = core = None
+            if phys is not None and core is not None:
+                cores.add((phys, core))
+                sockets.add(phys)
+    except OSError:
+        pass
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else logical
+    return {"logical_cpus": logical, "physical_cores": len(cores) or None, "sockets": len(sockets) or None, "usable_by_this_process": usable}
 
 
 def cpu_baseline(fm_cpu, class_fms_cpu, state, inverse, budget_s):
@@ -150,7 +179,9 @@ def cpu_baseline(fm_cpu, class_fms_cpu, state, inverse, budget_s):
             dt = time.perf_counter() - t0
             results.append((done / dt, threads, done, dt))
     best = max(results)
+    topo = host_cpu_topology()
     return {"value": round(best[0], 3), "unit": "query-image-pairs/s", "cores": best[1], "kind": "port",
+            "host_physical_cores": topo["physical_cores"], "host_logical_cpus": topo["logical_cpus"], "host_sockets": topo["sockets"],
             "sample": "{} class calls looped one at a time (reference evaluate.py:323-331 call pattern) on one "
                       "60x80x1024 feature map, {:.1f} s, torch CPU fp32, best of {} threads ({}) on {} hw threads"
                       .format(best[2], best[3], "/".join(str(r[1]) for r in results),
@@ -881,6 +912,23 @@ def run_bench(args, rank, local_rank, world, dev, use_dist):
         classes_total, scaling = 64, "weak"              # BASELINE.json configs[1]
     if classes_total < world:
         raise SystemExit("need at least one class per rank")
+    one_gpu = None
+    if use_dist and not args.no_one_gpu_reference:
+        # The N = 1 point of THIS curve, in THIS run: rank 0 alone times all classes_total classes of the same
+        # workload on its GPU - the others wait at the barrier - so that the line of an N > 1 run carries its own single-GPU
+        # reference and speed-up (the default N = 1 command measures configs[1], 64 classes: another workload).
+        if rank == 0:
+            w1 = Workload(dev, 0, 1, classes_total, args.variant, args.pyramid, False, "all")
+            n1 = max(2, min(args.steps, 10))
+            dt1, _ = w1.run(args.precision, n1, max(1, min(args.warmup, 2)))
+            one_gpu = {"pairs_per_s": round(classes_total * n1 / dt1, 2), "ms_per_step": round(dt1 / n1 * 1e3, 4), "steps": n1,
+                       "what": "all {} classes on rank 0's GPU alone, same process, before the sharded steps".format(classes_total)}
+            del w1
+            from os2d_amd.modeling import head as head_mod
+            head_mod.release_workspaces()
+            torch.cuda.empty_cache()
+        torch.cuda.synchronize(dev)
+        dist.barrier()
     w = Workload(dev, rank, world, classes_total, args.variant, args.pyramid, use_dist, args.gather)
 
     dt, stage_ms = w.run(args.precision, args.steps, args.warmup)
@@ -908,6 +956,9 @@ def run_bench(args, rank, local_rank, world, dev, use_dist):
                    "parallelism": ("class-sharded x{} ({} scaling) + RCCL all-gather per step of the {}".format(world, scaling, gather_desc[args.gather])
                                    if use_dist else "single GPU")},
     }
+    if one_gpu is not None:
+        result["one_gpu_same_workload"] = one_gpu
+        result["speedup_vs_one_gpu"] = round(value / one_gpu["pairs_per_s"], 3)
     if stage_ms:
         result["stages_ms"] = {k: round(v, 4) for k, v in zip(STAGES, stage_ms)}
     if stage_ms:
@@ -933,6 +984,15 @@ def run_bench(args, rank, local_rank, world, dev, use_dist):
                 o["stages_ms"] = {k: round(v, 4) for k, v in zip(STAGES, stage2)}
             o["roofline"] = w.roofline(other, stage2, dt2 / n2)
             result["other_precisions"].append(o)
+            if other == "fft32" and stage2 and not args.pyramid:
+                # the strict reading of the precision claim (no fp16 value anywhere) with a complete record of its own: the longest
+                # kernel of the fft32 step against ITS roof - 157.3 TFLOP/s of v_mfma_f32_32x32x2_f32, or 8 TB/s
+                pk = w.rooflines(stage2, "fft32")
+                lk = max(pk, key=lambda k: pk[k]["avg_launch_ms"])
+                result["roofline_strict_fp32"] = {"precision": "fft32", "pairs_per_s": o["value"], "ms_per_step": o["ms_per_step"], "stage": lk,
+                                                  "kernel": pk[lk].get("pmc_kernel"), "bound": pk[lk]["bound"], "achieved": pk[lk]["achieved"],
+                                                  "peak": pk[lk]["peak"], "unit": pk[lk]["unit"], "frac": pk[lk]["frac"],
+                                                  "avg_launch_ms": pk[lk]["avg_launch_ms"]}
         if not args.pyramid:
             result["max_abs_diff_vs_f32"] = precision_deviation(w)
     if use_dist:
@@ -1081,6 +1141,9 @@ def compact_line(result, budget=LINE_BUDGET):
     if isinstance(result.get("roofline_other"), dict):
         optional.append(("roofline_other", {k: [v.get("frac"), v.get("avg_launch_ms")] for k, v in result["roofline_other"].items()}))
         optional.append(("roofline_other_is", "{kernel: [frac of its bound (see bench_details.json), avg launch ms]}"))
+    for k in ("one_gpu_same_workload", "speedup_vs_one_gpu", "roofline_strict_fp32"):      # (first = dropped last)
+        if k in result:
+            optional.append((k, {f: v for f, v in result[k].items() if f != "what"} if isinstance(result[k], dict) else result[k]))
     for k in ("speedup_vs_cpu_baseline", "head_tflops_algorithmic", "f32_pairs_per_s", "fft32_pairs_per_s", "gather_wait_ms"):
         if k in result:
             optional.append((k, result[k]))

@@ -81,8 +81,8 @@ int os2d_class_prepare_batch(const float* const* srcs, const int* sizes, int B, 
  *   stride / rec_field: backbone stride and receptive field (16 / 16 for ResNet-C4, feature_extractor.py:115-117)
  *   outputs loc [A,B,4,H,W], cls [A,B,1,H,W], corners [A,B,8,H,W]  (cls_detached aliases cls in eval, head.py:400-402)
  * The workspace may be smaller than os2d_head_workspace_bytes(A,B,...) reports: classes are then processed in
- * chunks; it must hold at least os2d_head_workspace_bytes(A,1,...) bytes.  C must be a multiple of 4; W <= 3600 (the transform
- * planner's 48 tiles per axis), and W <= 209 for the DIRECT 7x7 kernels of os2d_head_forward / the non-frequency precisions
+ * chunks; it must hold at least os2d_head_workspace_bytes(A,1,...) bytes.  C must be a multiple of 4; W <= 3600 and H <= 2784 (the
+ * transform planner's 48 tiles per axis), and W <= 209 for the DIRECT 7x7 kernels of os2d_head_forward / the non-frequency precisions
  * (3344-px wide images at stride 16: they keep three halo rows in LDS); all checked before any launch. */
 int os2d_head_workspace_bytes(int A, int B, int C, int H, int W, int P, size_t* bytes);
 int os2d_head_workspace_bytes_ex(int A, int B, int C, int H, int W, int P, int precision, size_t* bytes);  /* + spectra (FFT mode) */
@@ -125,8 +125,15 @@ int os2d_class_split(const float* qp, void* qs, int B, int C, void* stream);
  *                 (= start of the spectral GEMM) and the end of the GEMM (= start of the inverse transform) inside stage 1;
  *   chunk_classes NULL, or receives the number of classes per chunk chosen for the given workspace;
  *   status        NULL, or a device-visible int (device memory or mapped pinned host memory) that receives sticky
- *                 status bits (plain system-scope stores, never cleared by the library): OS2D_STATUS_F16_RANGE when a split-fp16 activation left the
- *                 fp16 range (only possible with non-finite inputs) - the caller then re-runs in OS2D_PRECISION_F32;
+ *                 status bits (plain system-scope stores, never cleared by the library): OS2D_STATUS_F16_RANGE when an image
+ *                 feature was non-finite or a split-fp16 activation left the fp16 range (only possible with non-finite
+ *                 inputs).  The OUTPUTS of such a call are poisoned on the device, by the call itself: the split-fp16 kernels
+ *                 store the call's epoch into range words at the start of the workspace (one per image, one for the whole call)
+ *                 and the last kernel writes NaN into loc / cls / corners of every flagged image, as the reference's
+ *                 torch.relu / norm propagate a NaN (head.py:339, 650) - no host synchronisation, later calls unaffected.  The
+ *                 words are never cleared (a stale epoch matches no later call); zero-fill the first 4 KB of a NEW workspace
+ *                 once so that its initial content cannot match either.  A caller that wants the reference's exact NaN
+ *                 pattern re-runs a flagged call in OS2D_PRECISION_F32, whose kernels keep NaN through their ReLUs;
  *   wspec, twQ, twP  the frequency-domain precisions only (NULL otherwise; w1 / b1..b3 / w2 / w3 as for F16X3, FFT32: as for F32):
  *                 OS2D_PRECISION_FFT / _FFT32: the weight spectra of the 7x7 layer for THIS map's transform size in the layout of
  *                 os2d_spectral_gemm and the two twiddle tables of os2d_fft_forward;

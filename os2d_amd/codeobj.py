@@ -81,18 +81,14 @@ def kernels(path, arch="gfx950"):
     return out
 
 
-def demangled(name):
-    """A readable form of an Itanium-mangled kernel name without a demangler: the identifiers and template integers in order."""
-    import re
-    ids = re.findall(r"(?<![A-Za-z_])\d+([A-Za-z_][A-Za-z0-9_]*)", name)
-    return name if not ids else name
-
-
 def main(argv):
     here = os.path.dirname(os.path.abspath(__file__))
     path = argv[1] if len(argv) > 1 and os.path.exists(argv[1]) else os.path.join(here, "lib", "libos2d_hip.so")
-    pats = [a for a in argv[1:] if a != path]
+    pats = [a for a in argv[1:] if a != path and a != "--names"]
     ks = kernels(path)
+    if "--names" in argv:        # the sorted kernel symbols, one per line: tests/golden/kernels.txt is this output
+        print("\n".join(sorted(ks)))
+        return 0
     print("{:>5} {:>5} {:>6} {:>7} {:>7}  kernel".format("vgpr", "agpr", "spills", "scratch", "lds"))
     for name in sorted(ks):
         if pats and not any(p in name for p in pats):

@@ -4,7 +4,9 @@
 
 #include "../../include/os2d_hip.h"
 #include "os2d_common.h"
+#include <atomic>
 #include <mutex>
+#include <random>
 #include <vector>
 
 namespace {
@@ -30,7 +32,7 @@ int os2d_conv1_steps_padded() { return 25; }
 
 // workspace carve for a chunk of Bc classes
 struct Carve {
-  size_t sumsq, fs, corr, rpad, h1, h2, params, invn, sumfx, xspec, yspec, total;
+  size_t flags, sumsq, fs, corr, rpad, h1, h2, params, invn, sumfx, xspec, yspec, total;
 };
 Carve carve(int A, int Bc, int C, int H, int W, int P, int fft_bins = 0, int fft_tiles = 1, int xspec_channels = OS2D_K) {
   const size_t HW = (size_t)H * W, PL = os2d_plane(H, W), NB = (size_t)A * Bc;
@@ -41,6 +43,7 @@ Carve carve(int A, int Bc, int C, int H, int W, int P, int fft_bins = 0, int fft
     off = align_up(off + floats * sizeof(float), 256);
     return o;
   };
+  c.flags = take((size_t)A + 1);           // range words of the call: one per image + one for the whole call (Os2dRangeFlag); FIRST
   c.sumsq = take((size_t)A * HW);
   c.fs = take((size_t)A * os2d_corr_groups(C) * 2 * HW * 4);  // f16x3: split image features, 16 B per (group, part, cell)
   c.corr = take(NB * OS2D_K * HW);
@@ -61,7 +64,7 @@ Carve carve(int A, int Bc, int C, int H, int W, int P, int fft_bins = 0, int fft
 }
 
 // ---- debugging aid (tools/diag_pyramid_dump.py): copies of intermediate buffers of os2d_head_forward_ex, per stream.
-// Compiled only into DIAGNOSTIC builds (python -m os2d_amd.build --variant dump -DOS2D_DIAG_DUMP): a registered destination
+// Compiled only into DIAGNOSTIC builds (python -m os2d_amd.build --variant dump, with the macro below defined): a registered destination
 // is a raw pointer nobody can unregister safely once its tensor is freed, and the table would be consulted by every
 // production call.  In the product library os2d_debug_set_dump only reports that it does nothing.
 #ifdef OS2D_DIAG_DUMP
@@ -99,7 +102,25 @@ bool head_args_ok(int A, int B, int C, int H, int W, int P) {
                    "at stride 16 are not supported)", W, OS2D_MAX_W, OS2D_MAX_W * 16);
     return false;
   }
+  if (H > OS2D_MAX_H) {
+    os2d_set_error("feature map height %d > %d: beyond what the transform planner of the 7x7 layer tiles (images taller than %d px "
+                   "at stride 16 are not supported)", H, OS2D_MAX_H, OS2D_MAX_H * 16);
+    return false;
+  }
   return true;
+}
+// The epoch of a head call: what its kernels store into the range words of the workspace (os2d_common.h: Os2dRangeFlag).  Unique per
+// call of the process, never 0 (a zero-filled workspace) and never OS2D_STATUS_F16_RANGE; the base is random so that the stale
+// content of a workspace that was NOT zero-filled matches a call's epoch with probability 2^-32.
+int next_epoch() {
+  static std::atomic<unsigned> counter{[] {
+    std::random_device rd;
+    return (unsigned)rd() | 0x100u;
+  }()};
+  unsigned e;
+  do e = counter.fetch_add(1u, std::memory_order_relaxed) + 1u;
+  while (e < 2u);
+  return (int)e;
 }
 bool is_freq(int precision) {
   return precision == OS2D_PRECISION_FFT || precision == OS2D_PRECISION_FFTX3 || precision == OS2D_PRECISION_FFT32;
@@ -276,7 +297,7 @@ int os2d_corr_f16x3(const float* fm, const void* qs, float* corr, void* rshb, in
   float* sumsq = static_cast<float*>(workspace);
   void* fs = static_cast<char*>(workspace) + align_up((size_t)A * H * W * sizeof(float), 256);
   int rc = os2d_launch_fm_sumsq(fm, sumsq, A, C, H * W, S(stream));
-  if (!rc) rc = os2d_launch_split_fm(fm, sumsq, fs, A, C, H * W, nullptr, 0, nullptr, S(stream));
+  if (!rc) rc = os2d_launch_split_fm(fm, sumsq, fs, A, C, H * W, nullptr, 0, Os2dRangeFlag{nullptr, 0}, S(stream));
   if (!rc) rc = os2d_launch_border_zero_shb(rshb, A * B, H, W, S(stream));
   if (!rc) rc = os2d_launch_corr_f16x3(fs, qs, corr, rshb, nullptr, nullptr, 0, A, B, C, H, W, S(stream));
   return rc;
@@ -302,7 +323,7 @@ int os2d_corr_f16x3_packed(const float* fm, const void* qs, float* corr, float* 
   void* fs = static_cast<char*>(workspace) + align_up((size_t)A * H * W * sizeof(float), 256);
   void* sumfx = static_cast<char*>(workspace) + align_up(os2d_corr_f16x3_workspace_bytes(A, C, H, W), 256);
   int rc = os2d_launch_fm_sumsq(fm, sumsq, A, C, H * W, S(stream));
-  if (!rc) rc = os2d_launch_split_fm(fm, sumsq, fs, A, C, H * W, nullptr, 0, nullptr, S(stream));
+  if (!rc) rc = os2d_launch_split_fm(fm, sumsq, fs, A, C, H * W, nullptr, 0, Os2dRangeFlag{nullptr, 0}, S(stream));
   const bool packed = form > 0 || (form < 0 && os2d_corr_f16x3_use_packed(A, B, H, W));
   if (!rc && packed) rc = os2d_launch_corr_sums_clear(sumfx, A, B, H, W, S(stream));
   if (!rc) rc = os2d_launch_corr_f16x3(fs, qs, corr, nullptr, inv_norm, packed ? sumfx : nullptr, form == 2 ? 2 : 0, A, B, C, H, W, S(stream));
@@ -333,7 +354,7 @@ int os2d_sample_decode(const float* corr, const float* params, int NB, int H, in
     return -1;
   }
   return os2d_launch_sample_decode(corr, params, NB, H, W, P, inverse, stride, rec_field, NB, NB, 0, loc, cls,
-                                   corners, S(stream));
+                                   corners, nullptr, 0, nullptr, S(stream));
 }
 
 int os2d_decode_boxes(const float* loc, int NB, int H, int W, int stride, int rec_field, float img_w, float img_h,
@@ -480,6 +501,11 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
   float* h1 = reinterpret_cast<float*>(ws + c.h1);
   float* h2 = reinterpret_cast<float*>(ws + c.h2);
   float* params = reinterpret_cast<float*>(ws + c.params);
+  // range words (one per image, one for the whole call) and the value this call's kernels store there; the last kernel of every class
+  // chunk - the resampler - turns a raised word into NaN outputs and raises the caller's sticky host word
+  int* flags = reinterpret_cast<int*>(ws + c.flags);
+  const int epoch = next_epoch();
+  const Os2dRangeFlag per_image = {fp32_ops ? nullptr : flags, epoch}, whole_call = {fp32_ops ? nullptr : flags + A, epoch};
 
   if (chunk_classes) *chunk_classes = Bc;
   // optional per-stage events (first class chunk only): stage_events[2*s] / [2*s+1] bracket stage s
@@ -489,7 +515,7 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
   int rc = os2d_launch_fm_sumsq(fm, sumsq, A, C, H * W, st);
   if (rc) return rc;
   // (the packed correlation kernel's sums are cleared by the same launch; every chunk's norms pass leaves them cleared again)
-  if (!fp32_ops && (rc = os2d_launch_split_fm(fm, sumsq, fsplit, A, C, H * W, sumfx, sumfx ? (size_t)A * Bc * H * W : 0, status, st))) return rc;
+  if (!fp32_ops && (rc = os2d_launch_split_fm(fm, sumsq, fsplit, A, C, H * W, sumfx, sumfx ? (size_t)A * Bc * H * W : 0, per_image, st))) return rc;
   for (int b0 = 0; b0 < B; b0 += Bc) {
     const int bc = (B - b0 < Bc) ? (B - b0) : Bc;
     const int NB = A * bc;
@@ -535,11 +561,7 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
       }
       mark(b0, 10);
       // the split-half GEMM writes its output spectra in quads of bins (include/os2d_hip.h, OS2D_SPECTRA_QUADS)
-#ifdef OS2D_DIAG_SPECTRA_ROWS
-      const int layout = OS2D_SPECTRA_ROWS;
-#else
       const int layout = precision == OS2D_PRECISION_FFTX3 ? OS2D_SPECTRA_QUADS : OS2D_SPECTRA_ROWS;
-#endif
       if (dft) {
         // the transforms as matrix products on the half-precision matrix cores, spectra in quads of bins on both sides of the
         // per-bin GEMM (dft_mfma.hip); |X| <= number of samples of a window (every sample of the normalised maps is <= 1)
@@ -550,16 +572,16 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
                                                 os2d_spectral_xscale_for(tiles[4], tiles[5]), 1, xch, st)))
           return rc;
         mark(b0, 12);
-        if ((rc = os2d_launch_dft_inverse(yspec, b1, 128, h1, mats, NB, 128, H, W, status, inv_borders ? 1 : 0, st))) return rc;
+        if ((rc = os2d_launch_dft_inverse(yspec, b1, 128, h1, mats, NB, 128, H, W, whole_call, inv_borders ? 1 : 0, st))) return rc;
       } else {
         if ((rc = os2d_launch_fft_forward(corr, invn, xspec, twQ, twP, NB, OS2D_K, H, W, st))) return rc;
         mark(b0, 11);
         if ((rc = os2d_launch_spectral_gemm(wspec, xspec, yspec, NB * fft_T, OS2D_K, 128, fft_bins, st))) return rc;
         mark(b0, 12);
-        if ((rc = os2d_launch_fft_inverse(yspec, b1, 128, h1, twQ, twP, NB, 128, H, W, status, layout, f16 ? 0 : 1, st))) return rc;
+        if ((rc = os2d_launch_fft_inverse(yspec, b1, 128, h1, twQ, twP, NB, 128, H, W, whole_call, layout, f16 ? 0 : 1, st))) return rc;
       }
     } else if (f16) {
-      if ((rc = os2d_launch_conv_f16x3(1, rpad, w1, b1, status, h1, NB, P, H, W, terms1, st))) return rc;
+      if ((rc = os2d_launch_conv_f16x3(1, rpad, w1, b1, whole_call, h1, NB, P, H, W, terms1, st))) return rc;
     } else {
       if ((rc = os2d_launch_conv(1, rpad, static_cast<const float*>(w1), b1, h1, NB, P, H, W, st))) return rc;
     }
@@ -576,7 +598,7 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
       dump_slot(stream, 4, h1, (size_t)NB * 128 * PLb * 4);
     }
     if (f16) {
-      if ((rc = os2d_launch_conv_f16x3(2, h1, w2, b2, status, h2, NB, P, H, W, 3, st))) return rc;
+      if ((rc = os2d_launch_conv_f16x3(2, h1, w2, b2, whole_call, h2, NB, P, H, W, 3, st))) return rc;
     } else {
       if ((rc = os2d_launch_conv(2, h1, static_cast<const float*>(w2), b2, h2, NB, P, H, W, st))) return rc;
     }
@@ -584,7 +606,7 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     mark(b0, 6);
     if (dumps_active() && b0 == 0) dump_slot(stream, 5, h2, (size_t)NB * 64 * os2d_plane(H, W) * 4);
     if (f16) {
-      if ((rc = os2d_launch_conv_f16x3(3, h2, w3, b3, status, params, NB, P, H, W, 3, st))) return rc;
+      if ((rc = os2d_launch_conv_f16x3(3, h2, w3, b3, whole_call, params, NB, P, H, W, 3, st))) return rc;
     } else {
       if ((rc = os2d_launch_conv(3, h2, static_cast<const float*>(w3), b3, params, NB, P, H, W, st))) return rc;
     }
@@ -592,7 +614,7 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     mark(b0, 8);
     if (dumps_active() && b0 == 0) dump_slot(stream, 6, params, (size_t)NB * P * H * W * 4);
     if ((rc = os2d_launch_sample_decode(corr, params, NB, H, W, P, inverse, stride, rec_field, bc, B, b0, loc, cls,
-                                        corners, st)))
+                                        corners, fp32_ops ? nullptr : flags, epoch, status, st)))
       return rc;
     mark(b0, 9);
   }
@@ -673,7 +695,7 @@ int os2d_transform_conv_f16x3(int layer, const void* in, const void* packed_w, c
     os2d_set_error("os2d_transform_conv_f16x3: feature map width %d > %d", W, layer == 1 ? OS2D_MAX_W_DIRECT7 : OS2D_MAX_W);
     return -1;
   }
-  return os2d_launch_conv_f16x3(layer, in, packed_w, packed_b, status, out, NB, P, H, W, terms, S(stream));
+  return os2d_launch_conv_f16x3(layer, in, packed_w, packed_b, Os2dRangeFlag{status, OS2D_STATUS_F16_RANGE}, out, NB, P, H, W, terms, S(stream));
 }
 
 int os2d_fft_sizes(int H, int W, int* P, int* Q, int* nbins) {
@@ -723,7 +745,7 @@ int os2d_fft_inverse_ex(const float* Y, const float* packed_b, void* out, const 
   }
   int rc = os2d_launch_border_zero_shb_planes(out, NB * (Cout / 8) * 2, H, W, S(stream));
   if (rc) return rc;
-  return os2d_launch_fft_inverse(Y, packed_b, 128, out, twQ, twP, NB, Cout, H, W, status, layout, 0, S(stream));
+  return os2d_launch_fft_inverse(Y, packed_b, 128, out, twQ, twP, NB, Cout, H, W, Os2dRangeFlag{status, OS2D_STATUS_F16_RANGE}, layout, 0, S(stream));
 }
 
 int os2d_fft_inverse(const float* Y, const float* packed_b, void* out, const float* twQ, const float* twP, int NB, int Cout,
@@ -830,7 +852,7 @@ int os2d_dft_inverse(const float* Y, const float* packed_b, void* out, const voi
     os2d_set_error("os2d_dft_inverse: bad arguments (Cout must be 128: the 7x7 layer)");
     return -1;
   }
-  return os2d_launch_dft_inverse(Y, packed_b, 128, out, matrices, NB, Cout, H, W, status, 1, S(stream));   // incl. the plane borders
+  return os2d_launch_dft_inverse(Y, packed_b, 128, out, matrices, NB, Cout, H, W, Os2dRangeFlag{status, OS2D_STATUS_F16_RANGE}, 1, S(stream));   // incl. the plane borders
 }
 
 int os2d_spectral_weights_build_dft(const double* wfold, const double* twP64, const double* twQ64, int C, int Cout, int P, int Q,

@@ -56,7 +56,7 @@ template <int KS, int MTP, int MT, int WM, int WN, int NI, int SS, bool RELU, in
 __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_f16x3_kernel(const u32x4* in,  // SHB [NB][G][2][PLANE] (no __restrict__: invariant loads get
                                                              const u32x4* wp,  // rematerialised BEHIND the MFMAs by the register allocator)
                                                              const float* __restrict__ bp,  // [3][MTP] fp32 per output row: folded bias | 2^-weight_exp | 2^out_exp
-                                                             int* __restrict__ status,
+                                                             Os2dRangeFlag status,
                                                              void* __restrict__ outv, int G,
                                                              int CoutStore, int H, int W, int PLANE, int HALO,
                                                              int TILES, int NB, int SP /*STRIP: row pitch of a strip-plane*/,
@@ -349,10 +349,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_f16x3_kernel(const u3
       }
     }
   }
-  if (OUT_MODE == 0 && status != nullptr && __builtin_amdgcn_ballot_w64(out_of_range) != 0ull) {
-    // a plain system-scope store (the word may live in mapped host memory, where PCIe atomics are not a given); every
-    // writer stores the same bit pattern, so racing stores are benign
-    if (lane == 0) __hip_atomic_store(status, OS2D_STATUS_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (OUT_MODE == 0 && status.word != nullptr && __builtin_amdgcn_ballot_w64(out_of_range) != 0ull) {
+    if (lane == 0) os2d_raise(status);
   }
   // pad rows above the data (first tile) and whatever lies beyond the last tile
   {
@@ -378,7 +376,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_f16x3_kernel(const u3
 
 template <int KS, int MTP, int MT, int WM, int WN, int NI, int SS, bool RELU, int OUT_MODE, int TERMS = 3, int NBPF = 0, int MINW = 2,
           bool STRIP = false>
-int launch(const void* in, const void* wp, const float* bp, int* status, void* out, int NB, int G, int CoutStore, int H,
+int launch(const void* in, const void* wp, const float* bp, Os2dRangeFlag status, void* out, int NB, int G, int CoutStore, int H,
            int W, hipStream_t stream) {
   constexpr int R = KS / 2;
   constexpr int NT = WN * NI * 32;
@@ -434,12 +432,10 @@ int launch(const void* in, const void* wp, const float* bp, int* status, void* o
 // calling pattern, evaluate.py:323-331) still spreads over 160 / 80 / 40 groups instead of 40 / 20 / 20 and a group's
 // serial K loop issues 3 instead of 12 MFMAs per k-step.  Every output element accumulates the same products in the
 // same order in both shapes, so results do not depend on which one ran (tests: small batch == slice of a large batch).
-int os2d_launch_conv_f16x3(int layer, const void* in, const void* wp, const float* bp, int* status, void* out, int NB,
+int os2d_launch_conv_f16x3(int layer, const void* in, const void* wp, const float* bp, Os2dRangeFlag status, void* out, int NB,
                            int P, int H, int W, int terms, hipStream_t stream) {
-#ifndef OS2D_DIAG_CONV3_GENERIC
   // the last layer has its own kernel (16-row MFMA, conv3_f16x3.hip), one shape for every batch size
   if (layer == 3) return os2d_launch_conv3_f16x3(in, wp, bp, out, NB, P, H, W, stream);
-#endif
   if (layer != 1 && W > OS2D_MAX_W_LINEAR5) {    // wider than the linear slab takes: column strips, one shape for every batch size
     if (layer == 2) return launch<5, 64, 64, 1, 4, 2, 7, true, 0, 3, 0, 2, true>(in, wp, bp, status, out, NB, 16, 64, H, W, stream);
     return launch<5, 32, 32, 1, 4, 2, 7, false, 2, 3, 0, 2, true>(in, wp, bp, status, out, NB, 8, P, H, W, stream);

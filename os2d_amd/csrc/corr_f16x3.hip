@@ -43,9 +43,8 @@ constexpr int CH_UNITS = GC * 2 * 256;   // 16-byte units of one class-operand c
 // is what a call waits for).  Every output accumulates the same products in the same order in both shapes.
 //
 // WNW = waves along the positions (the rows are always split over 2 waves): 4 -> 8 waves of 128 x 64 (128 accumulators per
-// lane, two waves per SIMD); 2 -> 4 waves of 128 x 128 (NI = 4: 256 accumulators, one wave per SIMD with the whole register
-// file: 24 fragment reads per 48 matrix instructions become 32 per 96 - a third less LDS traffic per MFMA, which is what the
-// live counters say bounds the 8-wave shape: matrix pipe 0.58 busy with 2/3 of the LDS bandwidth in use).
+// lane, two waves per SIMD).  (Round 3 measured 4 waves of 128 x 128 - one wave per SIMD with the whole register file, a third
+// less LDS traffic per matrix instruction - slower: tools/patches/corr_f16x3_variants.patch.)
 constexpr int STACK_STRIDE = 228;   // stacked rows per class (225 rounded up to a multiple of 4)
 
 // WM = waves along the rows (2: a 256-row tile; 1: a 128-row tile - STACK only), KC = 8-channel groups per K chunk (4 | 2).
@@ -153,12 +152,6 @@ __global__ __launch_bounds__(64 * WM * WNW, (WM == 1 || WNW == 4) ? 2 : 1) void 
   }
 #define CF_NOHOOK(MI)
 #define CF_COMPUTE(T) CF_COMPUTE_H(T, CF_NOHOOK)
-#if defined(OS2D_DIAG_CORR_NO_MFMA)  /* diagnostic builds only: DMA + barriers, no fragment reads / MFMAs */
-#define CF_COMPUTE_H(T, HOOK)                                                                                     \
-  {                                                                                                               \
-    _Pragma("unroll") for (int mi = 0; mi < (KC / 2) * 4; ++mi) { HOOK(mi) }                                      \
-  }
-#else
 #define CF_COMPUTE_H(T, HOOK)                                                                                     \
   {                                                                                                               \
     const u32x4* aB_ = ldsA + ((T)&1) * AUNITS + wm * 128 + l31;                                                  \
@@ -182,23 +175,18 @@ __global__ __launch_bounds__(64 * WM * WNW, (WM == 1 || WNW == 4) ? 2 : 1) void 
       }                                                                                                           \
     }                                                                                                             \
   }
-#endif
 
   // The DMA of chunk t+1 is issued IN PIECES between the MFMA groups of chunk t (one class unit + one image unit per
   // thread after each of the first four groups): eight waves bursting 72 KB of loads right after the barrier queue up
   // behind each other in the CU's load path; spread out, the issue slots hide behind the matrix pipe.  The barrier at the
   // end of an iteration drains the wave's own DMAs (vmcnt(0), emitted by __syncthreads) and then orders them for
   // everybody's fragment reads of the next iteration.
-#if defined(OS2D_DIAG_CORR_NO_DMA)   /* diagnostic builds only (tools/diag_corr.sh): results are garbage */
-#define CF_PF_HOOK(MI)
-#else
 #define CF_PF_HOOK(MI)                                                                                            \
   if ((MI) < (NPF > NPFB ? NPF : NPFB)) {                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
     CF_DMA1(t + 1, MI)                                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
   }
-#endif
   CF_DMA(0)
   __syncthreads();
   for (int t = 0; t + 1 < nchunks; ++t) {
@@ -422,7 +410,7 @@ __global__ __launch_bounds__(64 * WM * WNW, (WM == 1 || WNW == 4) ? 2 : 1) void 
 __global__ __launch_bounds__(256) void split_fm_kernel(const float* __restrict__ fm, const float* __restrict__ sumsq,
                                                        u32x4* __restrict__ fs, int C, int HW, float scale,
                                                        unsigned long long* __restrict__ clear, size_t clear_words,
-                                                       int* __restrict__ status) {
+                                                       Os2dRangeFlag status) {
   const int n = blockIdx.x * 256 + threadIdx.x;
   const int g = blockIdx.y, a = blockIdx.z;
   if (clear_words) {       // the packed correlation kernel's sums, zeroed on the way (grid-stride over all work items)
@@ -434,10 +422,10 @@ __global__ __launch_bounds__(256) void split_fm_kernel(const float* __restrict__
   const float ss = sumsq[(size_t)a * HW + n];
   // A non-finite feature (NaN / Inf anywhere in the 1024 channels of this location) makes the reference's outputs NaN through
   // relu(NaN) = NaN (torch).  The ReLUs of this path are fmaxf(x, 0), which DROPS a NaN (the forward transform would hand finite
-  // zeros to the 7x7 layer - ADVICE r4), so the one place that sees every input value raises the sticky status word: the caller
-  // re-runs the call in the fp32 kernels, whose ReLU keeps a NaN (os2d_relu).
-  if (status != nullptr && g == 0 && __builtin_amdgcn_ballot_w64(!(ss <= 3.4028234e38f)) != 0ull && (threadIdx.x & 63) == 0)
-    __hip_atomic_store(status, OS2D_STATUS_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // zeros to the 7x7 layer - ADVICE r4), so the one place that sees every input value raises the range word of ITS IMAGE: the last
+  // kernel of the call (sample_decode_kernel) then writes NaN into every output of that image (round 6).
+  if (status.word != nullptr && g == 0 && __builtin_amdgcn_ballot_w64(!(ss <= 3.4028234e38f)) != 0ull && (threadIdx.x & 63) == 0)
+    os2d_raise(Os2dRangeFlag{status.word + a, status.value});
   const float inv = scale / (sqrtf(ss) + 1e-5f);
   half8 hi, lo;
 #pragma unroll
@@ -481,9 +469,6 @@ __global__ __launch_bounds__(256) void corr_norm_finalize_kernel(unsigned long l
   if (i < n) os2d_corr_norm_finalize_one(sumfx, invn, i);
 }
 
-#ifndef OS2D_CORR_W4
-#define OS2D_CORR_W4 0
-#endif
 constexpr int SCALE_LOG2 = 12;  // operands are L2-normalised (|x| <= 1): hi <= 4096, lo >= 2^-11 * 2^12 * x stays normal
 
 int check(const char* what) {
@@ -500,7 +485,7 @@ int check(const char* what) {
 int os2d_corr_groups(int C) { return os2d_round_up((C + 7) / 8, GC); }
 
 int os2d_launch_split_fm(const float* fm, const float* sumsq, void* fs, int A, int C, int HW, void* clear, size_t clear_words,
-                         int* status, hipStream_t stream) {
+                         Os2dRangeFlag status, hipStream_t stream) {
   hipLaunchKernelGGL(split_fm_kernel, dim3((HW + 255) / 256, os2d_round_up((C + 7) / 8, GC), A), dim3(256), 0, stream, fm, sumsq,
                      reinterpret_cast<u32x4*>(fs), C, HW, ldexpf(1.0f, SCALE_LOG2), static_cast<unsigned long long*>(clear),
                      clear ? clear_words : (size_t)0, status);
@@ -584,9 +569,6 @@ int os2d_launch_corr_f16x3(const void* fs, const void* qs, float* corr, void* rs
   if ((long long)((H * W + 127) / 128) * RT * A <= 256)
     return sx ? launch_corr<1, 4, true>(fs, qs, corr, rshb, invn, sx, defer_norms, A, B, C, H, W, stream)
               : launch_corr<1, 4, false>(fs, qs, corr, rshb, invn, sx, defer_norms, A, B, C, H, W, stream);
-#if OS2D_CORR_W4
-  return launch_corr<4, 2, false>(fs, qs, corr, rshb, invn, nullptr, defer_norms, A, B, C, H, W, stream);     // 4 waves of 128 x 128 (diagnostic)
-#else
   // ($OS2D_CORR_HALF=1: the packed form in half tiles - two 4-wave groups per CU; measurements)
   static const bool half_tiles = [] {
     const char* e = getenv("OS2D_CORR_HALF");
@@ -596,5 +578,4 @@ int os2d_launch_corr_f16x3(const void* fs, const void* qs, float* corr, void* rs
     return launch_corr<2, 4, true, 1, 2>(fs, qs, corr, rshb, invn, sx, defer_norms & 1, A, B, C, H, W, stream);
   return sx ? launch_corr<2, 4, true>(fs, qs, corr, rshb, invn, sx, defer_norms, A, B, C, H, W, stream)        // 8 waves of 128 x 64
             : launch_corr<2, 4, false>(fs, qs, corr, rshb, invn, sx, defer_norms, A, B, C, H, W, stream);
-#endif
 }

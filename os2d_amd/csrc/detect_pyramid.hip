@@ -230,11 +230,7 @@ __global__ __launch_bounds__(NTHR) void pyr_chunk_nms_kernel(int pass, int N, in
     }                                                                                                             \
     __syncthreads();                                                                                              \
   }
-#ifdef OS2D_DIAG_PYR_NOSORT       /* diagnostic (timing only): the keys stay unsorted */
-  for (int m = 1; m < 1; ++m) {
-#else
   for (int m = 1; (1 << m) <= NP2; ++m) {
-#endif
     const int k = 1 << m;
     for (int hi = m - 1; hi >= 0; hi -= 3) {
       const int nbits = min(3, hi + 1);
@@ -260,18 +256,10 @@ __global__ __launch_bounds__(NTHR) void pyr_chunk_nms_kernel(int pass, int N, in
   // still alive: 157 steps per 10,000-candidate chunk, now ~16 for the first batch (empty kept list) + ~1 per later batch.
   float4* wbox = reinterpret_cast<float4*>(smem);   // [WIN] = NP2full * 4 bytes / 16
   const int WIN = NP2full >> 2;
-#ifdef OS2D_DIAG_PYR_NONMS        /* diagnostic (timing only): no candidate is looked at */
-  for (int w0 = 0; w0 < 0; w0 += WIN) {
-#else
   for (int w0 = 0; w0 < n; w0 += WIN) {
-#endif
     const int wn = min(WIN, n - w0);
     __syncthreads();
-#ifdef OS2D_DIAG_PYR_NOGATHER     /* diagnostic (timing only): boxes read in list order instead of through the sorted ids */
-    for (int i = tid; i < wn; i += NTHR) wbox[i] = bx[min(N - 1, j0 + w0 + i)];
-#else
     for (int i = tid; i < wn; i += NTHR) wbox[i] = bx[srt[w0 + i]];
-#endif
     __syncthreads();
     for (int base = 0; base < wn; base += NTHR) {
       const int nk0 = kept_count;                       // kept before this batch (uniform: read right after a barrier)

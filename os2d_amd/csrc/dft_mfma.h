@@ -37,7 +37,7 @@
 #pragma once
 
 #ifndef DFT_DEV
-#error "the includer defines DFT_DEV, DFT_TID, DFT_BID, DFT_GRID, DFT_LDS, DFT_BARRIER, DFT_MFMA, DFT_SHFL_XOR, DFT_BALLOT, DFT_RAISE, DFT_UNIFORM"
+#error "the includer defines DFT_DEV, DFT_TID, DFT_BID, DFT_GRID, DFT_LDS, DFT_BARRIER, DFT_MFMA, DFT_SHFL_XOR, DFT_BALLOT, DFT_FLAG, DFT_FLAG_SET, DFT_RAISE, DFT_UNIFORM"
 #endif
 
 #ifndef DFT_HD
@@ -48,12 +48,6 @@
 #endif
 #ifndef DFT_LANDED
 #define DFT_LANDED(X)             /* device build: an empty asm that reads and writes X - see the Fp2 fragments in the forward kernel */
-#endif
-#ifndef DFT_FWD_SPREAD
-#define DFT_FWD_SPREAD 0          /* 1: the next window's loads are issued between the k-steps of step 2; 0: in one burst in front of it */
-#endif
-#ifndef DFT_INV_SPREAD
-#define DFT_INV_SPREAD 0          /* the same for the next spectra and step A */
 #endif
 #ifndef DFT_FWD_PREFETCH_AFTER
 #define DFT_FWD_PREFETCH_AFTER 2  /* the next window's loads right AFTER step 2 instead of in front of it: 0 never, 1 always, 2 for the
@@ -331,16 +325,11 @@ DFT_DEV f32x16v dft_mma3(half8 ah, half8 al, half8 bh, half8 bl, f32x16v acc) {
 // between the first fragment read and the last matrix instruction; KS == 0: any count up to DFT_KREG behind uniform guards.
 // The tiles of a k-step are INDEPENDENT accumulators interleaved in the matrix pipe: one tile after the other - a chain of 3 K
 // dependent instructions - measured 5.7 against 5.1 us.
-// ``between(ks, ksn)`` is called after the matrix instructions of k-step ks have been issued (ksn = number of k-steps): the caller's
-// global loads of the next iteration go there, a few per k-step, so that their issue (address arithmetic + 16 cycles of the
-// CU's load path per 1 KB wave instruction, all 8 waves at once) overlaps the matrix pipe instead of standing in front of the
-// product (round 5: ~2 us of "step 2" / "step A" were this burst).
-struct DftNoHook {
-  DFT_MEMBER void operator()(int, int) const {}
-};
-template <int NT, int KS, class Hook>
+// (The next iteration's global loads spread over the k-steps of this product instead of one burst next to it: measured slower,
+// tools/patches/dft_mfma_variants.patch.)
+template <int NT, int KS>
 DFT_DEV void dft_product_rega(f32x16v* acc, const half8* ah, const half8* al, int ksn, const u32x4v* B, int bstride, int nt0,
-                              int ntstep, int l31, int hw, const Hook& between) {
+                              int ntstep, int l31, int hw) {
   constexpr int KR = KS ? KS : DFT_KREG;
   half8 bh[2][NT], bl[2][NT];
 #define DFT_REGA_READ(KSTEP, SET)                                                                                          \
@@ -361,21 +350,17 @@ DFT_DEV void dft_product_rega(f32x16v* acc, const half8* ah, const half8* al, in
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[j] = dft_mma3(ah[ks], al[ks], bh[ks & 1][j], bl[ks & 1][j], acc[j]);
       if (DFT_PIPE_REGA) DFT_SCHED_FENCE();
-      between(ks, KS ? KS : ksn);
     }
   }
 #undef DFT_REGA_READ
 }
 
-template <int KS, class Hook>
+template <int KS>
 DFT_DEV void dft_product_rega_any(f32x16v* acc, int ntiles, const half8* ah, const half8* al, int ksn, const u32x4v* B, int bstride,
-                                  int nt0, int ntstep, int l31, int hw, const Hook& between) {
-  if (ntiles == 3) dft_product_rega<3, KS>(acc, ah, al, ksn, B, bstride, nt0, ntstep, l31, hw, between);
-  else if (ntiles == 2) dft_product_rega<2, KS>(acc, ah, al, ksn, B, bstride, nt0, ntstep, l31, hw, between);
-  else if (ntiles == 1) dft_product_rega<1, KS>(acc, ah, al, ksn, B, bstride, nt0, ntstep, l31, hw, between);
-  else {      // a wave without tiles still has its share of the loads to request
-    for (int ks = 0; ks < (KS ? KS : ksn); ++ks) between(ks, KS ? KS : ksn);
-  }
+                                  int nt0, int ntstep, int l31, int hw) {
+  if (ntiles == 3) dft_product_rega<3, KS>(acc, ah, al, ksn, B, bstride, nt0, ntstep, l31, hw);
+  else if (ntiles == 2) dft_product_rega<2, KS>(acc, ah, al, ksn, B, bstride, nt0, ntstep, l31, hw);
+  else if (ntiles == 1) dft_product_rega<1, KS>(acc, ah, al, ksn, B, bstride, nt0, ntstep, l31, hw);
 }
 
 // acc[j] += A[row tile mt_j] . B[column tile nt_j], both operands in LDS, tiles t = t0 + NW j of a grid of mtn row tiles;
@@ -579,33 +564,6 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
   const int r_ = dft_div(i_, pl.inv_c4), c4_ = i_ - r_ * (Wk / 4);                                          \
   const int y_ = Y0 + r_, x_ = X0 + 4 * c4_;
   // (a macro, not a lambda: register arrays captured by a closure end up in scratch memory with this compiler)
-  // one request q of a slot: q = 0 the inverse norms, q = 1 .. G the images (the per-element fix-up of a slot that leaves its plane
-  // rides on the last one).  DFT_FWD_ITER must be in scope.
-#define DFT_FWD_PREFETCH_ONE(TID, S, Q)                                                                      \
-  {                                                                                                          \
-    DFT_FWD_POS(TID, S)                                                                                      \
-    const bool rok = FAST ? (i_ < npos && r_ < LH && 4 * c4_ < LW) : (i_ < npos && r_ < LH && y_ >= 0 && y_ < H); \
-    const int off0 = y_ * W + x_;                                                                            \
-    const bool vec = FAST ? rok : (rok && off0 >= 0 && off0 + 3 < HW);                                       \
-    const int offv = vec ? off0 : 0;                                                                         \
-    if ((Q) == 0) {                                                                                          \
-      pn[S] = *reinterpret_cast<const f32x4u*>(invn + (size_t)nb_ * HW + offv);                              \
-    } else {                                                                                                 \
-      const int c = c0_ + (Q)-1 < C ? c0_ + (Q)-1 : C - 1;                                                   \
-      pc[S][(Q)-1] = *reinterpret_cast<const f32x4u*>(corr + ((size_t)nb_ * C + c) * HW + offv);             \
-    }                                                                                                        \
-    if (!FAST && (Q) == G && rok && !vec) {                                                                  \
-      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                        \
-        const bool ok = 4 * c4_ + e < LW && x_ + e >= 0 && x_ + e < W;                                       \
-        const int off = ok ? y_ * W + x_ + e : 0;                                                            \
-        pn[S][e] = invn[(size_t)nb_ * HW + off];                                                             \
-        _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                      \
-          const int c = c0_ + g < C ? c0_ + g : C - 1;                                                       \
-          pc[S][g][e] = corr[((size_t)nb_ * C + c) * HW + off];                                              \
-        }                                                                                                    \
-      }                                                                                                      \
-    }                                                                                                        \
-  }
 #define DFT_FWD_PREFETCH(IT, TID) DFT_FWD_PREFETCH_SLOTS(IT, TID, 0, NSLOT)
 #define DFT_FWD_PREFETCH_SLOTS(IT, TID, S0, S1)                                                              \
   {                                                                                                          \
@@ -768,25 +726,16 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
     // UNCONDITIONAL (round 5): the last iteration of a work-group requests its own window once more (cache hits, discarded).
     // Behind "if (it + DFT_GRID < iters)" the prefetch registers stayed live through the whole iteration on the path that skips
     // the loads - 60 registers the compiler had to keep next to the 64 of Fp2 in every phase - and the wait-count pass, merging
-    // the two paths, could not count what is in flight.  The NSLOT x (G + 1) requests are spread over the k-steps of
-    // the product (dft_product_rega: ``between``); DFT_FWD_SPREAD = 0 issues them in one burst in front of it (round 4).
+    // the two paths, could not count what is in flight.  One burst of NSLOT x (G + 1) requests, in front of the product
+    // or right behind it (DFT_FWD_PREFETCH_AFTER).
     const int itn = it + DFT_GRID < iters ? it + DFT_GRID : it;
     {
-      DFT_FWD_ITER(itn)
-      constexpr int NQ = NSLOT * (G + 1);
-      auto request = [&](int ks, int ksn) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-          if (q * ksn / NQ == ks) DFT_FWD_PREFETCH_ONE(tl, q / (G + 1), q % (G + 1))
-      };
-      if (DFT_FWD_SPREAD && KS2 > 0) {      // (compile-time k-step count: every request lands at a compile-time position)
-        dft_product_rega_any<KS2>(xc, nt2w, fp2h, fp2l, ks2n, ldsU, N2S, wv >> 2, NW / 4, l31, hw, request);
-      } else if (DFT_FWD_PREFETCH_AFTER == 1 || (DFT_FWD_PREFETCH_AFTER == 2 && KS2 > 0 && KS2 <= 6)) {      // the burst behind the product
-        dft_product_rega_any<KS2>(xc, nt2w, fp2h, fp2l, ks2n, ldsU, N2S, wv >> 2, NW / 4, l31, hw, DftNoHook());
+      if (DFT_FWD_PREFETCH_AFTER == 1 || (DFT_FWD_PREFETCH_AFTER == 2 && KS2 > 0 && KS2 <= 6)) {      // the burst behind the product
+        dft_product_rega_any<KS2>(xc, nt2w, fp2h, fp2l, ks2n, ldsU, N2S, wv >> 2, NW / 4, l31, hw);
         DFT_FWD_PREFETCH_SLOTS(itn, tl, 0, NSLOT)
       } else {
         DFT_FWD_PREFETCH_SLOTS(itn, tl, 0, NSLOT)
-        dft_product_rega_any<KS2>(xc, nt2w, fp2h, fp2l, ks2n, ldsU, N2S, wv >> 2, NW / 4, l31, hw, DftNoHook());
+        dft_product_rega_any<KS2>(xc, nt2w, fp2h, fp2l, ks2n, ldsU, N2S, wv >> 2, NW / 4, l31, hw);
       }
     }
     DFT_BARRIER();      // every wave is done reading R2: the region becomes the staging buffer of X
@@ -839,7 +788,6 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
 #undef DFT_FWD_ITER
 #undef DFT_FWD_POS
 #undef DFT_FWD_PREFETCH
-#undef DFT_FWD_PREFETCH_ONE
 #undef DFT_FWD_PREFETCH_SLOTS
 }
 
@@ -850,7 +798,7 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
                               const float* bp,       // [3][MTP]: bias | - | 2^out_exp
                               int MTP, unsigned char* out,   // SHB [NB][Cout / 8][2][PLANE] x 16 B
                               const u32x4v* E2, const u32x4v* Gq, const DftPlan& pl, int Cout, int NBT, int PLANE, int Ws,
-                              int BASE, int iters, int* bad_flag, int zero_borders) {
+                              int BASE, int iters, DFT_FLAG bad_flag, int zero_borders) {
   unsigned char* smem = DFT_LDS;
   const int tid = DFT_TID, lane = tid & 63, l31 = lane & 31, hw = lane >> 5;
   const int wv = DFT_UNIFORM(tid >> 6);
@@ -889,18 +837,6 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
   constexpr int NITEM = 3;                                      // ceil(G * V * Pp / 8 / 512) <= 4 * 48 * 8 / 512
   const int uoct = Pp / 8, nitem = DFT_G * V * uoct;
   f32x4v py[NITEM][4];
-  // request Q (0 .. 3) of item S: one 16-byte load.  pr_ / og_ / src_ / qstride of the iteration must be in scope.
-#define DFT_INV_PREFETCH_ONE(TID, S, Q)                                                     \
-  {                                                                                         \
-    const int e_ = (TID) + (S)*DFT_THR;                                                     \
-    const int ec_ = e_ < nitem ? e_ : 0;                                                    \
-    const int pimg_ = ec_ & (DFT_G - 1), prest_ = ec_ >> 2;                                 \
-    const int pv_ = dft_div(prest_, pl.inv_kg), puo_ = prest_ - pv_ * (Pp / 8);             \
-    const int q0_ = pv_ * (P / 4) + 2 * puo_;                                               \
-    const bool ptwo_ = 8 * puo_ + 4 < P;                                                    \
-    const float* pq_ = src_ + (size_t)(((Q) >> 1) && ptwo_ ? q0_ + 1 : q0_) * qstride + pimg_ * 8 + ((Q)&1) * 4; \
-    py[S][Q] = *reinterpret_cast<const f32x4v*>(pq_);                                       \
-  }
 #define DFT_INV_PREFETCH(IT, TID) DFT_INV_PREFETCH_ITEMS(IT, TID, 0, NITEM)
 #define DFT_INV_PREFETCH_ITEMS(IT, TID, S0, S1)                                             \
   {                                                                                         \
@@ -1043,26 +979,15 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
 #pragma unroll
       for (int r = 0; r < 16; ++r) ta[j][r] = 0.f;
     }
-    // the next spectra: unconditional, spread over the k-steps of the product (see the forward kernel)
+    // the next spectra: unconditional, one burst next to the product (see the forward kernel)
     const int itn = it + DFT_GRID < iters ? it + DFT_GRID : it;
     {
-      const int pr_ = dft_div(itn, pl.inv_og), og_ = itn - pr_ * OG;
-      size_t qstride;
-      const float* src_ = Y + dft_spectra_pair0(pr_, NBT, pl.NBINS / 4, Cout, &qstride) + (size_t)og_ * DFT_G * 8;
-      constexpr int NQ = NITEM * 4;
-      auto request = [&](int ks, int ksn) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-          if (q * ksn / NQ == ks) DFT_INV_PREFETCH_ONE(tl, q >> 2, q & 3)
-      };
-      if (DFT_INV_SPREAD && KSA > 0) {
-        dft_product_rega_any<KSA>(ta, ntaw, e2h, e2l, ksAn, ldsU, N2S, wv >> 2, 2, l31, hw, request);
-      } else if (DFT_INV_PREFETCH_AFTER == 1 || (DFT_INV_PREFETCH_AFTER == 2 && KSA > 0 && KSA <= 6)) {
-        dft_product_rega_any<KSA>(ta, ntaw, e2h, e2l, ksAn, ldsU, N2S, wv >> 2, 2, l31, hw, DftNoHook());
+      if (DFT_INV_PREFETCH_AFTER == 1 || (DFT_INV_PREFETCH_AFTER == 2 && KSA > 0 && KSA <= 6)) {
+        dft_product_rega_any<KSA>(ta, ntaw, e2h, e2l, ksAn, ldsU, N2S, wv >> 2, 2, l31, hw);
         DFT_INV_PREFETCH_ITEMS(itn, tl, 0, NITEM)
       } else {
         DFT_INV_PREFETCH_ITEMS(itn, tl, 0, NITEM)
-        dft_product_rega_any<KSA>(ta, ntaw, e2h, e2l, ksAn, ldsU, N2S, wv >> 2, 2, l31, hw, DftNoHook());
+        dft_product_rega_any<KSA>(ta, ntaw, e2h, e2l, ksAn, ldsU, N2S, wv >> 2, 2, l31, hw);
       }
     }
     DFT_BARRIER();      // every wave is done reading Y2: the region becomes Tt
@@ -1178,13 +1103,12 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
     DFT_STAMP(5)
   }
   DFT_STAMP_END(8)
-  if (bad_flag != nullptr && DFT_BALLOT(bad) != 0ull) {
+  if (DFT_FLAG_SET(bad_flag) && DFT_BALLOT(bad) != 0ull) {
     if ((tid & 63) == 0) DFT_RAISE(bad_flag);
   }
 #undef DFT_INV_MAXIMA
 #undef DFT_INV_ITEM
 #undef DFT_INV_PREFETCH
-#undef DFT_INV_PREFETCH_ONE
 #undef DFT_INV_PREFETCH_ITEMS
 }
 

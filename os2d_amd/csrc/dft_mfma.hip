@@ -2,6 +2,9 @@
 // precision "fftx3"): hardware hooks, kernel entry points, the constant-matrix builder and the launchers.  The kernel bodies
 // live in the header so that tests/host/dft_mfma_check.cpp can run the same source on the CPU (tests/host/spmd_emu.h).
 #include "os2d_common.h"
+#include <map>
+#include <mutex>
+#include <utility>
 
 extern __shared__ __attribute__((aligned(16))) unsigned char os2d_dft_smem[];
 
@@ -21,10 +24,10 @@ extern __shared__ __attribute__((aligned(16))) unsigned char os2d_dft_smem[];
 #define DFT_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #define DFT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define DFT_LANDED(X) asm volatile("" : "+v"(X))
-#ifndef OS2D_NO_MIX_SPLIT      /* (diagnostic: -DOS2D_NO_MIX_SPLIT restores the convert - subtract - convert form) */
 #define DFT_SPLIT_LO_PAIR(a, b, hi) os2d_split_lo_pair(a, b, hi)
-#endif
-#define DFT_RAISE(p) __hip_atomic_store(p, OS2D_STATUS_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+#define DFT_FLAG Os2dRangeFlag
+#define DFT_FLAG_SET(f) ((f).word != nullptr)
+#define DFT_RAISE(f) os2d_raise(f)
 #ifdef OS2D_DIAG_DFT_STAMPS
 // diagnostic build: thread 0 of every work-group accumulates the wall-clock ticks (100 MHz) between the phase barriers; the sums
 // over all work-groups land in os2d_dft_stamps[0..5] (forward: W | step 1 | R | step 2 | XS | ST) and [8..13] (inverse: max |
@@ -65,13 +68,13 @@ template <bool TILED, int KS>
 __global__ __launch_bounds__(DFT_THR, 1) void dft_inverse_kernel(const float* __restrict__ Y, const float* __restrict__ bp, int MTP,
                                                                  unsigned char* __restrict__ out, const u32x4v* __restrict__ E2,
                                                                  const u32x4v* __restrict__ Gq, DftPlan pl, int Cout, int NBT, int PLANE,
-                                                                 int Ws, int BASE, int iters, int* status, int zero_borders) {
+                                                                 int Ws, int BASE, int iters, Os2dRangeFlag status, int zero_borders) {
   dft_inverse_body<TILED, KS>(Y, bp, MTP, out, E2, Gq, pl, Cout, NBT, PLANE, Ws, BASE, iters, status, zero_borders);
 }
 
 typedef void (*dft_forward_fn)(const float*, const float*, float*, const u32x4v*, const u32x4v*, DftPlan, int, int, int, int);
 typedef void (*dft_inverse_fn)(const float*, const float*, int, unsigned char*, const u32x4v*, const u32x4v*, DftPlan, int, int, int, int, int,
-                               int, int*, int);
+                               int, Os2dRangeFlag, int);
 template <int G, int NW, int KS>
 dft_forward_fn dft_forward_variant(const DftPlan& pl) {
   return pl.T > 1 ? dft_forward_kernel<true, false, G, NW, KS> : (pl.fast ? dft_forward_kernel<false, true, G, NW, KS> : dft_forward_kernel<false, false, G, NW, KS>);
@@ -120,6 +123,32 @@ int dft_check(const char* what) {
   return 0;
 }
 
+// The planner tries up to 48 x 48 tilings x 6 canonical sizes and a head call needs the plan of its map four times (workspace
+// size, route, forward, inverse): memoised per process - a plan is a pure function of (H, W) under the process-wide size policy.
+bool dft_plan_cached(int H, int W, DftPlan* out) {
+  struct Entry {
+    bool ok;
+    DftPlan pl;
+  };
+  static std::mutex mu;
+  static std::map<std::pair<int, int>, Entry> cache;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find({H, W});
+    if (it != cache.end()) {
+      if (it->second.ok) *out = it->second.pl;
+      return it->second.ok;
+    }
+  }
+  Entry e = {};
+  e.ok = dft_make_plan(H, W, &e.pl);
+  if (e.ok) *out = e.pl;
+  std::lock_guard<std::mutex> lock(mu);
+  if (cache.size() >= 4096) cache.clear();
+  cache[{H, W}] = e;
+  return e.ok;
+}
+
 int dft_grid(int iters, int per_cu = 1) {
   int g = iters < 256 * per_cu ? iters : 256 * per_cu;      // work-groups resident on the chip at once (126 - 137 KB of LDS each, or 2 x 80)
   return (g + 7) / 8 * 8;                       // multiple of 8: XCD-aware iteration order
@@ -127,18 +156,8 @@ int dft_grid(int iters, int per_cu = 1) {
 
 // images per iteration of the forward kernel: 4 (one 8-wave work-group per CU).  The other shape - 2 images, 4 waves, TWO
 // independent work-groups per CU when they fit its LDS - was built to let the phases of two groups overlap and measured no faster
-// (profiles/r04/dft_phases_g2.txt: an iteration of 2 images takes 14.4 us against 15.0 us for 4: 0.261 vs 0.244 ms per 64 pairs
-// standalone); it is compiled into DIAGNOSTIC builds only (-DOS2D_DIAG_DFT_G2, then $OS2D_DFT_FORWARD_G = 2 selects it).
-int dft_forward_g(int H, int W, DftPlan* pl) {
-#ifdef OS2D_DIAG_DFT_G2
-  static const int pinned = [] {
-    const char* e = getenv("OS2D_DFT_FORWARD_G");
-    return e ? atoi(e) : 0;
-  }();
-  if (pinned == 2 && dft_make_forward_plan(H, W, 2, pl)) return 2;
-#endif
-  return dft_make_forward_plan(H, W, DFT_G, pl) ? DFT_G : 0;
-}
+// (profiles/r04/dft_phases_g2.txt, profiles/r05/dft_phases_g2_two_groups_per_cu.txt; tools/patches/dft_mfma_variants.patch).
+int dft_forward_g(int H, int W, DftPlan* pl) { return dft_plan_cached(H, W, pl) ? DFT_G : 0; }
 
 }  // namespace
 
@@ -146,7 +165,7 @@ int dft_forward_g(int H, int W, DftPlan* pl) {
 // tiles[6] (optional) = TY, TX, TH, TW, window rows, window columns.  0 if the map has no plan.
 int os2d_dft_plan(int H, int W, int* P, int* Q, int* nbins, int* tiles) {
   DftPlan pl;
-  if (H < 1 || W < 1 || !dft_make_plan(H, W, &pl)) return 0;
+  if (H < 1 || W < 1 || !dft_plan_cached(H, W, &pl)) return 0;
   if (P) *P = pl.P;
   if (Q) *Q = pl.Q;
   if (nbins) *nbins = pl.NBINS;
@@ -190,26 +209,22 @@ int os2d_launch_dft_forward(const float* corr, const float* inv, float* X, const
   pl.inv_cg = dft_magic((unsigned)CG);
   const u32x4v* FqT = static_cast<const u32x4v*>(matrices);
   const u32x4v* Fp2 = FqT + dft_units_fqt(pl.P, pl.Q);
-#ifdef OS2D_DIAG_DFT_G2
-  auto kern = G == 2 ? dft_forward_pick<2, 4>(pl) : dft_forward_pick<4, 8>(pl);
-#else
   auto kern = dft_forward_pick<4, 8>(pl);
-#endif
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds_total);
   if (e != hipSuccess) {
     os2d_set_error("hipFuncSetAttribute(dft_forward): %s", hipGetErrorString(e));
     return -4;
   }
-  hipLaunchKernelGGL(kern, dim3(dft_grid(iters, G == 2 ? 2 : 1)), dim3(G == 2 ? 256 : DFT_THR), pl.lds_total, stream, corr, inv, X, FqT, Fp2, pl,
+  hipLaunchKernelGGL(kern, dim3(dft_grid(iters)), dim3(DFT_THR), pl.lds_total, stream, corr, inv, X, FqT, Fp2, pl,
                      C, Cpad, NBT, iters);
   return dft_check("dft_forward");
 }
 
 // zero_borders != 0: the kernel also writes the zero border cells of the planes it fills (no os2d_launch_border_zero_shb_planes)
 int os2d_launch_dft_inverse(const float* Y, const float* bp, int MTP, void* out, const void* matrices, int NB, int Cout, int H, int W,
-                            int* status, int zero_borders, hipStream_t stream) {
+                            Os2dRangeFlag status, int zero_borders, hipStream_t stream) {
   DftPlan pl;
-  if (!dft_make_plan(H, W, &pl)) {
+  if (!dft_plan_cached(H, W, &pl)) {
     os2d_set_error("dft_inverse: no transform plan for a %dx%d map", H, W);
     return -3;
   }
@@ -232,7 +247,7 @@ int os2d_launch_dft_inverse(const float* Y, const float* bp, int MTP, void* out,
   return dft_check("dft_inverse");
 }
 
-// diagnostic builds only (-DOS2D_DIAG_DFT_STAMPS): copy the 16 phase counters to the host and optionally reset them
+// diagnostic builds only (phase stamps, see above): copy the 16 phase counters to the host and optionally reset them
 extern "C" int os2d_debug_dft_stamps(unsigned long long* out16, int reset) {
 #ifdef OS2D_DIAG_DFT_STAMPS
   if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(os2d_dft_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return -4;

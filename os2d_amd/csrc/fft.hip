@@ -22,6 +22,9 @@
 // kernels: X is [C][NB * T][NBINS], Y is [NB * T][Cout][NBINS], pair' = nb * T + tile; the weight spectra depend on (P, Q)
 // only, so every map that tiles to the same transform size shares them.
 #include "os2d_common.h"
+#include <map>
+#include <mutex>
+#include <utility>
 #include "fft_regs.h"
 
 namespace {
@@ -66,11 +69,7 @@ __device__ __forceinline__ int div_magic(int x, unsigned magic) { return magic ?
 // and stores.  __syncthreads() carries a full fence (s_waitcnt vmcnt(0)): inside the per-image loop it would wait for the
 // prefetch of the next image and for the stores of the previous one at every one of the ~10 barriers of an image - the
 // whole HBM latency serialised per image (measured: 8 us of an image's 17 us).
-#ifdef OS2D_DIAG_FFT_FULLBARRIER
-__device__ __forceinline__ void lds_barrier() { __syncthreads(); }
-#else
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#endif
 
 __device__ __forceinline__ f32x2 cmul(f32x2 a, f32x2 b) { return f32x2{a[0] * b[0] - a[1] * b[1], a[0] * b[1] + a[1] * b[0]}; }
 __device__ __forceinline__ f32x2 cconj(f32x2 a) { return f32x2{a[0], -a[1]}; }
@@ -95,11 +94,7 @@ __device__ __forceinline__ void stockham_pass(const f32x2* __restrict__ in, f32x
 #pragma unroll
     for (int q = 0; q < R; ++q) {
       v[q] = in[f * stride + j + q * nb];
-#ifdef OS2D_DIAG_FFT_TW0
-      if (q > 0) {
-#else
       if (q > 0 && Ns > 1) {      // the first pass (Ns = 1) has k = 0: all twiddles are 1
-#endif
         f32x2 w = tw[q * k * step];
         if (INV) w = cconj(w);
         v[q] = cmul(v[q], w);
@@ -266,11 +261,7 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 6 ? 4 : 2) void fft_forward_ker
     }
     lds_barrier();
     if (img + (int)gridDim.x < images) FFT_PREFETCH(img + gridDim.x, tl)
-#ifdef OS2D_DIAG_FFT_NOROW
-    f32x2* R = A;
-#else
     f32x2* R = fft_any<false>(pl.row_r1, pl.row_r2, A, Bf, Q, HP, QS, pl.zs_row, pl.inv_hp, pl.np_row, pl.rad_row, tQ, tid);
-#endif
     // ---- untangle the two real rows of every pair and transpose into the column buffer C[v][u]; rows >= H are zero
     f32x2* Cb = (R == A) ? Cc : Cc;   // C is separate from A | B
     for (int v = wv; v < V; v += NWV)
@@ -288,11 +279,7 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 6 ? 4 : 2) void fft_forward_ker
         Cb[v * PS + u] = o;
       }
     lds_barrier();
-#ifdef OS2D_DIAG_FFT_NOCOL
-    f32x2* Rc = Cb;
-#else
     f32x2* Rc = fft_any<false>(pl.col_r1, pl.col_r2, Cb, D, P, V, PS, pl.zs_col, pl.inv_v, pl.np_col, pl.rad_col, tP, tid);
-#endif
     // ---- store the half spectrum (bin = u * V + v, v fastest) + zero padding bins
     const int nb_ = m_ / C, ch_ = m_ - nb_ * C;
     const size_t pair_ = TILED ? (size_t)nb_ * pl.T + t_ : (size_t)nb_;
@@ -320,7 +307,7 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
                                                              int MTP, char* __restrict__ out,  // SHB [NB][Cout/8][2][PLANE] x 16 B
                                                              const f32x2* __restrict__ twQ, const f32x2* __restrict__ twP,
                                                              FftPlan pl, int Cout, int H, int W, int NBINS, int PLANE,
-                                                             int images, unsigned inv_v, int* __restrict__ status, int quad,
+                                                             int images, unsigned inv_v, Os2dRangeFlag status, int quad,
                                                              int out32 /* CPT == 0 only: out = fp32 planes [NB][Cout][PLANE] */) {
   // images = NB * T * Cout: image -> (pair' = nb * T + tile, output channel); RH = rows of the inverse that are needed.
   // quad == 0: Y[pair'][o][bin]; quad == 1 (what os2d_spectral_gemm_f16 writes): Y[bin / 4][pair'][o][bin % 4] - the GEMM
@@ -391,11 +378,7 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
     }
     lds_barrier();
     if (nxt < images) FFT_PREFETCH_Y(nxt, tl)
-#ifdef OS2D_DIAG_FFT_NOCOL
-    f32x2* Rc = Cc;
-#else
     f32x2* Rc = fft_any<true>(pl.col_r1, pl.col_r2, Cc, D, P, V, PS, pl.zs_col, pl.inv_v, pl.np_col, pl.rad_col, tP, tid);
-#endif
     // ---- rows 2p, 2p+1 (only h < H are needed) as one complex spectrum Z[v] = X_2p[v] + i X_2p+1[v], v < Q, with the
     // Hermitian halves of the two real rows: X[Q - v] = conj X[v].  Rc may be D = A | B: stage through registers per element
     // into the row buffer that does not overlap what is still to be read - rows go to Bf (second half of A | B) only after
@@ -419,11 +402,7 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
         A[p * QS + v] = f32x2{x0[0] - x1[1], x0[1] + x1[0]};      // x0 + i x1
       }
     lds_barrier();
-#ifdef OS2D_DIAG_FFT_NOROW
-    f32x2* R = A;
-#else
     f32x2* R = fft_any<true>(pl.row_r1, pl.row_r2, A, Bf, Q, HP, QS, pl.zs_row, pl.inv_hpr, pl.np_row, pl.rad_row, tQ, tid);
-#endif
     // ---- epilogue: y = re / im of R (rows 2p / 2p+1), + bias, ReLU, channel scale, fp16 hi | lo into the SHB unit of
     // (nb, o / 8) at slot o % 8 (2-byte stores: the 8 channels of a unit come from 8 different images)
     const float bias = bp[o], osc = bp[2 * MTP + o];
@@ -456,9 +435,6 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
           }
           if ((slot & (GRP - 1)) == GRP - 1) {
             const size_t off = ((size_t)BASE + (size_t)h * Ws + w) * 16 + (slot & (8 - GRP)) * 2;
-#ifdef OS2D_DIAG_FFT_NOSTORE
-            if (t == 123.456f)
-#endif
             {
               if constexpr (GRP == 4) {
                 *reinterpret_cast<uint2*>(hi_unit + off) = uint2{hreg[k][0], hreg[k][NR - 1]};
@@ -493,9 +469,6 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
           if (!(fabsf(t) <= 65504.f)) bad = true;
           const _Float16 hv = (_Float16)t;
           const size_t cell = (size_t)BASE + (size_t)h * Ws + w;
-#ifdef OS2D_DIAG_FFT_NOSTORE
-          if (t == 123.456f)
-#endif
           {
             hi[cell * 8] = hv;
             lo[cell * 8] = (_Float16)(t - (float)hv);
@@ -503,8 +476,8 @@ __global__ __launch_bounds__(FFT_THR, FFT_EPT <= 10 ? 4 : 2) void fft_inverse_ke
         }
     }
   }
-  if (status != nullptr && __builtin_amdgcn_ballot_w64(bad) != 0ull) {
-    if ((tid & 63) == 0) __hip_atomic_store(status, OS2D_STATUS_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (status.word != nullptr && __builtin_amdgcn_ballot_w64(bad) != 0ull) {
+    if ((tid & 63) == 0) os2d_raise(status);
   }
 }
 
@@ -532,14 +505,12 @@ bool split_size(int N, int* r1, int* r2) {
   static const int table[][3] = {{36, 6, 6}, {42, 6, 7}, {48, 8, 6}, {54, 9, 6}, {64, 8, 8},  {72, 9, 8},
                                  {84, 12, 7}, {96, 12, 8}, {108, 12, 9}, {128, 16, 8}};
   *r1 = *r2 = 0;
-#ifndef OS2D_DIAG_FFT_STOCKHAM
   for (const auto& e : table)
     if (e[0] == N) {
       *r1 = e[1];
       *r2 = e[2];
       return true;
     }
-#endif
   return false;
 }
 
@@ -560,11 +531,7 @@ bool plan_transform(int LH, int LW, int RH, int minP, int minQ, FftPlan* pl, siz
   pl->Q = next_size(minQ);
   pl->V = pl->Q / 2 + 1;
   pl->PS = pl->P + 1;
-#ifdef OS2D_DIAG_FFT_QS0
-  pl->QS = pl->Q;
-#else
   pl->QS = pl->Q + 1;
-#endif
   pl->np_row = factor(pl->Q, pl->rad_row);
   pl->np_col = factor(pl->P, pl->rad_col);
   const int HP = (LH + 1) / 2, HPR = (RH + 1) / 2;
@@ -608,7 +575,42 @@ void set_tiles(FftPlan* pl, int TY, int TX, int TH, int TW) {
 // size has no two-stage register form (Stockham passes: ~2x the LDS traffic), x 1.15 when only one work-group fits a CU (no
 // second group to hide the barriers behind): 96 x 128 -> 2 x 2 tiles at 54 x 72 (7992 bins, 48 KB, the transform the 48 x 64
 // level uses - one set of weight spectra for both) rather than 2 x 1 at 54 x 144 (7888 bins, 96 KB, Stockham rows).
+bool make_plan_search(int H, int W, FftPlan* pl, size_t* lds);
+
+// Plans are pure functions of (H, W) and a head call asks for the same one several times (workspace size, route, forward,
+// inverse): memoised per process (the search below runs plan_transform for up to 48 x 48 tilings).
 bool make_plan(int H, int W, FftPlan* pl, size_t* lds) {
+  struct Entry {
+    bool ok;
+    FftPlan pl;
+    size_t lds;
+  };
+  static std::mutex mu;
+  static std::map<std::pair<int, int>, Entry> cache;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find({H, W});
+    if (it != cache.end()) {
+      if (it->second.ok) {
+        *pl = it->second.pl;
+        *lds = it->second.lds;
+      }
+      return it->second.ok;
+    }
+  }
+  Entry e = {};
+  e.ok = make_plan_search(H, W, &e.pl, &e.lds);
+  if (e.ok) {
+    *pl = e.pl;
+    *lds = e.lds;
+  }
+  std::lock_guard<std::mutex> lock(mu);
+  if (cache.size() >= 4096) cache.clear();      // a dataset of arbitrary map sizes must not grow the table without bound
+  cache[{H, W}] = e;
+  return e.ok;
+}
+
+bool make_plan_search(int H, int W, FftPlan* pl, size_t* lds) {
   if (plan_transform(H, W, H, H + 3, W + 3, pl, lds)) {
     set_tiles(pl, 1, 1, H, W);
     return true;
@@ -683,9 +685,6 @@ int os2d_launch_fft_forward(const float* corr, const float* inv, float* X, const
     os2d_set_error("fft_forward: a %dx%d map does not fit the in-LDS transform", H, W);
     return -3;
   }
-#ifdef OS2D_DIAG_FFT_LDS_MIN
-  if (lds < (size_t)OS2D_DIAG_FFT_LDS_MIN) lds = OS2D_DIAG_FFT_LDS_MIN;
-#endif
   const int ept = (((pl.LH + 1) / 2) * pl.Q + FFT_THR - 1) / FFT_THR;
   auto kern = pl.T > 1 ? (ept <= 6 ? fft_forward_kernel<6, true> : ept <= 10 ? fft_forward_kernel<10, true> : fft_forward_kernel<14, true>)
                        : (ept <= 6 ? fft_forward_kernel<6, false> : ept <= 10 ? fft_forward_kernel<10, false> : fft_forward_kernel<14, false>);
@@ -704,7 +703,7 @@ int os2d_launch_fft_forward(const float* corr, const float* inv, float* X, const
 }
 
 int os2d_launch_fft_inverse(const float* Y, const float* bp, int MTP, void* out, const float* twQ, const float* twP, int NB,
-                            int Cout, int H, int W, int* status, int layout, int out_fp32, hipStream_t stream) {
+                            int Cout, int H, int W, Os2dRangeFlag status, int layout, int out_fp32, hipStream_t stream) {
   FftPlan pl;
   size_t lds;
   if (!make_plan(H, W, &pl, &lds)) {

@@ -26,10 +26,28 @@
                                  // (tiled) whatever the batch
 #define OS2D_MAX_W 3600      // widest feature map of the head (57,600-px images at stride 16): the transform planner cuts an axis into at most
                              // 48 overlap-save tiles of its largest canonical size (dft_mfma.h); the reference has no limit (head.py:619-629)
+#define OS2D_MAX_H 2784      // tallest feature map: 48 tiles of 58 rows (window 64 = the largest canonical transform height)
 #define OS2D_XSPEC_CPAD 232  // channel stride of the input spectra of the matrix-product transforms: 225 rounded up to the GEMM's k-steps of 8
 #define OS2D_G 29            // 8-channel groups of the 225 correlation channels (f16x3 path)
 #define OS2D_RNORM_EXP 12    // the relu+L2-normalised correlation (|x| <= 1) is stored as fp16 hi|lo of x * 2^12
 #define OS2D_STATUS_F16_RANGE 1  // sticky status bit: a split-fp16 activation left the fp16 range (non-finite input)
+
+// Where a split-fp16 kernel reports an activation outside the fp16 range / a non-finite input, and WHAT it stores there.
+// Per-stage entry points: the caller's word, value OS2D_STATUS_F16_RANGE.  os2d_head_forward_ex: a word of the call's
+// workspace and the call's EPOCH - sample_decode_kernel, the last kernel of the call, compares the words with the epoch and
+// writes NaN into the outputs of a flagged image (round 6): the words are never cleared, so no kernel has to run before the
+// ones that raise them and a stale value of an earlier call never matches.
+struct Os2dRangeFlag {
+  int* word;      // NULL: nowhere
+  int value;
+};
+#ifdef __HIPCC__
+// a plain system-scope store (the word may live in mapped host memory, where PCIe atomics are not a given); every writer of a
+// call stores the same value, so racing stores are benign
+__device__ __forceinline__ void os2d_raise(Os2dRangeFlag f) {
+  __hip_atomic_store(f.word, f.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -244,7 +262,7 @@ int os2d_launch_corr(const float* fm, const float* qp, const float* sumsq, float
 // conv_f16x3.hip
 int os2d_launch_conv3_f16x3(const void* in, const void* wp, const float* bp, void* out, int NB, int P, int H, int W,
                             hipStream_t stream);   // conv3_f16x3.hip: layer 3 on the 16-row MFMA
-int os2d_launch_conv_f16x3(int layer, const void* in, const void* wp, const float* bp, int* status, void* out, int NB,
+int os2d_launch_conv_f16x3(int layer, const void* in, const void* wp, const float* bp, Os2dRangeFlag status, void* out, int NB,
                            int P, int H, int W, int terms, hipStream_t stream);
 // conv_mfma.hip
 int os2d_launch_conv(int layer, const float* in, const float* wp, const float* bp, float* out,
@@ -252,7 +270,8 @@ int os2d_launch_conv(int layer, const float* in, const float* wp, const float* b
 // sample_decode.hip
 int os2d_launch_sample_decode(const float* corr, const float* params, int NB, int H, int W, int P, int inverse,
                               int stride, int rec_field, int Bc, int Btot, int b0, float* loc, float* cls,
-                              float* corners, hipStream_t stream);
+                              float* corners, const int* flags /* [A + 1] range words of the call or NULL */, int epoch,
+                              int* host_status /* or NULL */, hipStream_t stream);
 int os2d_launch_decode_boxes(const float* loc, int NB, int H, int W, int stride, int rec_field, float img_w,
                              float img_h, float* boxes, hipStream_t stream);
 int os2d_launch_alignment_grids(const float* params, int NB, int H, int W, int P, int inverse, float* theta,
@@ -270,7 +289,7 @@ int os2d_fft_plan(int H, int W, int* P, int* Q, int* nbins, int* tiles /* [6]: T
 int os2d_launch_fft_forward(const float* corr, const float* inv, float* X, const float* twQ, const float* twP, int NB, int C,
                             int H, int W, hipStream_t stream);
 int os2d_launch_fft_inverse(const float* Y, const float* bp, int MTP, void* out, const float* twQ, const float* twP, int NB,
-                            int Cout, int H, int W, int* status, int layout /* OS2D_SPECTRA_ROWS | OS2D_SPECTRA_QUADS */,
+                            int Cout, int H, int W, Os2dRangeFlag status, int layout /* OS2D_SPECTRA_ROWS | OS2D_SPECTRA_QUADS */,
                             int out_fp32 /* 1: out = fp32 zero-bordered planes [NB][Cout][PLANE] (all-fp32 mode), no scale / split */,
                             hipStream_t stream);
 // spectra_pack.hip
@@ -294,12 +313,13 @@ int os2d_launch_dft_matrices(const double* twP64, const double* twQ64, int P, in
 int os2d_launch_dft_forward(const float* corr, const float* inv, float* X, const void* matrices, int NB, int C, int Cpad, int H, int W,
                             hipStream_t stream);
 int os2d_launch_dft_inverse(const float* Y, const float* bp, int MTP, void* out, const void* matrices, int NB, int Cout, int H, int W,
-                            int* status, int zero_borders, hipStream_t stream);
+                            Os2dRangeFlag status, int zero_borders, hipStream_t stream);
 // corr_f16x3.hip
 int os2d_corr_groups(int C);  // 8-channel groups of the split correlation operands, padded to whole K chunks
 // clear / clear_words: 64-bit words zeroed by the same launch (the packed correlation kernel's sums; NULL / 0: none)
+// status: word[a] is raised for an image a with a non-finite feature (one word per image)
 int os2d_launch_split_fm(const float* fm, const float* sumsq, void* fs, int A, int C, int HW, void* clear, size_t clear_words,
-                         int* status, hipStream_t stream);
+                         Os2dRangeFlag status, hipStream_t stream);
 int os2d_launch_split_qp(const float* qp, void* qs, int B, int C, hipStream_t stream);
 // defer_norms & 1 (packed form only): the sums stay in sumfx; the caller's next launch turns them into invn; & 2: half tiles
 // (os2d_launch_border_zero_shb_planes_norms) - one launch less on the per-step path

@@ -16,10 +16,6 @@
 // each of the 121x4 gathers is a near-coalesced L2 read of the 4.3 MB per-class correlation block.
 #include "os2d_common.h"
 
-#ifndef OS2D_SAMPLE_BATCH
-#define OS2D_SAMPLE_BATCH 1
-#endif
-
 namespace {
 
 constexpr int POOL_LO = 2, POOL_HI = OS2D_T - 2;  // head.py:280,296-302: pool_border_width = 2
@@ -84,7 +80,9 @@ __global__ __launch_bounds__(256) void sample_decode_kernel(const float* __restr
                                                             int H, int W, int P, int inverse, float stride,
                                                             float half_box, int Bc, int Btot, int b0,
                                                             float* __restrict__ loc, float* __restrict__ cls,
-                                                            float* __restrict__ corners) {
+                                                            float* __restrict__ corners,
+                                                            const int* __restrict__ flags /* [A + 1] or NULL */, int A, int epoch,
+                                                            int* __restrict__ host_status /* or NULL */) {
   const int HW = H * W;
   const int n = blockIdx.x * 256 + threadIdx.x;
   const int nb = blockIdx.y;  // index inside the class chunk: a*Bc + b_local
@@ -93,6 +91,23 @@ __global__ __launch_bounds__(256) void sample_decode_kernel(const float* __restr
   const int img = nb / Bc;
   const size_t ob = (size_t)img * Btot + b0 + (nb - img * Bc);
   const int h = n / W, w = n - h * W;
+  // Non-finite input (reference head.py:339, 650: torch.relu / norm propagate a NaN; the fmaxf ReLUs and the fp16 splits of the
+  // split-fp16 kernels do not): an earlier kernel of THIS call raised the range word of the image (split_fm_kernel: a non-finite
+  // feature) or of the whole call (an activation outside the fp16 range) by storing the call's epoch there.  The outputs of such
+  // an image are NaN - all of them, where the reference has NaN in the neighbourhood of the offending cells - in the call that
+  // has the bad input, without a host synchronisation; the sticky host word is raised for ``Os2dHead.range_status``.  Two
+  // scalar loads per work-group (the image index is uniform).
+  if (flags != nullptr && (flags[img] == epoch || flags[A] == epoch)) {
+    const float qnan = __builtin_nanf("");
+    cls[ob * HW + n] = qnan;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) corners[(ob * 8 + k) * HW + n] = qnan;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) loc[(ob * 4 + k) * HW + n] = qnan;
+    if (host_status != nullptr && threadIdx.x == 0 && blockIdx.x == 0)
+      __hip_atomic_store(host_status, OS2D_STATUS_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
 
   float t00, t01, t02, t10, t11, t12;
   os2d_theta(params + (size_t)nb * P * HW + n, HW, P, inverse, t00, t01, t02, t10, t11, t12);
@@ -108,28 +123,6 @@ __global__ __launch_bounds__(256) void sample_decode_kernel(const float* __restr
   // per CU - the kernel was a chain of 121 cache round trips per thread (0.087 ms against 0.052 ms per 64 classes inside the
   // 1024-class launch, where occupancy hides them).  Same operations in the same order: the sums are bit-identical.
   constexpr int NTAP = POOL_HI - POOL_LO;
-#if !OS2D_SAMPLE_BATCH       /* diagnostic (-DOS2D_SAMPLE_BATCH=0): tap by tap, as rounds 1 - 4 */
-  for (int j = POOL_LO; j < POOL_HI; ++j) {
-    const float xj = os2d_template_coord(j);
-#pragma unroll
-    for (int i = POOL_LO; i < POOL_HI; ++i) {
-      const float yi = os2d_template_coord(i);
-      const float gx = t00 * xj + t01 * yi + t02;
-      const float gy = t10 * xj + t11 * yi + t12;
-      const float X = fminf(fmaxf(gx * half_t + cx, 0.f), wmax);
-      const float Y = fminf(fmaxf(gy * half_t + cy, 0.f), hmax);
-      const float fx0 = floorf(X), fy0 = floorf(Y);
-      const float ax = X - fx0, ay = Y - fy0;
-      const int x0 = (int)fx0, y0 = (int)fy0;
-      const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
-      const float* c = cbase + (size_t)(j * OS2D_T + i) * HW;
-      const float v00 = c[y0 * W + x0], v01 = c[y0 * W + x1];
-      const float v10 = c[y1 * W + x0], v11 = c[y1 * W + x1];
-      sum += (v00 * (1.f - ax) + v01 * ax) * (1.f - ay) + (v10 * (1.f - ax) + v11 * ax) * ay;
-    }
-  }
-  (void)NTAP;
-#else
   for (int j = POOL_LO; j < POOL_HI; ++j) {
     const float xj = os2d_template_coord(j);
     float axs[NTAP], ays[NTAP], v00[NTAP], v01[NTAP], v10[NTAP], v11[NTAP];
@@ -158,7 +151,6 @@ __global__ __launch_bounds__(256) void sample_decode_kernel(const float* __restr
       sum += (v00[k] * (1.f - ax) + v01[k] * ax) * (1.f - ay) + (v10[k] * (1.f - ax) + v11[k] * ax) * ay;
     }
   }
-#endif
   cls[ob * HW + n] = sum * (1.0f / ((POOL_HI - POOL_LO) * (POOL_HI - POOL_LO)));
 
   // ---- box of the transformed template in image coordinates (the 4 corners bound the affine image)
@@ -238,11 +230,11 @@ __global__ __launch_bounds__(256) void alignment_grids_kernel(const float* __res
 
 int os2d_launch_sample_decode(const float* corr, const float* params, int NB, int H, int W, int P, int inverse,
                               int stride, int rec_field, int Bc, int Btot, int b0, float* loc, float* cls,
-                              float* corners, hipStream_t stream) {
+                              float* corners, const int* flags, int epoch, int* host_status, hipStream_t stream) {
   const float half_box = 0.5f * (float)(stride * (OS2D_T - 1) + rec_field);  // head.py:236-237: 16*14+16 = 240
   dim3 grid((H * W + 255) / 256, NB);
   hipLaunchKernelGGL(sample_decode_kernel, grid, dim3(256), 0, stream, corr, params, H, W, P, inverse, (float)stride,
-                     half_box, Bc, Btot, b0, loc, cls, corners);
+                     half_box, Bc, Btot, b0, loc, cls, corners, flags, NB / Bc, epoch, host_status);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     os2d_set_error("sample_decode launch: %s", hipGetErrorString(e));

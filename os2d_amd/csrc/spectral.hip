@@ -133,12 +133,8 @@ __global__ __launch_bounds__(SG_THR, 2) void spectral_gemm_kernel(const f32x2* w
   for (int t = 0; t < nchunks; ++t) {
     const bool more = t + 1 < nchunks;
     if (more) {
-#ifndef OS2D_DIAG_SG_NOW
       SG_DMA_W(t + 1)
-#endif
-#ifndef OS2D_DIAG_SG_NOX
       SG_LOAD_X(t + 1)
-#endif
     }
     __builtin_amdgcn_sched_barrier(0);
     const f32x2* wB = ldsW + (t & 1) * (SG_WUNITS * 2) + wv * SG_OH + oq * 32 + l31;      // [c][bin = wv][o]
@@ -176,10 +172,8 @@ __global__ __launch_bounds__(SG_THR, 2) void spectral_gemm_kernel(const f32x2* w
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-#ifndef OS2D_DIAG_SG_NOSYNC
     if (more) SG_STORE_X(t + 1)
     __syncthreads();
-#endif
   }
 #undef SG_DMA_W
 #undef SG_LOAD_X
@@ -196,11 +190,7 @@ __global__ __launch_bounds__(SG_THR, 2) void spectral_gemm_kernel(const f32x2* w
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int nb = nb0 + (bq + b) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hw;
-#ifdef OS2D_DIAG_SG_NOSTORE
-        if (nb < NB && yr[a][b][r] == 123.456f) {
-#else
         if (nb < NB) {
-#endif
           const float vr = yr[a][b][r], vi = yi[a][b][r];   // (copies: see the ext-vector element note in corr_f16x3.hip)
           Y[((size_t)nb * Cout + o) * NBINS + bin] = f32x2{vr, vi};
         }

@@ -17,9 +17,9 @@
 //     the 2^-22 relative error of a split product) and the inverse transform is unchanged.
 //
 // Work decomposition (round 3; the round-2 kernel and the intermediate steps are timed in profiles/r03_spectral_gemm_*.txt):
-//   work-group = 8 waves = 4 consecutive bins x ALL 128 output channels x 64 pairs, one per CU (128 KB of LDS: weight ring
-//     3 x 32 KB + spectra 2 x 16 KB).  Round 2 ran two 4-wave groups of 64 output channels each, and each fetched, scaled and
-//     split the same spectra: component-removal builds (tools/diag_spectral.sh) put the spectra loads at 0.10 of the launch's
+//   work-group = 8 waves = 4 consecutive bins x ALL 128 output channels x 64 pairs, one per CU (96 KB of LDS: weight stages
+//     2 x 32 KB + spectra 2 x 16 KB; both operands go global -> registers -> LDS two k-steps ahead).
+//     Round 2 ran two 4-wave groups of 64 output channels each, and each fetched, scaled and split the same spectra: component-removal builds (tools/diag_spectral.sh) put the spectra loads at 0.10 of the launch's
 //     0.39 ms at 64 pairs and at 2.5 of 5.6 ms at 1024;
 //   wave = a 32 x 32 (pairs x output channels) tile of all FOUR bins (ot = wv & 3, pt = wv >> 2): a lane owns the 4 bins of a
 //     (pair, channel) row = 32 contiguous bytes (round 2: a wave = one bin of the whole tile, 8-byte stores; the stores were
@@ -47,38 +47,10 @@ constexpr int SH_OH = 64, SH_NB = 64;
 constexpr int SH_KC = 8;        // channels per k-step
 constexpr int SH_STAGE = SH_WB * 2 * 2 * 64;   // 16-byte units of one operand stage of 64 rows: [bin][group][hi|lo][row]: 16 KB
 constexpr int SH_WSTAGE = 2 * SH_STAGE;        // weights of both output-channel halves: 32 KB
-#ifndef OS2D_SH_WRING
-#define OS2D_SH_WRING 3
-#endif
-#ifdef OS2D_NO_MIX_SPLIT
-#define SH_MIX_SPLIT 0
-#else
-#define SH_MIX_SPLIT 1
-#endif
-#ifndef OS2D_SH_PINGPONG
-#define OS2D_SH_PINGPONG 0    /* 1: the two halves of the work-group run half a k-step apart (one multiplies while the other converts): measured no faster */
-#endif
-#ifndef OS2D_SH_AHEAD
-#define OS2D_SH_AHEAD 2       /* k-steps both operands run ahead (3: one more register set of each, experiment) */
-#endif
-#ifndef OS2D_SH_XAHEAD
-#define OS2D_SH_XAHEAD 2      /* k-steps the spectra loads run ahead of the matrix instructions; 4 (two more register sets) measured no faster */
-#endif
-#ifndef OS2D_SH_REGW
-#define OS2D_SH_REGW 1        /* 1: weights staged through registers (round 4); 0: by LDS-DMA into a ring of 3 (round 3) */
-#endif
-constexpr int SH_WRING = OS2D_SH_REGW ? 2 : OS2D_SH_WRING;        // weight stages in LDS (ring): the DMA of k-step s + WRING - 1 is in flight
-                                               // while k-step s is multiplied; the spectra are two k-steps ahead in registers
+constexpr int SH_WRING = 2;           // weight stages in LDS: k-step s + 1 is stored while k-step s is multiplied (both operands
+                                      // run two k-steps ahead in registers)
 
-#ifdef OS2D_DIAG_SH_NOMFMA   /* diagnostic: fragments are read and derived, the matrix instructions are skipped */
-__device__ __forceinline__ f32x16 sh_keep(half8 x, half8 y, f32x16 acc) {
-  asm volatile("" ::"v"(x), "v"(y));
-  return acc;
-}
-#define SH_MM(x_, y_, acc_) sh_keep(x_, y_, acc_)
-#else
 #define SH_MM(x_, y_, acc_) __builtin_amdgcn_mfma_f32_32x32x16_f16(x_, y_, acc_, 0, 0, 0)
-#endif
 
 // barrier for data exchanged through LDS that leaves the wave's global loads in flight (see fft.hip)
 __device__ __forceinline__ void sh_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -120,12 +92,9 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
       yi[j][r] = 0.f;
     }
 
-  typedef const void __attribute__((address_space(1))) * gptr_t;
-  typedef void __attribute__((address_space(3))) * lptr_t;
   // weights of k-step s for this work-group's 4 bins: 1024 contiguous units per output-channel half (waves 0-3 stage half 0,
   // waves 4-7 half 1)
   const u32x4* wbase = w16 + ((size_t)(g * 2 + wh) * KS) * (SH_BINS * 256) + bh * SH_STAGE;
-#if OS2D_SH_REGW
   // REGISTER staging (round 4).  The LDS-DMA of round 3 (global_load_lds) looked like a 2-step-deep pipeline and was none: the
   // compiler treats a FLAT-encoded instruction that may touch LDS as returning out of order, and from the first DMA on every
   // vmcnt wait it inserts is vmcnt(0).  The one wait this loop needs - for the spectra registers before their conversion - thus
@@ -136,37 +105,16 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
   // into the other LDS stage - vmcnt(6): this step's 4 + 2 requests stay in flight through the barrier and the next k-step's
   // matrix work.  Costs 32 registers and 4 LDS stores per thread and k-step; the LDS ring shrinks to 2 stages (96 KB in all).
   u32x4 wra[4], wrb[4];
-#ifdef OS2D_DIAG_SH_NOW
-#define SH_LOAD_W(S, wr)                                                                                            \
-  {                                                                                                                 \
-    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) wr[k_] = u32x4{(unsigned)(S), 0x3c003c00u, 0u, (unsigned)lane};  \
-  }
-#else
 #define SH_LOAD_W(S, wr)                                                                                            \
   {                                                                                                                 \
     const u32x4* src_ = wbase + (size_t)(S) * (SH_BINS * 256);                                                      \
     _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) wr[k_] = src_[(wq * 4 + k_) * 64 + lane];                      \
   }
-#endif
 #define SH_STORE_W(S, wr)                                                                                           \
   {                                                                                                                 \
     _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_)                                                                \
         ldsW[((S) % SH_WRING) * SH_WSTAGE + wh * SH_STAGE + (wq * 4 + k_) * 64 + lane] = wr[k_];                    \
   }
-#define SH_DMA_W(S) {}
-#elif defined(OS2D_DIAG_SH_NOW)      /* diagnostic: no weight DMA (tools/diag_spectral.sh) */
-#define SH_DMA_W(S) {}
-#else
-#define SH_DMA_W(S)                                                                                                 \
-  {                                                                                                                 \
-    const u32x4* src_ = wbase + (size_t)(S) * (SH_BINS * 256);                                                      \
-    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) {                                                              \
-      const int u_ = (wq * 4 + k_) * 64;                                                                            \
-      __builtin_amdgcn_global_load_lds((gptr_t)(src_ + u_ + lane),                                                  \
-                                       (lptr_t)(ldsW + ((S) % SH_WRING) * SH_WSTAGE + wh * SH_STAGE + u_), 16, 0, 0); \
-    }                                                                                                               \
-  }
-#endif
   // spectra of k-step s: this thread owns pair xn, bins 2 xj / 2 xj + 1 and TWO channels (xg * 4 + wh * 2 + {0, 1}).  A wave
   // covers 16 pairs x (2 bin pairs x 2 channel groups): with one pair per lane a load instruction would touch 64 rows 5 MB
   // apart and spend its time in address translation, not in the memory system
@@ -184,12 +132,6 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
                          : X + (size_t)min(nb0 + xn, NB - 1) * NBINS + bin0 + 2 * xj;
   const size_t xcs = XQ ? 4 : (size_t)NB * NBINS;      // channel stride: 4 bins | X [C][NB][NBINS]
   u32x4 pfa[2], pfb[2];     // two k-steps of spectra in flight (even / odd k-steps)
-#ifdef OS2D_DIAG_SH_NOX      /* diagnostic: no global loads of the spectra */
-#define SH_LOAD_X(S, pfx)                                                                                           \
-  {                                                                                                                 \
-    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) pfx[i_] = u32x4{(unsigned)(S), 1u, 2u, (unsigned)lane};        \
-  }
-#else
 #define SH_LOAD_X(S, pfx)                                                                                           \
   {                                                                                                                 \
     _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                              \
@@ -197,42 +139,11 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
       pfx[i_] = *reinterpret_cast<const u32x4*>(xrow + (size_t)c_ * xcs);                                           \
     }                                                                                                               \
   }
-#endif
-#ifdef OS2D_DIAG_SH_NOSPLIT  /* diagnostic: no scale / split arithmetic (raw bits as halves) */
-#define SH_SPLIT_VALUE                                                                                              \
-  h_[2 * i_ + p_] = __builtin_bit_cast(_Float16, (unsigned short)(ok_ ? raw_ : 0u));                                \
-  l_[2 * i_ + p_] = __builtin_bit_cast(_Float16, (unsigned short)(raw_ >> 16));
-#else
-#define SH_SPLIT_VALUE                                                                                              \
-  const float v_ = ok_ ? __uint_as_float(raw_) * xscale : 0.f;                                                      \
-  const _Float16 hv_ = (_Float16)v_;                                                                                \
-  h_[2 * i_ + p_] = hv_;                                                                                            \
-  l_[2 * i_ + p_] = (_Float16)(v_ - (float)hv_);
-#endif
-#define SH_STORE_X(S, pfx) SH_STORE_X_PART(S, pfx, 0, 2)
   // (the four values of a store as ONE vector conversion: v_cvt_pk_f16_f32 converts two values per instruction - a third fewer
   // conversion instructions than value by value; same roundings)
-#if defined(OS2D_DIAG_SH_NOSPLIT)
-#define SH_STORE_X_PART(S, pfx, B0, B1)                                                                             \
+#define SH_STORE_X(S, pfx)                                                                                          \
   {                                                                                                                 \
-    _Pragma("unroll") for (int b2_ = (B0); b2_ < (B1); ++b2_) {                                                     \
-      half4 h_, l_;                                                                                                 \
-      _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                            \
-        const bool ok_ = xn_ok && (S)*SH_KC + xg * 4 + xwh * 2 + i_ < C;                                            \
-        _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_) {                                                          \
-          const unsigned raw_ = pfx[i_][2 * b2_ + p_];                                                              \
-          SH_SPLIT_VALUE                                                                                            \
-        }                                                                                                           \
-      }                                                                                                             \
-      char* dst_ = reinterpret_cast<char*>(ldsX + ((S)&1) * SH_STAGE + (((2 * xj + b2_) * 2 + xg) * 2) * 64 + xn) + xwh * 8; \
-      *reinterpret_cast<half4*>(dst_) = h_;                                                                         \
-      *reinterpret_cast<half4*>(dst_ + 64 * 16) = l_;                                                               \
-    }                                                                                                               \
-  }
-#else
-#define SH_STORE_X_PART(S, pfx, B0, B1)                                                                             \
-  {                                                                                                                 \
-    _Pragma("unroll") for (int b2_ = (B0); b2_ < (B1); ++b2_) {                                                     \
+    _Pragma("unroll") for (int b2_ = 0; b2_ < 2; ++b2_) {                                                           \
       f32x4 v4_;                                                                                                    \
       _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                            \
         const bool ok_ = xn_ok && (S)*SH_KC + xg * 4 + xwh * 2 + i_ < C;                                            \
@@ -244,17 +155,13 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
       const half4 h_ = __builtin_convertvector(v4_, half4);                                                         \
       const u32x2 hp_ = __builtin_bit_cast(u32x2, h_);     /* lo halves: one mixed-precision instruction each (os2d_common.h) */ \
       const u32x2 lp_ = {os2d_split_lo_pair(v4_[0], v4_[1], hp_[0]), os2d_split_lo_pair(v4_[2], v4_[3], hp_[1])};    \
-      const half4 l_ = SH_MIX_SPLIT ? __builtin_bit_cast(half4, lp_)                                                \
-                                    : __builtin_convertvector(v4_ - __builtin_convertvector(h_, f32x4), half4);     \
+      const half4 l_ = __builtin_bit_cast(half4, lp_);                                                              \
       char* dst_ = reinterpret_cast<char*>(ldsX + ((S)&1) * SH_STAGE + (((2 * xj + b2_) * 2 + xg) * 2) * 64 + xn) + xwh * 8; \
       *reinterpret_cast<half4*>(dst_) = h_;              /* channels 2 wh, 2 wh + 1 of the unit (re, im each) */      \
       *reinterpret_cast<half4*>(dst_ + 64 * 16) = l_;                                                               \
     }                                                                                                               \
   }
-#endif
-#define SH_NOHOOK(J)
-#define SH_COMPUTE(S) SH_COMPUTE_H(S, SH_NOHOOK)
-#define SH_COMPUTE_H(S, HOOK)                                                                                       \
+#define SH_COMPUTE(S)                                                                                               \
   {                                                                                                                 \
     /* [half][bin][group = hw][hi|lo][o 64] and [bin][group][hi|lo][pair 64] */                                     \
     const u32x4* aB = ldsW + ((S) % SH_WRING) * SH_WSTAGE + (ot >> 1) * SH_STAGE + (hw * 2) * 64 + (ot & 1) * 32 + l31; \
@@ -279,57 +186,8 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
       yi[j] = SH_MM(bhf, ail, yi[j]);                                                                               \
       yi[j] = SH_MM(blf, aih, yi[j]);                                                                               \
       yi[j] = SH_MM(bhf, aih, yi[j]);                                                                               \
-      HOOK(j)                                                                                                       \
     }                                                                                                               \
   }
-  // one k-step: spectra of step S+2 -> registers PN (the registers PC hold step S+1, loaded one step ago), weights of step
-  // S + WRING - 1 -> LDS ring; multiply step S; split + store step S+1 into the other spectra buffer; barrier.  Per wave the
-  // memory operations complete in issue order and the weights of a step are issued BEFORE its spectra: when the spectra of
-  // step S+1 have arrived (the split below waits for them) its weights are in LDS as well; the barrier itself waits for LDS
-  // traffic only.
-#ifndef OS2D_SH_INTERLEAVE
-#define OS2D_SH_INTERLEAVE 0
-#endif
-#if OS2D_SH_INTERLEAVE
-  // DIAGNOSTIC (-DOS2D_SH_INTERLEAVE=1; round 4, measured 7 % SLOWER: 3.18 against 2.96 ms at 1024 pairs, 0.305 against 0.289 at
-  // 64, profiles/r04/spectral_gemm_interleave.txt): the split + store of the next k-step's spectra in two halves BETWEEN the
-  // matrix instructions of the bins instead of after the last one.  The idea: with every global load removed a k-step still
-  // takes 2,250 cycles against 1,536 of matrix time (profiles/r04/spectral_gemm_components.txt) because all 8 waves convert while
-  // the matrix pipes idle and multiply while the vector units idle.  What happens: the conversion waits for spectra loaded one
-  // k-step ago; placed after the first bin that wait stalls the wave with 18 matrix instructions still to issue, placed at the
-  // end it is covered by the 24 already in the pipe.
-#define SH_STEP(S, PC, PN)                                                                                          \
-  {                                                                                                                 \
-    if ((S) + SH_WRING - 1 < KS) SH_DMA_W((S) + SH_WRING - 1)                                                       \
-    if ((S) + 2 < KS) SH_LOAD_X((S) + 2, PN)                                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                                              \
-    const bool more_ = (S) + 1 < KS;                                                                                \
-    const int sh_next_ = (S) + 1;                                                                                   \
-    SH_COMPUTE_H(S, SH_STORE_HOOK_##PC)                                                                             \
-    sh_lds_barrier();                                                                                               \
-  }
-#define SH_STORE_HOOK_pfa(J) SH_STORE_HOOK(J, pfa)
-#define SH_STORE_HOOK_pfb(J) SH_STORE_HOOK(J, pfb)
-#define SH_STORE_HOOK(J, PC)                                                                                        \
-  if (more_ && ((J) == 1 || (J) == 2)) {                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                              \
-    SH_STORE_X_PART(sh_next_, PC, (J)-1, (J))                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                                              \
-  }
-#else
-#define SH_STEP(S, PC, PN)                                                                                          \
-  {                                                                                                                 \
-    if ((S) + SH_WRING - 1 < KS) SH_DMA_W((S) + SH_WRING - 1)                                                       \
-    if ((S) + 2 < KS) SH_LOAD_X((S) + 2, PN)                                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                                              \
-    SH_COMPUTE(S)                                                                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                                              \
-    if ((S) + 1 < KS) SH_STORE_X((S) + 1, PC)                                                                       \
-    sh_lds_barrier();                                                                                               \
-  }
-#endif
-
-#if OS2D_SH_REGW
   // k-step S: requests of step S + 2 -> set N (weights WN, spectra PN); multiply step S; the set requested a step ago (WC, PC:
   // step S + 1) -> the other LDS stage; barrier.  The sets alternate, so the loop runs two k-steps per pass.
 #define SH_STEPR(S, WC, PC, WN, PN)                                                                                 \
@@ -368,142 +226,6 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
     sh_lds_barrier();                                                                                               \
   }
   int s = 0;
-#if OS2D_SH_PINGPONG
-  // DIAGNOSTIC (-DOS2D_SH_PINGPONG=1; round 5, correct - tests/test_spectral_gpu.py passes - and measured NO faster: 2.95 / 2.94
-  // against 2.90 / 2.91 ms at 1024 pairs, 0.288 / 0.294 against 0.284 / 0.281 at 64, profiles/r05/spectral_gemm_pingpong.txt).
-  // PING-PONG.  In the loop below all 8 waves multiply together and then convert / store together: the matrix pipes idle
-  // while the vector units and the LDS stores work, and the other way round - with every global load removed a k-step took 2,250
-  // cycles for 1,536 of matrix time, with them 4,570 (profiles/r04/spectral_gemm_components.txt).  Here the two halves of the
-  // work-group - waves 0 .. 3 own pairs 0 .. 31, waves 4 .. 7 pairs 32 .. 63; both use all the weights - run half a k-step apart:
-  //   phase 1:  group 0 multiplies k-step S                     group 1 converts / stores ITS spectra and weight share of S + 1
-  //   barrier
-  //   phase 2:  group 0 converts / stores its share of S + 1     group 1 multiplies k-step S
-  //   barrier
-  // Stage (S + 1) % 2 of both operands is written while stage S % 2 is read; everybody's reads of stage (S + 1) % 2 (k-step
-  // S - 1) ended at the second barrier of k-step S - 1.  Two barriers per k-step instead of one, same requests, same wait counts.
-  // The requests are UNCONDITIONAL - a k-step beyond the last one is clamped to it (cache hits, never stored) - and the loop runs
-  // an even number of k-steps (the last one of an odd count multiplies and stores nothing): one loop per group, no guarded tail,
-  // every wait count exact.
-#define SH_PP0(S, WC, PC, WN, PN)                                                                                   \
-  {                                                                                                                 \
-    SH_LOAD_W(min((S) + 2, KS - 1), WN)                                                                             \
-    SH_LOAD_X(min((S) + 2, KS - 1), PN)                                                                             \
-    __builtin_amdgcn_sched_barrier(0);                                                                              \
-    if ((S) < KS) SH_COMPUTE(S)                                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                                              \
-    sh_lds_barrier();                                                                                               \
-    SH_STORE_W((S) + 1, WC) /* (beyond the last k-step: the clamped request's data, into a stage nobody reads again) */ \
-    SH_STORE_X((S) + 1, PC)                                                                                         \
-    sh_lds_barrier();                                                                                               \
-  }
-#define SH_PP1(S, WC, PC, WN, PN)                                                                                   \
-  {                                                                                                                 \
-    SH_LOAD_W(min((S) + 2, KS - 1), WN)                                                                             \
-    SH_LOAD_X(min((S) + 2, KS - 1), PN)                                                                             \
-    __builtin_amdgcn_sched_barrier(0);                                                                              \
-    SH_STORE_W((S) + 1, WC) /* (beyond the last k-step: the clamped request's data, into a stage nobody reads again) */ \
-    SH_STORE_X((S) + 1, PC)                                                                                         \
-    sh_lds_barrier();                                                                                               \
-    __builtin_amdgcn_sched_barrier(0);                                                                              \
-    if ((S) < KS) SH_COMPUTE(S)                                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                                              \
-    sh_lds_barrier();                                                                                               \
-  }
-  if (pt == 0) {
-    for (; s < KS; s += 2) {
-      SH_PP0(s, wra, pfa, wrb, pfb)
-      SH_PP0(s + 1, wrb, pfb, wra, pfa)
-    }
-  } else {
-    for (; s < KS; s += 2) {
-      SH_PP1(s, wra, pfa, wrb, pfb)
-      SH_PP1(s + 1, wrb, pfb, wra, pfa)
-    }
-  }
-#undef SH_PP0
-#undef SH_PP1
-#elif OS2D_SH_AHEAD == 3
-  // DIAGNOSTIC (-DOS2D_SH_AHEAD=3; measured no faster at 64 / 256 / 1024 pairs, profiles/r05/spectral_gemm_xahead.txt).  BOTH operands
-  // three k-steps ahead: at 64 pairs the weights - 634 of the launch's 1,131 MB - come from HBM,
-  // not from L2 as in the 16 pair blocks of a 1024-pair launch, and a k-step takes 3.3 us against 2.2 us there.  Three register sets
-  // of each operand (+ 24 registers), period 3: three k-steps per pass; requests unconditional and clamped, the pass count rounded
-  // up (a k-step beyond the last multiplies nothing and stores into a stage nobody reads): exact wait counts, no guarded tail.
-  u32x4 wrc[4], pfc[2];
-#define SH_STEP3(S, WC, PC, WN, PN)                                                                                 \
-  {                                                                                                                 \
-    SH_LOAD_W(min((S) + 3, KS - 1), WN)                                                                             \
-    SH_LOAD_X(min((S) + 3, KS - 1), PN)                                                                             \
-    __builtin_amdgcn_sched_barrier(0);                                                                              \
-    if ((S) < KS) SH_COMPUTE(S)                                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                                              \
-    SH_STORE_W((S) + 1, WC)                                                                                         \
-    SH_STORE_X((S) + 1, PC)                                                                                         \
-    sh_lds_barrier();                                                                                               \
-  }
-  // sets by k-step % 3: 0 -> (wrb, pfb) [k-step 0 was loaded there by the prologue], 1 -> (wra, pfa), 2 -> (wrc, pfc)
-  SH_LOAD_W(min(2, KS - 1), wrc)
-  SH_LOAD_X(min(2, KS - 1), pfc)
-  for (; s < KS; s += 3) {
-    SH_STEP3(s, wra, pfa, wrb, pfb)
-    SH_STEP3(s + 1, wrc, pfc, wra, pfa)
-    SH_STEP3(s + 2, wrb, pfb, wrc, pfc)
-  }
-#undef SH_STEP3
-#elif OS2D_SH_XAHEAD == 4
-  // DIAGNOSTIC (-DOS2D_SH_XAHEAD=4; round 5, measured NO faster: 2.97 / 3.00 against 2.94 / 2.95 ms at 1024 pairs, 0.283 / 0.292
-  // against 0.287 / 0.290 at 64, profiles/r05/spectral_gemm_xahead.txt - the k-step is not waiting for late spectra).  The idea:
-  // the SPECTRA four k-steps ahead, the weights two: the spectra come from HBM in 256-byte runs and every k-step ends
-  // in a barrier, so a k-step lasts as long as the slowest of the 512 x 2 spectra loads it waits for - with a lookahead of two
-  // k-steps (~4 us) the tail of the latency distribution showed (no spectra loads: 3.04 -> 2.23 ms at 1024 pairs, no matrix
-  // instructions: 2.65 ms, profiles/r04/spectral_gemm_components.txt); the weights hit in L2.  Two more register sets (16
-  // registers); the sets of the spectra rotate with period 4, those of the weights with period 2: four k-steps per pass.  A
-  // wave's loads complete in issue order, so the wait for the weights of step S + 1 (requested one step ago) also covers the
-  // spectra of steps S + 1 and S + 2; those of S + 3 and S + 4 stay in flight: vmcnt(8).
-#define SH_STEPF4(S, WC, WN, PC, PN)                                                                                \
-  {                                                                                                                 \
-    SH_LOAD_W((S) + 2, WN)                                                                                          \
-    SH_LOAD_X((S) + 4, PN)                                                                                          \
-    __builtin_amdgcn_sched_barrier(0);                                                                              \
-    SH_COMPUTE(S)                                                                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                                              \
-    SH_STORE_W((S) + 1, WC)                                                                                         \
-    SH_STORE_X((S) + 1, PC)                                                                                         \
-    sh_lds_barrier();                                                                                               \
-  }
-#define SH_STEPR4(S, WC, WN, PC, PN)                                                                                \
-  {                                                                                                                 \
-    if ((S) + 2 < KS) SH_LOAD_W((S) + 2, WN)                                                                        \
-    if ((S) + 4 < KS) SH_LOAD_X((S) + 4, PN)                                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                                              \
-    SH_COMPUTE(S)                                                                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                                              \
-    if ((S) + 1 < KS) {                                                                                             \
-      SH_STORE_W((S) + 1, WC)                                                                                       \
-      SH_STORE_X((S) + 1, PC)                                                                                       \
-    }                                                                                                               \
-    sh_lds_barrier();                                                                                               \
-  }
-  // (the prologue above requested the spectra of k-steps 0 and 1 into pfb and pfa: pfb = set 0, pfa = set 1; now sets 2 and 3)
-  // (unconditional: SH_LOAD_X clamps its channel index, and a conditional request would make the wait counts of the loop
-  // pessimistic - DESIGN 4.4)
-  u32x4 pfc[2], pfd[2];
-  SH_LOAD_X(2, pfc)
-  SH_LOAD_X(3, pfd)
-  for (; s + 7 < KS; s += 4) {
-    SH_STEPF4(s, wra, wrb, pfa, pfb)
-    SH_STEPF4(s + 1, wrb, wra, pfc, pfa)
-    SH_STEPF4(s + 2, wra, wrb, pfd, pfc)
-    SH_STEPF4(s + 3, wrb, wra, pfb, pfd)
-  }
-  for (; s < KS; s += 4) {
-    SH_STEPR4(s, wra, wrb, pfa, pfb)
-    if (s + 1 < KS) SH_STEPR4(s + 1, wrb, wra, pfc, pfa)
-    if (s + 2 < KS) SH_STEPR4(s + 2, wra, wrb, pfd, pfc)
-    if (s + 3 < KS) SH_STEPR4(s + 3, wrb, wra, pfb, pfd)
-  }
-#undef SH_STEPF4
-#undef SH_STEPR4
-#else
   for (; s + 3 < KS; s += 2) {
     SH_STEPF(s, wra, pfa, wrb, pfb)
     SH_STEPF(s + 1, wrb, pfb, wra, pfa)
@@ -512,42 +234,13 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
     SH_STEPR(s, wra, pfa, wrb, pfb)
     if (s + 1 < KS) SH_STEPR(s + 1, wrb, pfb, wra, pfa)
   }
-#endif
 #undef SH_STEPF
 #undef SH_STEPR
 #undef SH_LOAD_W
 #undef SH_STORE_W
-#else
-  static_assert(SH_WRING >= 3, "the spectra run two k-steps ahead: the weight ring must reach at least as far");
-  SH_DMA_W(0)
-  SH_LOAD_X(0, pfb)
-  if (1 < KS) {
-    SH_DMA_W(1)
-    SH_LOAD_X(1, pfa)
-  }
-#pragma unroll
-  for (int s = 2; s < SH_WRING - 1; ++s)
-    if (s < KS) SH_DMA_W(s)
-  SH_STORE_X(0, pfb)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // prologue only: weights of step 0 (.. WRING - 2) are in LDS
-  sh_lds_barrier();
-  for (int s = 0; s < KS; s += 2) {
-    SH_STEP(s, pfa, pfb)
-    if (s + 1 < KS) SH_STEP(s + 1, pfb, pfa)
-  }
-#endif
-#undef SH_STEP
-#undef SH_STORE_HOOK
-#undef SH_STORE_HOOK_pfa
-#undef SH_STORE_HOOK_pfb
-#undef SH_COMPUTE_H
-#undef SH_NOHOOK
-#undef SH_STORE_X_PART
 #undef SH_COMPUTE
-#undef SH_DMA_W
 #undef SH_LOAD_X
 #undef SH_STORE_X
-#undef SH_SPLIT_VALUE
 
   // ---- epilogue: undo the operand scales; Y[bin / 4][pair][o][bin % 4]: the lane's 4 bins are 32 contiguous bytes, the 32
   // lanes of a half-wave (32 consecutive output channels of one pair) 1 KB
@@ -558,17 +251,9 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int nb = nb0 + pt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hw;
-#ifdef OS2D_DIAG_SH_NOY       /* diagnostic: no output stores (kept alive by an impossible condition) */
-      if (nb < NB && yr[0][r] == 123.456f) {
-#else
       if (nb < NB) {
-#endif
-#ifdef OS2D_DIAG_SPECTRA_ROWS
-        float4* dst = reinterpret_cast<float4*>(Y + ((size_t)nb * Cout + o) * NBINS + bin0);
-#else
         float4* dst = XQ ? reinterpret_cast<float4*>(Y + ((qblk + (nb - nb0)) * Cout + o) * 4)
                          : reinterpret_cast<float4*>(Y + (((size_t)(bin0 >> 2) * NB + nb) * Cout + o) * 4);
-#endif
         dst[0] = make_float4(yr[0][r] * sc, yi[0][r] * sc, yr[1][r] * sc, yi[1][r] * sc);
         dst[1] = make_float4(yr[2][r] * sc, yi[2][r] * sc, yr[3][r] * sc, yi[3][r] * sc);
       }

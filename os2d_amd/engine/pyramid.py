@@ -54,7 +54,10 @@ class PyramidHeadRunner(object):
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         if num_streams is None:
-            num_streams = int(os.environ.get("OS2D_PYRAMID_STREAMS", "1"))
+            try:        # (an empty or malformed value means "not set")
+                num_streams = max(1, int(os.environ.get("OS2D_PYRAMID_STREAMS", "1").strip() or "1"))
+            except ValueError:
+                num_streams = 1
         self._num_streams = num_streams
         self.largest_first = os.environ.get("OS2D_PYRAMID_ORDER", "given") == "largest"     # queue order of the levels
 

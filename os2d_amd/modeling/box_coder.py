@@ -9,6 +9,7 @@ Only the inference half of the reference class is mirrored: target encoding / an
 remapping are training-only and out of scope.
 """
 import collections
+import weakref
 import ctypes
 from functools import lru_cache
 
@@ -138,26 +139,37 @@ def trace_box_transform(transform, img_size):
     bit-equal coordinates and the same output size, or they are not used."""
     if transform is None:
         return (), (), img_size
-    # the same callable on the same image size traces to the same chains: a small cache keyed by object identity - the entry
-    # holds the callable, so its id cannot be reused while it is cached (ADVICE r4: three closure runs + CPU probe tensors per
-    # level and image on the decode path; a dataloader that hands out one TransformList per image size hits this every time)
-    parts = getattr(transform, "transforms", None)       # a TransformList may be appended to after it was traced
-    ckey = (id(transform), int(img_size.w), int(img_size.h), tuple(id(t) for t in parts) if isinstance(parts, (list, tuple)) else None)
+    # Two steps: the TRACE (the closures run on _BoxTrace objects: no tensors, a few Python calls) is made on every call, the
+    # PROBE CHECK (three closure runs on CPU BoxLists) only once per (callable, image size, traced chains).  Keyed on the chains
+    # themselves, a hit cannot be stale: a TransformList that was appended to (whatever the attribute its list lives in - the
+    # reference keeps it in ``_transforms``, structures/transforms.py:18-22), or a closure whose captured state changed, traces to
+    # other chains and is probed again (ADVICE r5; round 5 keyed on object identity + an attribute named ``transforms`` only).
+    # The cache holds WEAK references: it keeps no transform (nor what it captured) alive, a dead entry's id may be reused and
+    # is then not a hit; callables that cannot be weakly referenced are not cached.
+    traced = _trace_chains(transform, img_size)
+    if traced is None:
+        return None
+    try:
+        ref = weakref.ref(transform)
+    except TypeError:
+        return traced if _probe_check(transform, img_size, traced) else None
+    ckey = (id(transform), int(img_size.w), int(img_size.h), traced[0], traced[1], int(traced[2].w), int(traced[2].h))
     hit = _TRACE_CACHE.get(ckey)
-    if hit is not None and hit[0] is transform:
+    if hit is not None and hit[0]() is transform:
         _TRACE_CACHE.move_to_end(ckey)
-        return hit[1]
-    result = _trace_box_transform(transform, img_size)
-    _TRACE_CACHE[ckey] = (transform, result)
+        return traced if hit[1] else None
+    ok = _probe_check(transform, img_size, traced)
+    _TRACE_CACHE[ckey] = (ref, ok)
     while len(_TRACE_CACHE) > 64:
         _TRACE_CACHE.popitem(last=False)
-    return result
+    return traced if ok else None
 
 
 _TRACE_CACHE = collections.OrderedDict()
 
 
-def _trace_box_transform(transform, img_size):
+def _trace_chains(transform, img_size):
+    """(box ops, anchor ops, output size) recorded by running the entry on _BoxTrace objects, or None."""
     try:
         root = _BoxTrace(img_size)
         root.add_field("default_boxes", _BoxTrace(img_size))
@@ -167,14 +179,26 @@ def _trace_box_transform(transform, img_size):
         anchors = transform(traced.get_field("default_boxes"))
         if not isinstance(anchors, _BoxTrace) or len(anchors.ops) > MAX_DEFAULT_BOX_OPS:
             return None
-        probe = torch.tensor(_PROBE_BOXES, dtype=torch.float32)
-        b, d, c, size = transform_level_boxes(transform, probe.clone(), probe.clone() + 0.5, probe.clone(), img_size)
-        if size != traced.image_size or not (torch.equal(b, apply_box_ops(probe, traced.ops)) and torch.equal(c, b)
-                                             and torch.equal(d, apply_box_ops(probe + 0.5, anchors.ops))):
-            return None
     except Exception:   # noqa: BLE001 - a closure that does anything else than the three BoxList operations
         return None
     return traced.ops, anchors.ops, traced.image_size
+
+
+def _probe_check(transform, img_size, traced):
+    """The recorded chains against the entry itself on the probe boxes: bit-equal coordinates and the same output size."""
+    try:
+        probe = torch.tensor(_PROBE_BOXES, dtype=torch.float32)
+        b, d, c, size = transform_level_boxes(transform, probe.clone(), probe.clone() + 0.5, probe.clone(), img_size)
+        return bool(size == traced[2] and torch.equal(b, apply_box_ops(probe, traced[0])) and torch.equal(c, b)
+                    and torch.equal(d, apply_box_ops(probe + 0.5, traced[1])))
+    except Exception:   # noqa: BLE001
+        return False
+
+
+def _trace_box_transform(transform, img_size):
+    """Uncached trace + probe check (tests)."""
+    traced = _trace_chains(transform, img_size)
+    return traced if traced is not None and _probe_check(transform, img_size, traced) else None
 
 
 def _ops_tables(ops_per_level, width=MAX_BOX_OPS):

@@ -103,6 +103,7 @@ def get_workspace(device, wanted, minimum):
     if buf is None or buf.numel() < size:
         _WORKSPACES[key] = None
         buf = torch.empty(size, dtype=torch.uint8, device=device)
+        buf[:4096].zero_()       # the range words of a head call live at the start of its workspace (include/os2d_hip.h)
         _WORKSPACES[key] = buf
     return buf
 
@@ -852,14 +853,9 @@ class Os2dHead(nn.Module):
             torch.cuda.synchronize(self._qp.device)
         return int(self._status_word()[0])
 
-    def _handle_range_flag(self):
-        """A previous split-fp16 call of THIS head overflowed (non-finite input: nothing else gets past the range plan).
-        The flag is cleared and the call that noticed it runs in exact fp32; later calls return to the configured arithmetic
-        (round 2 switched the head to fp32 for good: one NaN image made every later image 5.7x slower)."""
-        self._status[0] = 0
-        logging.getLogger("OS2D").warning(
-            "OS2D head: a split-fp16 activation left the fp16 range in an earlier call of this head (non-finite input); "
-            "this call runs in precision='f32'")
+    def clear_range_status(self):
+        """Reset the sticky word (the caller has seen it).  Kernels of calls still in flight may raise it again."""
+        self._status_word()[0] = 0
 
     @classmethod
     def cat(cls, heads):
@@ -876,9 +872,12 @@ class Os2dHead(nn.Module):
         ``out``: optional preallocated (loc, cls, corners) device tensors of exactly those shapes (contiguous) - used
         by the class-sharded wrapper to let the kernels write straight into the all-gather buffer.
         ``stage_events``: optional ctypes array of 13 event handles for os2d_head_forward_profiled (bench.py).
-        ``strict_range`` (default $OS2D_STRICT_RANGE, off): synchronise after a split-fp16 call and, if the range flag
-        was raised, re-run it in exact fp32 before returning.  Without it the flag is looked at when the next call
-        starts (no synchronisation): that call then runs in "f32".
+        Non-finite input (a NaN / Inf feature; nothing else gets past the range plan): the split-fp16 kernels raise a range word
+        in the call's workspace and the LAST kernel of the same call writes NaN into every output of the affected image - where
+        the reference has NaN around the offending cells (head.py:339, 650: torch.relu / norm propagate it) - and raises the
+        sticky host word (``range_status``).  No synchronisation, no effect on later calls.
+        ``strict_range`` (default $OS2D_STRICT_RANGE, off): synchronise after a split-fp16 call and, if the word was raised,
+        re-run the call in exact fp32 (the reference's own NaN pattern) before returning.
         ``route_pairs``: the number of (image, class) pairs the ROUTE decision of the frequency-domain modes is made for
         (default: this call's own A * B).  A class-sharded caller passes the GLOBAL pair count, so that a ragged tail rank
         holding fewer than ``FFT_MIN_PAIRS`` classes takes the same arithmetic route as the others and the sharded result
@@ -902,9 +901,6 @@ class Os2dHead(nn.Module):
         regressor = self.aligner.parameter_regressor
         P = regressor.output_dim
         precision, pinned = _resolve(precision or self.precision)
-        if precision not in FP32_MODES and int(self._status_word()[0]) != 0:
-            self._handle_range_flag()
-            precision = "f32"
         regressor.check_ready()                  # device / eval-mode errors before any torch op can trip over them
         spectra = None
         if W > MAX_W_DIRECT7:
@@ -950,7 +946,9 @@ class Os2dHead(nn.Module):
         if strict and precision not in FP32_MODES:
             torch.cuda.current_stream(dev).synchronize()
             if int(self._status[0]) != 0:
-                self._handle_range_flag()
+                self.clear_range_status()
+                logging.getLogger("OS2D").warning("OS2D head: non-finite input or an activation outside the fp16 range; strict_range "
+                                                  "re-runs this call in precision='f32'")
                 return self.forward(feature_maps, out=out, stage_events=stage_events, precision="f32")
         return loc, cls, cls, corners
 

@@ -20,6 +20,8 @@ static int emu_dft_policy = 0;      // 0: smallest transform per map, 1: the can
 #define DFT_MFMA(a, b, c) emu::mfma_32x32x16_f16(a, b, c)
 #define DFT_SHFL_XOR(v, m) emu::shfl_xor(v, m)
 #define DFT_BALLOT(p) emu::ballot(p)
+#define DFT_FLAG int*
+#define DFT_FLAG_SET(f) ((f) != nullptr)
 #define DFT_RAISE(p) (*(p) = 1)
 #define DFT_UNIFORM(x) (x)
 #include "dft_mfma.h"

@@ -58,6 +58,13 @@ def test_library_loads_and_reports_abi(lib_path):
     assert lib.os2d_head_workspace_bytes(1, 1, 1024, 60, 640, 6, ctypes.byref(n)) == 0
     assert lib.os2d_head_workspace_bytes(1, 1, 1024, 4, 3600, 6, ctypes.byref(n)) == 0
     assert lib.os2d_head_workspace_bytes(1, 1, 1024, 4, 3601, 6, ctypes.byref(n)) == -1 and b"width" in lib.os2d_last_error()
+    # tallest map: 2784 rows (48 tiles of 58 rows); one more fails in the argument check, and both frequency-domain planners have a
+    # plan for every height up to the limit at the benchmark's width (a taller map used to fail inside the planner)
+    assert lib.os2d_head_workspace_bytes(1, 1, 1024, 2784, 4, 6, ctypes.byref(n)) == 0
+    assert lib.os2d_head_workspace_bytes(1, 1, 1024, 2785, 4, 6, ctypes.byref(n)) == -1 and b"height" in lib.os2d_last_error()
+    for prec in (3, 4, 5):       # OS2D_PRECISION_FFT, FFTX3, FFT32
+        for h in (1, 61, 64, 65, 117, 1000, 2784):
+            assert lib.os2d_head_workspace_bytes_ex(1, 1, 64, h, 80, 6, prec, ctypes.byref(n)) == 0, (prec, h, lib.os2d_last_error())
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

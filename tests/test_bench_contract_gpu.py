@@ -47,6 +47,13 @@ def test_default_command_prints_one_compact_line(device):
     for k in ("classes_256_v1", "classes_1024_one_gpu", "pyramid_7_levels_128_classes"):
         assert d["config"][k]["pairs_per_s"] > 0, k
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    # the strict-fp32 reading has a complete record of its own, the CPU baseline names the host's physical cores
+    assert d["cpu_baseline"]["host_physical_cores"] is None or d["cpu_baseline"]["host_physical_cores"] >= 1
+    assert d["cpu_baseline"]["host_logical_cpus"] >= d["cpu_baseline"]["cores"]
+    rs = d["roofline_strict_fp32"]
+    assert rs["precision"] == "fft32" and rs["pairs_per_s"] > 0 and rs["peak"] in (157.3, 8000.0)
+    assert abs(rs["frac"] - rs["achieved"] / rs["peak"]) < 1e-3 and rs["avg_launch_ms"] <= rs["ms_per_step"]
+    assert len(json.dumps(rs)) <= 400
     full = _strict_loads(open(details).read())
     for k in ("other_precisions", "sweep", "live_counters", "roofline_other", "end_to_end"):
         assert k in full, k
@@ -68,3 +75,18 @@ def test_bench_line_contract(device):
     assert (r["bound"], r["unit"]) in (("mfma", "TFLOP/s"), ("hbm", "GB/s")) and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and isinstance(c["sample"], str)
+
+
+def test_forced_distributed_line_carries_its_own_one_gpu_reference(device):
+    """the N > 1 line is self-contained - rank 0 times the SAME workload on one GPU first and the line carries
+    ``one_gpu_same_workload`` + ``speedup_vs_one_gpu`` (here: world size 1 under --force-dist, so the speed-up is ~1)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "3", "--warmup", "1",
+                          "--classes-total", "128", "--no-other-precision", "--no-other-gather"], cwd=REPO, capture_output=True,
+                         text=True, timeout=600, env=env)
+    d = _one_line(out)
+    assert d["scaling"] == "strong" and d["config"]["classes_total"] == 128
+    one = d["one_gpu_same_workload"]
+    assert one["pairs_per_s"] > 0 and one["ms_per_step"] > 0
+    assert abs(d["speedup_vs_one_gpu"] - d["value"] / one["pairs_per_s"]) < 2e-3
+    assert 0.5 < d["speedup_vs_one_gpu"] < 1.5

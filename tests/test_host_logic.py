@@ -187,6 +187,44 @@ def test_dataloader_style_inverse_transforms_are_traced_exactly():
     assert trace_box_transform(long_chain, size) is None                                               # more than 6 operations
 
 
+def test_trace_cache_sees_a_transform_list_that_grew_after_it_was_traced():
+    """the reference's TransformList keeps its closures in ``_transforms`` (structures/transforms.py:18-22); a list that is
+    appended to after its first trace must trace to the longer chain (round 5's identity-keyed cache returned the stale chain), and so
+    must a closure whose captured state changed.  The cache keeps nothing alive."""
+    import gc
+    import weakref
+    import util
+    from os2d_amd.modeling import box_coder as bc
+    size, orig = FeatureMapSize(w=320, h=272), FeatureMapSize(w=500, h=380)
+    chain = util.InverseTransformList()
+    assert not hasattr(chain, "transforms")            # the list lives in an attribute the round-5 key did not look at
+    chain.append(lambda b: b.resize(orig))
+    first = bc.trace_box_transform(chain, size)
+    assert bc.trace_box_transform(chain, size) == first and len(first[0]) == 1
+    chain.append(lambda b: b.transpose(bc.FLIP_LEFT_RIGHT))
+    second = bc.trace_box_transform(chain, size)
+    assert second == bc._trace_box_transform(chain, size) and [o[0] for o in second[0]] == [bc.OP_HFLIP, bc.OP_SCALE]      # last appended runs first
+    state = {"target": orig}
+    closure = lambda b: b.resize(state["target"])      # noqa: E731
+    one = bc.trace_box_transform(closure, size)
+    state["target"] = FeatureMapSize(w=250, h=190)
+    two = bc.trace_box_transform(closure, size)
+    assert one[2] == orig and two[2] == state["target"] and two == bc._trace_box_transform(closure, size)
+    # probe checks are cached per traced chain (a second call does not run the CPU probe) ...
+    calls = []
+    real = bc._probe_check
+    bc._probe_check = lambda *a: calls.append(1) or real(*a)
+    try:
+        assert bc.trace_box_transform(chain, size) == second and not calls
+    finally:
+        bc._probe_check = real
+    # ... and the cache holds weak references only
+    ref = weakref.ref(chain)
+    del chain
+    gc.collect()
+    assert ref() is None
+
+
 def test_fixed_point_norm_sums_of_the_correlation_kernels():
     """The arithmetic of corr_f16x3.hip's per-position sums of relu(corr)^2, restated in numpy (float32 operations as the kernel
     does them): a run of 4 rows is added in fp32, the run's sum g goes to 2^-44 fixed point as two integers

@@ -82,6 +82,54 @@ def assert_head_outputs_close(name, loc, cls, corners, ref_loc, ref_cls, ref_cor
     assert_close(corners, ref_corners, TOL_CORNERS * scale * corners_scale, RTOL_CORNERS * scale, name + " corners")
 
 
+# ---- per-fixture pins (VERDICT r5 item 8): the error of every fp32-equivalent mode on every head fixture, MEASURED on an MI355X and
+# recorded in tests/golden/head_fixture_pins.json as the worst ratio |diff| / (atol + rtol |ref|) per output (the tolerance formula
+# above, so that fixtures whose coordinates reach 1e8 and those near the identity share one scale).  The golden test asserts at most
+# 3x the recorded ratio (never tighter than PIN_FLOOR of the global tolerance: ~ an ulp of the scores) - a regression by a factor of a
+# few in one of the 13 deformation cases fails, where the global 1e-5 / 1e-4 / 2e-3 let it pass.  The kernels are deterministic:
+# the same bits on every box.  Regenerate on a GPU box:  OS2D_WRITE_FIXTURE_PINS=gpurun_out/head_fixture_pins.json pytest -m gpu -k golden
+PINS_PATH = os.path.join(GOLDEN, "head_fixture_pins.json")
+PIN_FACTOR, PIN_FLOOR = 3.0, 0.02
+_PINS = None
+
+
+def tolerance_ratio(got, ref, atol, rtol=0.0):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    return float(((got - ref).abs() / (atol + rtol * ref.abs())).max())
+
+
+def head_error_ratios(name, loc, cls, corners, ref_loc, ref_cls, ref_corners):
+    """[cls, loc, corners] as fractions of the generic tolerance of ``assert_head_outputs_close`` (scale 1)."""
+    return [tolerance_ratio(cls, ref_cls, CLS_TOL_OVERRIDE.get(name, TOL_CLS)), tolerance_ratio(loc, ref_loc, TOL_LOC, RTOL_LOC),
+            tolerance_ratio(corners, ref_corners, TOL_CORNERS, RTOL_CORNERS)]
+
+
+def fixture_pins():
+    global _PINS
+    if _PINS is None:
+        import json
+        _PINS = json.load(open(PINS_PATH)) if os.path.exists(PINS_PATH) else {}
+    return _PINS
+
+
+def check_or_record_fixture_pin(name, precision, ratios):
+    """Assert the recorded pin of (fixture, mode) - or, under $OS2D_WRITE_FIXTURE_PINS, record the measured ratios instead."""
+    import json
+    out = os.environ.get("OS2D_WRITE_FIXTURE_PINS")
+    if out:
+        d = json.load(open(out)) if os.path.exists(out) else {}
+        d.setdefault(name, {})[precision] = [float("{:.4g}".format(r)) for r in ratios]
+        with open(out, "w") as f:
+            json.dump(d, f, indent=0, sort_keys=True)
+        return
+    pin = fixture_pins().get(name, {}).get(precision)
+    if pin is None:
+        return
+    for what, r, p in zip(("cls", "loc", "corners"), ratios, pin):
+        limit = max(PIN_FACTOR * p, PIN_FLOOR)
+        assert r <= limit, "{} [{}] {}: error {:.4g} of the generic tolerance, pinned at {:.4g} (measured {:.4g})".format(name, precision, what, r, limit, p)
+
+
 def adversarial_transform_net_state(P, seed, lo1=-3.0, hi1=6.0, lo2=-3.0, hi2=3.0):
     """A TransformNet that computes the SAME function as ``make_transform_net_state(P, seed)`` but whose intermediate
     ranges are hostile to a fixed-range number format:

@@ -804,8 +804,29 @@ def sweep_entry(dev, name, classes, variant, pyramid, precision, steps, warmup):
     return e, w
 
 
+_LINE_OUT = None      # the process's ORIGINAL stdout, kept for the one JSON line
+
+
+def claim_stdout():
+    """stdout carries ONE line - the record - and nothing else (the driver parses it).  Libraries print there too (RCCL's banner and
+    warnings under --force-dist / N > 1 put five more lines in front of the record in round 6's first run): file descriptor 1 is
+    pointed at stderr for the life of the process and the record is written to a duplicate of the original descriptor."""
+    global _LINE_OUT
+    if _LINE_OUT is None:
+        sys.stdout.flush()
+        _LINE_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def print_line(text):
+    out = _LINE_OUT or sys.stdout
+    out.write(text + "\n")
+    out.flush()
+
+
 def main():
     args = parse()
+    claim_stdout()
     if os.environ.get("OS2D_BENCH_WATCHDOG"):      # debugging aid: dump the Python stacks every N seconds to stderr
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["OS2D_BENCH_WATCHDOG"]), repeat=True)
@@ -844,7 +865,10 @@ def main():
                 "error": "{}: {}".format(type(e).__name__, e), "traceback_tail": traceback.format_exc()[-1500:]}
         if use_dist:
             line["rccl_log_tail"] = rccl_log_tail()
-        print(json.dumps(line), file=sys.stdout if rank == 0 else sys.stderr, flush=True)
+        if rank == 0:
+            print_line(json.dumps(line))
+        else:
+            print(json.dumps(line), file=sys.stderr, flush=True)
         raise
     finally:
         if use_dist and dist.is_initialized():
@@ -1178,7 +1202,7 @@ def emit(result):
             except OSError:
                 pass
     print("[bench_details] " + json.dumps(_finite(result), allow_nan=False), file=sys.stderr, flush=True)
-    print(compact_line(result), flush=True)
+    print_line(compact_line(result))
 
 
 if __name__ == "__main__":

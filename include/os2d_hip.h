@@ -178,9 +178,10 @@ int os2d_corr_f16x3(const float* fm, const void* qs, float* corr, void* rshb, in
  *   form 0  one padded 256-row tile per class (as os2d_corr_f16x3);
  *   form 1  the classes PACKED along the matrix rows: class b owns the stacked rows [228 b, 228 b + 225) and a work-group takes
  *           256 consecutive stacked rows across class boundaries - 228 / 256 of the matrix instructions;
- *   form 2  the packed form in HALF tiles (128 stacked rows, 4 waves, two work-groups per CU);
- *   form -1 the head's own choice (packed when that saves a round of the 256 CUs: 128 classes and up on a 60 x 80 map).
- * Both give the SAME BITS: the per-position sums of relu^2 are accumulated as 2^-44 fixed-point integers (an accumulator run
+ *   form -1 the head's own choice: whichever takes fewer rounds of the 256 CUs;
+ *   + 4     no half tiles: by default the tiles of the last, partial round of a launch are cut into two 128-position halves
+ *           (they take the chip half as long; same products in the same order).
+ * All of them give the SAME BITS: the per-position sums of relu^2 are accumulated as 2^-44 fixed-point integers (an accumulator run
  * of 4 rows in fp32, then integers: LDS / 64-bit atomics), which do not depend on the order of arrival nor on where in a batch
  * a class sits - a class alone and the same class anywhere in a batch give identical correlation values and norms.
  * workspace: os2d_corr_f16x3_packed_workspace_bytes (that of os2d_corr_f16x3 + A*B*H*W 64-bit sums), 256-byte aligned.     */

@@ -324,9 +324,13 @@ int os2d_corr_f16x3_packed(const float* fm, const void* qs, float* corr, float* 
   void* sumfx = static_cast<char*>(workspace) + align_up(os2d_corr_f16x3_workspace_bytes(A, C, H, W), 256);
   int rc = os2d_launch_fm_sumsq(fm, sumsq, A, C, H * W, S(stream));
   if (!rc) rc = os2d_launch_split_fm(fm, sumsq, fs, A, C, H * W, nullptr, 0, Os2dRangeFlag{nullptr, 0}, S(stream));
-  const bool packed = form > 0 || (form < 0 && os2d_corr_f16x3_use_packed(A, B, H, W));
+  if (form < -1 || form > 7 || (form >= 0 && (form & 3) > 1)) {
+    os2d_set_error("os2d_corr_f16x3_packed: form %d (0 padded | 1 packed | -1 the head's choice; + 4: no half tiles at the tail)", form);
+    return -1;
+  }
+  const bool packed = form < 0 ? os2d_corr_f16x3_use_packed(A, B, H, W) != 0 : (form & 1) != 0;
   if (!rc && packed) rc = os2d_launch_corr_sums_clear(sumfx, A, B, H, W, S(stream));
-  if (!rc) rc = os2d_launch_corr_f16x3(fs, qs, corr, nullptr, inv_norm, packed ? sumfx : nullptr, form == 2 ? 2 : 0, A, B, C, H, W, S(stream));
+  if (!rc) rc = os2d_launch_corr_f16x3(fs, qs, corr, nullptr, inv_norm, packed ? sumfx : nullptr, (form >= 0 && (form & 4)) ? 2 : 0, A, B, C, H, W, S(stream));
   return rc;
 }
 
@@ -512,10 +516,23 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
   auto mark = [&](int b0, int idx) {
     if (stage_events && b0 == 0 && stage_events[idx]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(stage_events[idx]), st);
   };
-  int rc = os2d_launch_fm_sumsq(fm, sumsq, A, C, H * W, st);
-  if (rc) return rc;
-  // (the packed correlation kernel's sums are cleared by the same launch; every chunk's norms pass leaves them cleared again)
-  if (!fp32_ops && (rc = os2d_launch_split_fm(fm, sumsq, fsplit, A, C, H * W, sumfx, sumfx ? (size_t)A * Bc * H * W : 0, per_image, st))) return rc;
+  // image features: sums of squares for the fp32 correlation kernel's epilogue | normalised, scaled and split into the half-precision
+  // operand in one launch (the packed correlation kernel's sums are cleared by the same launch; every chunk's norms pass leaves them
+  // cleared again).  $OS2D_FUSED_SPLIT=0: the two launches of rounds 1 - 5 (measurements; same bits)
+  static const bool fused_split = [] {
+    const char* e = getenv("OS2D_FUSED_SPLIT");
+    return !(e && e[0] == '0');
+  }();
+  int rc = 0;
+  if (fp32_ops || !fused_split) {
+    if ((rc = os2d_launch_fm_sumsq(fm, sumsq, A, C, H * W, st))) return rc;
+  }
+  if (!fp32_ops) {
+    const size_t clear_words = sumfx ? (size_t)A * Bc * H * W : 0;
+    rc = fused_split ? os2d_launch_fm_norm_split(fm, fsplit, A, C, H * W, sumfx, clear_words, per_image, st)
+                     : os2d_launch_split_fm(fm, sumsq, fsplit, A, C, H * W, sumfx, clear_words, per_image, st);
+    if (rc) return rc;
+  }
   for (int b0 = 0; b0 < B; b0 += Bc) {
     const int bc = (B - b0 < Bc) ? (B - b0) : Bc;
     const int NB = A * bc;

@@ -36,38 +36,27 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 constexpr int GC = 4;                    // 8-channel groups per K chunk (32 channels)
-constexpr int CH_UNITS = GC * 2 * 256;   // 16-byte units of one class-operand chunk: 2048 = 32 KB
+constexpr int STACK_STRIDE = 228;        // stacked rows per class (225 rounded up to a multiple of 4)
+constexpr int TM = 256;                  // rows per work-group: two waves of 128
+constexpr int WNW = 4;                   // waves along the positions: 8 waves of 128 x (32 NI)
 
-// NI = 32-column tiles per wave: 2 -> 256 positions per work-group (the throughput shape), 1 -> 128 positions (twice the
-// work-groups, half the MFMAs per K chunk: for a handful of classes, where the chip is empty and a group's serial K loop
-// is what a call waits for).  Every output accumulates the same products in the same order in both shapes.
-//
-// WNW = waves along the positions (the rows are always split over 2 waves): 4 -> 8 waves of 128 x 64 (128 accumulators per
-// lane, two waves per SIMD).  (Round 3 measured 4 waves of 128 x 128 - one wave per SIMD with the whole register file, a third
-// less LDS traffic per matrix instruction - slower: tools/patches/corr_f16x3_variants.patch.)
-constexpr int STACK_STRIDE = 228;   // stacked rows per class (225 rounded up to a multiple of 4)
-
-// WM = waves along the rows (2: a 256-row tile; 1: a 128-row tile - STACK only), KC = 8-channel groups per K chunk (4 | 2).
-// <2, 4, true, 1, 2> is the HALF-TILE shape (round 4): 4 waves, 128 stacked rows x 256 positions, chunks of 16 channels, 48 KB
-// of LDS - TWO independent work-groups per CU.  A quarter of the full-tile launch does not depend on K
-// (profiles/r04/corr_fixed_cost.txt): at the end of its K loop every work-group of a lockstep round writes its 262 KB of output
-// while the matrix pipes idle.  Two half-size groups per CU drift apart and each one's epilogue runs under the other's K loop;
-// the price is the image operand staged twice (once per row half) and a barrier every 24 instead of 48 matrix instructions.
-// MEASURED (profiles/r04/corr_fixed_cost.txt): the fixed part of a launch falls from 0.091 to 0.065 ms, the K-proportional part
-// grows from 0.313 to 0.375 ms per 1024 channels - 11 % slower.  Not used by the head (form 2 of os2d_corr_f16x3_packed /
-// $OS2D_CORR_HALF=1 for measurements; same bits as the other forms).
-template <int NI, int WNW, bool STACK, int WM = 2, int KC = GC>
-__global__ __launch_bounds__(64 * WM * WNW, (WM == 1 || WNW == 4) ? 2 : 1) void corr_f16x3_kernel(const u32x4* fs,  // [A][CGP][2][HW]  (no __restrict__, see
-                                                             const u32x4* qs,  // [B][CGP][2][256]   conv_f16x3.hip)
-                                                             float* __restrict__ corr, char* __restrict__ rshb,
-                                                             float* __restrict__ invn /*[A*B][HW] 1/(norm+eps) or NULL*/,
-                                                             unsigned long long* __restrict__ sumfx /*STACK: [A*B][HW] fixed-point sums*/,
-                                                             int A, int B, int CGP /*channel groups, padded to a multiple of GC*/,
-                                                             int H, int W, int PLANE, float unscale) {
-  extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
-  static_assert(WM == 2 || STACK, "128-row tiles exist for the packed form only (the norms cross work-groups)");
-  constexpr int NTHR = 64 * WM * WNW;
-  constexpr int TM = 128 * WM;           // rows per work-group
+// One tile: 256 rows x (128 NI) positions.  NI = 32-column tiles per wave: 2 -> 256 positions (the throughput shape: 128
+// accumulators per lane, two waves per SIMD); 1 -> 128 positions (half the matrix instructions per K chunk for the same class
+// operand: for a handful of classes, where a group's serial K loop is what a call waits for, and for the TAIL of a launch, see
+// the kernel).  Every output accumulates the same products in the same order in both shapes.
+// (Retired shapes, measured slower: 4 waves of 128 x 128 with the whole register file; 128-row half tiles, two groups per CU -
+// tools/patches/corr_f16x3_variants.patch, profiles/r04/corr_fixed_cost.txt.)
+template <int NI, bool STACK>
+__device__ __forceinline__ void corr_tile(const u32x4* fs,  // [A][CGP][2][HW]  (no __restrict__, see conv_f16x3.hip)
+                                          const u32x4* qs,  // [B][CGP][2][256]
+                                          float* __restrict__ corr, char* __restrict__ rshb,
+                                          float* __restrict__ invn /*[A*B][HW] 1/(norm+eps) or NULL*/,
+                                          unsigned long long* __restrict__ sumfx /*STACK: [A*B][HW] fixed-point sums*/,
+                                          int B, int CGP /*channel groups, padded to a multiple of GC*/, int H, int W, int PLANE,
+                                          float unscale, int a, int b /*class | STACK: row tile of the stacked matrix*/, int n0,
+                                          u32x4* smem16, unsigned long long (*red)[256]) {
+  constexpr int KC = GC;
+  constexpr int NTHR = 64 * 2 * WNW;
   constexpr int NT = WNW * 32 * NI;      // positions per work-group
   constexpr int AUNITS = KC * 2 * TM;    // 16-byte units of one class-operand chunk
   constexpr int BUNITS = KC * 2 * NT;    // 16-byte units of one image-operand chunk
@@ -76,28 +65,11 @@ __global__ __launch_bounds__(64 * WM * WNW, (WM == 1 || WNW == 4) ? 2 : 1) void 
   static_assert((NPF > NPFB ? NPF : NPFB) <= (KC / 2) * 4, "one DMA piece per matrix-instruction group of a chunk");
   u32x4* ldsA = smem16;                 // [2][AUNITS]
   u32x4* ldsB = smem16 + 2 * AUNITS;    // [2][BUNITS]
-  __shared__ unsigned long long red[2][NT];
 
   const int HW = H * W;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, hw = lane >> 5;
   const int wm = wid / WNW, wn = wid % WNW;  // wave tile: rows [wm*128,+128), cols [wn*32*NI,+32*NI)
-  // XCD-aware work mapping (work-group L runs on XCD L % 8): XCD x gets the contiguous range [x*per, (x+1)*per) of the
-  // logical order (image, group of 4 classes, position tile, class in group).  The 32 groups resident on an XCD (one per
-  // CU) are then ~8 tiles x 4 classes marching through K together: 12 MB of distinct operand bytes per 32 groups in
-  // that XCD's L2 instead of 20+ MB with classes or tiles spread round-robin over the XCDs.
-  // STACK: "b" below is a ROW TILE of the stacked class matrix (RT of them), not a class
-  const int RT = STACK ? (B * STACK_STRIDE + TM - 1) / TM : B;
-  const int tiles = (HW + NT - 1) / NT;
-  const int per = gridDim.x >> 3;
-  const int logical = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if (logical >= tiles * RT * A) return;
-  const int a = logical / (tiles * RT);
-  const int r_ = logical - a * tiles * RT;
-  const int gb0 = (r_ / (4 * tiles)) * 4, gsz = min(4, RT - gb0);
-  const int r2_ = r_ - gb0 * tiles;
-  const int b = gb0 + r2_ % gsz;
-  const int n0 = (r2_ / gsz) * NT;
   const int nb = a * B + b;
   const int R0 = b * TM;                         // STACK: first stacked row of this work-group
 
@@ -406,6 +378,46 @@ __global__ __launch_bounds__(64 * WM * WNW, (WM == 1 || WNW == 4) ? 2 : 1) void 
   }
 }
 
+// The launch.  Work-group L runs on XCD L % 8; XCD x takes the contiguous range [x tpx, (x + 1) tpx) of the logical tile order
+// (image, group of 4 row tiles, position tile, row tile in the group): the 32 groups resident on an XCD (one per CU) are then ~8
+// position tiles x 4 classes marching through K together - 12 MB of distinct operand bytes per 32 groups in that XCD's L2 instead
+// of 20+ MB with classes or tiles spread round-robin over the XCDs.  STACK: "b" is a ROW TILE of the stacked class matrix (RT of
+// them), not a class.
+// TAIL (round 6).  Every tile costs the same, so a launch takes ceil(tiles / 256) rounds of the chip however
+// few tiles its last round holds (64 classes, padded rows: 1216 tiles = 4.75 rounds, paid as 5).  The last ``rsplit`` tiles of every
+// XCD's range are therefore cut into two 128-position halves (the NI = 1 shape of the same code: same products, same order, same
+// bits), dispatched last: the partial round then costs about half a round per 32 halves.  NIM = NI of the main shape (1: every
+// tile is a 128-position tile and there is no tail).
+template <bool STACK, int NIM>
+__global__ __launch_bounds__(512, 2) void corr_f16x3_kernel(const u32x4* fs, const u32x4* qs, float* __restrict__ corr, char* __restrict__ rshb,
+                                                            float* __restrict__ invn, unsigned long long* __restrict__ sumfx, int A, int B,
+                                                            int CGP, int H, int W, int PLANE, float unscale, int tpx /*tiles per XCD*/,
+                                                            int rsplit /*of them, at the end of the range: cut into halves*/) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
+  __shared__ unsigned long long red[2][256];
+  const int HW = H * W;
+  const int RT = STACK ? (B * STACK_STRIDE + TM - 1) / TM : B;
+  const int tiles = (HW + 128 * NIM - 1) / (128 * NIM);
+  const int x = blockIdx.x & 7, s = blockIdx.x >> 3, nfull = tpx - rsplit;
+  int logical = x * tpx + s, half = -1;
+  if (NIM == 2 && s >= nfull) {
+    logical = x * tpx + nfull + ((s - nfull) >> 1);
+    half = (s - nfull) & 1;
+  }
+  if (s >= nfull + 2 * rsplit || logical >= min((x + 1) * tpx, tiles * RT * A)) return;
+  const int a = logical / (tiles * RT);
+  const int r_ = logical - a * tiles * RT;
+  const int gb0 = (r_ / (4 * tiles)) * 4, gsz = min(4, RT - gb0);
+  const int r2_ = r_ - gb0 * tiles;
+  const int b = gb0 + r2_ % gsz;
+  const int n0 = (r2_ / gsz) * (128 * NIM);
+  if (NIM == 2 && half >= 0) {
+    if (n0 + half * 128 < HW) corr_tile<1, STACK>(fs, qs, corr, rshb, invn, sumfx, B, CGP, H, W, PLANE, unscale, a, b, n0 + half * 128, smem16, red);
+  } else {
+    corr_tile<NIM, STACK>(fs, qs, corr, rshb, invn, sumfx, B, CGP, H, W, PLANE, unscale, a, b, n0, smem16, red);
+  }
+}
+
 // image features [A][C][HW] fp32 -> L2-normalised over channels (head.py:339, eps 1e-5), scaled, split, blocked
 __global__ __launch_bounds__(256) void split_fm_kernel(const float* __restrict__ fm, const float* __restrict__ sumsq,
                                                        u32x4* __restrict__ fs, int C, int HW, float scale,
@@ -439,6 +451,63 @@ __global__ __launch_bounds__(256) void split_fm_kernel(const float* __restrict__
   u32x4* o = fs + ((size_t)a * CG + g) * 2 * HW + n;
   *reinterpret_cast<half8*>(o) = hi;
   *reinterpret_cast<half8*>(o + HW) = lo;
+}
+
+// The two kernels above in ONE launch (round 6): a work-group owns 16 positions of an image, adds the squares of
+// their C channels exactly as fm_sumsq_kernel does (16 channel lanes per position, channels lane, lane + 16, ... in order, the 16
+// partial sums in lane order: the same bits) and then normalises, scales and splits the same 16 x C values - which it has just read:
+// the second pass comes from the caches - into the operand layout.  One launch and one pass over HBM less per head call; the
+// per-position sums never leave the chip.
+constexpr int FNS_LANES = 16, FNS_POS = 16;
+__global__ __launch_bounds__(FNS_LANES * FNS_POS) void fm_norm_split_kernel(const float* __restrict__ fm, u32x4* __restrict__ fs, int C, int HW,
+                                                                            float scale, unsigned long long* __restrict__ clear,
+                                                                            size_t clear_words, Os2dRangeFlag status) {
+  __shared__ float red[FNS_LANES][FNS_POS];
+  const int col = threadIdx.x % FNS_POS, cl = threadIdx.x / FNS_POS;
+  const int n = blockIdx.x * FNS_POS + col;
+  const int a = blockIdx.y;
+  if (clear_words) {       // the packed correlation kernel's sums, zeroed on the way (grid-stride over all work items)
+    const size_t nthr = (size_t)gridDim.x * gridDim.y * (FNS_LANES * FNS_POS);
+    for (size_t i = ((size_t)a * gridDim.x + blockIdx.x) * (FNS_LANES * FNS_POS) + threadIdx.x; i < clear_words; i += nthr) clear[i] = 0ull;
+  }
+  const int nc = min(n, HW - 1);      // (positions past the map: a valid address, nothing stored)
+  const float* p = fm + (size_t)a * C * HW + nc;
+  float s = 0.f;
+  for (int c0 = cl; c0 < C; c0 += FNS_LANES * 8) {  // 8 independent loads in flight, accumulated in channel order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(size_t)min(c0 + u * FNS_LANES, C - 1) * HW];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (c0 + u * FNS_LANES < C) s += v[u] * v[u];
+  }
+  red[cl][col] = s;
+  __syncthreads();
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < FNS_LANES; ++i) ss += red[i][col];
+  // a non-finite feature: see split_fm_kernel
+  if (status.word != nullptr && __builtin_amdgcn_ballot_w64(n < HW && !(ss <= 3.4028234e38f)) != 0ull && (threadIdx.x & 63) == 0)
+    os2d_raise(Os2dRangeFlag{status.word + a, status.value});
+  if (n >= HW) return;
+  const float inv = scale / (sqrtf(ss) + 1e-5f);
+  const int CG = os2d_round_up((C + 7) / 8, GC);  // zero groups pad the channel dimension to whole K chunks
+  for (int g = cl; g < CG; g += FNS_LANES) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = p[(size_t)min(g * 8 + j, C - 1) * HW];
+    half8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = g * 8 + j < C ? v[j] * inv : 0.f;
+      const _Float16 hv = (_Float16)x;
+      hi[j] = hv;
+      lo[j] = (_Float16)(x - (float)hv);
+    }
+    u32x4* o = fs + ((size_t)a * CG + g) * 2 * HW + n;
+    *reinterpret_cast<half8*>(o) = hi;
+    *reinterpret_cast<half8*>(o + HW) = lo;
+  }
 }
 
 // class operand [C][256] fp32 (os2d_class_prepare) -> [C/8][hi|lo][256] units, scaled
@@ -492,6 +561,14 @@ int os2d_launch_split_fm(const float* fm, const float* sumsq, void* fs, int A, i
   return check("split_fm");
 }
 
+int os2d_launch_fm_norm_split(const float* fm, void* fs, int A, int C, int HW, void* clear, size_t clear_words, Os2dRangeFlag status,
+                              hipStream_t stream) {
+  hipLaunchKernelGGL(fm_norm_split_kernel, dim3((HW + FNS_POS - 1) / FNS_POS, A), dim3(FNS_LANES * FNS_POS), 0, stream, fm,
+                     reinterpret_cast<u32x4*>(fs), C, HW, ldexpf(1.0f, SCALE_LOG2), static_cast<unsigned long long*>(clear),
+                     clear ? clear_words : (size_t)0, status);
+  return check("fm_norm_split");
+}
+
 int os2d_launch_split_qp(const float* qp, void* qs, int B, int C, hipStream_t stream) {
   hipLaunchKernelGGL(split_qp_kernel, dim3(os2d_round_up((C + 7) / 8, GC), B), dim3(256), 0, stream, qp, reinterpret_cast<u32x4*>(qs), C,
                      ldexpf(1.0f, SCALE_LOG2));
@@ -500,27 +577,51 @@ int os2d_launch_split_qp(const float* qp, void* qs, int B, int C, hipStream_t st
 
 namespace {
 
-template <int NI, int WNW, bool STACK, int WM = 2, int KC = GC>
-int launch_corr(const void* fs, const void* qs, float* corr, void* rshb, float* invn, unsigned long long* sumfx, int defer_norms, int A,
+// tiles per XCD and how many of them (at the end of every XCD's range) are cut into halves: the partial round of an XCD's 32 CUs
+// is split when it is at most 3/4 full (then 2 r halves <= 48: one and a half rounds of half-size groups at the worst); the same
+// figures feed the cost model of os2d_corr_f16x3_use_packed.  $OS2D_CORR_TAIL=0 disables the split (measurements).
+struct CorrGrid {
+  int tpx, rsplit;
+};
+CorrGrid corr_grid(long long tiles_total, bool allow_split) {
+  static const bool tail_enabled = [] {
+    const char* e = getenv("OS2D_CORR_TAIL");
+    return !(e && e[0] == '0');
+  }();
+  CorrGrid g;
+  g.tpx = (int)((tiles_total + 7) / 8);
+  const int r = g.tpx % 32;
+  g.rsplit = (allow_split && tail_enabled && g.tpx > 32 && r > 0 && r <= 24) ? r : 0;
+  return g;
+}
+// rounds of the chip a launch takes, in units of one full-tile round; a half tile keeps the whole class operand of its K loop
+// and half the matrix instructions: ~0.6 of a full tile (measured: corr_tail, profiles/r06/)
+double corr_rounds(long long tiles_total, bool allow_split) {
+  const CorrGrid g = corr_grid(tiles_total, allow_split);
+  const int nfull = g.tpx - g.rsplit;
+  return (double)((nfull + 31) / 32) + 0.6 * (double)((2 * g.rsplit + 31) / 32);
+}
+
+template <bool STACK, int NIM>
+int launch_corr(const void* fs, const void* qs, float* corr, void* rshb, float* invn, unsigned long long* sumfx, int flags, int A,
                 int B, int C, int H, int W, hipStream_t stream) {
-  constexpr int NT = WNW * 32 * NI, NTHR = 64 * WM * WNW, TM = 128 * WM;
   const int HW = H * W;
-  const size_t lds = (size_t)(2 * KC * 2 * TM + 2 * KC * 2 * NT) * 16;  // 128 KB (NI = 2) / 96 KB / 48 KB (half tile) dynamic (+ static)
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_f16x3_kernel<NI, WNW, STACK, WM, KC>),
+  const size_t lds = (size_t)(2 * GC * 2 * TM + 2 * GC * 2 * (128 * NIM)) * 16;  // 128 KB (NIM = 2) / 96 KB dynamic (+ 4 KB static)
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_f16x3_kernel<STACK, NIM>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) {
     os2d_set_error("hipFuncSetAttribute(corr f16x3): %s", hipGetErrorString(e));
     return -4;
   }
   const int RT = STACK ? (B * STACK_STRIDE + TM - 1) / TM : B;       // row tiles: stacked classes | one per class
-  const long long groups = (long long)((HW + NT - 1) / NT) * RT * A;
-  dim3 grid((unsigned)((groups + 7) / 8 * 8));  // multiple of 8: every XCD gets the same number of logical slots
-  hipLaunchKernelGGL((corr_f16x3_kernel<NI, WNW, STACK, WM, KC>), grid, dim3(NTHR), lds, stream, reinterpret_cast<const u32x4*>(fs),
+  const long long tiles_total = (long long)((HW + 128 * NIM - 1) / (128 * NIM)) * RT * A;
+  const CorrGrid g = corr_grid(tiles_total, NIM == 2 && !(flags & 2));
+  dim3 grid((unsigned)(8 * (g.tpx + g.rsplit)));      // per XCD: tpx - rsplit full tiles, then 2 rsplit halves
+  hipLaunchKernelGGL((corr_f16x3_kernel<STACK, NIM>), grid, dim3(512), lds, stream, reinterpret_cast<const u32x4*>(fs),
                      reinterpret_cast<const u32x4*>(qs), corr, reinterpret_cast<char*>(rshb), invn, sumfx, A, B,
-                     os2d_round_up((C + 7) / 8, GC), H, W,
-                     os2d_plane(H, W), ldexpf(1.0f, -2 * SCALE_LOG2));
+                     os2d_round_up((C + 7) / 8, GC), H, W, os2d_plane(H, W), ldexpf(1.0f, -2 * SCALE_LOG2), g.tpx, g.rsplit);
   int rc = check("corr_f16x3");
-  if (rc || !STACK || (defer_norms & 1)) return rc;
+  if (rc || !STACK || (flags & 1)) return rc;
   const size_t n = (size_t)A * B * HW;
   hipLaunchKernelGGL(corr_norm_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, sumfx, invn, n);
   return check("corr_norm_finalize");
@@ -528,11 +629,11 @@ int launch_corr(const void* fs, const void* qs, float* corr, void* rshb, float* 
 
 }  // namespace
 
-// Which form the head runs.  Both give the same bits (correlation AND inverse norms), so this is a pure scheduling decision:
-// the packed form executes 228 / 256 of the matrix instructions, but its sums cross work-groups as atomics and need the norms
-// pass, and - the package being power-limited - the all-zero padding rows of the padded form cost less time than their share
-// of the instructions (measured: packed is 1 % slower per step at 64 classes, where both forms need 5 rounds of 256
-// work-groups, 1 - 2 % faster at 256 and 1024 classes).  Packed when it saves at least one round of the 256 CUs.
+// Which form the head runs.  Both give the same bits (correlation AND inverse norms), so this is a pure scheduling decision: the
+// packed form executes 228 / 256 of the matrix instructions, but its sums cross work-groups as atomics and need the norms pass
+// (a small launch of its own in front of the forward transform: ~0.1 of a round at 64 classes).  Decided on the rounds of the chip
+// each form takes WITH the tail of its launch cut into half tiles (round 6; round 5 compared whole rounds only, which kept the
+// padded form at 64 classes: 1216 tiles = 5 rounds either way - now 4.9 against 4.3 + 0.1).
 // $OS2D_CORR_PACKED = 0 | 1 forces one form (measurements).
 int os2d_corr_f16x3_use_packed(int A, int B, int H, int W) {
   static const int forced = [] {
@@ -541,7 +642,7 @@ int os2d_corr_f16x3_use_packed(int A, int B, int H, int W) {
   }();
   if (forced >= 0) return forced;
   const long long tiles = (H * W + 255) / 256;
-  const long long plain = (tiles * B * A + 255) / 256, packed = (tiles * ((B * STACK_STRIDE + 255) / 256) * A + 255) / 256;
+  const double plain = corr_rounds(tiles * B * A, true), packed = corr_rounds(tiles * ((B * STACK_STRIDE + 255) / 256) * A, true) + 0.1;
   return packed < plain ? 1 : 0;
 }
 
@@ -556,26 +657,21 @@ int os2d_launch_corr_sums_clear(void* sumfx, int A, int B, int H, int W, hipStre
 }
 
 // sumfx != NULL: the classes packed along M (STACK; needs rshb == NULL and invn != NULL: the frequency-domain route), sumfx =
-// A * B * H * W cleared 64-bit words (os2d_launch_corr_sums_clear once; every launch leaves them cleared again)
-int os2d_launch_corr_f16x3(const void* fs, const void* qs, float* corr, void* rshb, float* invn, void* sumfx, int defer_norms, int A,
+// A * B * H * W cleared 64-bit words (os2d_launch_corr_sums_clear once; every launch leaves them cleared again).
+// flags & 1 (packed form only): the sums stay in sumfx, the caller's next launch turns them into invn
+// (os2d_launch_border_zero_shb_planes_norms); flags & 2: no half tiles at the tail of the launch (measurements / tests).
+int os2d_launch_corr_f16x3(const void* fs, const void* qs, float* corr, void* rshb, float* invn, void* sumfx, int flags, int A,
                            int B, int C, int H, int W, hipStream_t stream) {
   unsigned long long* sx = static_cast<unsigned long long*>(sumfx);
   if (sx && (rshb || !invn)) {
     os2d_set_error("corr_f16x3: the packed form writes inverse norms only (rshb must be NULL, invn not)");
     return -1;
   }
-  // the 128-position shape as long as its work-groups still fit the chip in one round (see the kernel's comment)
+  // the 128-position shape as long as its work-groups still fit the chip in one round (see corr_tile)
   const int RT = sx ? (B * STACK_STRIDE + 255) / 256 : B;
   if ((long long)((H * W + 127) / 128) * RT * A <= 256)
-    return sx ? launch_corr<1, 4, true>(fs, qs, corr, rshb, invn, sx, defer_norms, A, B, C, H, W, stream)
-              : launch_corr<1, 4, false>(fs, qs, corr, rshb, invn, sx, defer_norms, A, B, C, H, W, stream);
-  // ($OS2D_CORR_HALF=1: the packed form in half tiles - two 4-wave groups per CU; measurements)
-  static const bool half_tiles = [] {
-    const char* e = getenv("OS2D_CORR_HALF");
-    return e && e[0] == '1';
-  }();
-  if (sx && (half_tiles || (defer_norms & 2)))
-    return launch_corr<2, 4, true, 1, 2>(fs, qs, corr, rshb, invn, sx, defer_norms & 1, A, B, C, H, W, stream);
-  return sx ? launch_corr<2, 4, true>(fs, qs, corr, rshb, invn, sx, defer_norms, A, B, C, H, W, stream)        // 8 waves of 128 x 64
-            : launch_corr<2, 4, false>(fs, qs, corr, rshb, invn, sx, defer_norms, A, B, C, H, W, stream);
+    return sx ? launch_corr<true, 1>(fs, qs, corr, rshb, invn, sx, flags, A, B, C, H, W, stream)
+              : launch_corr<false, 1>(fs, qs, corr, rshb, invn, sx, flags, A, B, C, H, W, stream);
+  return sx ? launch_corr<true, 2>(fs, qs, corr, rshb, invn, sx, flags, A, B, C, H, W, stream)
+            : launch_corr<false, 2>(fs, qs, corr, rshb, invn, sx, flags, A, B, C, H, W, stream);
 }

@@ -320,10 +320,13 @@ int os2d_corr_groups(int C);  // 8-channel groups of the split correlation opera
 // status: word[a] is raised for an image a with a non-finite feature (one word per image)
 int os2d_launch_split_fm(const float* fm, const float* sumsq, void* fs, int A, int C, int HW, void* clear, size_t clear_words,
                          Os2dRangeFlag status, hipStream_t stream);
+// fm_sumsq + split_fm in one launch (the same bits; the sums are not written)
+int os2d_launch_fm_norm_split(const float* fm, void* fs, int A, int C, int HW, void* clear, size_t clear_words, Os2dRangeFlag status,
+                              hipStream_t stream);
 int os2d_launch_split_qp(const float* qp, void* qs, int B, int C, hipStream_t stream);
-// defer_norms & 1 (packed form only): the sums stay in sumfx; the caller's next launch turns them into invn; & 2: half tiles
+// flags & 1 (packed form only): the sums stay in sumfx; the caller's next launch turns them into invn; & 2: no half tiles at the tail
 // (os2d_launch_border_zero_shb_planes_norms) - one launch less on the per-step path
-int os2d_launch_corr_f16x3(const void* fs, const void* qs, float* corr, void* rshb, float* invn, void* sumfx, int defer_norms, int A,
+int os2d_launch_corr_f16x3(const void* fs, const void* qs, float* corr, void* rshb, float* invn, void* sumfx, int flags, int A,
                            int B, int C, int H, int W, hipStream_t stream);
 int os2d_corr_f16x3_use_packed(int A, int B, int H, int W);     // the head's choice between the two forms (same bits either way)
 int os2d_launch_corr_sums_clear(void* sumfx, int A, int B, int H, int W, hipStream_t stream);

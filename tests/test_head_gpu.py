@@ -370,8 +370,9 @@ def test_maps_at_the_planner_limits(W, H, precision, device):
         head = creator.create_os2d_head([c.to(device) for c in class_fms])
         loc, cls, _, cor = head(fm.to(device), precision=precision)
     assert head.last_precision == (precision or "fftx3")
-    assert util.maxdiff(cls, ref[1]) < TOL_CLS and util.maxdiff(loc, ref[0]) < TOL_LOC, (W, H)
-    assert util.maxdiff(cor, ref[3]) < 4e-6 * 16 * max(W, H) + 2e-3, (W, H)
+    # (2- and 3-cell wide maps: every template hangs over the border and the clamped sampling amplifies the parameters' last bits -
+    # the strict-fp32 mode shows the same 1.6e-4 on loc as the default one - so loc and corners get their relative terms)
+    util.assert_head_outputs_close("limits", loc, cls, cor, ref[0], ref[1], ref[3], scale=2.0, corners_scale=16.0 * max(W, H) / 1400.0)
 
 
 def _random_shapes(n, seed):
@@ -850,7 +851,7 @@ def test_packed_correlation_is_independent_of_the_batch_composition(H, W, C, B, 
         again = _packed_corr(lib, fm, head._split_class_operand(), B, device)
         assert torch.equal(again[0], corr) and torch.equal(again[1], invn)
         # the padded form (one 256-row tile per class) and whatever the head would pick: the same bits
-        for form in (0, 2, -1):
+        for form in (0, 4, 5, -1):          # padded, the same without half tiles at the tail, packed without them, the head's choice
             other = _packed_corr(lib, fm, head._split_class_operand(), B, device, form=form)
             assert torch.equal(other[0], corr) and torch.equal(other[1], invn), form
 

@@ -325,3 +325,16 @@ def test_bench_compact_line_of_a_multi_rank_record():
     assert d["allgather_probe"] == {"bytes_per_rank": 32 << 20, "ms": 0.9, "busbw_gbps": 260.0, "algbw_gbps": 298.0}
     assert d["other_gathers"] == {"scores": 410000.0, "detections": 380000.0} and d["gather_wait_ms"] == 0.01
     assert d["config"]["classes_per_gpu"] == [128] * 8
+
+
+def test_fixture_pins_cover_every_head_fixture_and_fp32_equivalent_mode():
+    """tests/golden/head_fixture_pins.json (measured on an MI355X, regenerated by the golden GPU test under
+    $OS2D_WRITE_FIXTURE_PINS) holds [cls, loc, corners] error ratios for every head fixture in every fp32-equivalent mode, all of them
+    far inside the generic tolerance - so the per-fixture assertion of tests/test_head_gpu.py has a pin wherever it looks one up."""
+    import util
+    pins = util.fixture_pins()
+    assert sorted(pins) == util.head_fixture_names()
+    for name, modes in pins.items():
+        assert sorted(modes) == sorted(util.FP32_EQUIVALENT), name
+        for mode, ratios in modes.items():
+            assert len(ratios) == 3 and all(0.0 <= r <= 0.25 for r in ratios), (name, mode, ratios)

@@ -14,6 +14,7 @@
 #         gemm[:<variant>] tools/time_spectral16_quads.py 64 256 1024 (the per-bin GEMM alone) with the product library or a variant
 #         power            tools/power_probe.sh: package power / clocks while the correlation, the step and the register-only MFMA loop run
 #         env:VAR=VALUE / unset:VAR   export / unset an environment variable for the steps that follow
+#         ab:VAR=VALUE[,VAR=VALUE]    the "stages" step under these variables (one A/B leg; runs in a sub-shell)
 #         bin:<name>       tools/bin/<name> (a standalone HIP program built on the dev box, e.g. split_mix_check)
 #         soak[:<rounds>]  tools/soak_multistream.sh: victim / aggressor rounds + the pyramid on 7 streams against the serial run (default 300)
 #         mfma             tools/bin/mfma_peak: what v_mfma_f32_32x32x16_f16 sustains (register-only loop, zero / random operands)
@@ -40,7 +41,7 @@ for STEP in "$@"; do
     stages|stages:*)
       V=""; [ "$STEP" != stages ] && V=${STEP#stages:}
       if [ -n "$V" ]; then export OS2D_HIP_LIB=tools/diag_libs/$V/libos2d_hip.so; fi
-      for N in 64 1024; do timeout 300 python bench.py --classes $N --steps 10 --warmup 3 --no-cpu-baseline --no-other-precision --no-end-to-end --no-sweep --no-live-counters 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('[${V:-product}] classes $N', d['ms_per_step'], d['stages_ms'])" | tee -a $OUT/stages.txt; done; unset OS2D_HIP_LIB;;
+      for N in 64 1024; do timeout 300 python bench.py --classes $N --steps 10 --warmup 3 --no-cpu-baseline --no-other-precision --no-end-to-end --no-sweep --no-live-counters 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('[${V:-product}${LABEL:+ $LABEL}] classes $N', d['ms_per_step'], d['stages_ms'])" | tee -a $OUT/stages.txt; done; unset OS2D_HIP_LIB;;
     bench1024)
       ( timeout 600 python bench.py --classes 1024 --steps 5 --warmup 2 --no-cpu-baseline --no-other-precision --no-end-to-end --no-sweep --no-live-counters ) > $OUT/bench1024.json 2> $OUT/bench1024.err; echo "rc=$?"; cat $OUT/bench1024.json;;
     prof)
@@ -58,6 +59,8 @@ for STEP in "$@"; do
       bash tools/power_probe.sh > $OUT/power_probe.log 2>&1; cp -f gpurun_out/power/power_probe.txt $OUT/power_probe_raw.txt 2>/dev/null; grep -v "^LOOP\|{" $OUT/power_probe.log | tail -12; grep "^LOOP" $OUT/power_probe.log;;
     env:*)
       export "${STEP#env:}"; echo "exported ${STEP#env:}";;
+    ab:*)        # ab:VAR=VALUE[,VAR=VALUE...]: the stage times of the 64- and the 1024-class step under these variables, labelled with them
+      SPEC=${STEP#ab:}; ( IFS=,; for KV in $SPEC; do export "$KV"; done; export LABEL="$SPEC"; bash "$0" "$TAG" stages ) | grep "classes";;
     unset:*)
       unset "${STEP#unset:}";;
     bin:*)

@@ -622,6 +622,23 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
     mark(b0, 5);
     mark(b0, 6);
     if (dumps_active() && b0 == 0) dump_slot(stream, 5, h2, (size_t)NB * 64 * os2d_plane(H, W) * 4);
+    // split-fp16 route: the last layer and the alignment epilogue in ONE launch (conv3_f16x3.hip, FUSE: the parameters go from the
+    // accumulators through LDS to the resampler, never to HBM).  $OS2D_FUSED_TAIL=0: the two launches of rounds 1 - 5 (measurements;
+    // same bits).  Diagnostic dumps of the parameters need the separate launches.
+    static const bool fused_tail_env = [] {
+      const char* e = getenv("OS2D_FUSED_TAIL");
+      return !(e && e[0] == '0');
+    }();
+    const bool fused_tail = f16 && fused_tail_env && !dumps_active();
+    if (fused_tail) {
+      if ((rc = os2d_launch_conv3_sample_decode(h2, w3, b3, corr, NB, H, W, P, inverse, stride, rec_field, bc, B, b0, loc, cls, corners,
+                                                flags, epoch, status, st)))
+        return rc;
+      mark(b0, 7);
+      mark(b0, 8);
+      mark(b0, 9);
+      continue;
+    }
     if (f16) {
       if ((rc = os2d_launch_conv_f16x3(3, h2, w3, b3, whole_call, params, NB, P, H, W, 3, st))) return rc;
     } else {

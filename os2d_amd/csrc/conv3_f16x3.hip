@@ -11,7 +11,15 @@
 // (28 x 2 x 16 units) arrive by LDS-DMA into the other half of a double buffer while the current group is multiplied.
 // Every output element accumulates its products in ONE order whatever the batch size (one kernel shape for all).
 // Maps wider than OS2D_MAX_W_LINEAR5 run in column strips (SP > 0: the strip-plane geometry of conv_f16x3.hip).
+//
+// FUSE (round 6): the layer's P outputs of a location are all the alignment epilogue needs for that location
+// (sample_decode.h: theta, resample + pool, box, corners, loc) - so the head's launch does that epilogue right here: the accumulators
+// go through LDS to one lane per cell ([P][256] floats in the operand buffer, which is free by then) and every lane runs
+// os2d_sample_decode_location for its cell.  The parameters never touch HBM, one launch and one dependent-launch gap (~11 us per
+// step at 64 classes) less, and the gather-bound epilogue of one work-group overlaps the load-bound matrix phase of its neighbours
+// on the CU.  The standalone kernels remain for the per-stage entry points (os2d_transform_conv_f16x3, os2d_sample_decode).
 #include "os2d_common.h"
+#include "sample_decode.h"
 
 namespace {
 
@@ -30,16 +38,27 @@ constexpr int C3_WG = C3_TAPS * 2 * 32;       // ... in the packed global layout
 #ifndef OS2D_C3_BUFS
 #define OS2D_C3_BUFS 1
 #endif
+#ifndef OS2D_C3_FUSE_GROUPS
+#define OS2D_C3_FUSE_GROUPS 5      /* work-groups per CU the register budget of the fused kernel is set for */
+#endif
 // BUFS = 2: the next group's operands land in the other half of a double buffer while this one is multiplied (53 KB: three
 // work-groups per CU).  BUFS = 1: one buffer (26.6 KB), load -> barrier -> multiply -> barrier, and FIVE work-groups per CU
 // cover each other's load latency (a group is only 0.6 us of matrix work against ~2 us of load latency); 1280 slots are
 // exactly the 1280 work-groups of 64 classes at 60 x 80.  Measured: 0.058 ms double-buffered, 0.049 ms with four single-
 // buffered groups per CU (16 weight rows), 8 weight rows + five groups below.
 constexpr int C3_BUFS = OS2D_C3_BUFS;
-__global__ __launch_bounds__(C3_THR, C3_BUFS == 1 ? 5 : 2) void conv3_f16x3_kernel(const u32x4* in, const u32x4* wp, const float* __restrict__ bp,
-                                                                float* __restrict__ out, int P, int H, int W, int PLANE,
-                                                                int TILES, int NB, int SP /*0: linear; else row pitch of a strip-plane*/,
-                                                                int TPS /*tiles per strip*/) {
+struct C3Fuse {            // what the fused epilogue needs on top of the layer's own arguments (os2d_launch_sample_decode's)
+  const float* corr;       // [NB][225][HW]
+  float *loc, *cls, *corners;
+  const int* flags;        // [A + 1] range words of the call or NULL
+  int* host_status;
+  int inverse, Bc, Btot, b0, A, epoch;
+  float stride, half_box;
+};
+template <bool FUSE>
+__global__ __launch_bounds__(C3_THR, C3_BUFS == 1 ? (FUSE ? OS2D_C3_FUSE_GROUPS : 5) : 2) void conv3_f16x3_kernel(
+    const u32x4* in, const u32x4* wp, const float* __restrict__ bp, float* __restrict__ out, int P, int H, int W, int PLANE, int TILES, int NB,
+    int SP /*0: linear; else row pitch of a strip-plane*/, int TPS /*tiles per strip*/, C3Fuse fz) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
   const int Ws = W + OS2D_PAD, BASE = os2d_base(W), DATA = H * Ws;
   const int PW = SP ? SP : Ws;                     // row pitch of the cells in the LDS slab
@@ -135,6 +154,48 @@ __global__ __launch_bounds__(C3_THR, C3_BUFS == 1 ? 5 : 2) void conv3_f16x3_kern
 #undef C3_DMA
 
   // ---- epilogue: a lane holds rows 4 kq .. 4 kq + 3 of column l15 of every block: undo the weight scale, add the bias
+  if (FUSE) {
+    // parameters -> LDS [8 rows][256 cells] (the operand buffer is free: the loop ended in a barrier), then one lane per cell
+    float* pl = reinterpret_cast<float*>(smem16);
+    if (kq < 2) {
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int m = 4 * kq + k;
+          const float a = acc[cb][k];
+          pl[m * C3_NT + wv * 64 + cb * 16 + l15] = a * bp[32 + (m & 7)] + bp[m & 7];
+        }
+    }
+    __syncthreads();
+    const int n = n0 + tid;
+    int hr, wc;
+    bool ok;
+    if (SP) {
+      hr = n / SP;
+      const int j = n - hr * SP;
+      wc = c0mR + j;
+      ok = !(j < 2 || j >= SP - 2 || hr >= H || wc >= W);
+    } else {
+      const int r = n - BASE;
+      hr = r / Ws;
+      wc = r - hr * Ws;
+      ok = !(n >= PLANE || r >= DATA || wc >= W);
+    }
+    if (!ok) return;
+    const int HW = H * W, nl = hr * W + wc;
+    const int img = nb / fz.Bc;
+    const size_t ob = (size_t)img * fz.Btot + fz.b0 + (nb - img * fz.Bc);
+    if (fz.flags != nullptr && (fz.flags[img] == fz.epoch || fz.flags[fz.A] == fz.epoch)) {      // non-finite input: see sample_decode.hip
+      os2d_sample_decode_poison(HW, ob, nl, fz.loc, fz.cls, fz.corners);
+      if (fz.host_status != nullptr && tile == 0 && tid == (SP ? 2 : 0))
+        __hip_atomic_store(fz.host_status, OS2D_STATUS_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+    os2d_sample_decode_location(fz.corr + (size_t)nb * OS2D_K * HW, pl + tid, C3_NT, H, W, P, fz.inverse, fz.stride, fz.half_box, ob, nl, hr, wc,
+                                fz.loc, fz.cls, fz.corners);
+    return;
+  }
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) {
     const int n = n0 + wv * 64 + cb * 16 + l15;
@@ -163,8 +224,9 @@ __global__ __launch_bounds__(C3_THR, C3_BUFS == 1 ? 5 : 2) void conv3_f16x3_kern
 
 }  // namespace
 
-int os2d_launch_conv3_f16x3(const void* in, const void* wp, const float* bp, void* out, int NB, int P, int H, int W,
-                            hipStream_t stream) {
+namespace {
+int launch_conv3(bool fuse, const C3Fuse& fz, const void* in, const void* wp, const float* bp, void* out, int NB, int P, int H, int W,
+                 hipStream_t stream) {
   const int Ws = os2d_ws(W), PLANE = os2d_plane(H, W);
   int NS = 1, SP = 0;
   if (W > OS2D_MAX_W_LINEAR5) os2d_conv_strips(W, 2, &NS, &SP);
@@ -174,8 +236,8 @@ int os2d_launch_conv3_f16x3(const void* in, const void* wp, const float* bp, voi
     os2d_set_error("conv3 (f16x3): feature map too wide for the input slab (W=%d)", W);
     return -3;
   }
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_f16x3_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  auto kern = fuse ? conv3_f16x3_kernel<true> : conv3_f16x3_kernel<false>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) {
     os2d_set_error("hipFuncSetAttribute(conv3 f16x3): %s", hipGetErrorString(e));
     return -4;
@@ -188,12 +250,40 @@ int os2d_launch_conv3_f16x3(const void* in, const void* wp, const float* bp, voi
     return -3;
   }
   dim3 grid((unsigned)((groups + 7) / 8 * 8));
-  hipLaunchKernelGGL(conv3_f16x3_kernel, grid, dim3(C3_THR), lds, stream, static_cast<const u32x4*>(in),
-                     static_cast<const u32x4*>(wp), bp, static_cast<float*>(out), P, H, W, PLANE, tiles, NB, SP, TPS);
+  hipLaunchKernelGGL(kern, grid, dim3(C3_THR), lds, stream, static_cast<const u32x4*>(in), static_cast<const u32x4*>(wp), bp,
+                     static_cast<float*>(out), P, H, W, PLANE, tiles, NB, SP, TPS, fz);
   e = hipGetLastError();
   if (e != hipSuccess) {
     os2d_set_error("conv3 f16x3 launch: %s", hipGetErrorString(e));
     return -4;
   }
   return 0;
+}
+}  // namespace
+
+int os2d_launch_conv3_f16x3(const void* in, const void* wp, const float* bp, void* out, int NB, int P, int H, int W, hipStream_t stream) {
+  return launch_conv3(false, C3Fuse{}, in, wp, bp, out, NB, P, H, W, stream);
+}
+
+// the last layer + the alignment epilogue of the head in one launch (arguments of os2d_launch_conv3_f16x3 and os2d_launch_sample_decode;
+// the parameters are not written anywhere)
+int os2d_launch_conv3_sample_decode(const void* in, const void* wp, const float* bp, const float* corr, int NB, int H, int W, int P,
+                                    int inverse, int stride, int rec_field, int Bc, int Btot, int b0, float* loc, float* cls, float* corners,
+                                    const int* flags, int epoch, int* host_status, hipStream_t stream) {
+  C3Fuse fz;
+  fz.corr = corr;
+  fz.loc = loc;
+  fz.cls = cls;
+  fz.corners = corners;
+  fz.flags = flags;
+  fz.host_status = host_status;
+  fz.inverse = inverse;
+  fz.Bc = Bc;
+  fz.Btot = Btot;
+  fz.b0 = b0;
+  fz.A = NB / Bc;
+  fz.epoch = epoch;
+  fz.stride = (float)stride;
+  fz.half_box = 0.5f * (float)(stride * (OS2D_T - 1) + rec_field);      // head.py:236-237
+  return launch_conv3(true, fz, in, wp, bp, nullptr, NB, P, H, W, stream);
 }

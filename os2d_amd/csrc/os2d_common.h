@@ -262,6 +262,9 @@ int os2d_launch_corr(const float* fm, const float* qp, const float* sumsq, float
 // conv_f16x3.hip
 int os2d_launch_conv3_f16x3(const void* in, const void* wp, const float* bp, void* out, int NB, int P, int H, int W,
                             hipStream_t stream);   // conv3_f16x3.hip: layer 3 on the 16-row MFMA
+int os2d_launch_conv3_sample_decode(const void* in, const void* wp, const float* bp, const float* corr, int NB, int H, int W, int P,
+                                    int inverse, int stride, int rec_field, int Bc, int Btot, int b0, float* loc, float* cls, float* corners,
+                                    const int* flags, int epoch, int* host_status, hipStream_t stream);   // + the alignment epilogue (head)
 int os2d_launch_conv_f16x3(int layer, const void* in, const void* wp, const float* bp, Os2dRangeFlag status, void* out, int NB,
                            int P, int H, int W, int terms, hipStream_t stream);
 // conv_mfma.hip

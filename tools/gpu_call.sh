@@ -44,6 +44,11 @@ for STEP in "$@"; do
       for N in 64 1024; do timeout 300 python bench.py --classes $N --steps 10 --warmup 3 --no-cpu-baseline --no-other-precision --no-end-to-end --no-sweep --no-live-counters 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('[${V:-product}${LABEL:+ $LABEL}] classes $N', d['ms_per_step'], d['stages_ms'])" | tee -a $OUT/stages.txt; done; unset OS2D_HIP_LIB;;
     bench1024)
       ( timeout 600 python bench.py --classes 1024 --steps 5 --warmup 2 --no-cpu-baseline --no-other-precision --no-end-to-end --no-sweep --no-live-counters ) > $OUT/bench1024.json 2> $OUT/bench1024.err; echo "rc=$?"; cat $OUT/bench1024.json;;
+    trace|trace:*)      # trace[:classes]: ONE rocprofv3 --kernel-trace --stats pass over the short bench of the step (kernel table + timeline of the last two steps)
+      N=64; [ "$STEP" != trace ] && N=${STEP#trace:}
+      D=$GRAFT_REPO_ROOT/gpurun_out/trace_${TAG}_$N${LABEL:+_x}; rm -rf $D; mkdir -p $D
+      ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $D/stats -o stats -- python $GRAFT_REPO_ROOT/bench.py --classes $N --steps 20 --warmup 5 --no-cpu-baseline --no-other-precision --no-end-to-end --no-sweep --no-live-counters ) > $OUT/trace_$N.log 2>&1
+      python tools/summarize_prof.py $D 2>&1 | grep -v "at6native\|rocclr\|vectorized\|reduce_kernel\|elementwise" | cut -c1-200 | sed "s/^/[${LABEL:-product} $N] /" | tee -a $OUT/trace_$N.txt | grep "_kernel\|span" | head -40; rm -rf $D;;
     prof)
       bash tools/profile_bench.sh ${TAG}_fftx3 --precision fftx3 > $OUT/prof.log 2>&1; python tools/summarize_prof.py gpurun_out/prof_${TAG}_fftx3 > $OUT/rocprof_summary.txt 2>&1; rm -rf gpurun_out/prof_${TAG}_fftx3; grep -v "at6native\|rocclr" $OUT/rocprof_summary.txt | cut -c1-260 | head -60;;
     prof1024)
@@ -59,8 +64,9 @@ for STEP in "$@"; do
       bash tools/power_probe.sh > $OUT/power_probe.log 2>&1; cp -f gpurun_out/power/power_probe.txt $OUT/power_probe_raw.txt 2>/dev/null; grep -v "^LOOP\|{" $OUT/power_probe.log | tail -12; grep "^LOOP" $OUT/power_probe.log;;
     env:*)
       export "${STEP#env:}"; echo "exported ${STEP#env:}";;
-    ab:*)        # ab:VAR=VALUE[,VAR=VALUE...]: the stage times of the 64- and the 1024-class step under these variables, labelled with them
-      SPEC=${STEP#ab:}; ( IFS=,; for KV in $SPEC; do export "$KV"; done; export LABEL="$SPEC"; bash "$0" "$TAG" stages ) | grep "classes";;
+    ab:*)        # ab:VAR=VALUE[,VAR=VALUE...][:step]: the stage times of the 64- and the 1024-class step (or another step) under these variables, labelled with them
+      SPEC=${STEP#ab:}; SUB=stages; case "$SPEC" in *:*) SUB=${SPEC#*:}; SPEC=${SPEC%%:*};; esac
+      ( IFS=,; for KV in $SPEC; do export "$KV"; done; export LABEL="$SPEC"; bash "$0" "$TAG" $SUB ) | grep "classes\|_kernel\|span";;
     unset:*)
       unset "${STEP#unset:}";;
     bin:*)

@@ -516,23 +516,10 @@ int os2d_head_forward_ex(const float* fm, const float* qp, const void* w1, const
   auto mark = [&](int b0, int idx) {
     if (stage_events && b0 == 0 && stage_events[idx]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(stage_events[idx]), st);
   };
-  // image features: sums of squares for the fp32 correlation kernel's epilogue | normalised, scaled and split into the half-precision
-  // operand in one launch (the packed correlation kernel's sums are cleared by the same launch; every chunk's norms pass leaves them
-  // cleared again).  $OS2D_FUSED_SPLIT=0: the two launches of rounds 1 - 5 (measurements; same bits)
-  static const bool fused_split = [] {
-    const char* e = getenv("OS2D_FUSED_SPLIT");
-    return !(e && e[0] == '0');
-  }();
-  int rc = 0;
-  if (fp32_ops || !fused_split) {
-    if ((rc = os2d_launch_fm_sumsq(fm, sumsq, A, C, H * W, st))) return rc;
-  }
-  if (!fp32_ops) {
-    const size_t clear_words = sumfx ? (size_t)A * Bc * H * W : 0;
-    rc = fused_split ? os2d_launch_fm_norm_split(fm, fsplit, A, C, H * W, sumfx, clear_words, per_image, st)
-                     : os2d_launch_split_fm(fm, sumsq, fsplit, A, C, H * W, sumfx, clear_words, per_image, st);
-    if (rc) return rc;
-  }
+  int rc = os2d_launch_fm_sumsq(fm, sumsq, A, C, H * W, st);
+  if (rc) return rc;
+  // (the packed correlation kernel's sums are cleared by the same launch; every chunk's norms pass leaves them cleared again)
+  if (!fp32_ops && (rc = os2d_launch_split_fm(fm, sumsq, fsplit, A, C, H * W, sumfx, sumfx ? (size_t)A * Bc * H * W : 0, per_image, st))) return rc;
   for (int b0 = 0; b0 < B; b0 += Bc) {
     const int bc = (B - b0 < Bc) ? (B - b0) : Bc;
     const int NB = A * bc;

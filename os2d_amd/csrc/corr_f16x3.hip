@@ -279,7 +279,7 @@ __device__ __forceinline__ void corr_tile(const u32x4* fs,  // [A][CGP][2][HW]  
           }
           if (mok && nq < HW) {
             f32x4 o4 = {__int_as_float(t0), __int_as_float(t1), __int_as_float(t2), __int_as_float(t3)};
-            *reinterpret_cast<f32x4*>(corr + orow * HW + nq) = o4;
+            os2d_stream_store<1>(reinterpret_cast<f32x4*>(corr + orow * HW + nq), o4);
           }
         }
       } else {
@@ -449,66 +449,13 @@ __global__ __launch_bounds__(256) void split_fm_kernel(const float* __restrict__
     lo[j] = (_Float16)(v - (float)hv);
   }
   u32x4* o = fs + ((size_t)a * CG + g) * 2 * HW + n;
-  *reinterpret_cast<half8*>(o) = hi;
-  *reinterpret_cast<half8*>(o + HW) = lo;
+  os2d_stream_store<64>(reinterpret_cast<half8*>(o), hi);
+  os2d_stream_store<64>(reinterpret_cast<half8*>(o + HW), lo);
 }
 
-// The two kernels above in ONE launch (round 6): a work-group owns 16 positions of an image, adds the squares of
-// their C channels exactly as fm_sumsq_kernel does (16 channel lanes per position, channels lane, lane + 16, ... in order, the 16
-// partial sums in lane order: the same bits) and then normalises, scales and splits the same 16 x C values - which it has just read:
-// the second pass comes from the caches - into the operand layout.  One launch and one pass over HBM less per head call; the
-// per-position sums never leave the chip.
-constexpr int FNS_LANES = 16, FNS_POS = 16;
-__global__ __launch_bounds__(FNS_LANES * FNS_POS) void fm_norm_split_kernel(const float* __restrict__ fm, u32x4* __restrict__ fs, int C, int HW,
-                                                                            float scale, unsigned long long* __restrict__ clear,
-                                                                            size_t clear_words, Os2dRangeFlag status) {
-  __shared__ float red[FNS_LANES][FNS_POS];
-  const int col = threadIdx.x % FNS_POS, cl = threadIdx.x / FNS_POS;
-  const int n = blockIdx.x * FNS_POS + col;
-  const int a = blockIdx.y;
-  if (clear_words) {       // the packed correlation kernel's sums, zeroed on the way (grid-stride over all work items)
-    const size_t nthr = (size_t)gridDim.x * gridDim.y * (FNS_LANES * FNS_POS);
-    for (size_t i = ((size_t)a * gridDim.x + blockIdx.x) * (FNS_LANES * FNS_POS) + threadIdx.x; i < clear_words; i += nthr) clear[i] = 0ull;
-  }
-  const int nc = min(n, HW - 1);      // (positions past the map: a valid address, nothing stored)
-  const float* p = fm + (size_t)a * C * HW + nc;
-  float s = 0.f;
-  for (int c0 = cl; c0 < C; c0 += FNS_LANES * 8) {  // 8 independent loads in flight, accumulated in channel order
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = p[(size_t)min(c0 + u * FNS_LANES, C - 1) * HW];
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (c0 + u * FNS_LANES < C) s += v[u] * v[u];
-  }
-  red[cl][col] = s;
-  __syncthreads();
-  float ss = 0.f;
-#pragma unroll
-  for (int i = 0; i < FNS_LANES; ++i) ss += red[i][col];
-  // a non-finite feature: see split_fm_kernel
-  if (status.word != nullptr && __builtin_amdgcn_ballot_w64(n < HW && !(ss <= 3.4028234e38f)) != 0ull && (threadIdx.x & 63) == 0)
-    os2d_raise(Os2dRangeFlag{status.word + a, status.value});
-  if (n >= HW) return;
-  const float inv = scale / (sqrtf(ss) + 1e-5f);
-  const int CG = os2d_round_up((C + 7) / 8, GC);  // zero groups pad the channel dimension to whole K chunks
-  for (int g = cl; g < CG; g += FNS_LANES) {
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = p[(size_t)min(g * 8 + j, C - 1) * HW];
-    half8 hi, lo;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float x = g * 8 + j < C ? v[j] * inv : 0.f;
-      const _Float16 hv = (_Float16)x;
-      hi[j] = hv;
-      lo[j] = (_Float16)(x - (float)hv);
-    }
-    u32x4* o = fs + ((size_t)a * CG + g) * 2 * HW + n;
-    *reinterpret_cast<half8*>(o) = hi;
-    *reinterpret_cast<half8*>(o + HW) = lo;
-  }
-}
+// (Round 6 measured fm_sumsq_kernel + this kernel as ONE launch - VERDICT r5 item 1a: 17.5 us against 8.8 + 10.5 us, but the launch
+// gaps around it grew from 6 + 0 + 6 to 15 + 20 us - all of its 19.7 MB of stores are still dirty in the L2s when it ends - and the
+// step did not move: 1.574 - 1.579 against 1.572 ms, profiles/r06/trace_64_fused_split_and_tail_vs_separate.txt.  Not kept.)
 
 // class operand [C][256] fp32 (os2d_class_prepare) -> [C/8][hi|lo][256] units, scaled
 __global__ __launch_bounds__(256) void split_qp_kernel(const float* __restrict__ qp, u32x4* __restrict__ qs, int C,
@@ -559,14 +506,6 @@ int os2d_launch_split_fm(const float* fm, const float* sumsq, void* fs, int A, i
                      reinterpret_cast<u32x4*>(fs), C, HW, ldexpf(1.0f, SCALE_LOG2), static_cast<unsigned long long*>(clear),
                      clear ? clear_words : (size_t)0, status);
   return check("split_fm");
-}
-
-int os2d_launch_fm_norm_split(const float* fm, void* fs, int A, int C, int HW, void* clear, size_t clear_words, Os2dRangeFlag status,
-                              hipStream_t stream) {
-  hipLaunchKernelGGL(fm_norm_split_kernel, dim3((HW + FNS_POS - 1) / FNS_POS, A), dim3(FNS_LANES * FNS_POS), 0, stream, fm,
-                     reinterpret_cast<u32x4*>(fs), C, HW, ldexpf(1.0f, SCALE_LOG2), static_cast<unsigned long long*>(clear),
-                     clear ? clear_words : (size_t)0, status);
-  return check("fm_norm_split");
 }
 
 int os2d_launch_split_qp(const float* qp, void* qs, int B, int C, hipStream_t stream) {

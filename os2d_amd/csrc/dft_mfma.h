@@ -66,6 +66,9 @@
 #ifndef DFT_SCHED_FENCE
 #define DFT_SCHED_FENCE()         /* device build: __builtin_amdgcn_sched_barrier(0) - the scheduler moves nothing across it */
 #endif
+#ifndef DFT_STREAM_STORE
+#define DFT_STREAM_STORE(CLASS, P, V) (*(P) = (V))      /* device build: os2d_stream_store (os2d_common.h) */
+#endif
 #ifndef DFT_STAMP
 #define DFT_STAMP(K)              /* diagnostic builds (-DOS2D_DIAG_DFT_STAMPS): time since the previous stamp -> phase K */
 #define DFT_STAMP_BEGIN()
@@ -775,7 +778,7 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
         const int v = dft_div(i, pl.inv_pq), rem = i - v * per_v;
         const int uq = rem / (2 * G), jj = rem - uq * (2 * G);
         const f32x4v val = *reinterpret_cast<const f32x4v*>(ldsUb + (size_t)v * XS + uq * (G * 32) + jj * 16);
-        *reinterpret_cast<f32x4v*>(dstbase + (size_t)(v * (P / 4) + uq) * qstride + jj * 4) = val;
+        DFT_STREAM_STORE(2, reinterpret_cast<f32x4v*>(dstbase + (size_t)(v * (P / 4) + uq) * qstride + jj * 4), val);
       }
       const int qpad0 = (P * V) / 4, qpad1 = pl.NBINS / 4;
       for (int i = tl; i < (qpad1 - qpad0) * 2 * G; i += THR)
@@ -1093,8 +1096,8 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
             u32x2v hi, lo;
             dft_split4(t[0], t[1], t[2], t[3], &hi, &lo);
             const size_t off = ((size_t)BASE + (size_t)h * Ws + w) * 16;
-            *reinterpret_cast<u32x2v*>(hi_unit + off) = hi;
-            *reinterpret_cast<u32x2v*>(lo_unit + off) = lo;
+            DFT_STREAM_STORE(8, reinterpret_cast<u32x2v*>(hi_unit + off), hi);
+            DFT_STREAM_STORE(8, reinterpret_cast<u32x2v*>(lo_unit + off), lo);
           }
         }
       }

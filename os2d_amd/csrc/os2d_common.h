@@ -75,6 +75,19 @@ __device__ __forceinline__ void os2d_corr_norm_finalize_one(unsigned long long* 
   const float s = (v >> 62) ? __builtin_nanf("") : (float)((double)v * 5.6843418860808015e-14);    // 2^-44
   invn[i] = 1.0f / (sqrtf(s) + 1e-6f);
 }
+// A store of a STREAMED result - written once, read by a LATER kernel only (correlation tensor, spectra, activation planes, the head's
+// outputs).  EXPERIMENT (round 6, -DOS2D_NT_STORES=mask): bit k of the mask makes the stores of kernel class k non-temporal
+// (1 correlation, 2 forward transform, 4 per-bin GEMM, 8 inverse transform, 16 5x5 layer, 32 resampler outputs, 64 split_fm), so
+// that a kernel does not end with megabytes of dirty lines in the per-XCD L2s (the write-back in front of the next launch is what
+// the 6 - 20 us between dependent kernels are) and its results do not evict the operands it shares through L2.
+#ifndef OS2D_NT_STORES
+#define OS2D_NT_STORES 0
+#endif
+template <int CLASS, class T>
+__device__ __forceinline__ void os2d_stream_store(T* p, const T& v) {
+  if (OS2D_NT_STORES & CLASS) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
 // lo halves of the fp16 hi + lo split of two fp32 values whose hi halves are packed in ``hi`` (x0 -> low 16 bits): rn16(x - hi) as
 // ONE mixed-precision instruction per value (v_fma_mixlo_f16 / v_fma_mixhi_f16: fma(x, 1.0, -hi) in fp32, rounded to fp16 into
 // the low / high half) instead of v_cvt_f32_f16 + v_sub_f32 per value and a v_cvt_pk_f16_f32 per pair - the split conversions
@@ -323,9 +336,6 @@ int os2d_corr_groups(int C);  // 8-channel groups of the split correlation opera
 // status: word[a] is raised for an image a with a non-finite feature (one word per image)
 int os2d_launch_split_fm(const float* fm, const float* sumsq, void* fs, int A, int C, int HW, void* clear, size_t clear_words,
                          Os2dRangeFlag status, hipStream_t stream);
-// fm_sumsq + split_fm in one launch (the same bits; the sums are not written)
-int os2d_launch_fm_norm_split(const float* fm, void* fs, int A, int C, int HW, void* clear, size_t clear_words, Os2dRangeFlag status,
-                              hipStream_t stream);
 int os2d_launch_split_qp(const float* qp, void* qs, int B, int C, hipStream_t stream);
 // flags & 1 (packed form only): the sums stay in sumfx; the caller's next launch turns them into invn; & 2: no half tiles at the tail
 // (os2d_launch_border_zero_shb_planes_norms) - one launch less on the per-step path

@@ -254,8 +254,8 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
       if (nb < NB) {
         float4* dst = XQ ? reinterpret_cast<float4*>(Y + ((qblk + (nb - nb0)) * Cout + o) * 4)
                          : reinterpret_cast<float4*>(Y + (((size_t)(bin0 >> 2) * NB + nb) * Cout + o) * 4);
-        dst[0] = make_float4(yr[0][r] * sc, yi[0][r] * sc, yr[1][r] * sc, yi[1][r] * sc);
-        dst[1] = make_float4(yr[2][r] * sc, yi[2][r] * sc, yr[3][r] * sc, yi[3][r] * sc);
+        os2d_stream_store<4>(reinterpret_cast<f32x4*>(dst), f32x4{yr[0][r] * sc, yi[0][r] * sc, yr[1][r] * sc, yi[1][r] * sc});
+        os2d_stream_store<4>(reinterpret_cast<f32x4*>(dst) + 1, f32x4{yr[2][r] * sc, yi[2][r] * sc, yr[3][r] * sc, yi[3][r] * sc});
       }
     }
   }

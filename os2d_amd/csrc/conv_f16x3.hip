@@ -333,8 +333,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_f16x3_kernel(const u3
           }
           const int Gout = (CoutStore + 7) >> 3;
           char* o = reinterpret_cast<char*>(outv) + (((size_t)nb * Gout + grp) * 2 * PLANE + n) * 16 + hw * 8;
-          os2d_stream_store<16>(reinterpret_cast<half4*>(o), hi4);
-          os2d_stream_store<16>(reinterpret_cast<half4*>(o + (size_t)PLANE * 16), lo4);
+          *reinterpret_cast<half4*>(o) = hi4;
+          *reinterpret_cast<half4*>(o + (size_t)PLANE * 16) = lo4;
         } else if (OUT_MODE == 1) {
           float* o = reinterpret_cast<float*>(outv);
 #pragma unroll

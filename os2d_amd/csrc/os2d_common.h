@@ -75,18 +75,26 @@ __device__ __forceinline__ void os2d_corr_norm_finalize_one(unsigned long long* 
   const float s = (v >> 62) ? __builtin_nanf("") : (float)((double)v * 5.6843418860808015e-14);    // 2^-44
   invn[i] = 1.0f / (sqrtf(s) + 1e-6f);
 }
-// A store of a STREAMED result - written once, read by a LATER kernel only (correlation tensor, spectra, activation planes, the head's
-// outputs).  EXPERIMENT (round 6, -DOS2D_NT_STORES=mask): bit k of the mask makes the stores of kernel class k non-temporal
-// (1 correlation, 2 forward transform, 4 per-bin GEMM, 8 inverse transform, 16 5x5 layer, 32 resampler outputs, 64 split_fm), so
-// that a kernel does not end with megabytes of dirty lines in the per-XCD L2s (the write-back in front of the next launch is what
-// the 6 - 20 us between dependent kernels are) and its results do not evict the operands it shares through L2.
-#ifndef OS2D_NT_STORES
-#define OS2D_NT_STORES 0
+// A NON-TEMPORAL store for a streamed result: the correlation tensor (276 MB per 64 classes) and the input spectra (326 MB), written
+// once in whole 16-byte-per-lane runs and read by the NEXT kernel only.  Round 6 measured the hint kernel by kernel (64-class step,
+// one box, profiles/r06/stages_nontemporal_stores_*.txt): correlation -16 us, forward transform -15 us (the per-bin GEMM that reads
+// its spectra runs 266 -> 238 us), both together -35 us (1.537 -> 1.505 ms); the 5x5 layer's and split_fm's stores: no effect;
+// the per-bin GEMM's output spectra +17 us, the resampler's 4-byte stores +13 us, the inverse transform's 8-byte half units +47 us
+// (1.06 ms at 1024 classes) - those keep plain stores.  The launch gaps did not change (6 / 10 us): the hint does not shorten the
+// end-of-kernel write-back, it keeps the streamed lines from displacing what the kernels share through L2.
+template <class T>
+__device__ __forceinline__ void os2d_stream_store(T* p, const T& v) {
+  __builtin_nontemporal_store(v, p);
+}
+// EXPERIMENT (-DOS2D_NT_LOADS=mask): the same hint for operands a kernel reads exactly once: 1 the per-bin GEMM's input spectra,
+// 2 the forward transform's correlation maps, 4 the inverse transform's output spectra, 8 the per-bin GEMM's weight spectra
+#ifndef OS2D_NT_LOADS
+#define OS2D_NT_LOADS 0
 #endif
 template <int CLASS, class T>
-__device__ __forceinline__ void os2d_stream_store(T* p, const T& v) {
-  if (OS2D_NT_STORES & CLASS) __builtin_nontemporal_store(v, p);
-  else *p = v;
+__device__ __forceinline__ T os2d_stream_load(const T* p) {
+  if (OS2D_NT_LOADS & CLASS) return __builtin_nontemporal_load(p);
+  return *p;
 }
 // lo halves of the fp16 hi + lo split of two fp32 values whose hi halves are packed in ``hi`` (x0 -> low 16 bits): rn16(x - hi) as
 // ONE mixed-precision instruction per value (v_fma_mixlo_f16 / v_fma_mixhi_f16: fma(x, 1.0, -hi) in fp32, rounded to fp16 into

@@ -113,7 +113,7 @@ __device__ __forceinline__ void os2d_sample_decode_location(const float* __restr
       sum += (v00[k] * (1.f - ax) + v01[k] * ax) * (1.f - ay) + (v10[k] * (1.f - ax) + v11[k] * ax) * ay;
     }
   }
-  os2d_stream_store<32>(cls + ob * HW + n, sum * (1.0f / ((POOL_HI - POOL_LO) * (POOL_HI - POOL_LO))));
+  cls[ob * HW + n] = sum * (1.0f / ((POOL_HI - POOL_LO) * (POOL_HI - POOL_LO)));
 
   // ---- box of the transformed template in image coordinates (the 4 corners bound the affine image)
   const float ecx = stride * cx, ecy = stride * cy;
@@ -124,8 +124,8 @@ __device__ __forceinline__ void os2d_sample_decode_location(const float* __restr
     const float xj = (k & 1) ? 1.0f : -1.0f;  // template col 0 / 14
     U[k] = (t00 * xj + t01 * yi + t02) * half_box + ecx;
     V[k] = (t10 * xj + t11 * yi + t12) * half_box + ecy;
-    os2d_stream_store<32>(corners + (ob * 8 + 2 * k) * HW + n, U[k]);
-    os2d_stream_store<32>(corners + (ob * 8 + 2 * k + 1) * HW + n, V[k]);
+    corners[(ob * 8 + 2 * k) * HW + n] = U[k];
+    corners[(ob * 8 + 2 * k + 1) * HW + n] = V[k];
   }
   float x1 = fminf(fminf(U[0], U[1]), fminf(U[2], U[3]));
   float x2 = fmaxf(fmaxf(U[0], U[1]), fmaxf(U[2], U[3]));
@@ -141,10 +141,10 @@ __device__ __forceinline__ void os2d_sample_decode_location(const float* __restr
   const float aw = (ecx + half_box) - ax1, ah = (ecy + half_box) - ay1;
   const float acx = ax1 + 0.5f * aw, acy = ay1 + 0.5f * ah;
   (void)size;
-  os2d_stream_store<32>(loc + (ob * 4 + 0) * HW + n, 10.0f * (gcx - acx) / aw);
-  os2d_stream_store<32>(loc + (ob * 4 + 1) * HW + n, 10.0f * (gcy - acy) / ah);
-  os2d_stream_store<32>(loc + (ob * 4 + 2) * HW + n, 5.0f * logf(bw / aw));
-  os2d_stream_store<32>(loc + (ob * 4 + 3) * HW + n, 5.0f * logf(bh / ah));
+  loc[(ob * 4 + 0) * HW + n] = 10.0f * (gcx - acx) / aw;
+  loc[(ob * 4 + 1) * HW + n] = 10.0f * (gcy - acy) / ah;
+  loc[(ob * 4 + 2) * HW + n] = 5.0f * logf(bw / aw);
+  loc[(ob * 4 + 3) * HW + n] = 5.0f * logf(bh / ah);
 }
 
 // the outputs of a location of a flagged image (non-finite input): NaN, as the reference's torch.relu / norm propagate it

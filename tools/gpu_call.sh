@@ -48,7 +48,7 @@ for STEP in "$@"; do
       N=64; [ "$STEP" != trace ] && N=${STEP#trace:}
       D=$GRAFT_REPO_ROOT/gpurun_out/trace_${TAG}_$N${LABEL:+_x}; rm -rf $D; mkdir -p $D
       ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $D/stats -o stats -- python $GRAFT_REPO_ROOT/bench.py --classes $N --steps 20 --warmup 5 --no-cpu-baseline --no-other-precision --no-end-to-end --no-sweep --no-live-counters ) > $OUT/trace_$N.log 2>&1
-      python tools/summarize_prof.py $D 2>&1 | grep -v "at6native\|rocclr\|vectorized\|reduce_kernel\|elementwise" | cut -c1-200 | sed "s/^/[${LABEL:-product} $N] /" | tee -a $OUT/trace_$N.txt | grep "_kernel\|span" | head -40; rm -rf $D;;
+      python tools/summarize_prof.py $D 2>&1 | grep -v "at6native\|rocclr\|vectorized\|reduce_kernel\|elementwise" | cut -c1-200 | sed "s|^|[${LABEL:-product} $N] |" | tee -a $OUT/trace_$N.txt | grep "_kernel\|span" | head -40; rm -rf $D;;
     prof)
       bash tools/profile_bench.sh ${TAG}_fftx3 --precision fftx3 > $OUT/prof.log 2>&1; python tools/summarize_prof.py gpurun_out/prof_${TAG}_fftx3 > $OUT/rocprof_summary.txt 2>&1; rm -rf gpurun_out/prof_${TAG}_fftx3; grep -v "at6native\|rocclr" $OUT/rocprof_summary.txt | cut -c1-260 | head -60;;
     prof1024)
@@ -66,7 +66,9 @@ for STEP in "$@"; do
       export "${STEP#env:}"; echo "exported ${STEP#env:}";;
     ab:*)        # ab:VAR=VALUE[,VAR=VALUE...][:step]: the stage times of the 64- and the 1024-class step (or another step) under these variables, labelled with them
       SPEC=${STEP#ab:}; SUB=stages; case "$SPEC" in *:*) SUB=${SPEC#*:}; SPEC=${SPEC%%:*};; esac
-      ( IFS=,; for KV in $SPEC; do export "$KV"; done; export LABEL="$SPEC"; bash "$0" "$TAG" $SUB ) | grep "classes\|_kernel\|span";;
+      ( IFS=,; for KV in $SPEC; do export "$KV"; done; export LABEL="$(echo "$SPEC" | sed 's|OS2D_HIP_LIB=tools/diag_libs/||; s|/libos2d_hip.so||')"
+        case "$OS2D_HIP_LIB" in ""|/*) ;; *) export OS2D_HIP_LIB="$GRAFT_REPO_ROOT/$OS2D_HIP_LIB";; esac      # (some steps run from /tmp)
+        bash "$0" "$TAG" $SUB ) | grep "classes\|_kernel\|span";;
     unset:*)
       unset "${STEP#unset:}";;
     bin:*)

@@ -37,17 +37,16 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 constexpr int GC = 4;                    // 8-channel groups per K chunk (32 channels)
 constexpr int STACK_STRIDE = 228;        // stacked rows per class (225 rounded up to a multiple of 4)
-constexpr int TM = 256;                  // rows per work-group
+constexpr int TM = 256;                  // rows per work-group: two waves of 128
+constexpr int WNW = 4;                   // waves along the positions: 8 waves of 128 x (32 NI)
 
-// One tile: 256 rows x NT positions, 8 waves.  MI / NI = 32-row / 32-column blocks per wave:
-//   MI = 4, NI = 2   2 x 4 waves of 128 x 64: 256 positions (the throughput shape: 128 accumulators per lane, two waves per SIMD);
-//   MI = 4, NI = 1   2 x 4 waves of 128 x 32: 128 positions (half the matrix instructions per K chunk for the same class operand:
-//                    for a handful of classes, where a group's serial K loop is what a call waits for, and for the TAIL of a launch);
-//   MI = 2, NI = 1   4 x 2 waves of 64 x 32: 64 positions (a quarter: the tail of a launch, see the kernel).
-// Every output accumulates the same products in the same order in all shapes.
+// One tile: 256 rows x (128 NI) positions.  NI = 32-column tiles per wave: 2 -> 256 positions (the throughput shape: 128
+// accumulators per lane, two waves per SIMD); 1 -> 128 positions (half the matrix instructions per K chunk for the same class
+// operand: for a handful of classes, where a group's serial K loop is what a call waits for, and for the TAIL of a launch, see
+// the kernel).  Every output accumulates the same products in the same order in both shapes.
 // (Retired shapes, measured slower: 4 waves of 128 x 128 with the whole register file; 128-row half tiles, two groups per CU -
 // tools/patches/corr_f16x3_variants.patch, profiles/r04/corr_fixed_cost.txt.)
-template <int MI, int NI, bool STACK>
+template <int NI, bool STACK>
 __device__ __forceinline__ void corr_tile(const u32x4* fs,  // [A][CGP][2][HW]  (no __restrict__, see conv_f16x3.hip)
                                           const u32x4* qs,  // [B][CGP][2][256]
                                           float* __restrict__ corr, char* __restrict__ rshb,
@@ -57,26 +56,26 @@ __device__ __forceinline__ void corr_tile(const u32x4* fs,  // [A][CGP][2][HW]  
                                           float unscale, int a, int b /*class | STACK: row tile of the stacked matrix*/, int n0,
                                           u32x4* smem16, unsigned long long (*red)[256]) {
   constexpr int KC = GC;
-  constexpr int NTHR = 512, WMW = TM / (32 * MI), WNW = 8 / WMW;      // waves along the rows / along the positions
+  constexpr int NTHR = 64 * 2 * WNW;
   constexpr int NT = WNW * 32 * NI;      // positions per work-group
   constexpr int AUNITS = KC * 2 * TM;    // 16-byte units of one class-operand chunk
   constexpr int BUNITS = KC * 2 * NT;    // 16-byte units of one image-operand chunk
   constexpr int NPF = AUNITS / NTHR;     // class units per thread
   constexpr int NPFB = BUNITS / NTHR;    // image units per thread
-  static_assert((NPF > NPFB ? NPF : NPFB) <= (KC / 2) * MI, "one DMA piece per matrix-instruction group of a chunk");
+  static_assert((NPF > NPFB ? NPF : NPFB) <= (KC / 2) * 4, "one DMA piece per matrix-instruction group of a chunk");
   u32x4* ldsA = smem16;                 // [2][AUNITS]
   u32x4* ldsB = smem16 + 2 * AUNITS;    // [2][BUNITS]
 
   const int HW = H * W;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, hw = lane >> 5;
-  const int wm = wid / WNW, wn = wid % WNW;  // wave tile: rows [wm*32*MI,+32*MI), cols [wn*32*NI,+32*NI)
+  const int wm = wid / WNW, wn = wid % WNW;  // wave tile: rows [wm*128,+128), cols [wn*32*NI,+32*NI)
   const int nb = a * B + b;
   const int R0 = b * TM;                         // STACK: first stacked row of this work-group
 
-  f32x16 acc[MI][NI];
+  f32x16 acc[4][NI];
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
+  for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -127,7 +126,7 @@ __device__ __forceinline__ void corr_tile(const u32x4* fs,  // [A][CGP][2][HW]  
 #define CF_COMPUTE(T) CF_COMPUTE_H(T, CF_NOHOOK)
 #define CF_COMPUTE_H(T, HOOK)                                                                                     \
   {                                                                                                               \
-    const u32x4* aB_ = ldsA + ((T)&1) * AUNITS + wm * (32 * MI) + l31;                                            \
+    const u32x4* aB_ = ldsA + ((T)&1) * AUNITS + wm * 128 + l31;                                                  \
     const u32x4* bB_ = ldsB + ((T)&1) * BUNITS + wn * (32 * NI) + l31;                                            \
     _Pragma("unroll") for (int ks = 0; ks < KC / 2; ++ks) {                                                       \
       const int rowh_ = ((2 * ks + hw) * 2 + 0) * TM, rowl_ = ((2 * ks + hw) * 2 + 1) * TM;                       \
@@ -136,7 +135,7 @@ __device__ __forceinline__ void corr_tile(const u32x4* fs,  // [A][CGP][2][HW]  
         bh_[ni] = *reinterpret_cast<const half8*>(bB_ + ((2 * ks + hw) * 2 + 0) * NT + ni * 32);                  \
         bl_[ni] = *reinterpret_cast<const half8*>(bB_ + ((2 * ks + hw) * 2 + 1) * NT + ni * 32);                  \
       }                                                                                                           \
-      _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                         \
+      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                                          \
         const half8 ah_ = *reinterpret_cast<const half8*>(aB_ + rowh_ + mi * 32);                                 \
         const half8 al_ = *reinterpret_cast<const half8*>(aB_ + rowl_ + mi * 32);                                 \
         _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                                       \
@@ -144,7 +143,7 @@ __device__ __forceinline__ void corr_tile(const u32x4* fs,  // [A][CGP][2][HW]  
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bl_[ni], acc[mi][ni], 0, 0, 0);               \
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bh_[ni], acc[mi][ni], 0, 0, 0);               \
         }                                                                                                         \
-        HOOK(ks * MI + mi)         /* 2 MI places per chunk to issue a piece of the next chunk's DMA */           \
+        HOOK(ks * 4 + mi)          /* eight places per chunk to issue a piece of the next chunk's DMA */          \
       }                                                                                                           \
     }                                                                                                             \
   }
@@ -191,7 +190,7 @@ __device__ __forceinline__ void corr_tile(const u32x4* fs,  // [A][CGP][2][HW]  
   // 4 k .. 4 k + 3 of ONE class, the same values in the same order wherever the class sits), converts the run's sum and adds
   // integers from there on.  Slot 1 (STACK only): the second class of the wave's 128 rows (they touch at most two: class cw0 up
   // to row `bound`, cw0 + 1 after).
-  const int Rw = R0 + wm * (32 * MI), cw0 = Rw / STACK_STRIDE, bound = (cw0 + 1) * STACK_STRIDE;
+  const int Rw = R0 + wm * 128, cw0 = Rw / STACK_STRIDE, bound = (cw0 + 1) * STACK_STRIDE;
   constexpr int NSL = STACK ? 2 : 1;
   unsigned fxh[NSL][NI], fxl[NSL][NI];
   bool fxbad[NSL][NI];
@@ -206,7 +205,7 @@ __device__ __forceinline__ void corr_tile(const u32x4* fs,  // [A][CGP][2][HW]  
       fxbad[sl][ni] = false;
     }
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
+    for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float g = 0.f;
@@ -264,7 +263,7 @@ __device__ __forceinline__ void corr_tile(const u32x4* fs,  // [A][CGP][2][HW]  
             t3 = up ? t3 : y13;
           }
           // this lane now holds row (.. + qc) at the 4 columns of its quad
-          const int m = wm * (32 * MI) + mi * 32 + 8 * q + 4 * hw + qc;
+          const int m = wm * 128 + mi * 32 + 8 * q + 4 * hw + qc;
           const int nq = ncol0 + (l31 & ~3);
           bool mok = m < OS2D_K;
           size_t orow = (size_t)nb * OS2D_K + m;
@@ -286,7 +285,7 @@ __device__ __forceinline__ void corr_tile(const u32x4* fs,  // [A][CGP][2][HW]  
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hw;
+          const int m = wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hw;
           bool mok = m < OS2D_K;
           size_t orow = (size_t)nb * OS2D_K + m;
           if (STACK) {
@@ -311,7 +310,7 @@ __device__ __forceinline__ void corr_tile(const u32x4* fs,  // [A][CGP][2][HW]  
         const unsigned l2 = fxl[sl][ni] + (unsigned)__shfl_xor((int)fxl[sl][ni], 32);
         const bool bad2 = (((int)fxbad[sl][ni]) | __shfl_xor((int)fxbad[sl][ni], 32)) != 0;
         const int cc = cw0 + sl;
-        const bool live = cc < B && (sl == 0 || bound < Rw + 32 * MI);      // wave-uniform
+        const bool live = cc < B && (sl == 0 || bound < Rw + 128);          // wave-uniform
         if (live && hw == 0 && n < HW) {
           unsigned long long* dst = sumfx + ((size_t)a * B + cc) * HW + n;
           atomicAdd(dst, ((unsigned long long)h2 << 24) + (unsigned long long)l2);
@@ -338,9 +337,7 @@ __device__ __forceinline__ void corr_tile(const u32x4* fs,  // [A][CGP][2][HW]  
     const bool nin = n < HW;   // lanes l and l+32 share n: both take part in the exchange below or neither stores
     // head.py:650,597 (eps 1e-6); the normalised values (<= 1) are stored scaled by 2^OS2D_RNORM_EXP so that their lo halves
     // stay normal fp16 numbers (the conv 7x7 epilogue undoes the scale exactly)
-    unsigned long long vs = 0ull;                                  // < 2^53; bit 62 / 63: a non-finite term
-#pragma unroll
-    for (int k = 0; k < WMW; ++k) vs += red[k][col];
+    const unsigned long long vs = red[0][col] + red[1][col];      // < 2^53; bit 62 / 63: a non-finite term
     const float ssum = (vs >> 62) ? __builtin_nanf("") : (float)((double)vs * 5.6843418860808015e-14);    // 2^-44, as os2d_corr_norm_finalize_one
     const float inv_r = 1.0f / (sqrtf(ssum) + 1e-6f);
     if (invn != nullptr && wm == 0 && hw == 0 && nin) invn[(size_t)nb * HW + n] = inv_r;   // for the frequency-domain 7x7 layer
@@ -350,10 +347,10 @@ __device__ __forceinline__ void corr_tile(const u32x4* fs,  // [A][CGP][2][HW]  
     const size_t cell = (size_t)BASE + (size_t)h * Ws + w;
     if (rshb == nullptr) continue;   // frequency-domain 7x7 layer: it reads corr + invn, the split activations are not needed
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+    for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int m0 = wm * (32 * MI) + mi * 32 + 8 * q + 4 * hw;
+        const int m0 = wm * 128 + mi * 32 + 8 * q + 4 * hw;
         const int grp = m0 >> 3;
         if (grp >= OS2D_G) continue;   // wave-uniform (depends on wm, mi, q only)
         half4 h4, l4;
@@ -388,43 +385,36 @@ __device__ __forceinline__ void corr_tile(const u32x4* fs,  // [A][CGP][2][HW]  
 // them), not a class.
 // TAIL (round 6).  Every tile costs the same, so a launch takes ceil(tiles / 256) rounds of the chip however
 // few tiles its last round holds (64 classes, padded rows: 1216 tiles = 4.75 rounds, paid as 5).  The last ``rsplit`` tiles of every
-// XCD's range are therefore cut into ``parts`` = 2 halves of 128 positions or 4 quarters of 64 (other shapes of the same code: same
-// products, same order, same bits), dispatched last, so that the partial round keeps every CU busy with a piece that takes a
-// fraction of a tile's time (measured: a half 0.67, profiles/r06/).  NIM = NI of the main shape (1: every tile is a 128-position
-// tile and there is no tail).
+// XCD's range are therefore cut into two 128-position halves (the NI = 1 shape of the same code: same products, same order, same
+// bits), dispatched last: the partial round then costs about half a round per 32 halves.  NIM = NI of the main shape (1: every
+// tile is a 128-position tile and there is no tail).
 template <bool STACK, int NIM>
 __global__ __launch_bounds__(512, 2) void corr_f16x3_kernel(const u32x4* fs, const u32x4* qs, float* __restrict__ corr, char* __restrict__ rshb,
                                                             float* __restrict__ invn, unsigned long long* __restrict__ sumfx, int A, int B,
                                                             int CGP, int H, int W, int PLANE, float unscale, int tpx /*tiles per XCD*/,
-                                                            int rsplit /*of them, at the end of the range: cut into pieces*/,
-                                                            int parts /*2 | 4 pieces per tile of the tail*/) {
+                                                            int rsplit /*of them, at the end of the range: cut into halves*/) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
-  __shared__ unsigned long long red[4][256];
+  __shared__ unsigned long long red[2][256];
   const int HW = H * W;
   const int RT = STACK ? (B * STACK_STRIDE + TM - 1) / TM : B;
   const int tiles = (HW + 128 * NIM - 1) / (128 * NIM);
   const int x = blockIdx.x & 7, s = blockIdx.x >> 3, nfull = tpx - rsplit;
-  int logical = x * tpx + s, piece = -1;
+  int logical = x * tpx + s, half = -1;
   if (NIM == 2 && s >= nfull) {
-    const int t = s - nfull;
-    logical = x * tpx + nfull + (parts == 4 ? t >> 2 : t >> 1);
-    piece = parts == 4 ? t & 3 : t & 1;
+    logical = x * tpx + nfull + ((s - nfull) >> 1);
+    half = (s - nfull) & 1;
   }
-  if (s >= nfull + parts * rsplit || logical >= min((x + 1) * tpx, tiles * RT * A)) return;
+  if (s >= nfull + 2 * rsplit || logical >= min((x + 1) * tpx, tiles * RT * A)) return;
   const int a = logical / (tiles * RT);
   const int r_ = logical - a * tiles * RT;
   const int gb0 = (r_ / (4 * tiles)) * 4, gsz = min(4, RT - gb0);
   const int r2_ = r_ - gb0 * tiles;
   const int b = gb0 + r2_ % gsz;
   const int n0 = (r2_ / gsz) * (128 * NIM);
-  if (NIM == 2 && piece >= 0) {
-    if (parts == 4) {
-      if (n0 + piece * 64 < HW) corr_tile<2, 1, STACK>(fs, qs, corr, rshb, invn, sumfx, B, CGP, H, W, PLANE, unscale, a, b, n0 + piece * 64, smem16, red);
-    } else {
-      if (n0 + piece * 128 < HW) corr_tile<4, 1, STACK>(fs, qs, corr, rshb, invn, sumfx, B, CGP, H, W, PLANE, unscale, a, b, n0 + piece * 128, smem16, red);
-    }
+  if (NIM == 2 && half >= 0) {
+    if (n0 + half * 128 < HW) corr_tile<1, STACK>(fs, qs, corr, rshb, invn, sumfx, B, CGP, H, W, PLANE, unscale, a, b, n0 + half * 128, smem16, red);
   } else {
-    corr_tile<4, NIM, STACK>(fs, qs, corr, rshb, invn, sumfx, B, CGP, H, W, PLANE, unscale, a, b, n0, smem16, red);
+    corr_tile<NIM, STACK>(fs, qs, corr, rshb, invn, sumfx, B, CGP, H, W, PLANE, unscale, a, b, n0, smem16, red);
   }
 }
 
@@ -526,47 +516,39 @@ int os2d_launch_split_qp(const float* qp, void* qs, int B, int C, hipStream_t st
 
 namespace {
 
-// tiles per XCD and how many of them (at the end of every XCD's range) are cut into pieces: the partial round of an XCD's 32 CUs is
-// split when its pieces still fit the 32 CUs in ONE round - up to 8 tiles into quarters, up to 16 into halves (a second round of
-// pieces would cost more than the round of full tiles it replaces).  The same figures feed the cost model of
-// os2d_corr_f16x3_use_packed.
+// tiles per XCD and how many of them (at the end of every XCD's range) are cut into halves: the partial round of an XCD's 32 CUs
+// is split when its halves still fit the 32 CUs in ONE round (up to 16 tiles): a half takes 0.67 of a full tile's time (measured:
+// 4 full rounds + 16 halves per XCD = 0.4055 ms against 0.434 ms for 5 rounds, profiles/r06/stages_corr_tail_*.txt), so a second
+// round of halves would cost more than the round of full tiles it replaces.  Quarter tiles (64 positions, 4 x 2 waves of 64 x 32)
+// for tails of up to 8 tiles were built and measured no faster than halves (1.532 against 1.523 ms per step: a quarter keeps the
+// whole class operand and the barriers of a tile's K loop).  The same figures feed the cost model of os2d_corr_f16x3_use_packed.
+// $OS2D_CORR_TAIL=0 disables the split (measurements).
 struct CorrGrid {
-  int tpx, rsplit, parts;
+  int tpx, rsplit;
 };
 CorrGrid corr_grid(long long tiles_total, bool allow_split) {
-  static const int tail_mode = [] {        // $OS2D_CORR_TAIL = 0: no split; 2: halves only; default: quarters where they fit
+  static const bool tail_enabled = [] {
     const char* e = getenv("OS2D_CORR_TAIL");
-    return e ? atoi(e) : 4;
+    return !(e && e[0] == '0');
   }();
   CorrGrid g;
   g.tpx = (int)((tiles_total + 7) / 8);
   const int r = g.tpx % 32;
-  g.rsplit = 0;
-  g.parts = 2;
-  if (allow_split && tail_mode && g.tpx > 32 && r > 0) {
-    if (r <= 8 && tail_mode >= 4) {
-      g.rsplit = r;
-      g.parts = 4;
-    } else if (r <= 16) {
-      g.rsplit = r;
-    }
-  }
+  g.rsplit = (allow_split && tail_enabled && g.tpx > 32 && r > 0 && r <= 16) ? r : 0;
   return g;
 }
-// rounds of the chip a launch takes, in units of one full-tile round.  A piece keeps the whole class operand of its K loop and a
-// half / a quarter of the matrix instructions: measured 0.67 / 0.5 of a full tile (profiles/r06/); the pieces of an XCD's tail fit
-// its 32 CUs in one round by construction (corr_grid).
+// rounds of the chip a launch takes, in units of one full-tile round
 double corr_rounds(long long tiles_total, bool allow_split) {
   const CorrGrid g = corr_grid(tiles_total, allow_split);
   const int nfull = g.tpx - g.rsplit;
-  return (double)((nfull + 31) / 32) + (g.rsplit ? (g.parts == 4 ? 0.5 : 0.67) : 0.0);
+  return (double)((nfull + 31) / 32) + (g.rsplit ? 0.67 : 0.0);
 }
 
 template <bool STACK, int NIM>
 int launch_corr(const void* fs, const void* qs, float* corr, void* rshb, float* invn, unsigned long long* sumfx, int flags, int A,
                 int B, int C, int H, int W, hipStream_t stream) {
   const int HW = H * W;
-  const size_t lds = (size_t)(2 * GC * 2 * TM + 2 * GC * 2 * (128 * NIM)) * 16;  // 128 KB (NIM = 2) / 96 KB dynamic (+ 8 KB static)
+  const size_t lds = (size_t)(2 * GC * 2 * TM + 2 * GC * 2 * (128 * NIM)) * 16;  // 128 KB (NIM = 2) / 96 KB dynamic (+ 4 KB static)
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_f16x3_kernel<STACK, NIM>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) {
@@ -576,10 +558,10 @@ int launch_corr(const void* fs, const void* qs, float* corr, void* rshb, float* 
   const int RT = STACK ? (B * STACK_STRIDE + TM - 1) / TM : B;       // row tiles: stacked classes | one per class
   const long long tiles_total = (long long)((HW + 128 * NIM - 1) / (128 * NIM)) * RT * A;
   const CorrGrid g = corr_grid(tiles_total, NIM == 2 && !(flags & 2));
-  dim3 grid((unsigned)(8 * (g.tpx + (g.parts - 1) * g.rsplit)));      // per XCD: tpx - rsplit full tiles, then parts x rsplit pieces
+  dim3 grid((unsigned)(8 * (g.tpx + g.rsplit)));      // per XCD: tpx - rsplit full tiles, then 2 rsplit halves
   hipLaunchKernelGGL((corr_f16x3_kernel<STACK, NIM>), grid, dim3(512), lds, stream, reinterpret_cast<const u32x4*>(fs),
                      reinterpret_cast<const u32x4*>(qs), corr, reinterpret_cast<char*>(rshb), invn, sumfx, A, B,
-                     os2d_round_up((C + 7) / 8, GC), H, W, os2d_plane(H, W), ldexpf(1.0f, -2 * SCALE_LOG2), g.tpx, g.rsplit, g.parts);
+                     os2d_round_up((C + 7) / 8, GC), H, W, os2d_plane(H, W), ldexpf(1.0f, -2 * SCALE_LOG2), g.tpx, g.rsplit);
   int rc = check("corr_f16x3");
   if (rc || !STACK || (flags & 1)) return rc;
   const size_t n = (size_t)A * B * HW;
@@ -593,7 +575,7 @@ int launch_corr(const void* fs, const void* qs, float* corr, void* rshb, float* 
 // packed form executes 228 / 256 of the matrix instructions, but its sums cross work-groups as atomics and need the norms pass
 // (a small launch of its own in front of the forward transform: ~0.1 of a round at 64 classes).  Decided on the rounds of the chip
 // each form takes WITH the tail of its launch cut into half tiles (round 6; round 5 compared whole rounds only, which kept the
-// padded form at 64 classes: 1216 tiles = 5 rounds either way - now 4.9 against 4.3 + 0.1).
+// padded form at 64 classes: 1216 tiles = 5 rounds either way - now 5 against 4.67 + 0.1; measured 0.428 -> 0.403 ms).
 // $OS2D_CORR_PACKED = 0 | 1 forces one form (measurements).
 int os2d_corr_f16x3_use_packed(int A, int B, int H, int W) {
   static const int forced = [] {

@@ -66,9 +66,6 @@
 #ifndef DFT_SCHED_FENCE
 #define DFT_SCHED_FENCE()         /* device build: __builtin_amdgcn_sched_barrier(0) - the scheduler moves nothing across it */
 #endif
-#ifndef DFT_STREAM_LOAD
-#define DFT_STREAM_LOAD(CLASS, P) (*(P))
-#endif
 #ifndef DFT_STREAM_STORE
 #define DFT_STREAM_STORE(P, V) (*(P) = (V))      /* device build: a non-temporal store (os2d_stream_store, os2d_common.h) */
 #endif
@@ -582,7 +579,7 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
         pn[s] = *reinterpret_cast<const f32x4v*>(invn + (size_t)nb_ * HW + off);                             \
         _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                  \
           const int c = c0_ + g < C ? c0_ + g : C - 1;                                                       \
-          pc[s][g] = DFT_STREAM_LOAD(2, reinterpret_cast<const f32x4v*>(corr + ((size_t)nb_ * C + c) * HW + off)); \
+          pc[s][g] = *reinterpret_cast<const f32x4v*>(corr + ((size_t)nb_ * C + c) * HW + off);              \
         }                                                                                                    \
       } else {                                                                                               \
         /* rows of any width / tiles: the slot's 4 columns as ONE 16-byte load with 4-byte alignment (global loads need no   \
@@ -599,7 +596,7 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
         pn[s] = *reinterpret_cast<const f32x4u*>(invn + (size_t)nb_ * HW + offv);                            \
         _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                      \
           const int c = c0_ + g < C ? c0_ + g : C - 1;                                                       \
-          pc[s][g] = DFT_STREAM_LOAD(2, reinterpret_cast<const f32x4u*>(corr + ((size_t)nb_ * C + c) * HW + offv)); \
+          pc[s][g] = *reinterpret_cast<const f32x4u*>(corr + ((size_t)nb_ * C + c) * HW + offv);             \
         }                                                                                                    \
         if (rok && !vec) {                                                                                   \
           _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                    \
@@ -858,10 +855,10 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
       const bool ptwo_ = 8 * puo_ + 4 < P;                                                  \
       const float* p0_ = src_ + (size_t)q0_ * qstride + pimg_ * 8;                          \
       const float* p1_ = src_ + (size_t)(ptwo_ ? q0_ + 1 : q0_) * qstride + pimg_ * 8;      \
-      py[s][0] = DFT_STREAM_LOAD(4, reinterpret_cast<const f32x4v*>(p0_));                  \
-      py[s][1] = DFT_STREAM_LOAD(4, reinterpret_cast<const f32x4v*>(p0_ + 4));              \
-      py[s][2] = DFT_STREAM_LOAD(4, reinterpret_cast<const f32x4v*>(p1_));                  \
-      py[s][3] = DFT_STREAM_LOAD(4, reinterpret_cast<const f32x4v*>(p1_ + 4));              \
+      py[s][0] = *reinterpret_cast<const f32x4v*>(p0_);                                     \
+      py[s][1] = *reinterpret_cast<const f32x4v*>(p0_ + 4);                                 \
+      py[s][2] = *reinterpret_cast<const f32x4v*>(p1_);                                     \
+      py[s][3] = *reinterpret_cast<const f32x4v*>(p1_ + 4);                                 \
     }                                                                                       \
   }
 #define DFT_INV_ITEM(E)                                                                     \

@@ -26,7 +26,6 @@ extern __shared__ __attribute__((aligned(16))) unsigned char os2d_dft_smem[];
 #define DFT_LANDED(X) asm volatile("" : "+v"(X))
 #define DFT_SPLIT_LO_PAIR(a, b, hi) os2d_split_lo_pair(a, b, hi)
 #define DFT_STREAM_STORE(P, V) os2d_stream_store(P, V)
-#define DFT_STREAM_LOAD(CLASS, P) os2d_stream_load<CLASS>(P)
 #define DFT_FLAG Os2dRangeFlag
 #define DFT_FLAG_SET(f) ((f).word != nullptr)
 #define DFT_RAISE(f) os2d_raise(f)

@@ -86,16 +86,9 @@ template <class T>
 __device__ __forceinline__ void os2d_stream_store(T* p, const T& v) {
   __builtin_nontemporal_store(v, p);
 }
-// EXPERIMENT (-DOS2D_NT_LOADS=mask): the same hint for operands a kernel reads exactly once: 1 the per-bin GEMM's input spectra,
-// 2 the forward transform's correlation maps, 4 the inverse transform's output spectra, 8 the per-bin GEMM's weight spectra
-#ifndef OS2D_NT_LOADS
-#define OS2D_NT_LOADS 0
-#endif
-template <int CLASS, class T>
-__device__ __forceinline__ T os2d_stream_load(const T* p) {
-  if (OS2D_NT_LOADS & CLASS) return __builtin_nontemporal_load(p);
-  return *p;
-}
+// (The same hint on LOADS of operands a kernel reads once - the per-bin GEMM's input and weight spectra, the forward transform's
+// correlation maps, the inverse transform's spectra - moved the 64-class step by -13 .. +5 us and the 1024-class step by -0.06 ..
+// +0.2 ms, inside the run-to-run spread: not adopted, profiles/r06/stages_nontemporal_loads.txt.)
 // lo halves of the fp16 hi + lo split of two fp32 values whose hi halves are packed in ``hi`` (x0 -> low 16 bits): rn16(x - hi) as
 // ONE mixed-precision instruction per value (v_fma_mixlo_f16 / v_fma_mixhi_f16: fma(x, 1.0, -hi) in fp32, rounded to fp16 into
 // the low / high half) instead of v_cvt_f32_f16 + v_sub_f32 per value and a v_cvt_pk_f16_f32 per pair - the split conversions

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
 #define SH_LOAD_W(S, wr)                                                                                            \
   {                                                                                                                 \
     const u32x4* src_ = wbase + (size_t)(S) * (SH_BINS * 256);                                                      \
-    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) wr[k_] = os2d_stream_load<8>(src_ + (wq * 4 + k_) * 64 + lane);                      \
+    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) wr[k_] = src_[(wq * 4 + k_) * 64 + lane];                      \
   }
 #define SH_STORE_W(S, wr)                                                                                           \
   {                                                                                                                 \
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
   {                                                                                                                 \
     _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                              \
       const int c_ = min((S)*SH_KC + xg * 4 + xwh * 2 + i_, C - 1);                                                 \
-      pfx[i_] = os2d_stream_load<1>(reinterpret_cast<const u32x4*>(xrow + (size_t)c_ * xcs));                                           \
+      pfx[i_] = *reinterpret_cast<const u32x4*>(xrow + (size_t)c_ * xcs);                                           \
     }                                                                                                               \
   }
   // (the four values of a store as ONE vector conversion: v_cvt_pk_f16_f32 converts two values per instruction - a third fewer

@@ -37,7 +37,7 @@
 #pragma once
 
 #ifndef DFT_DEV
-#error "the includer defines DFT_DEV, DFT_TID, DFT_BID, DFT_GRID, DFT_LDS, DFT_BARRIER, DFT_MFMA, DFT_SHFL_XOR, DFT_BALLOT, DFT_FLAG, DFT_FLAG_SET, DFT_RAISE, DFT_UNIFORM"
+#error "the includer defines DFT_DEV, DFT_TID, DFT_BID, DFT_GRID, DFT_LDS, DFT_BARRIER, DFT_MFMA, DFT_SHFL_XOR, DFT_SHFL_XOR_U32, DFT_BALLOT, DFT_FLAG, DFT_FLAG_SET, DFT_RAISE, DFT_UNIFORM"
 #endif
 
 #ifndef DFT_HD
@@ -108,8 +108,7 @@ struct DftPlan {
   int MB;                          // G * (MA / 2) : rows of step B = (h, img)
   int KB;                          // 2 V rounded up to 16: k of step B
   int NBo;                         // columns of step B that are needed (ox + TW | W) rounded up to 32
-  int G;                           // images per work-group iteration of the FORWARD kernel this plan is for (4, or 2: two work-groups
-                                   // of 256 work items per CU); the inverse kernel always takes 4
+  int G;                           // images per work-group iteration of both kernels: 4, or 8 for the small transforms (dft_plan_g8)
   int eT;                          // ceil(log2 P) + 1
   int fast;                        // 1: W % 4 == 0 and untiled (16-byte loads of the correlation rows)
   unsigned inv_cg, inv_t, inv_tx, inv_c4, inv_v, inv_pq, inv_og, inv_kg, inv_pp;   // ceil(2^32 / d) (0 where d == 1)
@@ -147,7 +146,7 @@ static inline bool dft_plan_transform(int LH, int LW, int RH, int ncols, int min
   pl->Mx = dft_round_up(G * pl->Pp, 32);
   pl->N2 = dft_round_up(G * pl->V, 32);
   pl->MA = dft_round_up(2 * RH, 32);
-  pl->MB = DFT_G * (pl->MA / 2);
+  pl->MB = G * (pl->MA / 2);
   pl->KB = dft_round_up(2 * pl->V, 16);
   pl->NBo = dft_round_up(ncols, 32);
   int e = 0;
@@ -165,13 +164,22 @@ static inline bool dft_plan_transform(int LH, int LW, int RH, int ncols, int min
   if (xs > u) u = xs;
   if (y2 > u) u = y2;
   if (tt > u) u = tt;
-  if (G != DFT_G) {      // a forward-only plan: FqT + x | R2 | X staging
-    u = x > r2 ? x : r2;
-    if (xs > u) u = xs;
-    pl->lds_const = fqt;
+  if (G == 8) {
+    // EIGHT images per iteration (round 6): the fixed phases of an iteration - six barriers, the fill and drain of
+    // four products, the burst of the next window's requests - do not shrink with the transform, so the small transforms of the
+    // pyramid paid 1.3 - 1.9x per location.  With 8 images the products have 20 - 24 tiles (three per wave: the tile grids of
+    // step 2 / step A no longer match the fixed "row tile in registers" ownership, so Fp2 / E2 live in LDS next to FqT / Gq
+    // and every product takes the LDS-LDS path), the inverse kernel owns all 8 channels of an activation unit and writes whole
+    // 16-byte units.  Fits the transforms up to 48 x 62.
+    const int fp2 = (2 * pl->Pp / 8) * 2 * pl->M2 * 16;      // = the size of E2 (MAfull = M2 rows)
+    const int ca = fqt + fp2, cb = gq + fp2;
+    pl->lds_const = ca > cb ? ca : cb;
     pl->lds_union = dft_round_up(u, 256);
-    pl->lds_total = pl->lds_const + pl->lds_union;
-    return 2 * dft_round_up(pl->lds_total, 512) <= 160 * 1024;    // two work-groups per CU
+    pl->lds_total = pl->lds_const + pl->lds_union + 1024;
+    const int t1 = (pl->Mx / 32) * (pl->N1 / 32), t2 = (pl->M2 / 32) * (pl->N2 / 32), tA = (pl->MA / 32) * (pl->N2 / 32),
+              tB = (pl->MB / 32) * (pl->NBo / 32);
+    const int npos = pl->Pp * (pl->Wk / 4), nitem = G * pl->V * (pl->Pp / 8);
+    return pl->lds_total <= 160 * 1024 && t1 <= 24 && t2 <= 24 && tA <= 24 && tB <= 24 && npos <= 2 * DFT_THR && nitem <= 3 * DFT_THR;
   }
   pl->lds_const = fqt > gq ? fqt : gq;
   pl->lds_union = dft_round_up(u, 256);
@@ -255,18 +263,12 @@ static inline int dft_size_policy() {
 static inline int dft_size_policy() { return emu_dft_policy; }
 #endif
 static inline bool dft_make_plan(int H, int W, DftPlan* out) { return dft_make_plan_policy(H, W, dft_size_policy(), out); }
-// The forward kernel's plan with G images per iteration: the SAME tiling and transform size as dft_make_plan (the spectra layouts
-// must agree with the GEMM's and the inverse kernel's), its own operand sizes; false when two such work-groups do not fit a CU.
-static inline bool dft_make_forward_plan(int H, int W, int G, DftPlan* out) {
-  DftPlan base;
-  if (!dft_make_plan(H, W, &base)) return false;
-  if (G == DFT_G) {
-    *out = base;
-    return true;
-  }
+// The plan of the same map with 8 images per iteration: the SAME tiling and transform size as ``base`` (= dft_make_plan: the spectra
+// layouts do not depend on G), its own operand sizes; false when the transform is too large for it (then both kernels take 4).
+static inline bool dft_plan_g8(const DftPlan& base, DftPlan* out) {
   DftPlan c = {};
-  if (!dft_plan_transform(base.LH, base.LW, base.RH, base.TX > 1 ? base.TW + 3 : W, base.P, base.Q, G, &c)) return false;
-  dft_set_tiles(&c, H, W, base.TY, base.TX, base.TH, base.TW);
+  if (!dft_plan_transform(base.LH, base.LW, base.RH, base.TX > 1 ? base.TW + 3 : base.W, base.P, base.Q, 8, &c)) return false;
+  dft_set_tiles(&c, base.H, base.W, base.TY, base.TX, base.TH, base.TW);
   *out = c;
   return true;
 }
@@ -506,14 +508,15 @@ DFT_DEV void dft_matrix_unit(int which, int unit, int P, int Q, const double* tw
 }
 
 // ---------------------------------------------------------------------------------------------------- forward transform
-// iteration it -> (pair' = it / CG, channel group cg = it % CG), pair' = nb * T + tile; channels 4 cg .. 4 cg + 3
+// iteration it -> (pair' = it / CG, channel group cg = it % CG), pair' = nb * T + tile; channels G cg .. G cg + G - 1
+// G = 4: Fp2 in registers (the wave owns one row tile of step 2); G = 8 (dft_plan_transform): Fp2 in LDS, free tile ownership
 template <bool TILED, bool FAST, int G, int NW, int KS2 = 0>
 DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
                               const float* invn,      // [NB][H * W]
                               float* X,               // [NBT / 64][NBINS / 4][64][Cpad][4][2] (dft_spectra_pair0)
                               const u32x4v* FqT, const u32x4v* Fp2, const DftPlan& pl, int C, int Cpad, int NBT, int iters) {
-  constexpr int THR = NW * 64;     // G = 4: 8 waves, one work-group per CU; G = 2: 4 waves, TWO independent work-groups per CU -
-                                   // their phases (VALU conversions, LDS-bound and matrix-bound products, stores) overlap
+  constexpr int THR = NW * 64;
+  constexpr bool ALDS = G == 8;    // the row operand of step 2 lives in LDS
   unsigned char* smem = DFT_LDS;
   const int tid = DFT_TID, lane = tid & 63, l31 = lane & 31, hw = lane >> 5;
   const int wv = DFT_UNIFORM(tid >> 6);      // wave-uniform (a scalar register): the tile ownership below is real branching, not exec masks
@@ -525,6 +528,9 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
   unsigned char* ldsUb = smem + pl.lds_const;
   const int nF = (Wk / 8) * 2 * N1;
   for (int i = tid; i < nF; i += THR) ldsF[i] = FqT[i];
+  u32x4v* ldsP = ldsF + nF;                                                         // ALDS: Fp2 [2 Pp / 8][2][M2]
+  if (ALDS)
+    for (int i = tid; i < (2 * Pp / 8) * 2 * pl.M2; i += THR) ldsP[i] = Fp2[i];
 
   // the wave's tiles.  step 1: (row tile of x, column tile of FqT), round robin - with 8 row tiles a wave keeps ONE row tile
   // and its A fragment serves all column tiles; step 2: row tile wv & 3 of Fp2 in REGISTERS, column tiles (wv >> 2) + 2 j
@@ -533,11 +539,13 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
   const int mt2 = wv & 3;
   constexpr int KR2 = KS2 ? KS2 : DFT_KREG;      // KS2 > 0: exactly the k-steps of step 2 (ks2n == KS2)
   half8 fp2h[KR2], fp2l[KR2];
+  if (!ALDS) {
 #pragma unroll
-  for (int ks = 0; ks < KR2; ++ks) {
-    const int kc = ks < ks2n ? ks : 0, mc = mt2 < mt2n ? mt2 : 0;
-    fp2h[ks] = dft_frag(Fp2 + ((size_t)((2 * kc + hw) * 2 + 0)) * pl.M2 + mc * 32 + l31);
-    fp2l[ks] = dft_frag(Fp2 + ((size_t)((2 * kc + hw) * 2 + 1)) * pl.M2 + mc * 32 + l31);
+    for (int ks = 0; ks < KR2; ++ks) {
+      const int kc = ks < ks2n ? ks : 0, mc = mt2 < mt2n ? mt2 : 0;
+      fp2h[ks] = dft_frag(Fp2 + ((size_t)((2 * kc + hw) * 2 + 0)) * pl.M2 + mc * 32 + l31);
+      fp2l[ks] = dft_frag(Fp2 + ((size_t)((2 * kc + hw) * 2 + 1)) * pl.M2 + mc * 32 + l31);
+    }
   }
   // The fragments must have LANDED, as far as the compiler's wait-count pass is concerned, on EVERY path into the loop (round 5).
   // Every wait on a global load below is conditional (a position slot beyond the window, the prefetch of an iteration that does
@@ -545,15 +553,17 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
   // and since the pass merges paths pessimistically, it guarded the matrix instructions of k-step ks with vmcnt(15 - 2 ks) ..
   // vmcnt(0) for good: in the steady state that made step 2 wait for the NEXT window's loads, issued right in front of it, one
   // by one (step 2 measured 5.3 us for 1.9 us of matrix time).  An unconditional use right here settles it.
+  if (!ALDS) {
 #pragma unroll
-  for (int ks = 0; ks < KR2; ++ks) {
-    DFT_LANDED(fp2h[ks]);
-    DFT_LANDED(fp2l[ks]);
+    for (int ks = 0; ks < KR2; ++ks) {
+      DFT_LANDED(fp2h[ks]);
+      DFT_LANDED(fp2l[ks]);
+    }
   }
 
   // ---- register prefetch of the next iteration's window: position slot s of a thread = (row r, 4 columns c4) of the window,
   // all G images; raw values only (any arithmetic here would make the compiler wait for each load where it is issued)
-  constexpr int NSLOT = 3 * 512 / THR;                         // ceil(Pp * Wk / 4 / THR) <= 64 * 24 / THR
+  constexpr int NSLOT = ALDS ? 2 : 3 * 512 / THR;              // ceil(Pp * Wk / 4 / THR) <= 64 * 24 / THR (G = 8: <= 48 * 16 / 512)
   const int npos = Pp * (Wk / 4);
   f32x4v pc[NSLOT][G], pn[NSLOT];
 #define DFT_FWD_ITER(IT)                                                                                     \
@@ -712,14 +722,17 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
     DFT_STAMP(2)
 
     // ---- step 2: X = Fp2 . R2 (Fp2 fragments in registers); this wave's column tiles (wv >> 2) + 2 j of row tile wv & 3
+    // (ALDS: tiles t = wv + NW j of the mt2n x nt2n grid, row tile fastest - as dft_product_lds counts them)
     f32x16v xc[3];
-    int un[3];
+    int un[3], um[3];      // column / row tile of accumulator j, -1: none
     int nt2w = 0;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const int nt = (wv >> 2) + (NW / 4) * j;
-      const bool mine = nt < nt2n && mt2 < mt2n;
+      const int t = wv + NW * j;
+      const int nt = ALDS ? t / mt2n : (wv >> 2) + (NW / 4) * j;
+      const bool mine = ALDS ? t < mt2n * nt2n : (nt < nt2n && mt2 < mt2n);
       un[j] = mine ? nt : -1;
+      um[j] = ALDS ? t - nt * mt2n : mt2;
       nt2w += mine ? 1 : 0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) xc[j][r] = 0.f;
@@ -733,7 +746,10 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
     // or right behind it (DFT_FWD_PREFETCH_AFTER).
     const int itn = it + DFT_GRID < iters ? it + DFT_GRID : it;
     {
-      if (DFT_FWD_PREFETCH_AFTER == 1 || (DFT_FWD_PREFETCH_AFTER == 2 && KS2 > 0 && KS2 <= 6)) {      // the burst behind the product
+      if (ALDS) {
+        dft_product_lds_any<NW, DFT_PIPE_LDS ? 2 : 0>(xc, nt2w, 0, ks2n, ldsP, pl.M2, ldsU, N2S, wv, mt2n, l31, hw);
+        DFT_FWD_PREFETCH_SLOTS(itn, tl, 0, NSLOT)
+      } else if (DFT_FWD_PREFETCH_AFTER == 1 || (DFT_FWD_PREFETCH_AFTER == 2 && KS2 > 0 && KS2 <= 6)) {      // the burst behind the product
         dft_product_rega_any<KS2>(xc, nt2w, fp2h, fp2l, ks2n, ldsU, N2S, wv >> 2, NW / 4, l31, hw);
         DFT_FWD_PREFETCH_SLOTS(itn, tl, 0, NSLOT)
       } else {
@@ -754,7 +770,7 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
       const int img = dft_div(n2, pl.inv_v), v = n2 - img * V;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int u0 = (mt2 * 32 + 8 * q + 4 * hw) >> 1;
+        const int u0 = (um[j] * 32 + 8 * q + 4 * hw) >> 1;
         if (img < G && u0 < P) {
           const float sc = 1.0f / 4194304.0f;      // 2^-22 = 1 / (2^8 * 2^14)
           f32x4v o;
@@ -795,8 +811,9 @@ DFT_DEV void dft_forward_body(const float* corr,      // [NB][C][H * W]
 }
 
 // ---------------------------------------------------------------------------------------------------- inverse transform
-// iteration it -> (pair' = it / OG, output channel group og = it % OG): output channels 4 og .. 4 og + 3 of pair' = nb * T + tile
-template <bool TILED, int KSA = 0>
+// iteration it -> (pair' = it / OG, output channel group og = it % OG): output channels G og .. G og + G - 1 of pair' = nb * T + tile
+// G = 4: E2 in registers, 8-byte halves of the activation units; G = 8 (dft_plan_transform): E2 in LDS, whole 16-byte units
+template <bool TILED, int KSA = 0, int G = DFT_G>
 DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64][Cout][4][2] (dft_spectra_pair0)
                               const float* bp,       // [3][MTP]: bias | - | 2^out_exp
                               int MTP, unsigned char* out,   // SHB [NB][Cout / 8][2][PLANE] x 16 B
@@ -807,7 +824,9 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
   const int wv = DFT_UNIFORM(tid >> 6);
   const int P = pl.P, V = pl.V, Pp = pl.Pp, N2 = pl.N2, MB = pl.MB, KB = pl.KB, NBo = pl.NBo, H = pl.H, W = pl.W;
   const int N2S = N2 + 1, MBS = MB + 1;
-  const int OG = Cout / DFT_G;
+  const int OG = Cout / G;
+  constexpr bool ALDS = G == 8;      // the row operand of step A lives in LDS
+  constexpr int LG = G == 8 ? 3 : 2; // log2 G
   u32x4v* ldsG = reinterpret_cast<u32x4v*>(smem);                                   // Gq [KB / 8][2][NBo]
   u32x4v* ldsU = reinterpret_cast<u32x4v*>(smem + pl.lds_const);                    // Y2 | Tt
   unsigned char* ldsUb = smem + pl.lds_const;
@@ -817,39 +836,44 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
     const int kh = i / NBo, n = i - kh * NBo;
     ldsG[i] = Gq[(size_t)kh * NQ + n];
   }
+  const int MAfull = dft_round_up(2 * P, 32);                    // row count of the E2 array
+  u32x4v* ldsE = ldsG + nG;                                      // ALDS: E2 [2 Pp / 8][2][MAfull]
+  if (ALDS)
+    for (int i = tid; i < (2 * Pp / 8) * 2 * MAfull; i += DFT_THR) ldsE[i] = E2[i];
 
   const int mtAn = pl.MA / 32, ntAn = N2 / 32, ksAn = 2 * Pp / 16;
   const int mtBn = MB / 32, ntBn = NBo / 32, ksBn = KB / 16;
   const int mtA = wv & 3;
   constexpr int KRA = KSA ? KSA : DFT_KREG;      // KSA > 0: exactly the k-steps of step A (ksAn == KSA)
   half8 e2h[KRA], e2l[KRA];
-  const int MAfull = dft_round_up(2 * P, 32);                    // row count of the E2 array
+  if (!ALDS) {
 #pragma unroll
-  for (int ks = 0; ks < KRA; ++ks) {
-    const int kc = ks < ksAn ? ks : 0, mc = mtA < mtAn ? mtA : 0;
-    e2h[ks] = dft_frag(E2 + ((size_t)((2 * kc + hw) * 2 + 0)) * MAfull + mc * 32 + l31);
-    e2l[ks] = dft_frag(E2 + ((size_t)((2 * kc + hw) * 2 + 1)) * MAfull + mc * 32 + l31);
-  }
+    for (int ks = 0; ks < KRA; ++ks) {
+      const int kc = ks < ksAn ? ks : 0, mc = mtA < mtAn ? mtA : 0;
+      e2h[ks] = dft_frag(E2 + ((size_t)((2 * kc + hw) * 2 + 0)) * MAfull + mc * 32 + l31);
+      e2l[ks] = dft_frag(E2 + ((size_t)((2 * kc + hw) * 2 + 1)) * MAfull + mc * 32 + l31);
+    }
 #pragma unroll
-  for (int ks = 0; ks < KRA; ++ks) {      // landed on every path into the loop: see the Fp2 fragments of the forward kernel
-    DFT_LANDED(e2h[ks]);
-    DFT_LANDED(e2l[ks]);
+    for (int ks = 0; ks < KRA; ++ks) {      // landed on every path into the loop: see the Fp2 fragments of the forward kernel
+      DFT_LANDED(e2h[ks]);
+      DFT_LANDED(e2l[ks]);
+    }
   }
 
   // ---- register prefetch: item = (img, v, octet of u) -> the two quads of bins u0 .. u0 + 7 of column v: 2 x 32 bytes
-  constexpr int NITEM = 3;                                      // ceil(G * V * Pp / 8 / 512) <= 4 * 48 * 8 / 512
-  const int uoct = Pp / 8, nitem = DFT_G * V * uoct;
+  constexpr int NITEM = 3;                                      // ceil(G * V * Pp / 8 / 512) <= 4 * 48 * 8 / 512 (G = 8: 8 * 32 * 6 / 512)
+  const int uoct = Pp / 8, nitem = G * V * uoct;
   f32x4v py[NITEM][4];
 #define DFT_INV_PREFETCH(IT, TID) DFT_INV_PREFETCH_ITEMS(IT, TID, 0, NITEM)
 #define DFT_INV_PREFETCH_ITEMS(IT, TID, S0, S1)                                             \
   {                                                                                         \
     const int pr_ = dft_div((IT), pl.inv_og), og_ = (IT)-pr_ * OG;                          \
     size_t qstride;                                                                         \
-    const float* src_ = Y + dft_spectra_pair0(pr_, NBT, pl.NBINS / 4, Cout, &qstride) + (size_t)og_ * DFT_G * 8; \
+    const float* src_ = Y + dft_spectra_pair0(pr_, NBT, pl.NBINS / 4, Cout, &qstride) + (size_t)og_ * G * 8; \
     _Pragma("unroll") for (int s = (S0); s < (S1); ++s) {                                   \
       const int e_ = (TID) + s * DFT_THR;                                                   \
       const int ec_ = e_ < nitem ? e_ : 0;                                                  \
-      const int pimg_ = ec_ & (DFT_G - 1), prest_ = ec_ >> 2;                               \
+      const int pimg_ = ec_ & (G - 1), prest_ = ec_ >> LG;                                  \
       const int pv_ = dft_div(prest_, pl.inv_kg), puo_ = prest_ - pv_ * (Pp / 8);           \
       const int q0_ = pv_ * (P / 4) + 2 * puo_;                                             \
       const bool ptwo_ = 8 * puo_ + 4 < P;                                                  \
@@ -862,11 +886,11 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
     }                                                                                       \
   }
 #define DFT_INV_ITEM(E)                                                                     \
-  const int img_ = (E) & (DFT_G - 1), rest_ = (E) >> 2;                                     \
+  const int img_ = (E) & (G - 1), rest_ = (E) >> LG;                                        \
   const int v_ = dft_div(rest_, pl.inv_kg), uo_ = rest_ - v_ * uoct;                        \
   const bool two_ = 8 * uo_ + 4 < P;
   // ---- M: the largest |component| of every image among the spectra in the prefetch registers (a thread's items all belong to
-  // image tid % 4) -> smaxw.  Run for the NEXT iteration's spectra right after step B, BEFORE the epilogue's stores: the first
+  // image tid % G) -> smaxw.  Run for the NEXT iteration's spectra right after step B, BEFORE the epilogue's stores: the first
   // use of the prefetched registers makes the compiler wait for them, and a wait placed after a loop of stores cannot count
   // what is in flight - it becomes vmcnt(0) and the work-group sat out the write latency of its own epilogue at the top of
   // every iteration (phase stamps: 1.1 us for this handful of instructions).  Up here the loads are the youngest requests.
@@ -884,11 +908,11 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
             _Pragma("unroll") for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(py[s][k][e])); \
           }                                                                                 \
       }                                                                                     \
-    m = fmaxf(m, DFT_SHFL_XOR(m, 4));                                                       \
+    if (G == 4) m = fmaxf(m, DFT_SHFL_XOR(m, 4));                                           \
     m = fmaxf(m, DFT_SHFL_XOR(m, 8));                                                       \
     m = fmaxf(m, DFT_SHFL_XOR(m, 16));                                                      \
     m = fmaxf(m, DFT_SHFL_XOR(m, 32));                                                      \
-    if (lane < DFT_G) smaxw[wv * DFT_G + lane] = m;                                         \
+    if (lane < G) smaxw[wv * G + lane] = m;                                                 \
   }
   bool bad = false;
   const int first = (DFT_GRID & 7) == 0 ? (DFT_BID & 7) * (DFT_GRID >> 3) + (DFT_BID >> 3) : DFT_BID;     // XCD-aware (see the forward kernel)
@@ -910,26 +934,27 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
     const int ty = TILED ? dft_div(tile, pl.inv_tx) : 0, tx = TILED ? tile - ty * pl.TX : 0;
     const int y0 = TILED ? ty * pl.TH : 0, x0 = TILED ? tx * pl.TW : 0, oy = TILED ? pl.oy : 0, ox = TILED ? pl.ox : 0;
     const int TH_ = TILED ? pl.TH : H, TW_ = TILED ? pl.TW : W;
-    const int o0 = og * DFT_G;
+    const int o0 = og * G;
 
     // (the maxima of this iteration's spectra are in smaxw: written before the previous iteration's epilogue / in the prologue)
     DFT_STAMP(0)
-    float simg = 1.f, cinv[DFT_G];
+    float simg = 1.f, cinv[4] = {0.f, 0.f, 0.f, 0.f};      // cinv: of this lane's 4 channels in the epilogue (G = 8: 4 hw .. 4 hw + 3)
     {
       // scale of an image: 2^(13 - E), E = floor(log2(max)): the largest component lands in [2^13, 2^14)
 #pragma unroll
-      for (int g = 0; g < DFT_G; ++g) {
+      for (int g = 0; g < G; ++g) {
         float m = 0.f;
 #pragma unroll
-        for (int w = 0; w < DFT_WAVES; ++w) m = fmaxf(m, smaxw[w * DFT_G + g]);
+        for (int w = 0; w < DFT_WAVES; ++w) m = fmaxf(m, smaxw[w * G + g]);
         int E = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu) - 127;
         if (!(m > 0.f) || E < -100) E = -100;
         if (E > 100) E = 100;
         const float s = __builtin_bit_cast(float, (unsigned)(13 - E + 127) << 23);
         const float sinv = __builtin_bit_cast(float, (unsigned)(E - 13 + 127) << 23);
-        if (g == (tl & (DFT_G - 1))) simg = s;
+        if (g == (tl & (G - 1))) simg = s;
         // output = acc * 2^(eT - 13) / (scale * P * Q)
-        cinv[g] = sinv * __builtin_bit_cast(float, (unsigned)(pl.eT - 13 + 127) << 23) / (float)(P * pl.Q);
+        const float ci = sinv * __builtin_bit_cast(float, (unsigned)(pl.eT - 13 + 127) << 23) / (float)(P * pl.Q);
+        if (G == 4 || (g >> 2) == hw) cinv[g & 3] = ci;      // (compile-time g: a select per value, no indexed register array)
       }
     }
     // ---- WY: units [k = (ri * Pp + u) / 8][hi|lo][n = img * V + v]: this item's 8 u of column (img, v), re and im
@@ -970,14 +995,17 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
     DFT_STAMP(1)
 
     // ---- step A: T = E2 . Y2 (E2 fragments in registers)
+    // (ALDS: tiles t = wv + 8 j of the mtAn x ntAn grid, row tile fastest - as dft_product_lds counts them)
     f32x16v ta[3];
-    int an[3];
+    int an[3], am[3];      // column / row tile of accumulator j, -1: none
     int ntaw = 0;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const int nt = (wv >> 2) + 2 * j;
-      const bool mine = nt < ntAn && mtA < mtAn;
+      const int t = wv + DFT_WAVES * j;
+      const int nt = ALDS ? t / mtAn : (wv >> 2) + 2 * j;
+      const bool mine = ALDS ? t < mtAn * ntAn : (nt < ntAn && mtA < mtAn);
       an[j] = mine ? nt : -1;
+      am[j] = ALDS ? t - nt * mtAn : mtA;
       ntaw += mine ? 1 : 0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) ta[j][r] = 0.f;
@@ -985,7 +1013,10 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
     // the next spectra: unconditional, one burst next to the product (see the forward kernel)
     const int itn = it + DFT_GRID < iters ? it + DFT_GRID : it;
     {
-      if (DFT_INV_PREFETCH_AFTER == 1 || (DFT_INV_PREFETCH_AFTER == 2 && KSA > 0 && KSA <= 6)) {
+      if (ALDS) {
+        dft_product_lds_any<DFT_WAVES, DFT_PIPE_LDS ? 1 : 0>(ta, ntaw, 0, ksAn, ldsE, MAfull, ldsU, N2S, wv, mtAn, l31, hw);
+        DFT_INV_PREFETCH_ITEMS(itn, tl, 0, NITEM)
+      } else if (DFT_INV_PREFETCH_AFTER == 1 || (DFT_INV_PREFETCH_AFTER == 2 && KSA > 0 && KSA <= 6)) {
         dft_product_rega_any<KSA>(ta, ntaw, e2h, e2l, ksAn, ldsU, N2S, wv >> 2, 2, l31, hw);
         DFT_INV_PREFETCH_ITEMS(itn, tl, 0, NITEM)
       } else {
@@ -1006,17 +1037,17 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
         if (an[j] < 0) continue;
         const int n = an[j] * 32 + l31;
         const int img = dft_div(n, pl.inv_v), v = n - img * V;
-        if (img >= DFT_G) continue;
+        if (img >= G) continue;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int h0 = (mtA * 32 + 8 * q + 4 * hw) >> 1;
+          const int h0 = (am[j] * 32 + 8 * q + 4 * hw) >> 1;
           u32x2v hi, lo;
           dft_split4(ta[j][4 * q] * sc, ta[j][4 * q + 1] * sc, ta[j][4 * q + 2] * sc, ta[j][4 * q + 3] * sc, &hi, &lo);
-          unsigned char* d0 = ldsUb + ((size_t)((v >> 2) * 2) * MBS + (size_t)h0 * DFT_G + img) * 16 + (v & 3) * 4;
+          unsigned char* d0 = ldsUb + ((size_t)((v >> 2) * 2) * MBS + (size_t)h0 * G + img) * 16 + (v & 3) * 4;
           *reinterpret_cast<unsigned*>(d0) = hi[0];
           *reinterpret_cast<unsigned*>(d0 + (size_t)MBS * 16) = lo[0];
-          *reinterpret_cast<unsigned*>(d0 + DFT_G * 16) = hi[1];
-          *reinterpret_cast<unsigned*>(d0 + DFT_G * 16 + (size_t)MBS * 16) = lo[1];
+          *reinterpret_cast<unsigned*>(d0 + G * 16) = hi[1];
+          *reinterpret_cast<unsigned*>(d0 + G * 16 + (size_t)MBS * 16) = lo[1];
         }
       }
       for (int v = V; v < KB / 2; ++v)       // v slots V .. KB / 2 - 1
@@ -1047,15 +1078,16 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
     DFT_INV_MAXIMA(tl)      // of the NEXT iteration's spectra (requested before step A; the last iteration's result is not used)
     DFT_STAMP(4)
 
-    // ---- epilogue: a lane owns window column w and, per accumulator run, the 4 channels of one row: + bias, ReLU, channel
-    // scale, fp16 hi | lo -> 8 + 8 bytes of the two 16-byte units of the cell (the other half of a unit comes from the
-    // work-group of the neighbouring channel group)
+    // ---- epilogue: a lane owns window column w and, per accumulator run, 4 channels of one row: + bias, ReLU, channel
+    // scale, fp16 hi | lo.  G = 4: 8 + 8 bytes of the two 16-byte units of the cell (the other half of a unit comes from the
+    // work-group of the neighbouring channel group).  G = 8: rows are (h, img) with 8 images per h, so the lower half-wave holds
+    // channels 0 - 3 and the upper one channels 4 - 7 of the SAME cell: they swap halves and each stores one whole unit.
     {
-      float bias[DFT_G], osc[DFT_G];
+      float bias[4], osc[4];     // of this lane's 4 channels: o0 + (G = 8: 4 hw) + k
 #pragma unroll
-      for (int g = 0; g < DFT_G; ++g) {
-        bias[g] = bp[o0 + g];
-        osc[g] = bp[2 * MTP + o0 + g];
+      for (int g = 0; g < 4; ++g) {
+        bias[g] = bp[o0 + (G == 8 ? 4 * hw : 0) + g];
+        osc[g] = bp[2 * MTP + o0 + (G == 8 ? 4 * hw : 0) + g];
       }
       const int grp = o0 >> 3, slot = o0 & 7;
       unsigned char* hi_unit = out + (((size_t)nb * ((Cout + 7) >> 3) + grp) * 2 + 0) * (size_t)PLANE * 16 + slot * 2;
@@ -1072,8 +1104,13 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
             const int jj = k - BASE, hr = jj / (Ws - W);
             cell = BASE + hr * Ws + W + (jj - hr * (Ws - W));
           } else cell = tail0 + (k - BASE - rows);
-          *reinterpret_cast<u32x2v*>(hi_unit + (size_t)cell * 16) = u32x2v{0u, 0u};
-          *reinterpret_cast<u32x2v*>(lo_unit + (size_t)cell * 16) = u32x2v{0u, 0u};
+          if (G == 8) {
+            *reinterpret_cast<u32x4v*>(hi_unit + (size_t)cell * 16) = u32x4v{0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4v*>(lo_unit + (size_t)cell * 16) = u32x4v{0u, 0u, 0u, 0u};
+          } else {
+            *reinterpret_cast<u32x2v*>(hi_unit + (size_t)cell * 16) = u32x2v{0u, 0u};
+            *reinterpret_cast<u32x2v*>(lo_unit + (size_t)cell * 16) = u32x2v{0u, 0u};
+          }
         }
       }
 #pragma unroll
@@ -1082,22 +1119,35 @@ DFT_DEV void dft_inverse_body(const float* Y,        // [NBT / 64][NBINS / 4][64
         const int wwin = bn[j] * 32 + l31, tw = wwin - ox;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int hwin = (bm[j] * 32 + 8 * q + 4 * hw) >> 2, th = hwin - oy;
+          // row m = h G + img of the window: G = 4: 4 rows = the 4 images of h = m / 4; G = 8: img = 4 hw .. 4 hw + 3 of h = m / 8
+          const int hwin = G == 8 ? bm[j] * 4 + q : (bm[j] * 32 + 8 * q + 4 * hw) >> 2, th = hwin - oy;
           const int h = y0 + th, w = x0 + tw;
-          if (th >= 0 && th < TH_ && tw >= 0 && tw < TW_ && h < H && w < W) {
-            float t[DFT_G];
+          const bool inside = th >= 0 && th < TH_ && tw >= 0 && tw < TW_ && h < H && w < W;      // (G = 8: the same for lanes l, l + 32)
+          if (G == 8 || inside) {
+            float t[4];
 #pragma unroll
-            for (int g = 0; g < DFT_G; ++g) {
+            for (int g = 0; g < 4; ++g) {
               const float pre = yc[j][4 * q + g] * cinv[g] + bias[g];
               t[g] = fmaxf(pre, 0.f) * osc[g];
               // out of the fp16 range, or NaN: the pre-activation is tested too, fmaxf(NaN, 0) = 0 hid a NaN spectrum
-              if (!(fabsf(t[g]) <= 65504.f) || pre != pre) bad = true;
+              if (inside && (!(fabsf(t[g]) <= 65504.f) || pre != pre)) bad = true;
             }
             u32x2v hi, lo;
             dft_split4(t[0], t[1], t[2], t[3], &hi, &lo);
             const size_t off = ((size_t)BASE + (size_t)h * Ws + w) * 16;
-            *reinterpret_cast<u32x2v*>(hi_unit + off) = hi;
-            *reinterpret_cast<u32x2v*>(lo_unit + off) = lo;
+            if (G == 8) {
+              // the lower lane sends its lo half and receives the partner's hi half (-> the complete hi unit), the upper lane sends its
+              // hi half and receives the partner's lo half (-> the complete lo unit); every lane of the wave takes part
+              const u32x2v send = hw ? hi : lo, keep = hw ? lo : hi;
+              u32x2v recv;
+              recv[0] = DFT_SHFL_XOR_U32(send[0], 32);
+              recv[1] = DFT_SHFL_XOR_U32(send[1], 32);
+              const u32x4v unit = hw ? u32x4v{recv[0], recv[1], keep[0], keep[1]} : u32x4v{keep[0], keep[1], recv[0], recv[1]};
+              if (inside) *reinterpret_cast<u32x4v*>((hw ? lo_unit : hi_unit) + off) = unit;
+            } else {
+              *reinterpret_cast<u32x2v*>(hi_unit + off) = hi;
+              *reinterpret_cast<u32x2v*>(lo_unit + off) = lo;
+            }
           }
         }
       }

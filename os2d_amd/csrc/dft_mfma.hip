@@ -20,6 +20,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char os2d_dft_smem[];
 #define DFT_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define DFT_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 #define DFT_SHFL_XOR(v, m) __shfl_xor(v, m, 64)
+#define DFT_SHFL_XOR_U32(v, m) ((unsigned)__shfl_xor((int)(v), m, 64))
 #define DFT_BALLOT(p) __builtin_amdgcn_ballot_w64(p)
 #define DFT_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #define DFT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -65,12 +66,12 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void dft_forward_kernel(const floa
   dft_forward_body<TILED, FAST, G, NW, KS>(corr, invn, X, FqT, Fp2, pl, C, Cpad, NBT, iters);
 }
 
-template <bool TILED, int KS>
+template <bool TILED, int KS, int G>
 __global__ __launch_bounds__(DFT_THR, 1) void dft_inverse_kernel(const float* __restrict__ Y, const float* __restrict__ bp, int MTP,
                                                                  unsigned char* __restrict__ out, const u32x4v* __restrict__ E2,
                                                                  const u32x4v* __restrict__ Gq, DftPlan pl, int Cout, int NBT, int PLANE,
                                                                  int Ws, int BASE, int iters, Os2dRangeFlag status, int zero_borders) {
-  dft_inverse_body<TILED, KS>(Y, bp, MTP, out, E2, Gq, pl, Cout, NBT, PLANE, Ws, BASE, iters, status, zero_borders);
+  dft_inverse_body<TILED, KS, G>(Y, bp, MTP, out, E2, Gq, pl, Cout, NBT, PLANE, Ws, BASE, iters, status, zero_borders);
 }
 
 typedef void (*dft_forward_fn)(const float*, const float*, float*, const u32x4v*, const u32x4v*, DftPlan, int, int, int, int);
@@ -82,19 +83,24 @@ dft_forward_fn dft_forward_variant(const DftPlan& pl) {
 }
 template <int G, int NW>
 dft_forward_fn dft_forward_pick(const DftPlan& pl) {
-  switch (2 * pl.Pp / 16) {      // k-steps of step 2
-    case 5: return dft_forward_variant<G, NW, 5>(pl);
-    case 6: return dft_forward_variant<G, NW, 6>(pl);
-    case 7: return dft_forward_variant<G, NW, 7>(pl);
-    case 8: return dft_forward_variant<G, NW, 8>(pl);
-    default: return dft_forward_variant<G, NW, 0>(pl);
+  if constexpr (G == 8) {
+    return dft_forward_variant<G, NW, 0>(pl);      // (Fp2 in LDS: no register-resident k-steps to count)
+  } else {
+    switch (2 * pl.Pp / 16) {      // k-steps of step 2
+      case 5: return dft_forward_variant<G, NW, 5>(pl);
+      case 6: return dft_forward_variant<G, NW, 6>(pl);
+      case 7: return dft_forward_variant<G, NW, 7>(pl);
+      case 8: return dft_forward_variant<G, NW, 8>(pl);
+      default: return dft_forward_variant<G, NW, 0>(pl);
+    }
   }
 }
-template <int KS>
+template <int KS, int G = DFT_G>
 dft_inverse_fn dft_inverse_variant(const DftPlan& pl) {
-  return pl.T > 1 ? dft_inverse_kernel<true, KS> : dft_inverse_kernel<false, KS>;
+  return pl.T > 1 ? dft_inverse_kernel<true, KS, G> : dft_inverse_kernel<false, KS, G>;
 }
 dft_inverse_fn dft_inverse_pick(const DftPlan& pl) {
+  if (pl.G == 8) return dft_inverse_variant<0, 8>(pl);
   switch (2 * pl.Pp / 16) {      // k-steps of step A
     case 5: return dft_inverse_variant<5>(pl);
     case 6: return dft_inverse_variant<6>(pl);
@@ -126,10 +132,15 @@ int dft_check(const char* what) {
 
 // The planner tries up to 48 x 48 tilings x 6 canonical sizes and a head call needs the plan of its map four times (workspace
 // size, route, forward, inverse): memoised per process - a plan is a pure function of (H, W) under the process-wide size policy.
-bool dft_plan_cached(int H, int W, DftPlan* out) {
+// ``g8``: the plan with 8 images per iteration where the map's transform takes it (dft_plan_g8; $OS2D_DFT_G8=0: never - measurements)
+bool dft_plan_cached(int H, int W, DftPlan* out, bool g8 = true) {
+  static const bool g8_enabled = [] {
+    const char* e = getenv("OS2D_DFT_G8");
+    return !(e && e[0] == '0');
+  }();
   struct Entry {
-    bool ok;
-    DftPlan pl;
+    bool ok, ok8;
+    DftPlan pl, pl8;
   };
   static std::mutex mu;
   static std::map<std::pair<int, int>, Entry> cache;
@@ -137,13 +148,14 @@ bool dft_plan_cached(int H, int W, DftPlan* out) {
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find({H, W});
     if (it != cache.end()) {
-      if (it->second.ok) *out = it->second.pl;
+      if (it->second.ok) *out = (g8 && g8_enabled && it->second.ok8) ? it->second.pl8 : it->second.pl;
       return it->second.ok;
     }
   }
   Entry e = {};
   e.ok = dft_make_plan(H, W, &e.pl);
-  if (e.ok) *out = e.pl;
+  e.ok8 = e.ok && dft_plan_g8(e.pl, &e.pl8);
+  if (e.ok) *out = (g8 && g8_enabled && e.ok8) ? e.pl8 : e.pl;
   std::lock_guard<std::mutex> lock(mu);
   if (cache.size() >= 4096) cache.clear();
   cache[{H, W}] = e;
@@ -154,11 +166,6 @@ int dft_grid(int iters, int per_cu = 1) {
   int g = iters < 256 * per_cu ? iters : 256 * per_cu;      // work-groups resident on the chip at once (126 - 137 KB of LDS each, or 2 x 80)
   return (g + 7) / 8 * 8;                       // multiple of 8: XCD-aware iteration order
 }
-
-// images per iteration of the forward kernel: 4 (one 8-wave work-group per CU).  The other shape - 2 images, 4 waves, TWO
-// independent work-groups per CU when they fit its LDS - was built to let the phases of two groups overlap and measured no faster
-// (profiles/r04/dft_phases_g2.txt, profiles/r05/dft_phases_g2_two_groups_per_cu.txt; tools/patches/dft_mfma_variants.patch).
-int dft_forward_g(int H, int W, DftPlan* pl) { return dft_plan_cached(H, W, pl) ? DFT_G : 0; }
 
 }  // namespace
 
@@ -197,20 +204,21 @@ int os2d_launch_dft_matrices(const double* twP64, const double* twQ64, int P, in
 int os2d_launch_dft_forward(const float* corr, const float* inv, float* X, const void* matrices, int NB, int C, int Cpad, int H, int W,
                             hipStream_t stream) {
   DftPlan pl;
-  const int G = dft_forward_g(H, W, &pl);
-  if (!G) {
+  if (!dft_plan_cached(H, W, &pl)) {
     os2d_set_error("dft_forward: no transform plan for a %dx%d map", H, W);
     return -3;
   }
-  if (Cpad < dft_round_up(C, DFT_G)) {
-    os2d_set_error("dft_forward: channel stride %d < %d", Cpad, dft_round_up(C, DFT_G));
+  if (pl.G == 8 && Cpad < dft_round_up(C, 8)) dft_plan_cached(H, W, &pl, false);      // a channel stride for 4 images per iteration only
+  const int G = pl.G;
+  if (Cpad < dft_round_up(C, G)) {
+    os2d_set_error("dft_forward: channel stride %d < %d", Cpad, dft_round_up(C, G));
     return -1;
   }
   const int CG = (C + G - 1) / G, NBT = NB * pl.T, iters = NBT * CG;
   pl.inv_cg = dft_magic((unsigned)CG);
   const u32x4v* FqT = static_cast<const u32x4v*>(matrices);
   const u32x4v* Fp2 = FqT + dft_units_fqt(pl.P, pl.Q);
-  auto kern = dft_forward_pick<4, 8>(pl);
+  auto kern = G == 8 ? dft_forward_pick<8, 8>(pl) : dft_forward_pick<4, 8>(pl);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds_total);
   if (e != hipSuccess) {
     os2d_set_error("hipFuncSetAttribute(dft_forward): %s", hipGetErrorString(e));
@@ -233,7 +241,7 @@ int os2d_launch_dft_inverse(const float* Y, const float* bp, int MTP, void* out,
     os2d_set_error("dft_inverse: Cout %d must be a multiple of 8", Cout);
     return -1;
   }
-  const int OG = Cout / DFT_G, NBT = NB * pl.T, iters = NBT * OG;
+  const int OG = Cout / pl.G, NBT = NB * pl.T, iters = NBT * OG;
   pl.inv_og = dft_magic((unsigned)OG);
   const u32x4v* E2 = static_cast<const u32x4v*>(matrices) + dft_units_fqt(pl.P, pl.Q) + dft_units_fp2(pl.P, pl.Q);
   const u32x4v* Gq = E2 + dft_units_e2(pl.P, pl.Q);

@@ -19,6 +19,7 @@ static int emu_dft_policy = 0;      // 0: smallest transform per map, 1: the can
 #define DFT_BARRIER() emu::group_barrier()
 #define DFT_MFMA(a, b, c) emu::mfma_32x32x16_f16(a, b, c)
 #define DFT_SHFL_XOR(v, m) emu::shfl_xor(v, m)
+#define DFT_SHFL_XOR_U32(v, m) emu::shfl_xor_u32(v, m)
 #define DFT_BALLOT(p) emu::ballot(p)
 #define DFT_FLAG int*
 #define DFT_FLAG_SET(f) ((f) != nullptr)
@@ -77,17 +78,18 @@ static int check_case(int H, int W, int C, int NB, int grid) {
   for (auto& v : corr) v = (float)(frand(seed) * 2.0 - 0.7);
   for (auto& v : invn) v = (float)(0.2 + 0.5 * frand(seed));          // relu(corr) * invn <= 1.3 * 0.7 < 1
   std::vector<float> X((size_t)(pl.NBINS / 4) * NBT * Cpad * 8, 777.0f);
-  // both shapes of the forward kernel: 4 images per iteration / 8 waves, and (when two such work-groups fit a CU) 2 images / 4 waves
-  for (int G = 4; G >= 2; G -= 2) {
-    DftPlan fp;
-    if (!dft_make_forward_plan(H, W, G, &fp)) {
-      std::printf("  (no G = %d forward plan: %d bytes of LDS)\n", G, fp.lds_total);
-      continue;
-    }
+  // both shapes of the kernels: 4 images per iteration (row operand of step 2 / step A in registers), and - where the transform takes
+  // it - 8 images (row operand in LDS, whole activation units)
+  DftPlan pl8;
+  const bool have8 = dft_plan_g8(pl, &pl8) && Cpad % 8 == 0;
+  if (!have8) std::printf("  (no 8-image plan for this transform)\n");
+  for (int G = 4; G <= 8; G += 4) {
+    if (G == 8 && !have8) continue;
+    DftPlan fp = G == 8 ? pl8 : pl;
     const int CGf = (C + G - 1) / G, itf = NBT * CGf;
     fp.inv_cg = dft_magic((unsigned)CGf);
     std::fill(X.begin(), X.end(), 777.0f);
-    emu::launch(grid, G == 4 ? 512 : 256, fp.lds_total, [&] {
+    emu::launch(grid, 512, fp.lds_total, [&] {
       if (G == 4) {
         // the k-step count of step 2 as a template parameter where the device build has one (dft_mfma.hip: dft_forward_pick)
 #define FWD4(KS)                                                                                                             \
@@ -103,9 +105,9 @@ static int check_case(int H, int W, int C, int NB, int grid) {
         }
 #undef FWD4
       } else {
-        if (fp.T > 1) dft_forward_body<true, false, 2, 4>(corr.data(), invn.data(), X.data(), FqT, Fp2, fp, C, Cpad, NBT, itf);
-        else if (fp.fast) dft_forward_body<false, true, 2, 4>(corr.data(), invn.data(), X.data(), FqT, Fp2, fp, C, Cpad, NBT, itf);
-        else dft_forward_body<false, false, 2, 4>(corr.data(), invn.data(), X.data(), FqT, Fp2, fp, C, Cpad, NBT, itf);
+        if (fp.T > 1) dft_forward_body<true, false, 8, 8>(corr.data(), invn.data(), X.data(), FqT, Fp2, fp, C, Cpad, NBT, itf);
+        else if (fp.fast) dft_forward_body<false, true, 8, 8>(corr.data(), invn.data(), X.data(), FqT, Fp2, fp, C, Cpad, NBT, itf);
+        else dft_forward_body<false, false, 8, 8>(corr.data(), invn.data(), X.data(), FqT, Fp2, fp, C, Cpad, NBT, itf);
       }
     });
   double worst = 0.0, scale = 0.0;
@@ -167,8 +169,8 @@ static int check_case(int H, int W, int C, int NB, int grid) {
   }
   }
 
-  // ---------------- inverse (Cout = 8 output channels = 2 groups)
-  const int Cout = 8, MTP = 128, PLANE = os2d_plane(H, W), Ws = os2d_ws(W), BASE = os2d_base(W);
+  // ---------------- inverse (Cout = 16 output channels: 4 / 2 groups)
+  const int Cout = 16, MTP = 128, PLANE = os2d_plane(H, W), Ws = os2d_ws(W), BASE = os2d_base(W);
   std::vector<float> Y((size_t)(pl.NBINS / 4) * NBT * Cout * 8);
   for (size_t i = 0; i < Y.size(); ++i) {
     const double mag = std::exp(6.0 * frand(seed) - 2.0);              // a wide dynamic range between bins
@@ -176,7 +178,7 @@ static int check_case(int H, int W, int C, int NB, int grid) {
   }
   for (int o = 0; o < Cout; ++o)                                       // and between images: scales 1e-3 .. 1e4
     for (size_t q = 0; q < (size_t)(pl.NBINS / 4) * NBT; ++q)
-      for (int e = 0; e < 8; ++e) Y[(q * Cout + o) * 8 + e] *= (float)std::pow(10.0, o - 3.0);
+      for (int e = 0; e < 8; ++e) Y[(q * Cout + o) * 8 + e] *= (float)std::pow(10.0, (o % 8) - 3.0);
   // float64 inverse first: the channel scales of the epilogue are chosen from it the way the range plan does for the real
   // network (activations a few binades below 2^15: both fp16 halves normal)
   std::vector<double> yref((size_t)NB * Cout * HW, 0.0), ymaxo(Cout, 0.0);
@@ -218,18 +220,25 @@ static int check_case(int H, int W, int C, int NB, int grid) {
       }
   std::vector<float> bp(3 * MTP, 0.f);
   for (int o = 0; o < Cout; ++o) {
-    bp[o] = (float)(0.1 * (o - 3) * ymaxo[o]);
+    bp[o] = (float)(0.1 * ((o % 8) - 3) * ymaxo[o]);
     bp[2 * MTP + o] = (float)std::ldexp(1.0, (int)std::floor(std::log2(4096.0 / (1.4 * ymaxo[o]))));
   }
+  for (int G = 4; G <= 8; G += 4) {
+  if (G == 8 && !have8) continue;
+  DftPlan ip = G == 8 ? pl8 : pl;
   std::vector<unsigned char> out((size_t)NB * ((Cout + 7) / 8) * 2 * PLANE * 16, 0x5A);     // a pattern: the kernel writes the borders too
   int flag = 0;
-  const int OG = Cout / DFT_G, iters_i = NBT * OG;
-  pl.inv_og = dft_magic((unsigned)OG);
-  emu::launch(grid, DFT_THR, pl.lds_total, [&] {
+  const int OG = Cout / G, iters_i = NBT * OG;
+  ip.inv_og = dft_magic((unsigned)OG);
+  emu::launch(grid, DFT_THR, ip.lds_total, [&] {
 #define INV(KS)                                                                                                                     \
-  if (pl.T > 1) dft_inverse_body<true, KS>(Y.data(), bp.data(), MTP, out.data(), E2, Gq, pl, Cout, NBT, PLANE, Ws, BASE, iters_i, &flag, 1); \
-  else dft_inverse_body<false, KS>(Y.data(), bp.data(), MTP, out.data(), E2, Gq, pl, Cout, NBT, PLANE, Ws, BASE, iters_i, &flag, 1);
-    switch (2 * pl.Pp / 16) {      // as dft_inverse_pick of the device build
+  if (ip.T > 1) dft_inverse_body<true, KS>(Y.data(), bp.data(), MTP, out.data(), E2, Gq, ip, Cout, NBT, PLANE, Ws, BASE, iters_i, &flag, 1); \
+  else dft_inverse_body<false, KS>(Y.data(), bp.data(), MTP, out.data(), E2, Gq, ip, Cout, NBT, PLANE, Ws, BASE, iters_i, &flag, 1);
+    if (G == 8) {
+      if (ip.T > 1) dft_inverse_body<true, 0, 8>(Y.data(), bp.data(), MTP, out.data(), E2, Gq, ip, Cout, NBT, PLANE, Ws, BASE, iters_i, &flag, 1);
+      else dft_inverse_body<false, 0, 8>(Y.data(), bp.data(), MTP, out.data(), E2, Gq, ip, Cout, NBT, PLANE, Ws, BASE, iters_i, &flag, 1);
+    } else
+    switch (2 * ip.Pp / 16) {      // as dft_inverse_pick of the device build
       case 5: INV(5) break;
       case 6: INV(6) break;
       case 7: INV(7) break;
@@ -267,10 +276,11 @@ static int check_case(int H, int W, int C, int NB, int grid) {
           }
       }
     }
-  std::printf("  inverse: max |y - float64| / max |y| = %.3e, flag %d\n", worst_rel, flag);
+  std::printf("  inverse (G = %d): max |y - float64| / max |y| = %.3e, flag %d\n", G, worst_rel, flag);
   if (!(worst_rel <= 1.5e-6) || flag != 0) {
     std::printf("INVERSE MISMATCH\n");
     return 1;
+  }
   }
   return 0;
 }

@@ -86,6 +86,16 @@ inline float shfl_xor(float v, int mask) {
   return r;
 }
 
+inline unsigned shfl_xor_u32(unsigned v, int mask) {
+  WaveScratch& w = wave();
+  const int l = ctx.tid % WAVE;
+  w.i[l] = (int)v;
+  wave_barrier();
+  const unsigned r = (unsigned)w.i[l ^ mask];
+  wave_barrier();
+  return r;
+}
+
 inline unsigned long long ballot(bool p) {
   WaveScratch& w = wave();
   const int l = ctx.tid % WAVE;

@@ -33,3 +33,10 @@ def test_dft_mfma_kernels_on_the_host_emulator(tmp_path):
     out = subprocess.run([exe, "canonical", "60", "80", "4", "1", "48", "64", "8", "1", "38", "50", "4", "2"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-3000:] + out.stderr[-2000:]
     assert "P=64 Q=84" in out.stdout and "P=52 Q=68" in out.stdout and "P=44 Q=54" in out.stdout
+    # round 6: the 8-image shape of both kernels (row operand of step 2 / step A in LDS, whole activation units) on the transforms
+    # that take it - the small levels of the pyramid and the 2 x 2 tiles of the 72 x 96 / 84 x 112 levels - next to the 4-image shape
+    out = subprocess.run([exe, "canonical", "30", "40", "17", "1", "72", "96", "5", "1", "84", "112", "9", "1", "45", "61", "8", "2"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-3000:] + out.stderr[-2000:]
+    assert out.stdout.count("forward (G = 8)") == 3 and out.stdout.count("inverse (G = 8)") == 3      # 36x46, 44x54 (tiled), 48x62 (tiled)
+    assert "no 8-image plan" in out.stdout                                                               # 52x68 stays with 4 images

@@ -40,6 +40,22 @@ constexpr int STACK_STRIDE = 228;        // stacked rows per class (225 rounded 
 constexpr int TM = 256;                  // rows per work-group: two waves of 128
 constexpr int WNW = 4;                   // waves along the positions: 8 waves of 128 x (32 NI)
 
+// LDS-DMA as inline assembly (round 6): 64 lanes x 16 bytes from (scalar base + the lane's 32-bit byte offset) to the 1 KB of LDS at
+// ``lds`` (M0).  The builtin (__builtin_amdgcn_global_load_lds) is a FLAT-encoded instruction that "may access LDS" to LLVM's
+// wait-count pass, which then treats every later counter wait as out of order: with one such instruction in a loop, every wait it
+// inserts is vmcnt(0) / lgkmcnt(0) - a fragment read requested a group ahead was waited for where it was issued, and the software
+// pipeline of the matrix loop below was none (the ISA of the first build).  As assembly the pass does not see it; the counters of
+// the DMAs are handled by hand (cf_barrier_drain), the LDS reads keep exact compiler-made counts.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void cf_dma16(const void* sbase, unsigned voff, unsigned lds) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+// end of a K chunk: this wave's DMAs have landed and its fragment reads have returned (vmcnt(0), lgkmcnt(0)), then the barrier
+// orders both for every wave of the group
+__device__ __forceinline__ void cf_barrier_drain() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // One tile: 256 rows x (128 NI) positions.  NI = 32-column tiles per wave: 2 -> 256 positions (the throughput shape: 128
 // accumulators per lane, two waves per SIMD); 1 -> 128 positions (half the matrix instructions per K chunk for the same class
 // operand: for a handful of classes, where a group's serial K loop is what a call waits for, and for the TAIL of a launch, see
@@ -94,7 +110,6 @@ __device__ __forceinline__ void corr_tile(const u32x4* fs,  // [A][CGP][2][HW]  
   // form cost ~14 instructions and an M0 dependency stall each).  Both operands are padded with zero channel groups to a
   // whole number of chunks (split_fm / split_qp), columns past H*W read the last valid column instead: their products
   // land in accumulator columns that are never stored.
-  typedef const void __attribute__((address_space(1))) * gptr_t;
   typedef void __attribute__((address_space(3))) * lptr_t;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index as a scalar
   // STACK: this thread always stages the same stacked row (its units are 256 apart): row p of class bfirst + d, clamped to the
@@ -106,72 +121,100 @@ __device__ __forceinline__ void corr_tile(const u32x4* fs,  // [A][CGP][2][HW]  
   const int colB = (wv * 64) % NT + lane;
   const unsigned voffB = (unsigned)min(colB, HW - 1 - n0) * 16u;
   const char* baseA0 = reinterpret_cast<const char*>(qb);
+  const unsigned ldsA0 = (unsigned)(uintptr_t)(lptr_t)ldsA, ldsB0 = (unsigned)(uintptr_t)(lptr_t)ldsB;      // LDS byte addresses (M0)
   const char* baseB0 = reinterpret_cast<const char*>(fa) + ((size_t)((wv * 64) / NT) * HW + n0) * 16;
 #define CF_DMA1(T, K)                                                                                             \
   {                                                                                                               \
     if ((K) < NPF) {                                                                                              \
       const char* ga_ = baseA0 + ((size_t)((T)*KC * 2 + ((K)*NTHR + wv * 64) / TM) * 256) * 16;                    \
-      __builtin_amdgcn_global_load_lds((gptr_t)(ga_ + voffA), (lptr_t)(ldsA + ((T)&1) * AUNITS + (K)*NTHR + wv * 64), 16, 0, 0); \
+      cf_dma16(ga_, voffA, ldsA0 + (unsigned)((((T)&1) * AUNITS + (K)*NTHR + wv * 64) * 16));                      \
     }                                                                                                             \
     if ((K) < NPFB) {                                                                                             \
       const char* gb_ = baseB0 + ((size_t)((T)*KC * 2 + ((K)*NTHR) / NT) * HW) * 16;                              \
-      __builtin_amdgcn_global_load_lds((gptr_t)(gb_ + voffB), (lptr_t)(ldsB + ((T)&1) * BUNITS + (K)*NTHR + wv * 64), 16, 0, 0); \
+      cf_dma16(gb_, voffB, ldsB0 + (unsigned)((((T)&1) * BUNITS + (K)*NTHR + wv * 64) * 16));                      \
     }                                                                                                             \
   }
 #define CF_DMA(T)                                                                                                 \
   {                                                                                                               \
     _Pragma("unroll") for (int k = 0; k < (NPF > NPFB ? NPF : NPFB); ++k) CF_DMA1(T, k)                            \
   }
-#define CF_NOHOOK(MI)
-#define CF_COMPUTE(T) CF_COMPUTE_H(T, CF_NOHOOK)
-#define CF_COMPUTE_H(T, HOOK)                                                                                     \
+  // The matrix loop, software-pipelined in the source (round 6).  A K chunk is 8 GROUPS of 3 NI matrix instructions - group g =
+  // (k-step g >> 2, row tile g & 3): one class fragment pair (hi, lo) against the k-step's NI image fragment pairs.  Left to the
+  // compiler, every group's class fragments were read right in front of its first matrix instruction (ds_read_b128, s_waitcnt
+  // lgkmcnt(0), v_mfma ...: the ISA of rounds 2 - 5) - eight exposed LDS latencies per chunk and wave, covered only by the other
+  // wave of the SIMD, and the matrix pipe 55 - 58 % busy.  Now the fragments of group g + 1 (and of the next k-step's image
+  // columns) are requested into the OTHER of two register sets before the matrix instructions of group g are issued, and the
+  // scheduler is fenced to that order (as in dft_mfma.h, round 5).  The barrier that ends a chunk sits in front of the LAST group's
+  // matrix instructions: that group's fragments have landed (they were requested a group earlier; the barrier's lgkmcnt(0)), so
+  // every wave is done reading the stage, the next chunk's first fragments are requested right behind the barrier, and the last
+  // group's 3 NI instructions cover their latency.  Same products, same order per accumulator: same bits.
+  half8 fa_[2][2], fb_[2][NI][2];      // [set][hi | lo], [set = k-step parity][ni][hi | lo]
+#define CF_READ_A(T, G, SET)                                                                                      \
   {                                                                                                               \
-    const u32x4* aB_ = ldsA + ((T)&1) * AUNITS + wm * 128 + l31;                                                  \
+    const u32x4* aB_ = ldsA + ((T)&1) * AUNITS + wm * 128 + l31 + ((G)&3) * 32;                                    \
+    fa_[SET][0] = *reinterpret_cast<const half8*>(aB_ + ((2 * ((G) >> 2) + hw) * 2 + 0) * TM);                    \
+    fa_[SET][1] = *reinterpret_cast<const half8*>(aB_ + ((2 * ((G) >> 2) + hw) * 2 + 1) * TM);                    \
+  }
+#define CF_READ_B(T, KS, SET)                                                                                     \
+  {                                                                                                               \
     const u32x4* bB_ = ldsB + ((T)&1) * BUNITS + wn * (32 * NI) + l31;                                            \
-    _Pragma("unroll") for (int ks = 0; ks < KC / 2; ++ks) {                                                       \
-      const int rowh_ = ((2 * ks + hw) * 2 + 0) * TM, rowl_ = ((2 * ks + hw) * 2 + 1) * TM;                       \
-      half8 bh_[NI], bl_[NI];                                                                                     \
-      _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                                         \
-        bh_[ni] = *reinterpret_cast<const half8*>(bB_ + ((2 * ks + hw) * 2 + 0) * NT + ni * 32);                  \
-        bl_[ni] = *reinterpret_cast<const half8*>(bB_ + ((2 * ks + hw) * 2 + 1) * NT + ni * 32);                  \
-      }                                                                                                           \
-      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                                          \
-        const half8 ah_ = *reinterpret_cast<const half8*>(aB_ + rowh_ + mi * 32);                                 \
-        const half8 al_ = *reinterpret_cast<const half8*>(aB_ + rowl_ + mi * 32);                                 \
-        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                                       \
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al_, bh_[ni], acc[mi][ni], 0, 0, 0);               \
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bl_[ni], acc[mi][ni], 0, 0, 0);               \
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bh_[ni], acc[mi][ni], 0, 0, 0);               \
-        }                                                                                                         \
-        HOOK(ks * 4 + mi)          /* eight places per chunk to issue a piece of the next chunk's DMA */          \
-      }                                                                                                           \
+    _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                                           \
+      fb_[SET][ni][0] = *reinterpret_cast<const half8*>(bB_ + ((2 * (KS) + hw) * 2 + 0) * NT + ni * 32);          \
+      fb_[SET][ni][1] = *reinterpret_cast<const half8*>(bB_ + ((2 * (KS) + hw) * 2 + 1) * NT + ni * 32);          \
     }                                                                                                             \
   }
-
+#define CF_MMA(G)                                                                                                 \
+  {                                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                                           \
+      acc[(G)&3][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[(G)&1][1], fb_[(G) >> 2][ni][0], acc[(G)&3][ni], 0, 0, 0); \
+      acc[(G)&3][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[(G)&1][0], fb_[(G) >> 2][ni][1], acc[(G)&3][ni], 0, 0, 0); \
+      acc[(G)&3][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[(G)&1][0], fb_[(G) >> 2][ni][0], acc[(G)&3][ni], 0, 0, 0); \
+    }                                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+  }
+  static_assert(KC == 4, "a chunk is two k-steps x four row tiles: eight groups");
   // The DMA of chunk t+1 is issued IN PIECES between the MFMA groups of chunk t (one class unit + one image unit per
   // thread after each of the first four groups): eight waves bursting 72 KB of loads right after the barrier queue up
-  // behind each other in the CU's load path; spread out, the issue slots hide behind the matrix pipe.  The barrier at the
-  // end of an iteration drains the wave's own DMAs (vmcnt(0), emitted by __syncthreads) and then orders them for
-  // everybody's fragment reads of the next iteration.
-#define CF_PF_HOOK(MI)                                                                                            \
-  if ((MI) < (NPF > NPFB ? NPF : NPFB)) {                                                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                                            \
-    CF_DMA1(t + 1, MI)                                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                            \
-  }
+  // behind each other in the CU's load path; spread out, the issue slots hide behind the matrix pipe.  The barrier of a
+  // chunk drains the wave's own DMAs (cf_barrier_drain) and then orders them for everybody's fragment reads of the next chunk.
   CF_DMA(0)
-  __syncthreads();
+  cf_barrier_drain();
+  CF_READ_B(0, 0, 0)
+  CF_READ_A(0, 0, 0)
+  // (the last chunk is peeled: behind "if (more)" the wait in front of the last group's matrix instructions became lgkmcnt(0) -
+  // it waited for the next chunk's fragments it was meant to cover)
   for (int t = 0; t + 1 < nchunks; ++t) {
-    CF_COMPUTE_H(t, CF_PF_HOOK)
-    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 7; ++g) {
+      CF_READ_A(t, g + 1, (g + 1) & 1)
+      if (g == 2) CF_READ_B(t, 1, 1)         // the second k-step's image columns, a group and a half ahead
+      CF_MMA(g)
+      if (g < (NPF > NPFB ? NPF : NPFB)) {
+        CF_DMA1(t + 1, g)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    cf_barrier_drain();
+    CF_READ_B(t + 1, 0, 0)
+    CF_READ_A(t + 1, 0, 0)
+    CF_MMA(7)
   }
-  CF_COMPUTE(nchunks - 1)
-#undef CF_PF_HOOK
+  {
+    const int t = nchunks - 1;
+#pragma unroll
+    for (int g = 0; g < 7; ++g) {
+      CF_READ_A(t, g + 1, (g + 1) & 1)
+      if (g == 2) CF_READ_B(t, 1, 1)
+      CF_MMA(g)
+    }
+    CF_MMA(7)
+  }
+#undef CF_MMA
+#undef CF_READ_B
+#undef CF_READ_A
 #undef CF_DMA
 #undef CF_DMA1
-#undef CF_NOHOOK
-#undef CF_COMPUTE_H
-#undef CF_COMPUTE
 
   // ---- epilogue (features were normalised before the split, so only the 2^-24 operand scale is undone).
   // A lane holds a 32x32 block as 4 consecutive rows x ONE column per register quadruple: stored as is, that is 128 dword

@@ -51,6 +51,12 @@ constexpr int SH_WRING = 2;           // weight stages in LDS: k-step s + 1 is s
                                       // run two k-steps ahead in registers)
 
 #define SH_MM(x_, y_, acc_) __builtin_amdgcn_mfma_f32_32x32x16_f16(x_, y_, acc_, 0, 0, 0)
+#ifndef OS2D_SH_AREG
+#define OS2D_SH_AREG 0        /* 1: the weight fragments straight from global memory (L2) into registers, one k-step ahead: no LDS round trip for the A operand */
+#endif
+#ifndef OS2D_SH_FRAGPIPE
+#define OS2D_SH_FRAGPIPE 1    /* 1: the LDS fragments of bin j + 1 are read before the matrix instructions of bin j */
+#endif
 
 // barrier for data exchanged through LDS that leaves the wave's global loads in flight (see fft.hip)
 __device__ __forceinline__ void sh_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -161,6 +167,47 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
       *reinterpret_cast<half4*>(dst_ + 64 * 16) = l_;                                                               \
     }                                                                                                               \
   }
+#if OS2D_SH_FRAGPIPE
+#define SH_COMPUTE(S)                                                                                               \
+  {                                                                                                                 \
+    /* [half][bin][group = hw][hi|lo][o 64] and [bin][group][hi|lo][pair 64] */                                     \
+    const u32x4* aB = ldsW + ((S) % SH_WRING) * SH_WSTAGE + (ot >> 1) * SH_STAGE + (hw * 2) * 64 + (ot & 1) * 32 + l31; \
+    const u32x4* bB = ldsX + ((S)&1) * SH_STAGE + (hw * 2) * 64 + pt * 32 + l31;                                    \
+    half8 bq[2][2];                                                                                                 \
+    u32x4 kq[2][2];                                                                                                 \
+    bq[0][0] = *reinterpret_cast<const half8*>(bB);                                                                 \
+    bq[0][1] = *reinterpret_cast<const half8*>(bB + 64);                                                            \
+    kq[0][0] = aB[0];                                                                                               \
+    kq[0][1] = aB[64];                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < SH_WB; ++j) {                                                             \
+      if (j + 1 < SH_WB) {                                                                                          \
+        bq[(j + 1) & 1][0] = *reinterpret_cast<const half8*>(bB + (j + 1) * 256);                                   \
+        bq[(j + 1) & 1][1] = *reinterpret_cast<const half8*>(bB + (j + 1) * 256 + 64);                              \
+        kq[(j + 1) & 1][0] = aB[(j + 1) * 256];                                                                     \
+        kq[(j + 1) & 1][1] = aB[(j + 1) * 256 + 64];                                                                \
+      }                                                                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                                            \
+      const half8 bhf = bq[j & 1][0], blf = bq[j & 1][1];                                                           \
+      const u32x4 kh = kq[j & 1][0], kl = kq[j & 1][1];                                                             \
+      u32x4 rh, rl, ih, il;                                                                                         \
+      _Pragma("unroll") for (int d = 0; d < 4; ++d) {                                                               \
+        rh[d] = kh[d] ^ 0x80000000u; /* [Kr, -Ki] */                                                                \
+        rl[d] = kl[d] ^ 0x80000000u;                                                                                \
+        ih[d] = __builtin_amdgcn_alignbit(kh[d], kh[d], 16); /* [Ki, Kr] */                                         \
+        il[d] = __builtin_amdgcn_alignbit(kl[d], kl[d], 16);                                                        \
+      }                                                                                                             \
+      const half8 arh = __builtin_bit_cast(half8, rh), arl = __builtin_bit_cast(half8, rl);                         \
+      const half8 aih = __builtin_bit_cast(half8, ih), ail = __builtin_bit_cast(half8, il);                         \
+      yr[j] = SH_MM(bhf, arl, yr[j]);                                                                               \
+      yr[j] = SH_MM(blf, arh, yr[j]);                                                                               \
+      yr[j] = SH_MM(bhf, arh, yr[j]);                                                                               \
+      yi[j] = SH_MM(bhf, ail, yi[j]);                                                                               \
+      yi[j] = SH_MM(blf, aih, yi[j]);                                                                               \
+      yi[j] = SH_MM(bhf, aih, yi[j]);                                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                                            \
+    }                                                                                                               \
+  }
+#else
 #define SH_COMPUTE(S)                                                                                               \
   {                                                                                                                 \
     /* [half][bin][group = hw][hi|lo][o 64] and [bin][group][hi|lo][pair 64] */                                     \
@@ -188,6 +235,7 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
       yi[j] = SH_MM(bhf, aih, yi[j]);                                                                               \
     }                                                                                                               \
   }
+#endif
   // k-step S: requests of step S + 2 -> set N (weights WN, spectra PN); multiply step S; the set requested a step ago (WC, PC:
   // step S + 1) -> the other LDS stage; barrier.  The sets alternate, so the loop runs two k-steps per pass.
 #define SH_STEPR(S, WC, PC, WN, PN)                                                                                 \
@@ -205,6 +253,82 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
     }                                                                                                               \
     sh_lds_barrier();                                                                                               \
   }
+#if OS2D_SH_AREG
+  // ---- weights as REGISTER FRAGMENTS straight from L2 (round 6): the wave's 8 units of a k-step (4 bins x hi | lo of its
+  // 32 output channels) are requested one k-step ahead into one of two register sets; the LDS holds the spectra only.
+  const u32x4* abase = w16 + ((size_t)(g * 2 + (ot >> 1)) * KS) * (SH_BINS * 256) + bh * SH_STAGE + (hw * 2) * 64 + (ot & 1) * 32 + l31;
+  u32x4 afa[8], afb[8];
+#define SH_LOAD_A(S, af)                                                                                            \
+  {                                                                                                                 \
+    const u32x4* src_ = abase + (size_t)min((S), KS - 1) * (SH_BINS * 256);                                         \
+    _Pragma("unroll") for (int j_ = 0; j_ < SH_WB; ++j_) {                                                          \
+      af[2 * j_] = src_[j_ * 256];                                                                                  \
+      af[2 * j_ + 1] = src_[j_ * 256 + 64];                                                                         \
+    }                                                                                                               \
+  }
+#define SH_MMA6(J, bhf, blf, kh, kl)                                                                                \
+  {                                                                                                                 \
+    u32x4 rh, rl, ih, il;                                                                                           \
+    _Pragma("unroll") for (int d = 0; d < 4; ++d) {                                                                 \
+      rh[d] = kh[d] ^ 0x80000000u; /* [Kr, -Ki] */                                                                  \
+      rl[d] = kl[d] ^ 0x80000000u;                                                                                  \
+      ih[d] = __builtin_amdgcn_alignbit(kh[d], kh[d], 16); /* [Ki, Kr] */                                           \
+      il[d] = __builtin_amdgcn_alignbit(kl[d], kl[d], 16);                                                          \
+    }                                                                                                               \
+    const half8 arh = __builtin_bit_cast(half8, rh), arl = __builtin_bit_cast(half8, rl);                           \
+    const half8 aih = __builtin_bit_cast(half8, ih), ail = __builtin_bit_cast(half8, il);                           \
+    yr[J] = SH_MM(bhf, arl, yr[J]);                                                                                 \
+    yr[J] = SH_MM(blf, arh, yr[J]);                                                                                 \
+    yr[J] = SH_MM(bhf, arh, yr[J]);                                                                                 \
+    yi[J] = SH_MM(bhf, ail, yi[J]);                                                                                 \
+    yi[J] = SH_MM(blf, aih, yi[J]);                                                                                 \
+    yi[J] = SH_MM(bhf, aih, yi[J]);                                                                                 \
+  }
+#define SH_COMPUTE_A(S, af)                                                                                         \
+  {                                                                                                                 \
+    const u32x4* bB = ldsX + ((S)&1) * SH_STAGE + (hw * 2) * 64 + pt * 32 + l31;                                    \
+    half8 bq[2][2];                                                                                                 \
+    bq[0][0] = *reinterpret_cast<const half8*>(bB);                                                                 \
+    bq[0][1] = *reinterpret_cast<const half8*>(bB + 64);                                                            \
+    _Pragma("unroll") for (int j = 0; j < SH_WB; ++j) {                                                             \
+      if (j + 1 < SH_WB) {                                                                                          \
+        bq[(j + 1) & 1][0] = *reinterpret_cast<const half8*>(bB + (j + 1) * 256);                                   \
+        bq[(j + 1) & 1][1] = *reinterpret_cast<const half8*>(bB + (j + 1) * 256 + 64);                              \
+      }                                                                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                                            \
+      SH_MMA6(j, bq[j & 1][0], bq[j & 1][1], af[2 * j], af[2 * j + 1])                                              \
+      __builtin_amdgcn_sched_barrier(0);                                                                            \
+    }                                                                                                               \
+  }
+  // k-step S: requests of the weights of step S + 1 (set AN) and of the spectra of step S + 2 (set PN); multiply step S from
+  // set AC; the spectra requested a step ago (PC: step S + 1) -> the other LDS stage; barrier.  Every request is unconditional
+  // (indices clamped: the wait counts stay exact), the store of a step beyond the last goes to the stage nobody reads.
+#define SH_STEPA(S, AC, AN, PC, PN)                                                                                 \
+  {                                                                                                                 \
+    SH_LOAD_A((S) + 1, AN)                                                                                          \
+    SH_LOAD_X((S) + 2, PN)                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    SH_COMPUTE_A(S, AC)                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    SH_STORE_X((S) + 1, PC)                                                                                         \
+    sh_lds_barrier();                                                                                               \
+  }
+  SH_LOAD_A(0, afa)
+  SH_LOAD_X(0, pfb)
+  SH_LOAD_X(1, pfa)
+  SH_STORE_X(0, pfb)
+  sh_lds_barrier();
+  int s = 0;
+  for (; s + 1 < KS; s += 2) {
+    SH_STEPA(s, afa, afb, pfa, pfb)
+    SH_STEPA(s + 1, afb, afa, pfb, pfa)
+  }
+  if (s < KS) SH_STEPA(s, afa, afb, pfa, pfb)
+#undef SH_STEPA
+#undef SH_COMPUTE_A
+#undef SH_MMA6
+#undef SH_LOAD_A
+#else
   SH_LOAD_W(0, wrb)
   SH_LOAD_X(0, pfb)
   SH_LOAD_W(min(1, KS - 1), wra)       // (unconditional, clamped: a conditional request makes the loop's wait counts pessimistic)
@@ -236,6 +360,7 @@ __global__ __launch_bounds__(SH_THR, 1) void spectral_gemm_f16_kernel(const u32x
   }
 #undef SH_STEPF
 #undef SH_STEPR
+#endif
 #undef SH_LOAD_W
 #undef SH_STORE_W
 #undef SH_COMPUTE

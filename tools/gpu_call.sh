@@ -18,6 +18,7 @@
 #         bin:<name>       tools/bin/<name> (a standalone HIP program built on the dev box, e.g. split_mix_check)
 #         soak[:<rounds>]  tools/soak_multistream.sh: victim / aggressor rounds + the pyramid on 7 streams against the serial run (default 300)
 #         mfma             tools/bin/mfma_peak: what v_mfma_f32_32x32x16_f16 sustains (register-only loop, zero / random operands)
+#         counters:<classes>[:<kernel>]  FETCH x 2 / WRITE bytes and launch times of the step's kernels (tools/ab_counters.py; inside ab:...:counters:N for a variant)
 #         smoke            __graft_entry__.smoke()
 #         py:<script> ...  python <script> (rest of the arguments up to the next known step are NOT consumed: one script, no args)
 TAG=$1; shift
@@ -78,6 +79,9 @@ for STEP in "$@"; do
       ( time bash tools/soak_multistream.sh $R ) > $OUT/soak.log 2>&1; cp -f gpurun_out/soak.txt $OUT/soak.txt 2>/dev/null; grep -c "^ *[0-9]* same" $OUT/soak.txt; grep -i "DIFF\|RESULT\|real" $OUT/soak.log $OUT/soak.txt | cut -c1-200 | head -12;;
     mfma)
       tools/bin/mfma_peak 2>&1 | tee $OUT/mfma_peak.txt;;
+    counters:*)      # counters:<classes>[:<kernel substring>]: tools/ab_counters.py under the current $OS2D_HIP_LIB / environment
+      SPEC=${STEP#counters:}; N=${SPEC%%:*}; K=""; case "$SPEC" in *:*) K=$(echo "${SPEC#*:}" | tr ':' ' ');; esac
+      timeout 600 python tools/ab_counters.py $N $K 2>&1 | grep "^\[\|error" | tee -a $OUT/counters.txt;;
     smoke)
       python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3;;
     py:*)

@@ -332,9 +332,18 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_f16x3_kernel(const u3
             lo4[k] = l_;
           }
           const int Gout = (CoutStore + 7) >> 3;
-          char* o = reinterpret_cast<char*>(outv) + (((size_t)nb * Gout + grp) * 2 * PLANE + n) * 16 + hw * 8;
-          *reinterpret_cast<half4*>(o) = hi4;
-          *reinterpret_cast<half4*>(o + (size_t)PLANE * 16) = lo4;
+          // lanes l and l + 32 hold channels 0-3 / 4-7 of the same unit of the same cell (n depends on l31 only, grp on neither
+          // half): v_permlane32_swap hands the upper lane's hi half to the lower lane and the lower lane's lo half to the upper
+          // one - the lower lane stores the complete hi unit, the upper lane the complete lo unit: one 16-byte store per lane
+          // instead of two 8-byte halves of two units (round 6: the same time, half the store instructions, no partially
+          // written lines; profiles/r06/stages_store_policies_and_corr_order.txt).
+          typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+          const u32x2 hw_ = __builtin_bit_cast(u32x2, hi4), lw_ = __builtin_bit_cast(u32x2, lo4);
+          const u32x2 s0 = __builtin_amdgcn_permlane32_swap(hw_[0], lw_[0], false, false);
+          const u32x2 s1 = __builtin_amdgcn_permlane32_swap(hw_[1], lw_[1], false, false);
+          const u32x4 unit = {s0[0], s1[0], s0[1], s1[1]};
+          char* o = reinterpret_cast<char*>(outv) + ((((size_t)nb * Gout + grp) * 2 + hw) * PLANE + n) * 16;
+          *reinterpret_cast<u32x4*>(o) = unit;
         } else if (OUT_MODE == 1) {
           float* o = reinterpret_cast<float*>(outv);
 #pragma unroll

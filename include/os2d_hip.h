@@ -81,7 +81,7 @@ int os2d_class_prepare_batch(const float* const* srcs, const int* sizes, int B, 
  *   stride / rec_field: backbone stride and receptive field (16 / 16 for ResNet-C4, feature_extractor.py:115-117)
  *   outputs loc [A,B,4,H,W], cls [A,B,1,H,W], corners [A,B,8,H,W]  (cls_detached aliases cls in eval, head.py:400-402)
  * The workspace may be smaller than os2d_head_workspace_bytes(A,B,...) reports: classes are then processed in
- * chunks; it must hold at least os2d_head_workspace_bytes(A,1,...) bytes.  C must be a multiple of 4; W <= 3600 and H <= 2784 (the
+ * chunks; it must hold at least os2d_head_workspace_bytes(A,1,...) bytes.  Any C >= 1 (zero channel groups pad the operands); W <= 3600 and H <= 2784 (the
  * transform planner's 48 tiles per axis), and W <= 209 for the DIRECT 7x7 kernels of os2d_head_forward / the non-frequency precisions
  * (3344-px wide images at stride 16: they keep three halo rows in LDS); all checked before any launch. */
 int os2d_head_workspace_bytes(int A, int B, int C, int H, int W, int P, size_t* bytes);

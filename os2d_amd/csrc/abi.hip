@@ -92,8 +92,8 @@ inline void dump_slot(void*, int, const void*, size_t) {}
 #endif
 
 bool head_args_ok(int A, int B, int C, int H, int W, int P) {
-  if (A < 1 || B < 1 || C < 4 || (C & 3) || H < 1 || W < 1 || (P != 6 && P != 4)) {
-    os2d_set_error("bad head shape A=%d B=%d C=%d H=%d W=%d P=%d (need A,B,H,W>=1, C%%4==0, P in {6,4})", A, B, C, H,
+  if (A < 1 || B < 1 || C < 1 || H < 1 || W < 1 || (P != 6 && P != 4)) {
+    os2d_set_error("bad head shape A=%d B=%d C=%d H=%d W=%d P=%d (need A,B,C,H,W>=1, P in {6,4})", A, B, C, H,
                    W, P);
     return false;
   }

@@ -208,7 +208,8 @@ def test_singular_transform_is_regularised_locally(device):
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
-@pytest.mark.parametrize("C,H,W,B", [(12, 2, 3, 1), (20, 3, 2, 2), (8, 7, 1 + 4, 3), (36, 33, 40, 2)])
+@pytest.mark.parametrize("C,H,W,B", [(12, 2, 3, 1), (20, 3, 2, 2), (8, 7, 1 + 4, 3), (36, 33, 40, 2), (1, 4, 5, 2), (7, 5, 4, 3), (13, 9, 11, 2),
+                                     (33, 12, 10, 7)])
 def test_odd_shapes_match_oracle(C, H, W, B, precision, device):
     """Tiny / ragged shapes: C not a multiple of 8 (half-empty channel group), maps smaller than one tile, a single
     class, a map spanning several tiles with a ragged last one."""
@@ -381,12 +382,18 @@ def _random_shapes(n, seed):
     while len(shapes) < n:
         shapes.append((int(rs.randint(1, 17)) * 4, int(rs.randint(1, 41)), int(rs.randint(1, 61)), int(rs.randint(1, 3)),
                        int(rs.randint(1, 10)), int(rs.choice([4, 6])), bool(rs.randint(0, 2))))
+    # channel counts that are NOT a multiple of 4 (round 6: any C, as in the reference): a second stream, so that the shapes above keep
+    # their values
+    rs2 = np.random.RandomState(seed + 1)
+    for _ in range(4):
+        shapes.append((int(rs2.randint(1, 70)) | 1, int(rs2.randint(1, 41)), int(rs2.randint(1, 61)), int(rs2.randint(1, 3)),
+                       int(rs2.randint(1, 10)), int(rs2.choice([4, 6])), bool(rs2.randint(0, 2))))
     return shapes
 
 
 @pytest.mark.parametrize("C,H,W,A,B,P,inverse", _random_shapes(14, seed=2024))
 def test_random_shapes_all_precisions_match_oracle(C, H, W, A, B, P, inverse, device):
-    """Seeded sweep over channel counts (any multiple of 4), map sizes from 1x1 to 40x60 (partial tiles, single rows /
+    """Seeded sweep over channel counts (multiples of 4 and odd ones), map sizes from 1x1 to 40x60 (partial tiles, single rows /
     columns), image batches and class counts, both head variants: every arithmetic mode against the oracle."""
     from os2d_amd.utils import synthetic
     state = synthetic.make_transform_net_state(P, seed=C + H)

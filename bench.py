@@ -838,6 +838,9 @@ def main():
     if os.environ.get("OS2D_BENCH_WATCHDOG"):      # debugging aid: dump the Python stacks every N seconds to stderr
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["OS2D_BENCH_WATCHDOG"]), repeat=True)
+    # the host driver of these boxes supports dmabuf IPC only: without this RCCL / cross-process tensor sharing fails with
+    # "hipIpcGetMemHandle: invalid argument" (already exported on the GPU boxes; kept for any environment that launches us bare)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
